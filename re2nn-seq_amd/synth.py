@@ -1,0 +1,299 @@
+"""Synthetic, schema-identical inputs for the tagging path.
+
+No data ships with the reference (its ``data.zip`` is an external download), so every test,
+fixture and benchmark here runs on generated inputs that follow the reference's on-disk
+schemas:
+
+  * ``dataset.pkl``        -- writer ``src_seq/data.py:412-418``
+  * automaton dict         -- writer ``src_seq/wfa/create_dataset_automata.py:109-141``
+  * ``IIID.automata.*.pkl`` -- writer ``src_seq/wfa/decompose_automata.py:373-431``
+  * ``glove.<dim>.emb``     -- writer ``src_seq/data.py:80``
+
+Everything is driven by a ``numpy.random.RandomState`` (frozen legacy stream) so fixtures
+are reproducible from their seed.
+"""
+import numpy as np
+
+
+# --------------------------------------------------------------------------- vocabularies
+def make_vocab(n_words, n_numbers=6, with_punct=True):
+    """t2i / i2t without the '<pad>' entry (the drivers append it last,
+    reference train_onehot.py:47-48)."""
+    words = []
+    if with_punct:
+        words += [',', '.', '?']
+    nums = ['3', '17', '24', '25', '2021', '9.5', '0', '12', '100', '7'][:n_numbers]
+    words += nums
+    k = 0
+    while len(words) < n_words:
+        words.append('w{}'.format(k))
+        k += 1
+    words = words[:n_words]
+    t2i = {w: i for i, w in enumerate(words)}
+    i2t = {i: w for w, i in t2i.items()}
+    return t2i, i2t
+
+
+def make_slots(n_entity_types):
+    """BIO slot vocabulary: 'o' plus b-/i- pairs (lower-cased like the reference's s2i)."""
+    names = ['o']
+    for k in range(n_entity_types):
+        names.append('b-e{}'.format(k))
+        names.append('i-e{}'.format(k))
+    s2i = {s: i for i, s in enumerate(names)}
+    i2s = {i: s for s, i in s2i.items()}
+    return s2i, i2s
+
+
+# --------------------------------------------------------------------------- rule automaton
+def make_rule_automaton(t2i, s2i, n_states, rng, max_rule_len=4, words_per_edge=3,
+                        special_edge_prob=0.15):
+    """A slot-filling rule automaton in the reference's dict schema with the i-FST property
+    (every state has a single incoming label, cf. ``wfa_convert.fix_inedge_node``).
+
+    State 0 is start and final and carries a ``$<:>oo`` self loop (the "no rule fired" path);
+    the last state is a shared accepting sink with the same loop; rules are chains
+    ``0 -> q1 -> ... -> qk`` whose edges carry word sets and BIO labels.
+    Returns (automaton_dict, rules) where rules lists the word/label chains (used to plant
+    matches into generated sentences).
+    """
+    assert n_states >= 3
+    words = [w for w in t2i if w not in ('<pad>',)]
+    plain = [w for w in words if w.startswith('w')] or words
+    ent = sorted({s[2:] for s in s2i if s.startswith('b-')})
+    sink = n_states - 1
+    trans = {0: {0: {'$<:>oo'}}, sink: {sink: {'$<:>oo'}}}
+    finals = {0, sink}
+    rules = []
+    nxt = 1
+
+    def add(fr, to, lab):
+        trans.setdefault(fr, {}).setdefault(to, set()).add(lab)
+
+    while nxt < sink:
+        k = int(rng.randint(1, max_rule_len + 1))
+        k = min(k, sink - nxt)
+        e = ent[int(rng.randint(len(ent)))] if ent else None
+        n_ctx = int(rng.randint(0, k)) if k > 1 else 0       # leading context edges tagged 'o'
+        prev = 0
+        chain = []
+        for pos in range(k):
+            q = nxt
+            nxt += 1
+            if pos < n_ctx or e is None:
+                tag = 'o'
+            elif pos == n_ctx:
+                tag = 'b-' + e
+            else:
+                tag = 'i-' + e
+            u = rng.rand()
+            if u < special_edge_prob / 3:
+                wset = ['%']
+            elif u < 2 * special_edge_prob / 3:
+                wset = ['&']
+            elif u < special_edge_prob and pos > 0:
+                wset = ['$']
+            else:
+                n_w = int(rng.randint(1, words_per_edge + 1))
+                wset = [plain[int(i)] for i in rng.randint(0, len(plain), size=n_w)]
+            for w in wset:
+                add(prev, q, '{}<:>{}'.format(w, tag))
+            chain.append((sorted(set(wset)), tag))
+            prev = q
+        # the chain end accepts, may repeat an i- label, and drains into the sink
+        finals.add(prev)
+        last_tag = chain[-1][1]
+        if last_tag.startswith('i-') and rng.rand() < 0.5:
+            for w in chain[-1][0]:
+                add(prev, prev, '{}<:>{}'.format(w, last_tag))
+        add(prev, sink, '$<:>oo')
+        rules.append(chain)
+    automaton = {
+        'states': set(range(n_states)),
+        'startstate': [0],
+        'finalstates': sorted(finals),
+        'transitions': trans,
+    }
+    return automaton, rules
+
+
+def make_sentences(t2i, s2i, rules, n, max_len, rng, min_len=1, plant_prob=0.7,
+                   zipf_a=1.1, full_length_rows=1):
+    """Token-id sentences (lists of ints) + gold slot ids.  Tokens follow a Zipf law over the
+    vocabulary; with probability `plant_prob` one rule's word chain is planted so that rules
+    actually fire."""
+    V = len(t2i)
+    words = list(t2i.keys())
+    ranks = np.arange(1, V + 1, dtype=np.float64)
+    pz = ranks ** (-zipf_a)
+    pz /= pz.sum()
+    perm = rng.permutation(V)
+    numbers = [w for w in words if w.replace('.', '', 1).isdigit()]
+    puncts = [w for w in words if w in (',', '.', '?')]
+    o_idx = s2i['o']
+    queries, slots = [], []
+    for k in range(n):
+        ln = max_len if k < full_length_rows else int(rng.randint(min_len, max_len + 1))
+        q = [int(perm[i]) for i in rng.choice(V, size=ln, p=pz)]
+        s = [o_idx] * ln
+        if rules and rng.rand() < plant_prob:
+            chain = rules[int(rng.randint(len(rules)))]
+            if len(chain) <= ln:
+                at = int(rng.randint(0, ln - len(chain) + 1))
+                for j, (wset, tag) in enumerate(chain):
+                    w = wset[int(rng.randint(len(wset)))]
+                    if w == '%':
+                        w = numbers[int(rng.randint(len(numbers)))] if numbers else None
+                    elif w == '&':
+                        w = puncts[int(rng.randint(len(puncts)))] if puncts else None
+                    elif w == '$':
+                        w = None
+                    if w is not None:
+                        q[at + j] = t2i[w]
+                    s[at + j] = s2i[tag]
+        queries.append(q)
+        slots.append(s)
+    return queries, slots
+
+
+def make_dataset(n_words, n_entity_types, n_states, seed, n_train=64, n_dev=32, n_test=32,
+                 max_len=20):
+    """A complete synthetic problem: vocabularies, automaton and a ``dataset.pkl``-shaped dict."""
+    rng = np.random.RandomState(seed)
+    t2i, i2t = make_vocab(n_words)
+    s2i, i2s = make_slots(n_entity_types)
+    automaton, rules = make_rule_automaton(t2i, s2i, n_states, rng)
+    dset = {'t2i': t2i, 'i2t': i2t, 's2i': s2i, 'i2s': i2s}
+    for name, n in (('train', n_train), ('dev', n_dev), ('test', n_test)):
+        q, s = make_sentences(t2i, s2i, rules, n, max_len, rng)
+        dset['query_' + name] = q
+        dset['intent_' + name] = s          # slot ids despite the name (data.py:412-418)
+    return dset, automaton, rules
+
+
+# --------------------------------------------------------------------------- padded batches
+def pad_batch(queries, max_len, pad_id):
+    """reference utils.pad_dataset_1 (:28-56) for one batch -> (x[B,L] int64, lengths[B])."""
+    keep = [q for q in queries if len(q) > 0]
+    x = np.full((len(keep), max_len), pad_id, dtype=np.int64)
+    lengths = np.zeros(len(keep), dtype=np.int64)
+    for b, q in enumerate(keep):
+        n = min(len(q), max_len)
+        x[b, :n] = q[:n]
+        lengths[b] = n
+    return x, lengths
+
+
+def random_batch(V, B, L, rng, min_len=5, zipf_a=1.1, full_length_rows=1):
+    """Bench-style batch: Zipf tokens over the V-1 real ids, lengths ~ U[min_len, L] with
+    `full_length_rows` rows of full length, pad id = V-1."""
+    ranks = np.arange(1, V, dtype=np.float64)
+    pz = ranks ** (-zipf_a)
+    pz /= pz.sum()
+    perm = rng.permutation(V - 1)
+    lengths = rng.randint(min(min_len, L), L + 1, size=B).astype(np.int64)
+    lengths[:full_length_rows] = L
+    x = np.full((B, L), V - 1, dtype=np.int64)
+    for b in range(B):
+        n = int(lengths[b])
+        x[b, :n] = perm[rng.choice(V - 1, size=n, p=pz)]
+    return x, lengths
+
+
+# --------------------------------------------------------------------------- direct tensors
+def random_ifst_tensors(V, S, C, rng, edges_per_word=2.0, n_final=4, wildcard_moves=2):
+    """Automaton-like dense i-FST tensors without going through an automaton dict
+    (used at sizes where building an edge list would be slow): 0/1 ``T[V,S,S]`` with at most
+    one successor per (word, from-state), wildcard self loops on the start state and the
+    accepting states, one label per destination state, the ``oo`` column (C-1) on the
+    wildcard states.  The last word id (V-1) is the pad row and stays all-zero.
+    Path counts stay far below 2**24, so fp32 arithmetic on them is exact."""
+    T = np.zeros((V, S, S), dtype=np.float32)
+    n_edges = int(edges_per_word * (V - 1))
+    w = rng.randint(0, V - 1, size=n_edges)
+    s = rng.randint(0, S, size=n_edges)
+    j = rng.randint(1, S, size=n_edges)
+    # keep at most one successor per (word, from-state): later draws are dropped
+    _, first = np.unique(w.astype(np.int64) * S + s, return_index=True)
+    T[w[first], s[first], j[first]] = 1.0
+    W = np.zeros((S, S), dtype=np.float32)
+    finals = np.unique(np.concatenate([[0, S - 1], rng.randint(1, S, size=n_final)]))
+    W[finals, finals] = 1.0
+    for _ in range(wildcard_moves):
+        a, b = int(rng.randint(1, S)), int(finals[rng.randint(len(finals))])
+        if a != b:
+            W[a, b] = 1.0
+    O = np.zeros((C, S), dtype=np.float32)
+    lab = rng.randint(0, C - 1, size=S)
+    O[lab, np.arange(S)] = 1.0
+    O[:, finals] = 0.0
+    O[C - 1, finals] = 1.0
+    h0 = np.zeros(S, dtype=np.float32); h0[0] = 1.0
+    hT = np.zeros(S, dtype=np.float32); hT[finals] = 1.0
+    return T, W, O, h0, hT
+
+
+def exact_cp_factors(T, rank=None, rng=None, noise=0.0):
+    """An exact CP decomposition of a 0/1 language tensor: one rank-1 term per distinct
+    (from-state, to-state) pair, ``T[w,s,j] = sum_r V[w,r] S1[s,r] S2[j,r]``.
+    Optionally zero-pads to `rank` columns and adds gaussian noise.  Gives the decomposed
+    model realistic, structured factors without tensorly (absent from this image)."""
+    Vn, S, _ = T.shape
+    pairs = np.argwhere(T.sum(0) > 0)
+    R0 = len(pairs)
+    R = R0 if rank is None else int(rank)
+    assert R >= R0, "rank {} < number of (from,to) pairs {}".format(R, R0)
+    Vf = np.zeros((Vn, R)); S1 = np.zeros((S, R)); S2 = np.zeros((S, R))
+    for r, (s, j) in enumerate(pairs):
+        Vf[:, r] = T[:, s, j]
+        S1[s, r] = 1.0
+        S2[j, r] = 1.0
+    if noise and rng is not None:
+        Vf += noise * rng.randn(*Vf.shape)
+        S1 += noise * rng.randn(*S1.shape)
+        S2 += noise * rng.randn(*S2.shape)
+    return Vf, S1, S2
+
+
+def make_iiid_pickle_dict(automaton, t2i, s2i, ranks, rng, noise=0.01, n_seeds=4,
+                          dataset='MITR-BIO'):
+    """A dict with the schema of ``IIID.automata.*.pkl`` (decompose_automata.py:373-431):
+    {'automata': dict, seed: [ {rank: {'V','S1','S2','wildcard_mat'}},
+                               {'output_mat'[C,S], 'output_wildcard_vector'[S]},
+                               {'output_mat'[C+1,S], 'output_wildcard_vector'[S]} ]}.
+    `t2i` must NOT contain '<pad>' (the loader appends the pad row, init_params.py:280-281)."""
+    from .wfa.fsa_to_tensor import dfa_to_tensor_slot_single_wildcard
+    lang, _, wild, out_mat, out_wild, _, _, _ = dfa_to_tensor_slot_single_wildcard(
+        automaton, t2i, s2i, dataset=dataset)
+    out = {'automata': automaton}
+    for seed in range(n_seeds):
+        per_rank = {}
+        for R in ranks:
+            Vf, S1, S2 = exact_cp_factors(lang, rank=R, rng=rng, noise=noise)
+            per_rank[R] = {'V': Vf, 'S1': S1, 'S2': S2, 'wildcard_mat': wild.copy()}
+        out[seed] = [per_rank,
+                     {'output_mat': out_mat[:-1].copy(), 'output_wildcard_vector': out_wild.copy()},
+                     {'output_mat': out_mat.copy(), 'output_wildcard_vector': out_wild.copy()}]
+    return out
+
+
+def random_decomposed_params(V, S, C, R, D, rng, scale=None):
+    """Dense gaussian factors for size/throughput runs of the decomposed path."""
+    if scale is None:
+        scale = 0.9 / float(np.cbrt(S * R) ** 0.5)
+    p = {
+        'V_embed': (rng.randn(V, R) * scale).astype(np.float64),
+        'S1': (rng.randn(S, R) * scale).astype(np.float64),
+        'S2': (rng.randn(S, R) * scale).astype(np.float64),
+        'wildcard_mat': (rng.rand(S, S) < 2.0 / S).astype(np.float64) * 0.5,
+        'C_output_mat': (rng.rand(C, S) < 1.5 / C).astype(np.float64),
+        'wildcard_output_vector': np.zeros(S),
+        'embed': (rng.randn(V, D) * 0.3).astype(np.float64),
+    }
+    p['V_embed'][V - 1] = 0.0
+    p['embed'][V - 1] = 0.0
+    h0 = np.zeros(S); h0[0] = 1.0
+    hT = (rng.rand(S) < 0.1).astype(np.float64); hT[0] = 1.0
+    p['start_vector'] = h0
+    p['final_vector'] = hT
+    return p
