@@ -1,0 +1,178 @@
+/*
+ * farnn.h -- C-ABI of the MI355X-native FA-RNN forward tagging path (libfarnn_hip.so).
+ *
+ * The reference (jeffchy/RE2NN-SEQ) is pure PyTorch and has no FFI of its own; the seam this
+ * library replaces is the nn.Module method contract consumed by the reference's callers
+ * (SURVEY.md section 8b).  Each entry point cites the reference interface it stands in for
+ * (paths relative to the reference checkout).  The reference-side binding a maintainer would
+ * add (a ctypes stub inside the model classes) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes only, no torch / C++ types in any signature;
+ *   - every function returns FARNN_OK (0) or a negative errno-style code, never throws;
+ *     farnn_last_error() returns a human-readable message for the calling thread;
+ *   - weights are given as HOST pointers (float32, C-contiguous) unless desc.weights_on_device
+ *     is set; create() copies them into device-resident, re-laid-out storage that the handle
+ *     owns until farnn_destroy();
+ *   - x / lengths / tags / scores of farnn_tag() are DEVICE pointers (e.g. tensor.data_ptr()
+ *     of PyTorch-ROCm tensors used purely as containers); the library never retains them
+ *     after the call's work has been enqueued on `stream`;
+ *   - one caller thread per handle (the reference is single-threaded Python).
+ */
+#ifndef FARNN_H
+#define FARNN_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FARNN_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------------------- */
+#define FARNN_OK         0
+#define FARNN_EINVAL   (-22)   /* bad argument / unsupported combination               */
+#define FARNN_ENOMEM   (-12)   /* device or host allocation failed                     */
+#define FARNN_ENODEV   (-19)   /* no usable HIP device                                 */
+#define FARNN_EIO       (-5)   /* a HIP runtime call failed (see farnn_last_error)     */
+#define FARNN_ERANGE   (-34)   /* size beyond what the kernels support                 */
+
+/* ---- enumerations ------------------------------------------------------------------- */
+/* --update_nonlinear (reference main.py:93, model_onehot.py:379-386) */
+#define FARNN_NL_NONE      0
+#define FARNN_NL_RELU      1
+#define FARNN_NL_TANH      2
+#define FARNN_NL_RELUTANH  3
+#define FARNN_NL_SIGMOID   4   /* only --additional_nonlinear uses it (model_decompose.py:232) */
+/* --train_mode (reference main.py:33, utils.py:192-199) */
+#define FARNN_SEMIRING_SUM 0
+#define FARNN_SEMIRING_MAX 1
+/* farnn_tag() modes */
+#define FARNN_MODE_LOCAL   0   /* forward_local: valid positions only (model_onehot.py:131-146) */
+#define FARNN_MODE_FULL    1   /* forward_RE / forward_score: all L positions incl. pads (:148-160) */
+
+typedef struct farnn_model farnn_model;   /* opaque handle */
+
+/* ---- onehot i-FST: FARNN_S_O_I_S (reference model_onehot.py:310-428), --independent 2 ---- */
+typedef struct farnn_onehot_ifst_desc {
+    int32_t V, S, C;            /* vocabulary (incl. pad row), states, label columns (len(s2i)+1) */
+    const float *T;             /* [V,S,S] language_tensor   (:326-328)                     */
+    const float *W;             /* [S,S]   wildcard_mat      (:329-331)                     */
+    const float *O;             /* [C,S]   output_mat        (:332-333)                     */
+    const float *h0;            /* [S]     start_vector      (:322-323)                     */
+    const float *hT;            /* [S]     final_vector      (:324-325)                     */
+    const float *P;             /* [C,C] expanded priority matrix (priority.py:6-18) or NULL */
+    int32_t nl;                 /* FARNN_NL_*                                                */
+    int32_t semiring;           /* FARNN_SEMIRING_*                                          */
+    float   threshold;          /* --threshold: clamp of the `oo` column (:166-167)          */
+    int32_t o_idx;              /* s2i['o']: what the `oo` column decodes to (:169)          */
+    int32_t use_crf;            /* 0: threshold+argmax; 1: Viterbi over C+2 tags */
+    const float *crf_trans;     /* [(C+2),(C+2)] CRF.transitions (crf.py:39-46) or NULL=defaults */
+    int32_t weights_on_device;  /* 1: T/W/O/h0/hT/P/crf_trans are device pointers            */
+} farnn_onehot_ifst_desc;
+
+int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *desc, int device, farnn_model **out);
+
+/* ---- onehot FST 4-D: FARNN_S_O (reference model_onehot.py:8-129), --independent 0 ---- */
+typedef struct farnn_onehot_fst4_desc {
+    int32_t V, S, C;
+    const float *T4;            /* [V,C,S,S] language_tensor (:34)  */
+    const float *W4;            /* [C,S,S]   wildcard_tensor (:35)  */
+    const float *h0, *hT;       /* [S]                              */
+    const float *P;             /* [C,C] or NULL                    */
+    int32_t semiring;           /* relu is unconditional (:93-94)   */
+    float   threshold;
+    int32_t o_idx;
+    int32_t weights_on_device;
+} farnn_onehot_fst4_desc;
+
+int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *desc, int device, farnn_model **out);
+
+/* ---- onehot independent=1: FARNN_S_O_I (reference model_onehot.py:184-306) ---- */
+typedef struct farnn_onehot_ind1_desc {
+    int32_t V, S, C;
+    const float *T;             /* [V,S,S]                           */
+    const float *W;             /* [S,S]                             */
+    const float *Oten;          /* [C,S,S] output_tensor (:212-213)  */
+    const float *h0, *hT;
+    const float *P;
+    int32_t semiring;
+    int32_t mask_by_output;     /* the `args.independent == 2` branch (:259-262) */
+    float   threshold;
+    int32_t o_idx;
+    int32_t weights_on_device;
+} farnn_onehot_ind1_desc;
+
+int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *desc, int device, farnn_model **out);
+
+/* ---- decomposed i-FST: FARNN_S_D_W_I_S (reference model_decompose_single.py:12-304) ---- */
+typedef struct farnn_decomp_ifst_desc {
+    int32_t V, S, R, K;         /* S incl. additional_states; K = score columns (C, or C+2 with CRF) */
+    const float *Vgen;          /* [V,R] generalized word table: V_embed*beta + nl_add(E@G)*(1-beta),
+                                   model_decompose.py:222-241, precomputed once (weights frozen)   */
+    const float *S1, *S2;       /* [S,R]  (model_decompose_single.py:70-71)                        */
+    const float *W;             /* [S,S]  wildcard_mat (:84-86)                                     */
+    const float *Cout;          /* [K,S]  C_output_mat (:81-82)                                     */
+    const float *h0, *hT;       /* [S]                                                              */
+    const float *P;             /* [K,K] or NULL                                                    */
+    int32_t farnn;              /* 0 plain, 1 update gate, 2 update+reset gates (:143-154)          */
+    const float *Wss1, *Wrs1, *bs1;   /* [S,S], [R,S], [S]   (farnn >= 1)                           */
+    const float *Wss2, *Wrs2, *bs2;   /* [S,S], [R,S], [S]   (farnn == 2)                           */
+    float   sigmoid_exponent;   /* gate_activation scale (model_decompose.py:97-102)                */
+    int32_t nl;
+    int32_t semiring;
+    float   threshold;
+    int32_t o_idx;
+    int32_t use_crf;
+    const float *crf_trans;     /* [K,K] when use_crf                                               */
+    int32_t weights_on_device;
+} farnn_decomp_ifst_desc;
+
+int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *desc, int device, farnn_model **out);
+
+/* ---- the hot path ------------------------------------------------------------------- */
+/*
+ * farnn_tag: model.forward_local / forward_RE / forward_score of the reference
+ *            (model_onehot.py:131-160, model_decompose_single.py:207-304), minus the loss.
+ *
+ *   x        int64 [B,L]   token ids, pad id at positions >= lengths[b]        (device)
+ *   lengths  int64 [B]     1..L                                                (device)
+ *   mode     FARNN_MODE_LOCAL: only positions < lengths[b] are tagged; FARNN_MODE_FULL: all L
+ *            positions run through the recurrence exactly like the reference's padded loop.
+ *   tags     int32 [B,L] or NULL. LOCAL: positions >= lengths[b] are set to -1.       (device)
+ *   flat_tags int64 [sum(lengths)] or NULL: the reference's flattened prediction order
+ *            (utils.py:153-164): for b in batch, positions 0..lengths[b]-1.            (device)
+ *   scores   float32 [B,L,K] or NULL: per-token label scores BEFORE the threshold clamp
+ *            (K = farnn_num_columns()).  LOCAL: rows at pad positions are zero-filled. (device)
+ *   stream   hipStream_t (as void*), NULL = the default stream.  Work is enqueued, not awaited.
+ */
+int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
+              int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream);
+
+/* Pre-size the handle's device workspace so that farnn_tag() for up to (B,L) allocates nothing
+ * (required before capturing farnn_tag() into a hipGraph). */
+int farnn_reserve(farnn_model *m, int32_t B, int32_t L);
+
+void farnn_destroy(farnn_model *m);
+
+/* ---- introspection / measurement ----------------------------------------------------- */
+int  farnn_abi_version(void);
+int  farnn_device_count(void);
+const char *farnn_last_error(void);
+int  farnn_num_columns(const farnn_model *m);              /* K of the scores tensor */
+/* algorithmic HBM bytes of one farnn_tag() call with `valid_tokens` tagged tokens
+ * (SURVEY.md 8d / DESIGN.md: per-token figure x tokens), for the roofline line of bench.py */
+double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_tokens);
+/* per-kernel timing with HIP events recorded on the launch stream.  enable=1 starts
+ * collecting; farnn_kernel_time() synchronises, then reports the accumulated milliseconds
+ * and launch count of kernel `which` (0 = recurrence chain, 1 = score+decode, 2 = prep). */
+int  farnn_set_profiling(farnn_model *m, int32_t enable);
+int  farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms, int64_t *launches);
+const char *farnn_kernel_name(const farnn_model *m, int32_t which);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FARNN_H */

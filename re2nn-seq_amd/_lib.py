@@ -1,0 +1,220 @@
+"""ctypes binding of the C-ABI in include/farnn.h (libfarnn_hip.so).
+
+There is no CPU fallback: if the shared library has not been built (``__graft_entry__.build()``
+or ``python -m re2nn_seq_amd.csrc.build``) or no MI355X is visible, the functions here raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libfarnn_hip.so')
+
+OK = 0
+NL = {'none': 0, 'relu': 1, 'tanh': 2, 'relutanh': 3, 'sigmoid': 4}
+SEMIRING = {'sum': 0, 'max': 1}
+MODE_LOCAL, MODE_FULL = 0, 1
+KERN_CHAIN, KERN_SCORE, KERN_PREP = 0, 1, 2
+
+_f32p = C.POINTER(C.c_float)
+
+
+class FarnnError(RuntimeError):
+    pass
+
+
+class OnehotIfstDesc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('T', _f32p), ('W', _f32p), ('O', _f32p), ('h0', _f32p), ('hT', _f32p), ('P', _f32p),
+                ('nl', C.c_int32), ('semiring', C.c_int32), ('threshold', C.c_float),
+                ('o_idx', C.c_int32), ('use_crf', C.c_int32), ('crf_trans', _f32p),
+                ('weights_on_device', C.c_int32)]
+
+
+class OnehotFst4Desc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('T4', _f32p), ('W4', _f32p), ('h0', _f32p), ('hT', _f32p), ('P', _f32p),
+                ('semiring', C.c_int32), ('threshold', C.c_float), ('o_idx', C.c_int32),
+                ('weights_on_device', C.c_int32)]
+
+
+class OnehotInd1Desc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('C', C.c_int32),
+                ('T', _f32p), ('W', _f32p), ('Oten', _f32p), ('h0', _f32p), ('hT', _f32p), ('P', _f32p),
+                ('semiring', C.c_int32), ('mask_by_output', C.c_int32), ('threshold', C.c_float),
+                ('o_idx', C.c_int32), ('weights_on_device', C.c_int32)]
+
+
+class DecompIfstDesc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('K', C.c_int32),
+                ('Vgen', _f32p), ('S1', _f32p), ('S2', _f32p), ('W', _f32p), ('Cout', _f32p),
+                ('h0', _f32p), ('hT', _f32p), ('P', _f32p),
+                ('farnn', C.c_int32),
+                ('Wss1', _f32p), ('Wrs1', _f32p), ('bs1', _f32p),
+                ('Wss2', _f32p), ('Wrs2', _f32p), ('bs2', _f32p),
+                ('sigmoid_exponent', C.c_float), ('nl', C.c_int32), ('semiring', C.c_int32),
+                ('threshold', C.c_float), ('o_idx', C.c_int32), ('use_crf', C.c_int32),
+                ('crf_trans', _f32p), ('weights_on_device', C.c_int32)]
+
+
+# every symbol include/farnn.h declares, with its ctypes signature (tests check the exports)
+_vp = C.c_void_p
+SIGNATURES = {
+    'farnn_onehot_ifst_create': (C.c_int, [C.POINTER(OnehotIfstDesc), C.c_int, C.POINTER(_vp)]),
+    'farnn_onehot_fst4_create': (C.c_int, [C.POINTER(OnehotFst4Desc), C.c_int, C.POINTER(_vp)]),
+    'farnn_onehot_ind1_create': (C.c_int, [C.POINTER(OnehotInd1Desc), C.c_int, C.POINTER(_vp)]),
+    'farnn_decomp_ifst_create': (C.c_int, [C.POINTER(DecompIfstDesc), C.c_int, C.POINTER(_vp)]),
+    'farnn_tag': (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
+    'farnn_reserve': (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    'farnn_destroy': (None, [_vp]),
+    'farnn_abi_version': (C.c_int, []),
+    'farnn_device_count': (C.c_int, []),
+    'farnn_last_error': (C.c_char_p, []),
+    'farnn_num_columns': (C.c_int, [_vp]),
+    'farnn_algorithmic_bytes': (C.c_double, [_vp, C.c_int64]),
+    'farnn_set_profiling': (C.c_int, [_vp, C.c_int32]),
+    'farnn_kernel_time': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    'farnn_kernel_name': (C.c_char_p, [_vp, C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libfarnn_hip.so (once).  Raises FarnnError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FarnnError(
+            'HIP library not built: {} is missing. Run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(LIB_PATH))
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != OK:
+        msg = load().farnn_last_error()
+        raise FarnnError('{} failed with code {}: {}'.format(what or 'farnn call', rc,
+                                                             msg.decode() if msg else ''))
+
+
+def f32(a):
+    """float32 C-contiguous numpy view/copy (the reference stores float64 and calls .float())."""
+    return np.ascontiguousarray(np.asarray(a), dtype=np.float32)
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_f32p)
+
+
+class Handle:
+    """Owns one farnn_model*."""
+
+    def __init__(self, raw, keepalive=()):
+        self._raw = raw
+        self._keep = keepalive
+
+    @property
+    def raw(self):
+        if not self._raw:
+            raise FarnnError('model handle already destroyed')
+        return self._raw
+
+    def close(self):
+        if self._raw:
+            load().farnn_destroy(self._raw)
+            self._raw = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thin wrappers -----------------------------------------------------------------------
+    def num_columns(self):
+        return load().farnn_num_columns(self.raw)
+
+    def reserve(self, B, L):
+        check(load().farnn_reserve(self.raw, B, L), 'farnn_reserve')
+
+    def tag(self, x_ptr, len_ptr, B, L, mode, tags_ptr=None, flat_ptr=None, scores_ptr=None, stream=None):
+        check(load().farnn_tag(self.raw, x_ptr, len_ptr, B, L, mode, tags_ptr, flat_ptr, scores_ptr,
+                               stream), 'farnn_tag')
+
+    def algorithmic_bytes(self, valid_tokens):
+        return load().farnn_algorithmic_bytes(self.raw, int(valid_tokens))
+
+    def set_profiling(self, on):
+        check(load().farnn_set_profiling(self.raw, 1 if on else 0), 'farnn_set_profiling')
+
+    def kernel_time(self, which):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(load().farnn_kernel_time(self.raw, which, C.byref(ms), C.byref(n)), 'farnn_kernel_time')
+        return ms.value, n.value
+
+    def kernel_name(self, which):
+        return load().farnn_kernel_name(self.raw, which).decode()
+
+
+def _create(fn_name, desc, device, keep):
+    lib = load()
+    out = _vp()
+    check(getattr(lib, fn_name)(C.byref(desc), int(device), C.byref(out)), fn_name)
+    return Handle(out, keep)
+
+
+def create_onehot_ifst(T, W, O, h0, hT, P=None, nl='none', semiring='sum', threshold=0.5, o_idx=0,
+                       use_crf=False, crf_trans=None, device=0):
+    T, W, O, h0, hT = f32(T), f32(W), f32(O), f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    crf_trans = None if crf_trans is None else f32(crf_trans)
+    V, S, _ = T.shape
+    d = OnehotIfstDesc(V, S, O.shape[0], ptr(T), ptr(W), ptr(O), ptr(h0), ptr(hT), ptr(P),
+                       NL[nl], SEMIRING[semiring], float(threshold), int(o_idx), int(bool(use_crf)),
+                       ptr(crf_trans), 0)
+    return _create('farnn_onehot_ifst_create', d, device, (T, W, O, h0, hT, P, crf_trans))
+
+
+def create_onehot_fst4(T4, W4, h0, hT, P=None, semiring='sum', threshold=0.5, o_idx=0, device=0):
+    T4, W4, h0, hT = f32(T4), f32(W4), f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    V, Cn, S, _ = T4.shape
+    d = OnehotFst4Desc(V, S, Cn, ptr(T4), ptr(W4), ptr(h0), ptr(hT), ptr(P), SEMIRING[semiring],
+                       float(threshold), int(o_idx), 0)
+    return _create('farnn_onehot_fst4_create', d, device, (T4, W4, h0, hT, P))
+
+
+def create_onehot_ind1(T, W, Oten, h0, hT, P=None, semiring='sum', mask_by_output=False, threshold=0.5,
+                       o_idx=0, device=0):
+    T, W, Oten, h0, hT = f32(T), f32(W), f32(Oten), f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    V, S, _ = T.shape
+    d = OnehotInd1Desc(V, S, Oten.shape[0], ptr(T), ptr(W), ptr(Oten), ptr(h0), ptr(hT), ptr(P),
+                       SEMIRING[semiring], int(bool(mask_by_output)), float(threshold), int(o_idx), 0)
+    return _create('farnn_onehot_ind1_create', d, device, (T, W, Oten, h0, hT, P))
+
+
+def create_decomp_ifst(Vgen, S1, S2, W, Cout, h0, hT, P=None, farnn=0, gates=None, sigmoid_exponent=5,
+                       nl='none', semiring='sum', threshold=0.5, o_idx=0, use_crf=False, crf_trans=None,
+                       device=0):
+    Vgen, S1, S2, W, Cout, h0, hT = (f32(a) for a in (Vgen, S1, S2, W, Cout, h0, hT))
+    P = None if P is None else f32(P)
+    crf_trans = None if crf_trans is None else f32(crf_trans)
+    g = {k: f32(v) for k, v in (gates or {}).items()}
+    S, R = S1.shape
+    d = DecompIfstDesc(Vgen.shape[0], S, R, Cout.shape[0], ptr(Vgen), ptr(S1), ptr(S2), ptr(W), ptr(Cout),
+                       ptr(h0), ptr(hT), ptr(P), int(farnn),
+                       ptr(g.get('Wss1')), ptr(g.get('Wrs1')), ptr(g.get('bs1')),
+                       ptr(g.get('Wss2')), ptr(g.get('Wrs2')), ptr(g.get('bs2')),
+                       float(sigmoid_exponent), NL[nl], SEMIRING[semiring], float(threshold), int(o_idx),
+                       int(bool(use_crf)), ptr(crf_trans), 0)
+    return _create('farnn_decomp_ifst_create', d, device, (Vgen, S1, S2, W, Cout, h0, hT, P, crf_trans, g))

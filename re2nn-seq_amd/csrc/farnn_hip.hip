@@ -1,0 +1,614 @@
+// libfarnn_hip.so -- C-ABI entry points (include/farnn.h) of the MI355X-native FA-RNN tagging path.
+// gfx950 only; no CPU fallback lives here (the CPU oracle is test infrastructure under oracle/).
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <new>
+#include <vector>
+
+#include "common.hip.h"
+#include "chain.hip.h"
+#include "score_decode.hip.h"
+#include "layout.hip.h"
+#include "fst4_score.hip.h"
+#include "decomp_chain.hip.h"
+
+namespace farnn {
+thread_local char g_err[512] = "";
+}
+using namespace farnn;
+
+enum { KIND_IFST = 2, KIND_IND1 = 1, KIND_FST4 = 0, KIND_DECOMP = 12 };
+enum { KERN_CHAIN = 0, KERN_SCORE = 1, KERN_PREP = 2, KERN_COUNT = 3 };
+
+struct Prof {
+    std::vector<hipEvent_t> ev[KERN_COUNT];   // (start, stop) pairs
+    double ms[KERN_COUNT] = {0, 0, 0};
+    long long n[KERN_COUNT] = {0, 0, 0};
+};
+
+struct farnn_model {
+    int kind = 0, device = 0;
+    int V = 0, S = 0, SP = 0, C = 0, K = 0, Kp = 0, R = 0, Rp = 0;
+    int nl = 0, semiring = 0, o_idx = 0, use_crf = 0, farnn_gate = 0, mask_by_output = 0;
+    float threshold = 0.5f, sig_k = 1.0f;
+    // device-resident, library-owned weights
+    float *Mf = nullptr, *Mb = nullptr;     // chain blocks [V][S][SP] (+ transposed)
+    float *Ms = nullptr;                    // ind1: unmasked blocks for scoring
+    float *A4 = nullptr;                    // fst4: [V][C][S][SP] premixed T4+W4
+    float *Oten = nullptr;                  // ind1: [C][S][SP]
+    float *o = nullptr, *h0 = nullptr, *hT = nullptr;
+    float *OT = nullptr, *P = nullptr, *tr = nullptr;
+    DecompWeights dw;                       // decomposed model weights
+    // workspace
+    float *A = nullptr, *Bk = nullptr;
+    int64_t *offs = nullptr;
+    int wsB = 0, wsL = 0;
+    ChainGeom geom;
+    int profiling = 0;
+    Prof prof;
+    std::vector<void *> owned;              // everything to hipFree at destroy
+};
+
+// ---- small helpers ---------------------------------------------------------------------------
+static int dev_alloc(farnn_model *m, void **p, size_t bytes) {
+    FARNN_HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    m->owned.push_back(*p);
+    return FARNN_OK;
+}
+
+// copy (host or device) floats into a fresh device buffer of `n_alloc` floats (zero padded)
+static int dev_upload(farnn_model *m, float **dst, const float *src, size_t n, size_t n_alloc,
+                      int on_device) {
+    int rc = dev_alloc(m, (void **)dst, n_alloc * sizeof(float));
+    if (rc) return rc;
+    FARNN_HIP_TRY(hipMemset(*dst, 0, n_alloc * sizeof(float)));
+    if (src && n)
+        FARNN_HIP_TRY(hipMemcpy(*dst, src, n * sizeof(float),
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return FARNN_OK;
+}
+
+// a temporary device view of a (host|device) array
+struct TmpDev {
+    const float *p = nullptr;
+    float *owned = nullptr;
+    ~TmpDev() { if (owned) (void)hipFree(owned); }
+    int init(const float *src, size_t n, int on_device) {
+        if (on_device || !src) { p = src; return FARNN_OK; }
+        FARNN_HIP_TRY(hipMalloc((void **)&owned, n * sizeof(float)));
+        FARNN_HIP_TRY(hipMemcpy(owned, src, n * sizeof(float), hipMemcpyHostToDevice));
+        p = owned;
+        return FARNN_OK;
+    }
+};
+
+// rows x cols (row-major, host|device) -> device [rows_alloc][cols_p], zero padded
+static int upload_padded(farnn_model *m, float **dst, const float *src, int rows, int cols,
+                         int rows_alloc, int cols_p, int on_device) {
+    int rc = dev_alloc(m, (void **)dst, (size_t)rows_alloc * cols_p * sizeof(float));
+    if (rc) return rc;
+    FARNN_HIP_TRY(hipMemset(*dst, 0, (size_t)rows_alloc * cols_p * sizeof(float)));
+    if (src)
+        FARNN_HIP_TRY(hipMemcpy2D(*dst, (size_t)cols_p * 4, src, (size_t)cols * 4, (size_t)cols * 4,
+                                  rows, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+    return FARNN_OK;
+}
+
+// transposed upload: src [rows][cols] -> dst [cols][rows_p]
+static int upload_transposed(farnn_model *m, float **dst, const float *src, int rows, int cols,
+                             int rows_p, int on_device) {
+    TmpDev t;
+    int rc = t.init(src, (size_t)rows * cols, on_device);
+    if (rc) return rc;
+    rc = dev_alloc(m, (void **)dst, (size_t)cols * rows_p * sizeof(float));
+    if (rc) return rc;
+    FARNN_HIP_TRY(hipMemset(*dst, 0, (size_t)cols * rows_p * sizeof(float)));
+    int n = rows * cols;
+    transpose_pad_kernel<<<(n + 255) / 256, 256>>>(t.p, *dst, rows, cols, rows_p);
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    return FARNN_OK;
+}
+
+static int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(FARNN_ENODEV, "no HIP device visible%s%s");
+    if (device < 0 || device >= n) return fail(FARNN_EINVAL, "device index out of range%s%s");
+    FARNN_HIP_TRY(hipSetDevice(device));
+    return FARNN_OK;
+}
+
+static int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+static int default_crf_transitions(std::vector<float> &tr, int K) {
+    // CRF.__init__ (crf.py:39-46): zeros, [:,START]=-1e4, [STOP,:]=-1e4
+    tr.assign((size_t)K * K, 0.0f);
+    for (int i = 0; i < K; i++) tr[(size_t)i * K + (K - 2)] = -10000.0f;
+    for (int j = 0; j < K; j++) tr[(size_t)(K - 1) * K + j] = -10000.0f;
+    return FARNN_OK;
+}
+
+static int setup_priority(farnn_model *m, const float *P, int on_device) {
+    // P is [K][K] (already expanded, priority.py:6-18); stored [K][Kp]
+    if (!P) return FARNN_OK;
+    return upload_padded(m, &m->P, P, m->K, m->K, m->K, m->Kp, on_device);
+}
+
+static int setup_crf(farnn_model *m, const float *crf_trans, int on_device) {
+    if (!m->use_crf) return FARNN_OK;
+    std::vector<float> dflt;
+    if (!crf_trans) { default_crf_transitions(dflt, m->K); crf_trans = dflt.data(); on_device = 0; }
+    return upload_padded(m, &m->tr, crf_trans, m->K, m->K, m->K, m->Kp, on_device);
+}
+
+// ---- create: onehot i-FST --------------------------------------------------------------------
+extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->C <= 0 || !d->T || !d->W || !d->O || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "onehot_ifst: sizes must be positive and T/W/O/h0/hT non-null%s%s");
+    if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "onehot_ifst: bad nl%s%s");
+    if (d->semiring != FARNN_SEMIRING_SUM && d->semiring != FARNN_SEMIRING_MAX)
+        return fail(FARNN_EINVAL, "onehot_ifst: bad semiring%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_IFST; m->device = device;
+    m->V = d->V; m->S = d->S; m->C = d->C;
+    m->use_crf = d->use_crf ? 1 : 0;
+    m->K = d->C + (m->use_crf ? 2 : 0);
+    m->Kp = round_up(m->K, 4);
+    m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->SP = m->geom.SP;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
+    if (m->geom.NCH > 4) return bail(fail(FARNN_ERANGE, "more than 1024 states%s%s"));
+
+    {   // premix T+W once (the reference re-adds it on every call, model_onehot.py:366)
+        const size_t nT = (size_t)m->V * m->S * m->S;
+        TmpDev T, W;
+        if ((rc = T.init(d->T, nT, od))) return bail(rc);
+        if ((rc = W.init(d->W, (size_t)m->S * m->S, od))) return bail(rc);
+        const size_t nM = (size_t)m->V * m->S * m->SP;
+        if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
+        if ((rc = launch_premix(T.p, W.p, nullptr, m->Mf, m->Mb, m->V, m->S, m->SP))) return bail(rc);
+    }
+    // o = sum_c O[c,:]  (CE1, model_onehot.py:368); OT = O^T padded, with zero rows for START/STOP
+    {
+        TmpDev O;
+        if ((rc = O.init(d->O, (size_t)m->C * m->S, od))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kp * 4))) return bail(rc);
+        FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kp * 4));
+        colsum_kernel<<<(m->S + 255) / 256, 256>>>(O.p, m->o, m->C, m->S);
+        int n = m->C * m->S;
+        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(O.p, m->OT, m->C, m->S, m->Kp);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+    }
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    // the priority matrix of the onehot models is [C][C]; with CRF the two extra tags pass through
+    if (d->P && m->use_crf) {
+        std::vector<float> Pc((size_t)m->C * m->C), Pk((size_t)m->K * m->K, 0.0f);
+        FARNN_HIP_TRY(hipMemcpy(Pc.data(), d->P, Pc.size() * 4,
+                                od ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+        for (int i = 0; i < m->C; i++)
+            for (int j = 0; j < m->C; j++) Pk[(size_t)i * m->K + j] = Pc[(size_t)i * m->C + j];
+        Pk[(size_t)(m->K - 2) * m->K + m->K - 2] = 1.0f;
+        Pk[(size_t)(m->K - 1) * m->K + m->K - 1] = 1.0f;
+        if ((rc = setup_priority(m, Pk.data(), 0))) return bail(rc);
+    } else if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
+// ---- workspace -------------------------------------------------------------------------------
+extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
+    if (!m || B <= 0 || L <= 0) return fail(FARNN_EINVAL, "reserve: bad arguments%s%s");
+    if (B <= m->wsB && L <= m->wsL) return FARNN_OK;
+    FARNN_HIP_TRY(hipSetDevice(m->device));
+    int nB = B > m->wsB ? B : m->wsB, nL = L > m->wsL ? L : m->wsL;
+    if (m->A) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); }
+    m->A = m->Bk = nullptr; m->offs = nullptr; m->wsB = m->wsL = 0;
+    size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
+    FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
+    FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
+    FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
+    FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
+    FARNN_HIP_TRY(hipMemset(m->Bk, 0, stash));
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    m->wsB = nB; m->wsL = nL;
+    return FARNN_OK;
+}
+
+// ---- profiling -------------------------------------------------------------------------------
+struct KernelTimer {
+    farnn_model *m; int which; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
+    KernelTimer(farnn_model *m_, int w, hipStream_t s_) : m(m_), which(w), s(s_) {
+        if (m->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+            (void)hipEventRecord(e0, s);
+    }
+    ~KernelTimer() {
+        if (e0 && e1) {
+            (void)hipEventRecord(e1, s);
+            m->prof.ev[which].push_back(e0);
+            m->prof.ev[which].push_back(e1);
+        }
+    }
+};
+
+static void prof_fold(farnn_model *m) {
+    for (int k = 0; k < KERN_COUNT; k++) {
+        auto &v = m->prof.ev[k];
+        for (size_t i = 0; i + 1 < v.size(); i += 2) {
+            float ms = 0.f;
+            if (hipEventSynchronize(v[i + 1]) == hipSuccess &&
+                hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) {
+                m->prof.ms[k] += ms; m->prof.n[k] += 1;
+            }
+            (void)hipEventDestroy(v[i]); (void)hipEventDestroy(v[i + 1]);
+        }
+        v.clear();
+    }
+}
+
+extern "C" int farnn_set_profiling(farnn_model *m, int32_t enable) {
+    if (!m) return fail(FARNN_EINVAL, "null model%s%s");
+    prof_fold(m);
+    if (enable) for (int k = 0; k < KERN_COUNT; k++) { m->prof.ms[k] = 0; m->prof.n[k] = 0; }
+    m->profiling = enable ? 1 : 0;
+    return FARNN_OK;
+}
+
+extern "C" int farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms, int64_t *launches) {
+    if (!m || which < 0 || which >= KERN_COUNT) return fail(FARNN_EINVAL, "kernel_time: bad arguments%s%s");
+    prof_fold(m);
+    if (total_ms) *total_ms = m->prof.ms[which];
+    if (launches) *launches = m->prof.n[which];
+    return FARNN_OK;
+}
+
+extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
+    if (!m) return "";
+    switch (which) {
+        case KERN_CHAIN: return m->kind == KIND_DECOMP ? "decomp_chain_kernel" : "chain_kernel";
+        case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
+                              : (m->kind == KIND_IND1 ? "ind1_score_kernel" : "score_decode_kernel");
+        case KERN_PREP:  return "lengths_scan_kernel";
+        default: return "";
+    }
+}
+
+// ---- the hot path ----------------------------------------------------------------------------
+template <typename KernelT>
+static int raise_lds_limit(KernelT kern, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(FARNN_ERANGE, "kernel needs more than 160 KiB of LDS%s%s");
+    if (bytes > 48 * 1024)
+        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return FARNN_OK;
+}
+
+static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, int B, int L, int full,
+                        hipStream_t s) {
+    const ChainGeom &g = m->geom;
+    ChainParams p;
+    p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->S * m->SP;
+    p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR;
+    p.NW = g.NW; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
+    p.nl = m->nl; p.full = full;
+    (void)L;
+    const size_t lds = g.lds_bytes(m->wsL);
+    const dim3 grid(2 * B), block(g.NW * 64);
+    const bool mx = m->semiring == FARNN_SEMIRING_MAX;
+    int rc = FARNN_OK;
+#define FARNN_LAUNCH_CHAIN(NCH, MX)                                                           \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(chain_kernel<NCH, MX>, lds))) return rc;                    \
+        chain_kernel<NCH, MX><<<grid, block, lds, s>>>(p);                                    \
+    } while (0)
+    KernelTimer kt(m, KERN_CHAIN, s);
+    switch (g.NCH * 2 + (mx ? 1 : 0)) {
+        case 2: FARNN_LAUNCH_CHAIN(1, false); break;
+        case 3: FARNN_LAUNCH_CHAIN(1, true); break;
+        case 4: FARNN_LAUNCH_CHAIN(2, false); break;
+        case 5: FARNN_LAUNCH_CHAIN(2, true); break;
+        case 6: case 8: FARNN_LAUNCH_CHAIN(4, false); break;
+        case 7: case 9: FARNN_LAUNCH_CHAIN(4, true); break;
+        default: return fail(FARNN_ERANGE, "unsupported state count%s%s");
+    }
+#undef FARNN_LAUNCH_CHAIN
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
+                               int64_t *flat, float *scores, hipStream_t s) {
+    ScoreParams p;
+    p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.tr = m->tr; p.len = len;
+    p.offs = flat ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp;
+    p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
+    // LDS residency of the shared tables, largest benefit first
+    const size_t cap = 150 * 1024;
+    p.ot_in_lds = 0; p.tr_in_lds = 0;
+    if (score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, m->use_crf, 1, 0) <= cap) p.ot_in_lds = 1;
+    if (m->use_crf && score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, 1, p.ot_in_lds, 1) <= cap)
+        p.tr_in_lds = 1;
+    const size_t lds = score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, m->use_crf, p.ot_in_lds, p.tr_in_lds);
+    int rc = raise_lds_limit(score_decode_kernel, lds);
+    if (rc) return rc;
+    KernelTimer kt(m, KERN_SCORE, s);
+    score_decode_kernel<<<dim3(B), dim3(SCORE_WAVES * 64), lds, s>>>(p);
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
+                         int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream) {
+    if (!m || !x || !lengths) return fail(FARNN_EINVAL, "tag: null model / x / lengths%s%s");
+    if (B <= 0 || L <= 0) return fail(FARNN_EINVAL, "tag: B and L must be positive%s%s");
+    if (mode != FARNN_MODE_LOCAL && mode != FARNN_MODE_FULL) return fail(FARNN_EINVAL, "tag: bad mode%s%s");
+    FARNN_HIP_TRY(hipSetDevice(m->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    // the stash is indexed with the workspace's L; keep it equal to the call's L
+    if (B > m->wsB || L != m->wsL) {
+        if (L != m->wsL && m->A) { m->wsB = 0; }
+        int keepB = m->wsB;
+        m->wsL = 0;
+        if ((rc = farnn_reserve(m, B > keepB ? B : keepB, L))) return rc;
+    }
+    const int full = mode == FARNN_MODE_FULL;
+    if (flat_tags) {
+        KernelTimer kt(m, KERN_PREP, s);
+        lengths_scan_kernel<<<1, 1024, 0, s>>>(lengths, m->offs, B);
+        FARNN_HIP_TRY(hipGetLastError());
+    }
+    switch (m->kind) {
+        case KIND_IFST:
+            if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
+            return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+        case KIND_FST4:
+            if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
+            {
+                KernelTimer kt(m, KERN_SCORE, s);
+                return launch_fst4_score(m->A4, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
+                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kp, full,
+                                         m->o_idx, m->threshold, /*Oten*/ nullptr, s);
+            }
+        case KIND_IND1:
+            if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
+            {
+                KernelTimer kt(m, KERN_SCORE, s);
+                return launch_fst4_score(m->Ms, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
+                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kp, full,
+                                         m->o_idx, m->threshold, m->Oten, s);
+            }
+        case KIND_DECOMP: {
+            {
+                KernelTimer kt(m, KERN_CHAIN, s);
+                if ((rc = launch_decomp_chain(m->dw, x, lengths, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+            }
+            return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+        }
+        default:
+            return fail(FARNN_EINVAL, "tag: unknown model kind%s%s");
+    }
+}
+
+// ---- create: onehot FST 4-D -------------------------------------------------------------------
+extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->C <= 0 || !d->T4 || !d->W4 || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "onehot_fst4: sizes must be positive and T4/W4/h0/hT non-null%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_FST4; m->device = device;
+    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4);
+    m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
+    m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->SP = m->geom.SP;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 1024) return bail(fail(FARNN_ERANGE, "more than 1024 label columns%s%s"));
+    if (m->geom.NCH > 4) return bail(fail(FARNN_ERANGE, "more than 1024 states%s%s"));
+    {
+        const size_t nT = (size_t)m->V * m->C * m->S * m->S;
+        TmpDev T4, W4;
+        if ((rc = T4.init(d->T4, nT, od))) return bail(rc);
+        if ((rc = W4.init(d->W4, (size_t)m->C * m->S * m->S, od))) return bail(rc);
+        const size_t nM = (size_t)m->V * m->S * m->SP;
+        if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->A4, nM * m->C * 4))) return bail(rc);
+        if ((rc = launch_premix_fst4(T4.p, W4.p, m->Mf, m->Mb, m->A4, m->V, m->C, m->S, m->SP))) return bail(rc);
+    }
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
+// ---- create: onehot independent=1 -------------------------------------------------------------
+extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->C <= 0 || !d->T || !d->W || !d->Oten || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "onehot_ind1: sizes must be positive and T/W/Oten/h0/hT non-null%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_IND1; m->device = device;
+    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4);
+    m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
+    m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->mask_by_output = d->mask_by_output;
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->SP = m->geom.SP;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 1024) return bail(fail(FARNN_ERANGE, "more than 1024 label columns%s%s"));
+    if (m->geom.NCH > 4) return bail(fail(FARNN_ERANGE, "more than 1024 states%s%s"));
+    {
+        const size_t nT = (size_t)m->V * m->S * m->S;
+        TmpDev T, W, Ot;
+        if ((rc = T.init(d->T, nT, od))) return bail(rc);
+        if ((rc = W.init(d->W, (size_t)m->S * m->S, od))) return bail(rc);
+        if ((rc = Ot.init(d->Oten, (size_t)m->C * m->S * m->S, od))) return bail(rc);
+        const size_t nM = (size_t)m->V * m->S * m->SP;
+        if ((rc = dev_alloc(m, (void **)&m->Ms, nM * 4))) return bail(rc);
+        if ((rc = upload_padded(m, &m->Oten, Ot.p, m->C * m->S, m->S, m->C * m->S, m->SP, 1))) return bail(rc);
+        float *osum = nullptr;
+        if (m->mask_by_output) {
+            if ((rc = dev_alloc(m, (void **)&osum, (size_t)m->S * m->S * 4))) return bail(rc);
+            colsum_kernel<<<(m->S * m->S + 255) / 256, 256>>>(Ot.p, osum, m->C, m->S * m->S);
+            FARNN_HIP_TRY(hipGetLastError());
+            if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
+            if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
+            if ((rc = launch_premix(T.p, W.p, osum, m->Mf, m->Mb, m->V, m->S, m->SP))) return bail(rc);
+            float *dummy = nullptr;
+            if ((rc = dev_alloc(m, (void **)&dummy, nM * 4))) return bail(rc);
+            if ((rc = launch_premix(T.p, W.p, nullptr, m->Ms, dummy, m->V, m->S, m->SP))) return bail(rc);
+        } else {
+            if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
+            if ((rc = launch_premix(T.p, W.p, nullptr, m->Ms, m->Mb, m->V, m->S, m->SP))) return bail(rc);
+            m->Mf = m->Ms;
+        }
+    }
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
+// ---- create: decomposed i-FST ------------------------------------------------------------------
+extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0 || !d->Vgen || !d->S1 || !d->S2 || !d->W ||
+        !d->Cout || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "decomp_ifst: sizes must be positive and factor pointers non-null%s%s");
+    if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "decomp_ifst: farnn must be 0, 1 or 2%s%s");
+    if (d->farnn >= 1 && (!d->Wss1 || !d->Wrs1 || !d->bs1))
+        return fail(FARNN_EINVAL, "decomp_ifst: farnn>=1 needs Wss1/Wrs1/bs1%s%s");
+    if (d->farnn == 2 && (!d->Wss2 || !d->Wrs2 || !d->bs2))
+        return fail(FARNN_EINVAL, "decomp_ifst: farnn==2 needs Wss2/Wrs2/bs2%s%s");
+    if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "decomp_ifst: bad nl%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_DECOMP; m->device = device;
+    m->V = d->V; m->S = d->S; m->R = d->R; m->K = d->K; m->Kp = round_up(d->K, 4);
+    m->C = d->use_crf ? d->K - 2 : d->K;
+    m->SP = round_up(d->S, 4); m->Rp = round_up(d->R, 4);
+    m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->use_crf = d->use_crf ? 1 : 0; m->farnn_gate = d->farnn; m->sig_k = d->sigmoid_exponent;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
+    if (m->S > 1024 || m->R > 4096) return bail(fail(FARNN_ERANGE, "decomp_ifst: S<=1024, R<=4096%s%s"));
+    DecompWeights &w = m->dw;
+    w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
+    w.farnn = d->farnn; w.nl = d->nl; w.semiring = d->semiring; w.sig_k = d->sigmoid_exponent;
+    float *tmp = nullptr;
+    if ((rc = upload_padded(m, &tmp, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc); w.Vgen = tmp;
+    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S1 = tmp;
+    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S2 = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->S1, m->S, m->R, m->SP, od))) return bail(rc); w.S1T = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->S2, m->S, m->R, m->SP, od))) return bail(rc); w.S2T = tmp;
+    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.W = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->W, m->S, m->S, m->SP, od))) return bail(rc); w.WT = tmp;
+    if (d->farnn >= 1) {
+        if ((rc = upload_padded(m, &tmp, d->Wss1, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss1 = tmp;
+        if ((rc = upload_padded(m, &tmp, d->Wrs1, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs1 = tmp;
+        if ((rc = dev_upload(m, &tmp, d->bs1, m->S, m->SP, od))) return bail(rc); w.bs1 = tmp;
+    }
+    if (d->farnn == 2) {
+        if ((rc = upload_padded(m, &tmp, d->Wss2, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss2 = tmp;
+        if ((rc = upload_padded(m, &tmp, d->Wrs2, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs2 = tmp;
+        if ((rc = dev_upload(m, &tmp, d->bs2, m->S, m->SP, od))) return bail(rc); w.bs2 = tmp;
+    }
+    {   // o = sum_k Cout[k,:] (CE1, model_decompose_single.py:232); OT = Cout^T
+        TmpDev Co;
+        if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kp * 4))) return bail(rc);
+        FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kp * 4));
+        colsum_kernel<<<(m->S + 255) / 256, 256>>>(Co.p, m->o, m->K, m->S);
+        int n = m->K * m->S;
+        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(Co.p, m->OT, m->K, m->S, m->Kp);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+        w.o = m->o;
+    }
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    w.h0 = m->h0; w.hT = m->hT;
+    if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
+extern "C" void farnn_destroy(farnn_model *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    (void)hipDeviceSynchronize();
+    prof_fold(m);
+    for (void *p : m->owned) (void)hipFree(p);
+    if (m->A) (void)hipFree(m->A);
+    if (m->Bk) (void)hipFree(m->Bk);
+    if (m->offs) (void)hipFree(m->offs);
+    delete m;
+}
+
+// ---- introspection ---------------------------------------------------------------------------
+extern "C" int farnn_abi_version(void) { return FARNN_ABI_VERSION; }
+
+extern "C" int farnn_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *farnn_last_error(void) { return g_err; }
+
+extern "C" int farnn_num_columns(const farnn_model *m) { return m ? m->K : 0; }
+
+extern "C" double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_tokens) {
+    if (!m) return 0.0;
+    const double S = m->S, C = m->C, R = m->R, K = m->K;
+    double per_tok = 0.0, once = 0.0;
+    switch (m->kind) {
+        case KIND_IFST: per_tok = 2.0 * S * S * 4 + 12; break;
+        case KIND_IND1: per_tok = 3.0 * S * S * 4 + 12; once = C * S * S * 4; break;
+        case KIND_FST4: per_tok = (C + 2.0) * S * S * 4 + 12; break;
+        case KIND_DECOMP:
+            per_tok = R * 4 + 12;
+            once = (2.0 * S * R + S * S + K * S) * 4;
+            break;
+    }
+    return per_tok * (double)valid_tokens + once;
+}

@@ -1,0 +1,94 @@
+// One-time weight re-layout kernels run by the create() entry points.
+//
+// The reference re-materialises `language_tensor + wildcard_mat` (19 MB at ATIS size, 2.5 GB for
+// the 4-D FST) on EVERY forward call (model_onehot.py:82,87,250,366).  Weights are frozen on the
+// tagging path, so the sum is taken once here, rows are padded to a multiple of 16 bytes (every
+// row then starts on a dwordx4 boundary) and a transposed copy is written for the backward chain.
+#pragma once
+#include "common.hip.h"
+
+namespace farnn {
+
+// dst[c][r] = src[r][c]; dst rows padded to rows_p
+__global__ void transpose_pad_kernel(const float *src, float *dst, int rows, int cols, int rows_p) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    int r = i / cols, c = i - r * cols;
+    dst[(long long)c * rows_p + r] = src[i];
+}
+
+// dst[c] = sum_r src[r][c]   (ascending r, fp32)
+__global__ void colsum_kernel(const float *src, float *dst, int rows, int cols) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.0f;
+    for (int r = 0; r < rows; r++) s += src[(long long)r * cols + c];
+    dst[c] = s;
+}
+
+// Mf[v][s][jp] = (T[v][s][j] + W[s][j]) * mask[s][j];  Mb[v][j][sp] = the same value transposed.
+// grid = (ceil(S*SP/256), V)
+__global__ void premix_kernel(const float *T, const float *W, const float *mask, float *Mf, float *Mb,
+                              int S, int SP) {
+    const long long v = blockIdx.y;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * SP) return;
+    int r = idx / SP, cpad = idx - r * SP;
+    const float *Tv = T + v * S * S;
+    float f = 0.0f, bwd = 0.0f;
+    if (cpad < S) {
+        f = Tv[r * S + cpad] + W[r * S + cpad];
+        if (mask) f *= mask[r * S + cpad];
+        bwd = Tv[cpad * S + r] + W[cpad * S + r];
+        if (mask) bwd *= mask[cpad * S + r];
+    }
+    Mf[v * S * SP + idx] = f;
+    if (Mb) Mb[v * S * SP + idx] = bwd;
+}
+
+inline int launch_premix(const float *T, const float *W, const float *mask, float *Mf, float *Mb,
+                         int V, int S, int SP) {
+    dim3 grid((S * SP + 255) / 256, V);
+    premix_kernel<<<grid, 256>>>(T, W, mask, Mf, Mb, S, SP);
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    return FARNN_OK;
+}
+
+// 4-D FST (model_onehot.py:82, :87):
+//   Ts[v] = sum_c T4[v][c] + sum_c W4[c]        -> chain blocks Mf / Mb
+//   A4[v][c] = T4[v][c] + W4[c]                 -> scoring stream, rows padded
+// grid = (ceil(S*SP/256), V)
+__global__ void premix_fst4_kernel(const float *T4, const float *W4, float *Mf, float *Mb, float *A4,
+                                   int C, int S, int SP) {
+    const long long v = blockIdx.y;
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * SP) return;
+    int r = idx / SP, cpad = idx - r * SP;
+    const long long SS = (long long)S * S;
+    float tsum = 0.0f, wsum = 0.0f, tsum_b = 0.0f, wsum_b = 0.0f;
+    for (int c = 0; c < C; c++) {
+        float a = 0.0f;
+        if (cpad < S) {
+            float t = T4[(v * C + c) * SS + r * S + cpad];
+            float w = W4[c * SS + r * S + cpad];
+            tsum += t; wsum += w; a = t + w;
+            tsum_b += T4[(v * C + c) * SS + cpad * S + r];
+            wsum_b += W4[c * SS + cpad * S + r];
+        }
+        A4[((v * C + c) * S) * SP + idx] = a;
+    }
+    Mf[v * S * SP + idx] = tsum + wsum;
+    Mb[v * S * SP + idx] = tsum_b + wsum_b;
+}
+
+inline int launch_premix_fst4(const float *T4, const float *W4, float *Mf, float *Mb, float *A4,
+                              int V, int C, int S, int SP) {
+    dim3 grid((S * SP + 255) / 256, V);
+    premix_fst4_kernel<<<grid, 256>>>(T4, W4, Mf, Mb, A4, C, S, SP);
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    return FARNN_OK;
+}
+
+}  // namespace farnn

@@ -212,15 +212,15 @@ def random_ifst_tensors(V, S, C, rng, edges_per_word=2.0, n_final=4, wildcard_mo
     n_edges = int(edges_per_word * (V - 1))
     w = rng.randint(0, V - 1, size=n_edges)
     s = rng.randint(0, S, size=n_edges)
-    j = rng.randint(1, S, size=n_edges)
+    j = rng.randint(min(1, S - 1), S, size=n_edges)
     # keep at most one successor per (word, from-state): later draws are dropped
     _, first = np.unique(w.astype(np.int64) * S + s, return_index=True)
     T[w[first], s[first], j[first]] = 1.0
     W = np.zeros((S, S), dtype=np.float32)
-    finals = np.unique(np.concatenate([[0, S - 1], rng.randint(1, S, size=n_final)]))
+    finals = np.unique(np.concatenate([[0, S - 1], rng.randint(min(1, S - 1), S, size=n_final)]))
     W[finals, finals] = 1.0
     for _ in range(wildcard_moves):
-        a, b = int(rng.randint(1, S)), int(finals[rng.randint(len(finals))])
+        a, b = int(rng.randint(min(1, S - 1), S)), int(finals[rng.randint(len(finals))])
         if a != b:
             W[a, b] = 1.0
     O = np.zeros((C, S), dtype=np.float32)
