@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the FA-RNN forward tagging path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload ifst|ifst_crf|fst4|decomp]
+
+A "step" is one pass of the hot path (farnn_tag through the C-ABI: recurrence chain +
+score/decode kernels, plus the RCCL gather of tag ids when N > 1) over one batch of synthetic
+input already resident in HBM.  Default workload = BASELINE.json configs[1]: ATIS-BIO-sized
+onehot i-FST (V=950, S=71, C=128), batch 256 x seqlen 64 per GPU, lengths ~ U[5,64] with one
+full-length row.  Weak scaling: every rank tags its own 256-sequence
+shard; `value` = valid (non-pad) tokens tagged by all ranks per second.
+
+Rank 0 prints ONE JSON line (contract in the task statement), carrying
+  roofline     the dominant kernel (chain_kernel) priced against the HBM peak: algorithmic bytes
+               per launch ((2*S*S*4+12) per valid token) / its mean duration measured
+               with HIP events on the launch stream inside the timed region;
+  cpu_baseline the C port of the oracle (oracle/farnn_oracle.c, OpenMP over sequences) timed on
+               this host's cores on the same batch (N=1, rank 0 only) -- also used to re-check
+               the GPU tags after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+WORKLOADS = {
+    # name: (description, V, S, C)
+    'ifst': ('ATIS-BIO-sized onehot i-FST (--method onehot --independent 2)', 950, 71, 128),
+    'ifst_crf': ('ATIS-BIO-sized onehot i-FST + fused Viterbi decode (use_crf=1)', 950, 71, 128),
+    'fst4': ('ATIS-BIO-sized onehot FST, dense T[V,C,S,S] (--independent 0)', 950, 71, 128),
+    'decomp': ('SNIPS-BIO-sized decomposed i-FST (--method decompose --independent 2)', 11000, 104, 73),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--workload', default='ifst', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
+    ap.add_argument('--seqlen', type=int, default=64)
+    ap.add_argument('--rank', type=int, default=50, help='decomp: CP rank')
+    ap.add_argument('--full-length', action='store_true', help='all sequences at full length')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    return ap.parse_args()
+
+
+def build_workload(name, B, L, rank_id, cp_rank, full_length):
+    """Returns (handle, x, lengths, extras).  Weights use one seed on every rank (replicated
+    model); the batch is seeded per rank (each rank owns a different shard)."""
+    from re2nn_seq_amd import _lib, synth
+    _, V, S, C = WORKLOADS[name]
+    wrng = np.random.RandomState(1234)
+    brng = np.random.RandomState(4321 + rank_id)
+    dev = torch.cuda.current_device()
+    extras = {}
+    if name in ('ifst', 'ifst_crf'):
+        T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
+        crf = name == 'ifst_crf'
+        tr = None
+        if crf:
+            K = C + 2
+            tr = (wrng.randn(K, K) * 0.1).astype(np.float32)
+            tr[:, K - 2] = -10000.0
+            tr[K - 1, :] = -10000.0
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=crf, crf_trans=tr, device=dev)
+        extras.update(Tf=T + W, O=O, h0=h0, hT=hT)
+    elif name == 'fst4':
+        T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
+        # the 4-D layout of the same automaton: label c lives on the edges into states with O[c,j]=1
+        T4 = np.einsum('vsj,cj->vcsj', T, O).astype(np.float32)
+        W4 = np.einsum('sj,cj->csj', W, O).astype(np.float32)
+        h = _lib.create_onehot_fst4(T4, W4, h0, hT, device=dev)
+        del T4
+    else:
+        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
+        Vgen = p['V_embed']          # beta = 1: the generalized table is V_embed itself
+        h = _lib.create_decomp_ifst(Vgen, p['S1'], p['S2'], p['wildcard_mat'], p['C_output_mat'],
+                                    p['start_vector'], p['final_vector'], nl='tanh', device=dev)
+    x, lengths = synth.random_batch(V, B, L, brng)
+    if full_length:
+        lengths[:] = L
+        x, _ = synth.random_batch(V, B, L, brng, min_len=L)
+    return h, x, lengths, extras
+
+
+def cpu_baseline(extras, x, lengths, gpu_tags, seconds):
+    """Time the C port of the oracle on this host (all cores) on the same batch; also re-check
+    the GPU tags against it."""
+    from oracle import c_port
+    c_port.load(native=True)
+    cores = os.cpu_count() or 1
+    args = (extras['Tf'], extras['O'], extras['h0'], extras['hT'], x, lengths)
+    tags, _, used = c_port.onehot_ifst_tag(*args, nthreads=cores)           # warm-up + check
+    parity = bool(np.array_equal(tags, gpu_tags))
+    n, t0 = 0, time.perf_counter()
+    while True:
+        c_port.onehot_ifst_tag(*args, nthreads=cores)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 2000:
+            break
+    tok = int(lengths.sum())
+    return {'value': tok * n / el, 'unit': 'tokens/s', 'cores': int(used), 'kind': 'port',
+            'sample': '{} passes of the same {}x{} batch ({} valid tokens) in {:.1f} s, C port of '
+                      'the oracle with T+W hoisted, OpenMP over sequences'.format(
+                          n, x.shape[0], x.shape[1], tok, el)}, parity
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+    from re2nn_seq_amd import _lib
+
+    B, L = a.batch, a.seqlen
+    h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length)
+    xd = torch.from_numpy(x).to(dev)
+    ld = torch.from_numpy(lengths).to(dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    gathered = torch.empty((world * B, L), dtype=torch.int32, device=dev) if world > 1 else None
+    h.reserve(B, L)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None, stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, tags)       # RCCL gather of tag ids over xGMI
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    h.set_profiling(True)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    chain_ms, chain_n = h.kernel_time(_lib.KERN_CHAIN)
+    score_ms, score_n = h.kernel_time(_lib.KERN_SCORE)
+    h.set_profiling(False)
+
+    tok_local = int(lengths.sum())
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        n = torch.tensor([tok_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        tok_total = int(n.item())
+    else:
+        tok_total = tok_local
+
+    if rank == 0:
+        desc, V, S, C = WORKLOADS[a.workload]
+        alg_bytes = h.algorithmic_bytes(tok_local)
+        chain_avg_s = (chain_ms / max(chain_n, 1)) * 1e-3
+        achieved = alg_bytes / chain_avg_s / 1e9 if chain_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(a.workload, {}).get('hbm_bytes_per_launch')
+        out = {
+            'metric': 'tagged tokens/sec @ batch=256, seqlen=64; achieved HBM GB/s vs peak',
+            'value': tok_total * a.steps / elapsed,
+            'unit': 'tokens/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+            'ms_per_step': elapsed / a.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '{}: V={} S={} C={}, batch {} x seqlen {} per GPU, lengths {}'
+                                   .format(desc, V, S, C, B, L,
+                                           'all {}'.format(L) if a.full_length else 'U[5,{}]'.format(L)),
+                       'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
+                       'parallelism': 'batch-sharded x{} (weights replicated{})'.format(
+                           world, ', RCCL all_gather of tag ids' if world > 1 else '')},
+            'roofline': {'bound': 'hbm', 'kernel': h.kernel_name(_lib.KERN_CHAIN),
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'algorithmic_bytes_per_launch': alg_bytes,
+                         'kernel_avg_us': chain_avg_s * 1e6, 'launches_timed': chain_n,
+                         'score_decode_avg_us': score_ms / max(score_n, 1) * 1e3},
+        }
+        if world == 1 and not a.no_cpu_baseline and 'Tf' in extras and a.workload == 'ifst':
+            cb, parity = cpu_baseline(extras, x, lengths, tags.cpu().numpy(), a.cpu_seconds)
+            out['cpu_baseline'] = cb
+            out['parity_vs_cpu_port'] = parity
+            if not parity:
+                print('WARNING: GPU tags differ from the CPU port of the oracle', file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,121 @@
+/*
+ * CPU ORACLE (C port) of the onehot i-FST tagging path -- TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C, per-sequence restatement of FARNN_S_O_I_S.forward_score + local_decode
+ * (reference src_seq/farnn/model_onehot.py:351-428, :162-180) over the VALID positions of every
+ * sequence, with T+W hoisted out of the call ("fair" CPU variant of BASELINE.md section 3).
+ * It exists for two things only: (1) a second, independent checker beside the numpy oracle
+ * (tests/test_oracle_c.py pins it to the same reference fixtures) and (2) the `cpu_baseline`
+ * leg of bench.py (kind "port"), parallelised over sequences with OpenMP.
+ * Nothing under re2nn-seq_amd/ links or loads this file.
+ *
+ * Build: make -C oracle     (gcc -O3 -fopenmp -shared -fPIC)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static float nlf(float v, int nl) {            /* model_onehot.py:379-386 */
+    switch (nl) {
+        case 1: return v > 0.f ? v : 0.f;
+        case 2: return tanhf(v);
+        case 3: return tanhf(v > 0.f ? v : 0.f);
+        default: return v;
+    }
+}
+
+/* Tf = T + W premixed [V,S,S]; O [C,S]; x [B,L]; len [B]; tags [B,L] (-1 at pads);
+ * scores [B,L,C] or NULL (zero at pads). semiring: 0 sum, 1 max. Returns threads used. */
+int oracle_onehot_ifst_tag(const float *Tf, const float *O, const float *h0, const float *hT,
+                           int V, int S, int C, const int64_t *x, const int64_t *len, int B, int L,
+                           int nl, int semiring, float threshold, int o_idx, int32_t *tags,
+                           float *scores, int nthreads) {
+    (void)V;
+    float *o = (float *)calloc((size_t)S, sizeof(float));
+    for (int c = 0; c < C; c++)                        /* :368 (CE1) */
+        for (int s = 0; s < S; s++) o[s] += O[(size_t)c * S + s];
+    int used = 1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+    used = nthreads > 0 ? nthreads : omp_get_max_threads();
+#pragma omp parallel
+#endif
+    {
+        float *a = (float *)malloc(sizeof(float) * (size_t)(L + 1) * S);   /* a[k]: after k tokens  */
+        float *bt = (float *)malloc(sizeof(float) * (size_t)(L + 1) * S);  /* bt[k]: before token k */
+        float *tmp = (float *)malloc(sizeof(float) * (size_t)S);
+        float *sc = (float *)malloc(sizeof(float) * (size_t)C);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < B; b++) {
+            const int n = (int)len[b];
+            const int64_t *xb = x + (size_t)b * L;
+            memcpy(a, h0, sizeof(float) * S);
+            for (int t = 0; t < n; t++) {               /* :374-387 */
+                const float *M = Tf + (size_t)xb[t] * S * S;
+                const float *ai = a + (size_t)t * S;
+                float *ao = a + (size_t)(t + 1) * S;
+                for (int j = 0; j < S; j++) ao[j] = semiring ? -INFINITY : 0.f;
+                for (int s = 0; s < S; s++) {
+                    const float hs = ai[s];
+                    const float *row = M + (size_t)s * S;
+                    if (semiring) { for (int j = 0; j < S; j++) { float p = hs * row[j]; if (p > ao[j]) ao[j] = p; } }
+                    else          { for (int j = 0; j < S; j++) ao[j] += hs * row[j]; }
+                }
+                for (int j = 0; j < S; j++) ao[j] = nlf(ao[j] * o[j], nl);
+            }
+            memcpy(bt + (size_t)n * S, hT, sizeof(float) * S);
+            for (int t = n - 1; t >= 0; t--) {          /* :390-403 */
+                const float *M = Tf + (size_t)xb[t] * S * S;
+                const float *bi = bt + (size_t)(t + 1) * S;
+                float *bo = bt + (size_t)t * S;
+                for (int j = 0; j < S; j++) tmp[j] = bi[j] * o[j];
+                for (int s = 0; s < S; s++) {
+                    const float *row = M + (size_t)s * S;
+                    float acc = semiring ? -INFINITY : 0.f;
+                    if (semiring) { for (int j = 0; j < S; j++) { float p = tmp[j] * row[j]; if (p > acc) acc = p; } }
+                    else          { for (int j = 0; j < S; j++) acc += row[j] * tmp[j]; }
+                    bo[s] = nlf(acc, nl);
+                }
+            }
+            for (int t = 0; t < L; t++) {
+                int32_t *tg = tags ? tags + (size_t)b * L + t : NULL;
+                float *so = scores ? scores + ((size_t)b * L + t) * C : NULL;
+                if (t >= n) {
+                    if (tg) *tg = -1;
+                    if (so) memset(so, 0, sizeof(float) * C);
+                    continue;
+                }
+                const float *at = a + (size_t)(t + 1) * S, *bb = bt + (size_t)(t + 1) * S;
+                for (int s = 0; s < S; s++) tmp[s] = at[s] * bb[s];           /* :347 */
+                int best = 0; float bv = -INFINITY;
+                for (int c = 0; c < C; c++) {
+                    const float *orow = O + (size_t)c * S;
+                    float acc = 0.f;
+                    for (int s = 0; s < S; s++) acc += orow[s] * tmp[s];       /* :348 */
+                    sc[c] = acc;
+                    float v = (c == C - 1 && acc > threshold) ? threshold : acc;   /* :167 */
+                    if (v > bv) { bv = v; best = c; }                          /* first max (:168) */
+                }
+                if (so) memcpy(so, sc, sizeof(float) * C);
+                if (tg) *tg = (best == C - 1) ? o_idx : best;                  /* :169 */
+            }
+        }
+        free(a); free(bt); free(tmp); free(sc);
+    }
+    free(o);
+    return used;
+}
+
+int oracle_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -90,6 +90,10 @@ def load():
         raise FarnnError(
             'HIP library not built: {} is missing. Run `python -c "import __graft_entry__ as g; '
             'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.'.format(LIB_PATH))
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as /opt/rocm's).  The tensors this
+    # library receives live in THAT runtime's address space, so it must be the one already loaded
+    # when libfarnn_hip.so resolves its HIP symbols: import torch first.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)

@@ -11,18 +11,28 @@
 // keeping a transposed copy of every block in HBM (288 GB makes the 2x footprint a non-issue and
 // it keeps every load of either direction a fully coalesced 16-byte-per-lane row read).
 //
-// Mapping (one workgroup per (sequence, direction), NW wavefronts):
-//   * the S rows of a block are split into NW*G contiguous row groups of RPG rows; a wavefront
-//     owns G groups; lane (g, c) streams the 16-byte column chunk c of the rows of group g;
-//   * the block is never staged through LDS: every byte is used once by one lane, so it goes
-//     straight to VGPRs through a 3-deep register ring of 4-row chunks.  The addresses depend only
-//     on the token ids (known up front), never on the state, so the ring runs ahead across step
-//     boundaries and the serial dependence is only the tiny state vector;
-//   * per step each lane holds partial column sums; they meet in LDS (double-buffered by step
-//     parity), ONE workgroup barrier, then every wavefront reduces only the rows it will need as
-//     `in[row]` next step -- no second barrier;
-//   * every state a[k], b[k] is written once to the stash in HBM (S floats per token per direction,
-//     <1.5% of the block bytes) for the scoring kernel.
+// One workgroup per (sequence, direction), specialised wavefronts:
+//   * NW COMPUTE wavefronts.  The S rows of a block are split into NW*G contiguous row groups of
+//     RPG rows; a compute wavefront owns G groups and lane (g, c) owns the 16-byte column chunk c
+//     of the rows of group g.  Per step it reads its share of the block from the LDS ring
+//     (ds_read_b128, each lane exactly the 16 bytes a DMA lane deposited), FMAs it against the
+//     state, drops partial column sums in LDS, meets the others at ONE barrier and reduces only
+//     the rows it consumes next step.  Compute wavefronts issue no vector-memory instruction at
+//     all: the step chain is a short sequence of LDS round trips.
+//   * NLD LOADER wavefronts stream the blocks HBM -> LDS with LDS-DMA (global_load_lds_dwordx4,
+//     1 KiB per wave-instruction, no VGPR destination) into a ring of KS whole steps.  Block
+//     addresses depend only on the token ids (known up front), never on the state, so the loaders
+//     run KS-1 steps ahead of the recurrence; they retire DMA with a counted `s_waitcnt vmcnt(N)`
+//     (never 0 in the loop) and publish a landed step through the step barrier.
+//   * 1 WRITER wavefront copies every finished state from LDS to the HBM stash one step behind
+//     (S floats per token per direction, <1.5% of the block bytes).  vmcnt is a per-wave in-order
+//     counter shared by loads and stores, so stores live in their own wavefront.
+// All barriers are raw `s_barrier` + lgkmcnt(0): a __syncthreads() would also drain vmcnt and
+// stall the loaders / writer on a full memory round trip every step.
+//
+// Measured history (profiles/): a compiler-scheduled register ring drained with vmcnt(0) every few
+// chunks; with every wavefront doing load+FMA+reduce itself a step took 1.37 us however deep the
+// prefetch, because each wavefront's dependent LDS/SALU/VMEM-issue latencies added up serially.
 //
 // Roofline: HBM/MALL-bandwidth bound; algorithmic bytes per token = 2 * S*S*4.
 #pragma once
@@ -31,42 +41,93 @@
 namespace farnn {
 
 struct ChainParams {
-    const float *Mf;        // [V][S][SP] blocks, row-major, rows padded to SP floats
-    const float *Mb;        // [V][S][SP] the transposed blocks
-    long long blk;          // floats per block (S*SP)
+    const float *Mf;        // [V][SR][SP] blocks, row-major, rows padded to SP floats, SR >= S rows
+    const float *Mb;        // [V][SR][SP] the transposed blocks
+    long long blk;          // floats per block (SR*SP)
     const float *o;         // [SP] output-sum vector or nullptr (no scaling)
     const float *h0, *hT;   // [S]
     const int64_t *x;       // [B][L]
     const int64_t *len;     // [B]
     float *A, *Bk;          // stash [B][L+1][SP]: forward / backward states by step count
     int B, L, S, SP, CPR;   // CPR = SP/4 column chunks per row
-    int NW, G, LPR, RPG, RPGp, NQ;
+    int NW, NLD, G, LPR, RPG, RPGp, NQ, KS;
+    int NQP, PPS;           // chunks per phase per compute wave; phases per step (ring/barrier unit)
     int nl, full;
+    int dbg;                // diagnostic ablation mask (FARNN_DBG); 0 in production
 };
 
-// register-ring depth in 4-row chunks, and the workgroup-size cap that keeps the ring in VGPRs
-constexpr int chain_pf(int nch) { return nch <= 2 ? 3 : 2; }
-constexpr int chain_max_threads(int nch) { return nch == 1 ? 1024 : 512; }
+constexpr int CHAIN_MAX_THREADS = 512;     // NW compute + NLD loader + 1 writer wavefronts <= 8
+constexpr int CHAIN_MAX_NP = 20;           // partial vectors per step (NW * G)
+constexpr int CHAIN_MAX_G = 4;
+
+// One LDS-DMA piece: 64 lanes x 16 bytes from (base + voff) land at LDS byte address `lds`
+// (wave-uniform) + lane*16.  M0 carries the LDS base and is compiler-reserved, so it is saved and
+// restored inside the statement (cdna_hip_programming.md 5.7).  The leading s_nop covers the
+// SGPR-write -> VMEM-read wait states of operands fresh from v_readfirstlane / SALU.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const char *base, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds)
+                 : "memory");
+}
+
+// Workgroup barrier that orders LDS traffic only (lgkmcnt), never the vector-memory counter.
+__device__ __forceinline__ void wg_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define FARNN_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
+        FARNN_VMC(0) FARNN_VMC(1) FARNN_VMC(2) FARNN_VMC(3) FARNN_VMC(4) FARNN_VMC(5) FARNN_VMC(6) FARNN_VMC(7)
+        FARNN_VMC(8) FARNN_VMC(9) FARNN_VMC(10) FARNN_VMC(11) FARNN_VMC(12) FARNN_VMC(13) FARNN_VMC(14)
+        FARNN_VMC(15) FARNN_VMC(16) FARNN_VMC(17) FARNN_VMC(18) FARNN_VMC(19) FARNN_VMC(20) FARNN_VMC(21)
+        FARNN_VMC(22) FARNN_VMC(23) FARNN_VMC(24) FARNN_VMC(25) FARNN_VMC(26) FARNN_VMC(27) FARNN_VMC(28)
+        FARNN_VMC(29) FARNN_VMC(30) FARNN_VMC(31) FARNN_VMC(32) FARNN_VMC(33) FARNN_VMC(34) FARNN_VMC(35)
+        FARNN_VMC(36) FARNN_VMC(37) FARNN_VMC(38) FARNN_VMC(39) FARNN_VMC(40) FARNN_VMC(41) FARNN_VMC(42)
+        FARNN_VMC(43) FARNN_VMC(44) FARNN_VMC(45) FARNN_VMC(46) FARNN_VMC(47) FARNN_VMC(48) FARNN_VMC(49)
+        FARNN_VMC(50) FARNN_VMC(51) FARNN_VMC(52) FARNN_VMC(53) FARNN_VMC(54) FARNN_VMC(55) FARNN_VMC(56)
+        FARNN_VMC(57) FARNN_VMC(58) FARNN_VMC(59) FARNN_VMC(60) FARNN_VMC(61) FARNN_VMC(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef FARNN_VMC
+}
 
 template <int NCH, bool MAXSR>
-__global__ void __launch_bounds__(chain_max_threads(NCH))
+__global__ void __launch_bounds__(CHAIN_MAX_THREADS)
 chain_kernel(const ChainParams p) {
-    constexpr int CHAIN_PF = chain_pf(NCH);
+    constexpr int PER = 4 * NCH;                 // DMA pieces (1 KiB each) per 4-row chunk
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int nthreads = blockDim.x;
     const int item = blockIdx.x;
     const int b = item >> 1, dir = item & 1;
     const int len = (int)p.len[b];
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ;
-    const int NP = p.NW * p.G;
+    const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ, KS = p.KS;
+    const int NW = p.NW, NLD = p.NLD, NP = NW * p.G;
 
     // ---- LDS carve (all offsets multiples of 16 bytes) --------------------------------------
     const int Lr = (p.L + 3) & ~3;
     int *tok = reinterpret_cast<int *>(smem);           // [Lr]   tokens in consumption order
     float *hp = smem + Lr;                              // [NP*RPGp] state in padded row space
     float *part = hp + NP * RPGp;                       // [2][NP][SP] partial column sums
+    float *ol = part + 2 * NP * SP;                     // [SP] output-sum vector (1.0 when unused)
+    float *hfull = ol + SP;                             // [2][SP] finished states awaiting the writer
+    char *ring = reinterpret_cast<char *>(hfull + 2 * SP);   // [KS][NW*NQ][PER] x 1 KiB
+    const int NQP = p.NQP, PPS = p.PPS;
+    const unsigned phase_bytes = (unsigned)(NW * NQP * PER) * 1024u;
+    const int NF = nsteps * PPS;                        // phases of this item
+    // a generic pointer into LDS is {shared aperture : 32-bit LDS byte address}: truncate it
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)ring);
 
     for (int k = tid; k < nsteps; k += nthreads) {
         int idx = (dir == 0) ? k : (k < len ? len - 1 - k : k);
@@ -84,159 +145,253 @@ chain_kernel(const ChainParams p) {
         }
         hp[idx] = v;
     }
-    for (int j = tid; j < SP; j += nthreads) stash[j] = (j < S) ? hinit[j] : 0.0f;
+    for (int j = tid; j < SP; j += nthreads) {
+        stash[j] = (j < S) ? hinit[j] : 0.0f;
+        ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
+    }
     __syncthreads();
     if (nsteps == 0) return;
 
-    // ---- lane -> (row group, column chunk) ---------------------------------------------------
+    // ---- lane -> (row group, column chunk); the loaders reproduce the compute lanes' mapping ---
     int g = lane / p.LPR;
     const int c = lane - g * p.LPR;
     const bool active = g < p.G;
-    if (!active) g = 0;
+    if (!active) g = 0;                  // idle lanes shadow group 0 (same lines, results unused)
+    const unsigned rowb = (unsigned)SP * 4u;
+    // Blocks are allocated with SR >= (NG-1)*RPG + RPGp zero-filled rows, so every row index the
+    // 4-row chunks can form is in bounds: no clamping or predication in the load stream.
+    unsigned lane_off[NCH];              // byte offset of (group g of wavefront 0, chunk c + 64m)
+#pragma unroll
+    for (int m = 0; m < NCH; m++) {
+        int cc = c + 64 * m;
+        cc = cc < p.CPR ? cc : p.CPR - 1;
+        lane_off[m] = ((unsigned)(g * RPG) * (unsigned)SP + (unsigned)cc * 4u) * 4u;
+    }
+    const unsigned wave_stride = (unsigned)(p.G * RPG) * rowb;     // rows owned by one compute wave
+
+    // =========================================================================================
+    // writer wavefront
+    // =========================================================================================
+    if (w == NW + NLD) {
+        wg_barrier_lds();                                            // B_{-1}
+        for (int f = (p.dbg & 4) ? NF : 0; f <= NF; f++) {
+            wg_barrier_lds();                                        // B_f (f == NF: the final one)
+            if (f > 0 && f % PPS == 0) {                             // step f/PPS-1 finished one barrier ago
+                const int t = f / PPS - 1;
+                const float *src = hfull + (t & 1) * SP;
+                float *srow = stash + (long long)(t + 1) * SP;
+                for (int j = lane; j < S; j += WAVE) srow[j] = src[j];
+            }
+        }
+        return;
+    }
+
+    // =========================================================================================
+    // loader wavefronts
+    // =========================================================================================
+    if (w >= NW) {
+        const int l = w - NW;
+        const char *Mbase = reinterpret_cast<const char *>((dir == 0) ? p.Mf : p.Mb);
+        const long long blk_bytes = p.blk * 4;
+        const int nchunks = NW * NQP;                                // chunks of one phase
+        int mine = 0;                                                // DMA pieces per phase, this loader
+        for (int ch = l; ch < nchunks; ch += NLD) mine += PER;
+
+        auto issue_phase = [&](int f) {
+            int t = f / PPS;
+            const int ph = f - t * PPS;
+            t = t < nsteps ? t : nsteps - 1;                         // past the end: dummy refills
+            const char *blkp = Mbase + (long long)__builtin_amdgcn_readfirstlane(tok[t]) * blk_bytes;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)blkp);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)blkp >> 32));
+            const char *base = reinterpret_cast<const char *>(((size_t)hi << 32) | lo);
+            const unsigned dst0 = ring_lds + (unsigned)(f % KS) * phase_bytes;
+            for (int ch = l; ch < nchunks; ch += NLD) {
+                const int w2 = ch / NQP, qq = ch - w2 * NQP;
+                int q = ph * NQP + qq;
+                q = q < NQ ? q : NQ - 1;                             // ragged last phase: harmless re-read
+                const unsigned goff = (unsigned)w2 * wave_stride + (unsigned)(q * 4) * rowb;
+                const unsigned dst = dst0 + (unsigned)ch * (PER * 1024u);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int m = 0; m < NCH; m++)
+                        lds_dma16(lane_off[m] + goff + u * rowb, base, dst + (u * NCH + m) * 1024u);
+            }
+        };
+
+        if (!(p.dbg & 1)) {
+            for (int f = 0; f < KS; f++) issue_phase(f);
+            wait_vmcnt((KS - 1) * mine);                             // phase 0 has landed
+        }
+        wg_barrier_lds();                                            // B_{-1}
+        if (!(p.dbg & 4)) {
+            for (int f = 0; f < NF; f++) {
+                if (!(p.dbg & 1)) wait_vmcnt((KS - 2) * mine);       // phase f+1 has landed
+                wg_barrier_lds();                                    // B_f: slot f%KS is free again
+                if (!(p.dbg & 1)) issue_phase(f + KS);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // dummies land before LDS is freed
+        wg_barrier_lds();                                            // final barrier
+        return;
+    }
+
+    // =========================================================================================
+    // compute wavefronts
+    // =========================================================================================
     const int gid = w * p.G + g;
     const int row0 = gid * RPG;
-    const float *Mbase = (dir == 0) ? p.Mf : p.Mb;
-
-    float4 ring[CHAIN_PF][4][NCH];
-    float4 acc[NCH];
     const float ninf = -INFINITY;
-#pragma unroll
-    for (int m = 0; m < NCH; m++) acc[m] = MAXSR ? make_float4(ninf, ninf, ninf, ninf)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 acc[NCH];
+    const char *myring = ring + (unsigned)(w * NQP) * (PER * 1024u) + lane * 16;
+    const float *myhp = hp + gid * RPGp;
+    const int rows_w = p.G * RPG;
+    // the output-sum entry of the row this lane finishes (rows_w <= 64 in the common geometries)
+    const float my_o = (lane < rows_w && w * rows_w + lane < S) ? ol[w * rows_w + lane] : 1.0f;
 
-    // Row/column indices are clamped instead of predicated: a clamped load re-reads a line the
-    // neighbouring lanes fetch anyway, and its product is multiplied by a zero state entry
-    // (padded hp rows stay 0) or lands in a column nobody reads.
-    auto issue = [&](int t, int q, float4 (&dst)[4][NCH]) {
-        int tt = t < nsteps ? t : nsteps - 1;
-        const float *blkp = Mbase + (long long)__builtin_amdgcn_readfirstlane(tok[tt]) * p.blk;
-        if (active) {
+    wg_barrier_lds();                                                // B_{-1}: phase 0 is in LDS
+    int pb = 0, f = 0;
+    for (int t = 0; t < nsteps && !(p.dbg & 4); t++) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int row = row0 + q * 4 + u;
-                row = row < S ? row : S - 1;
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    int cc = c + 64 * m;
-                    cc = cc < p.CPR ? cc : p.CPR - 1;
-                    dst[u][m] = ld4(blkp + (long long)row * SP + cc * 4);
-                }
-            }
-        }
-    };
-
-    auto consume = [&](int q, const float4 (&src)[4][NCH]) {
-        const float4 hv4 = ld4(hp + gid * RPGp + q * 4);
-        const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (MAXSR) {
-                int i = q * 4 + u;
-                bool ok = i < RPG && (row0 + i) < S;
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    acc[m].x = fmaxf(acc[m].x, ok ? hv[u] * src[u][m].x : ninf);
-                    acc[m].y = fmaxf(acc[m].y, ok ? hv[u] * src[u][m].y : ninf);
-                    acc[m].z = fmaxf(acc[m].z, ok ? hv[u] * src[u][m].z : ninf);
-                    acc[m].w = fmaxf(acc[m].w, ok ? hv[u] * src[u][m].w : ninf);
-                }
-            } else {
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    acc[m].x = fmaf(hv[u], src[u][m].x, acc[m].x);
-                    acc[m].y = fmaf(hv[u], src[u][m].y, acc[m].y);
-                    acc[m].z = fmaf(hv[u], src[u][m].z, acc[m].z);
-                    acc[m].w = fmaf(hv[u], src[u][m].w, acc[m].w);
-                }
-            }
-        }
-    };
-
-    int pb = 0;
-    auto step_end = [&](int t) {
+        for (int m = 0; m < NCH; m++) acc[m] = MAXSR ? make_float4(ninf, ninf, ninf, ninf)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         float *pp = part + (long long)pb * NP * SP;
-        if (active) {
+        for (int ph = 0; ph < PPS; ph++, f++) {
+            const char *src = myring + (unsigned)(f % KS) * phase_bytes;
+            if (!(p.dbg & 2)) {
+                for (int qq = 0; qq < NQP; qq++) {
+                    const int q = ph * NQP + qq;
+                    if (q >= NQ) break;
+                    const float4 hv4 = ld4(myhp + q * 4);
+                    float4 v[4][NCH];
 #pragma unroll
-            for (int m = 0; m < NCH; m++) {
-                int cc = c + 64 * m;
-                if (cc < p.CPR) st4(pp + gid * SP + cc * 4, acc[m]);
-            }
-        }
-        __syncthreads();
-        // each wavefront finishes exactly the rows it consumes next step
-        const int rows_w = p.G * RPG;
-        float *srow = stash + (long long)(t + 1) * SP;
-        for (int li = lane; li < rows_w; li += WAVE) {
-            int row = w * rows_w + li;
-            if (row < S) {
-                float s = pp[row];
-                for (int q2 = 1; q2 < NP; q2++) {
-                    float v = pp[q2 * SP + row];
-                    s = MAXSR ? fmaxf(s, v) : s + v;
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int m = 0; m < NCH; m++)
+                            v[u][m] = *reinterpret_cast<const float4 *>(src + (qq * PER + u * NCH + m) * 1024);
+                    const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        bool ok = true;
+                        if (MAXSR) {
+                            const int i = q * 4 + u;
+                            ok = i < RPG && (row0 + i) < S;
+                        }
+#pragma unroll
+                        for (int m = 0; m < NCH; m++) {
+                            if (MAXSR) {
+                                acc[m].x = fmaxf(acc[m].x, ok ? hv[u] * v[u][m].x : ninf);
+                                acc[m].y = fmaxf(acc[m].y, ok ? hv[u] * v[u][m].y : ninf);
+                                acc[m].z = fmaxf(acc[m].z, ok ? hv[u] * v[u][m].z : ninf);
+                                acc[m].w = fmaxf(acc[m].w, ok ? hv[u] * v[u][m].w : ninf);
+                            } else {
+                                acc[m].x = fmaf(hv[u], v[u][m].x, acc[m].x);
+                                acc[m].y = fmaf(hv[u], v[u][m].y, acc[m].y);
+                                acc[m].z = fmaf(hv[u], v[u][m].z, acc[m].z);
+                                acc[m].w = fmaf(hv[u], v[u][m].w, acc[m].w);
+                            }
+                        }
+                    }
                 }
-                float ov = p.o ? p.o[row] : 1.0f;
+            }
+            if (ph == PPS - 1 && active) {          // step end: partial sums meet in LDS
+#pragma unroll
+                for (int m = 0; m < NCH; m++) {
+                    const int cc = c + 64 * m;
+                    if (cc < p.CPR) st4(pp + gid * SP + cc * 4, acc[m]);
+                }
+            }
+            wg_barrier_lds();                                        // B_f
+        }
+        pb ^= 1;
+        if (p.dbg & 8) continue;
+        // each compute wavefront finishes exactly the rows it consumes next step
+        float *srow = hfull + (t & 1) * SP;                          // picked up by the writer
+        for (int li = lane; li < rows_w; li += WAVE) {
+            const int row = w * rows_w + li;
+            if (row < S) {
+                float pv[CHAIN_MAX_NP];
+#pragma unroll
+                for (int q2 = 0; q2 < CHAIN_MAX_NP; q2++) pv[q2] = (q2 < NP) ? pp[q2 * SP + row] : 0.0f;
+                float s = pv[0];
+#pragma unroll
+                for (int q2 = 1; q2 < CHAIN_MAX_NP; q2++)
+                    if (q2 < NP) s = MAXSR ? fmaxf(s, pv[q2]) : s + pv[q2];
+                const float ov = (li == lane) ? my_o : ol[row];
                 float hn, hnext;
                 if (dir == 0) { hn = apply_nl(s * ov, p.nl); hnext = hn; }      // (:377-386)
                 else          { hn = apply_nl(s, p.nl);      hnext = hn * ov; } // (:393-402)
                 srow[row] = hn;
-                int gi = li / RPG, ii = li - gi * RPG;
+                const int gi = li / RPG, ii = li - gi * RPG;
                 hp[(w * p.G + gi) * RPGp + ii] = hnext;
             }
         }
-        pb ^= 1;
-#pragma unroll
-        for (int m = 0; m < NCH; m++) acc[m] = MAXSR ? make_float4(ninf, ninf, ninf, ninf)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-    };
-
-    // ---- software pipeline over the flat (step, chunk) stream --------------------------------
-    int it = 0, iq = 0;
-#pragma unroll
-    for (int s = 0; s < CHAIN_PF; s++) {
-        issue(it, iq, ring[s]);
-        if (++iq == NQ) { iq = 0; it++; }
     }
-    int ct = 0, cq = 0;
-    const int total = nsteps * NQ;
-    for (int n = 0; n < total; n += CHAIN_PF) {
-#pragma unroll
-        for (int s = 0; s < CHAIN_PF; s++) {
-            if (n + s < total) {
-                consume(cq, ring[s]);
-                issue(it, iq, ring[s]);
-                if (++iq == NQ) { iq = 0; it++; }
-                if (++cq == NQ) { step_end(ct); cq = 0; ct++; }
-            }
-        }
-    }
+    wg_barrier_lds();                                                // final: last state -> writer
 }
 
 // Host-side geometry choice for a given S.
 struct ChainGeom {
-    int NCH, NW, G, LPR, RPG, RPGp, NQ, CPR, SP;
-    size_t lds_bytes(int L) const {
+    int NCH, NW, NLD, G, LPR, RPG, RPGp, NQ, CPR, SP, SR;
+    size_t shared_bytes(int L) const {      // everything but the DMA ring
         int Lr = (L + 3) & ~3;
-        return sizeof(float) * ((size_t)Lr + (size_t)NW * G * RPGp + 2ull * NW * G * SP);
+        return sizeof(float) * ((size_t)Lr + (size_t)NW * G * RPGp + 2ull * NW * G * SP + 3ull * SP);
+    }
+    size_t phase_bytes(int nqp) const { return (size_t)NW * nqp * NCH * 4096; }
+    size_t lds_bytes(int L, int ks, int nqp) const { return shared_bytes(L) + (size_t)ks * phase_bytes(nqp); }
+    // Ring shape: phases of `nqp` chunks per compute wavefront, `ks` phases deep.  Prefer a whole
+    // step per phase (one barrier per step) and two workgroups per CU; shrink the phase, then the
+    // depth, then give up co-residency, until it fits the CU's 160 KiB.
+    bool pick_ring(int L, int want_ks, int &ks, int &nqp) const {
+        const size_t cap2 = 80 * 1024, cap1 = 158 * 1024;
+        want_ks = want_ks < 2 ? 2 : (want_ks > 8 ? 8 : want_ks);
+        for (int pass = 0; pass < 2; pass++) {
+            const size_t cap = pass == 0 ? cap2 : cap1;
+            for (nqp = NQ; nqp >= 1; nqp = (nqp + 1) / 2 == nqp ? nqp - 1 : (nqp + 1) / 2) {
+                for (ks = want_ks; ks >= 2; ks--)
+                    if (lds_bytes(L, ks, nqp) <= cap) return true;
+                if (nqp == 1) break;
+            }
+        }
+        return false;
     }
 };
 
-inline ChainGeom chain_geometry(int S, int rows_per_group_target) {
+inline ChainGeom chain_geometry_nw(int S, int nw, int nld) {
     ChainGeom gm;
     gm.SP = round_up(S, 4);
     gm.CPR = gm.SP / 4;
-    if (gm.CPR <= 64) { gm.NCH = 1; gm.LPR = gm.CPR; gm.G = 64 / gm.CPR; }
-    else              { gm.NCH = (gm.CPR + 63) / 64; gm.LPR = 64; gm.G = 1; }
-    int groups = (S + rows_per_group_target - 1) / rows_per_group_target;
-    int nw = (groups + gm.G - 1) / gm.G;
-    const int nw_max = chain_max_threads(gm.NCH) / 64;
-    if (nw < 1) nw = 1;
-    if (nw > nw_max) nw = nw_max;
+    if (gm.CPR <= 64) {
+        gm.NCH = 1; gm.LPR = gm.CPR; gm.G = 64 / gm.CPR;
+        if (gm.G > CHAIN_MAX_G) gm.G = CHAIN_MAX_G;
+    } else { gm.NCH = (gm.CPR + 63) / 64; gm.LPR = 64; gm.G = 1; }
+    gm.NLD = nld;
     gm.NW = nw;
     int ng = gm.NW * gm.G;
     gm.RPG = (S + ng - 1) / ng;
     gm.RPGp = round_up(gm.RPG, 4);
     gm.NQ = gm.RPGp / 4;
+    gm.SR = (ng - 1) * gm.RPG + gm.RPGp;      // allocated (zero-padded) rows per block
+    if (gm.SR < S) gm.SR = S;
     return gm;
+}
+
+inline ChainGeom chain_geometry(int S, int rows_per_group_target, int nld, int L_hint = 128) {
+    nld = nld < 1 ? 1 : (nld > 3 ? 3 : nld);
+    const int nw_max = CHAIN_MAX_THREADS / 64 - 1 - nld;
+    ChainGeom g0 = chain_geometry_nw(S, 1, nld);
+    int groups = (S + rows_per_group_target - 1) / rows_per_group_target;
+    int nw = (groups + g0.G - 1) / g0.G;
+    if (nw < 1) nw = 1;
+    if (nw > nw_max) nw = nw_max;
+    // fewer compute wavefronts when even the smallest ring would not fit the LDS
+    for (; nw >= 1; nw--) {
+        ChainGeom gm = chain_geometry_nw(S, nw, nld);
+        int ks, nqp;
+        if (gm.pick_ring(L_hint, 2, ks, nqp) || nw == 1) return gm;
+    }
+    return chain_geometry_nw(S, 1, nld);
 }
 
 }  // namespace farnn

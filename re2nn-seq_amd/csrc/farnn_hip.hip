@@ -28,7 +28,7 @@ struct Prof {
 
 struct farnn_model {
     int kind = 0, device = 0;
-    int V = 0, S = 0, SP = 0, C = 0, K = 0, Kp = 0, R = 0, Rp = 0;
+    int V = 0, S = 0, SP = 0, C = 0, K = 0, Kp = 0, Kc = 0, R = 0, Rp = 0;
     int nl = 0, semiring = 0, o_idx = 0, use_crf = 0, farnn_gate = 0, mask_by_output = 0;
     float threshold = 0.5f, sig_k = 1.0f;
     // device-resident, library-owned weights
@@ -44,6 +44,7 @@ struct farnn_model {
     int64_t *offs = nullptr;
     int wsB = 0, wsL = 0;
     ChainGeom geom;
+    int chain_ks = 3;
     int profiling = 0;
     Prof prof;
     std::vector<void *> owned;              // everything to hipFree at destroy
@@ -133,16 +134,17 @@ static int default_crf_transitions(std::vector<float> &tr, int K) {
 }
 
 static int setup_priority(farnn_model *m, const float *P, int on_device) {
-    // P is [K][K] (already expanded, priority.py:6-18); stored [K][Kp]
+    // P is [K][K] (already expanded, priority.py:6-18); stored [K][Kc]
     if (!P) return FARNN_OK;
-    return upload_padded(m, &m->P, P, m->K, m->K, m->K, m->Kp, on_device);
+    return upload_padded(m, &m->P, P, m->K, m->K, m->K, m->Kc, on_device);
 }
 
 static int setup_crf(farnn_model *m, const float *crf_trans, int on_device) {
     if (!m->use_crf) return FARNN_OK;
     std::vector<float> dflt;
     if (!crf_trans) { default_crf_transitions(dflt, m->K); crf_trans = dflt.data(); on_device = 0; }
-    return upload_padded(m, &m->tr, crf_trans, m->K, m->K, m->K, m->Kp, on_device);
+    // stored transposed (trT[j][i] = tr[i][j]) so the Viterbi inner loop walks contiguous memory
+    return upload_transposed(m, &m->tr, crf_trans, m->K, m->K, m->Kp, on_device);
 }
 
 // ---- create: onehot i-FST --------------------------------------------------------------------
@@ -162,9 +164,10 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
     m->V = d->V; m->S = d->S; m->C = d->C;
     m->use_crf = d->use_crf ? 1 : 0;
     m->K = d->C + (m->use_crf ? 2 : 0);
-    m->Kp = round_up(m->K, 4);
+    m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -176,22 +179,22 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
         TmpDev T, W;
         if ((rc = T.init(d->T, nT, od))) return bail(rc);
         if ((rc = W.init(d->W, (size_t)m->S * m->S, od))) return bail(rc);
-        const size_t nM = (size_t)m->V * m->S * m->SP;
+        const size_t nM = (size_t)m->V * m->geom.SR * m->SP;
         if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
-        if ((rc = launch_premix(T.p, W.p, nullptr, m->Mf, m->Mb, m->V, m->S, m->SP))) return bail(rc);
+        if ((rc = launch_premix(T.p, W.p, nullptr, m->Mf, m->Mb, m->V, m->S, m->SP, m->geom.SR))) return bail(rc);
     }
     // o = sum_c O[c,:]  (CE1, model_onehot.py:368); OT = O^T padded, with zero rows for START/STOP
     {
         TmpDev O;
         if ((rc = O.init(d->O, (size_t)m->C * m->S, od))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
-        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kp * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kc * 4))) return bail(rc);
         FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
-        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kp * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kc * 4));
         colsum_kernel<<<(m->S + 255) / 256, 256>>>(O.p, m->o, m->C, m->S);
         int n = m->C * m->S;
-        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(O.p, m->OT, m->C, m->S, m->Kp);
+        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(O.p, m->OT, m->C, m->S, m->Kc);
         FARNN_HIP_TRY(hipGetLastError());
         FARNN_HIP_TRY(hipDeviceSynchronize());
     }
@@ -304,14 +307,19 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
                         hipStream_t s) {
     const ChainGeom &g = m->geom;
     ChainParams p;
-    p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->S * m->SP;
+    p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR;
-    p.NW = g.NW; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
-    p.nl = m->nl; p.full = full;
+    p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
+    p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
     (void)L;
-    const size_t lds = g.lds_bytes(m->wsL);
-    const dim3 grid(2 * B), block(g.NW * 64);
+    // ring shape: a whole step per phase when it fits, KS phases deep
+    int ks = 2, nqp = g.NQ;
+    if (!g.pick_ring(m->wsL, m->chain_ks, ks, nqp))
+        return fail(FARNN_ERANGE, "chain kernel: LDS ring does not fit (sequence too long for this S)%s%s");
+    p.KS = ks; p.NQP = nqp; p.PPS = (g.NQ + nqp - 1) / nqp;
+    const size_t lds = g.lds_bytes(m->wsL, ks, nqp);
+    const dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);   // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
 #define FARNN_LAUNCH_CHAIN(NCH, MX)                                                           \
@@ -319,16 +327,14 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         if ((rc = raise_lds_limit(chain_kernel<NCH, MX>, lds))) return rc;                    \
         chain_kernel<NCH, MX><<<grid, block, lds, s>>>(p);                                    \
     } while (0)
+#define FARNN_LAUNCH_CHAIN_MX(NCH)                                                            \
+    do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true); else FARNN_LAUNCH_CHAIN(NCH, false); } while (0)
     KernelTimer kt(m, KERN_CHAIN, s);
-    switch (g.NCH * 2 + (mx ? 1 : 0)) {
-        case 2: FARNN_LAUNCH_CHAIN(1, false); break;
-        case 3: FARNN_LAUNCH_CHAIN(1, true); break;
-        case 4: FARNN_LAUNCH_CHAIN(2, false); break;
-        case 5: FARNN_LAUNCH_CHAIN(2, true); break;
-        case 6: case 8: FARNN_LAUNCH_CHAIN(4, false); break;
-        case 7: case 9: FARNN_LAUNCH_CHAIN(4, true); break;
-        default: return fail(FARNN_ERANGE, "unsupported state count%s%s");
-    }
+    if (g.NCH == 1) FARNN_LAUNCH_CHAIN_MX(1);
+    else if (g.NCH == 2) FARNN_LAUNCH_CHAIN_MX(2);
+    else if (g.NCH <= 4) FARNN_LAUNCH_CHAIN_MX(4);
+    else return fail(FARNN_ERANGE, "unsupported state count%s%s");
+#undef FARNN_LAUNCH_CHAIN_MX
 #undef FARNN_LAUNCH_CHAIN
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
@@ -337,21 +343,30 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
                                int64_t *flat, float *scores, hipStream_t s) {
     ScoreParams p;
-    p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.tr = m->tr; p.len = len;
+    p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
     p.offs = flat ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
+    p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     // LDS residency of the shared tables, largest benefit first
-    const size_t cap = 150 * 1024;
-    p.ot_in_lds = 0; p.tr_in_lds = 0;
-    if (score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, m->use_crf, 1, 0) <= cap) p.ot_in_lds = 1;
-    if (m->use_crf && score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, 1, p.ot_in_lds, 1) <= cap)
-        p.tr_in_lds = 1;
-    const size_t lds = score_lds_bytes(m->S, m->SP, m->K, m->Kp, p.L, m->use_crf, p.ot_in_lds, p.tr_in_lds);
-    int rc = raise_lds_limit(score_decode_kernel, lds);
-    if (rc) return rc;
+    const size_t cap = 156 * 1024;
+    const int hasP = m->P ? 1 : 0;
+    int ot = 0, tr = 0;
+    if (score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, m->use_crf, hasP, 1, 0) <= cap) ot = 1;
+    if (m->use_crf && score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, 1, hasP, ot, 1) <= cap) tr = 1;
+    const size_t lds = score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, m->use_crf, hasP, ot, tr);
+    int rc;
+#define FARNN_LAUNCH_SCORE(OT_, TR_)                                                          \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(score_decode_kernel<OT_, TR_>, lds))) return rc;            \
+        score_decode_kernel<OT_, TR_><<<dim3(B), dim3(SCORE_WAVES * 64), lds, s>>>(p);        \
+    } while (0)
     KernelTimer kt(m, KERN_SCORE, s);
-    score_decode_kernel<<<dim3(B), dim3(SCORE_WAVES * 64), lds, s>>>(p);
+    if (ot && tr) FARNN_LAUNCH_SCORE(true, true);
+    else if (ot) FARNN_LAUNCH_SCORE(true, false);
+    else if (tr) FARNN_LAUNCH_SCORE(false, true);
+    else FARNN_LAUNCH_SCORE(false, false);
+#undef FARNN_LAUNCH_SCORE
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -386,7 +401,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
             {
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->A4, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
-                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kp, full,
+                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
                                          m->o_idx, m->threshold, /*Oten*/ nullptr, s);
             }
         case KIND_IND1:
@@ -394,7 +409,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
             {
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->Ms, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
-                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kp, full,
+                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
                                          m->o_idx, m->threshold, m->Oten, s);
             }
         case KIND_DECOMP: {
@@ -420,10 +435,11 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
     m->kind = KIND_FST4; m->device = device;
-    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4);
+    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -434,11 +450,12 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
         TmpDev T4, W4;
         if ((rc = T4.init(d->T4, nT, od))) return bail(rc);
         if ((rc = W4.init(d->W4, (size_t)m->C * m->S * m->S, od))) return bail(rc);
-        const size_t nM = (size_t)m->V * m->S * m->SP;
+        const size_t nM = (size_t)m->V * m->geom.SR * m->SP;
         if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
-        if ((rc = dev_alloc(m, (void **)&m->A4, nM * m->C * 4))) return bail(rc);
-        if ((rc = launch_premix_fst4(T4.p, W4.p, m->Mf, m->Mb, m->A4, m->V, m->C, m->S, m->SP))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->A4, (size_t)m->V * m->C * m->S * m->SP * 4))) return bail(rc);
+        if ((rc = launch_premix_fst4(T4.p, W4.p, m->Mf, m->Mb, m->A4, m->V, m->C, m->S, m->SP, m->geom.SR)))
+            return bail(rc);
     }
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
     if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
@@ -458,11 +475,12 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
     m->kind = KIND_IND1; m->device = device;
-    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4);
+    m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     m->mask_by_output = d->mask_by_output;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -474,8 +492,9 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
         if ((rc = T.init(d->T, nT, od))) return bail(rc);
         if ((rc = W.init(d->W, (size_t)m->S * m->S, od))) return bail(rc);
         if ((rc = Ot.init(d->Oten, (size_t)m->C * m->S * m->S, od))) return bail(rc);
-        const size_t nM = (size_t)m->V * m->S * m->SP;
-        if ((rc = dev_alloc(m, (void **)&m->Ms, nM * 4))) return bail(rc);
+        const size_t nM = (size_t)m->V * m->geom.SR * m->SP;     // chain blocks (SR rows)
+        const size_t nS = (size_t)m->V * m->S * m->SP;           // scoring blocks (S rows)
+        if ((rc = dev_alloc(m, (void **)&m->Ms, nS * 4))) return bail(rc);
         if ((rc = upload_padded(m, &m->Oten, Ot.p, m->C * m->S, m->S, m->C * m->S, m->SP, 1))) return bail(rc);
         float *osum = nullptr;
         if (m->mask_by_output) {
@@ -484,15 +503,13 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
             FARNN_HIP_TRY(hipGetLastError());
             if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
             if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
-            if ((rc = launch_premix(T.p, W.p, osum, m->Mf, m->Mb, m->V, m->S, m->SP))) return bail(rc);
-            float *dummy = nullptr;
-            if ((rc = dev_alloc(m, (void **)&dummy, nM * 4))) return bail(rc);
-            if ((rc = launch_premix(T.p, W.p, nullptr, m->Ms, dummy, m->V, m->S, m->SP))) return bail(rc);
+            if ((rc = launch_premix(T.p, W.p, osum, m->Mf, m->Mb, m->V, m->S, m->SP, m->geom.SR))) return bail(rc);
         } else {
+            if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
             if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
-            if ((rc = launch_premix(T.p, W.p, nullptr, m->Ms, m->Mb, m->V, m->S, m->SP))) return bail(rc);
-            m->Mf = m->Ms;
+            if ((rc = launch_premix(T.p, W.p, nullptr, m->Mf, m->Mb, m->V, m->S, m->SP, m->geom.SR))) return bail(rc);
         }
+        if ((rc = launch_premix(T.p, W.p, nullptr, m->Ms, nullptr, m->V, m->S, m->SP, m->S))) return bail(rc);
     }
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
     if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
@@ -519,7 +536,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
     m->kind = KIND_DECOMP; m->device = device;
-    m->V = d->V; m->S = d->S; m->R = d->R; m->K = d->K; m->Kp = round_up(d->K, 4);
+    m->V = d->V; m->S = d->S; m->R = d->R; m->K = d->K; m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);
     m->C = d->use_crf ? d->K - 2 : d->K;
     m->SP = round_up(d->S, 4); m->Rp = round_up(d->R, 4);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
@@ -553,12 +570,12 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
         TmpDev Co;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
-        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kp * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kc * 4))) return bail(rc);
         FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
-        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kp * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kc * 4));
         colsum_kernel<<<(m->S + 255) / 256, 256>>>(Co.p, m->o, m->K, m->S);
         int n = m->K * m->S;
-        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(Co.p, m->OT, m->K, m->S, m->Kp);
+        transpose_pad_kernel<<<(n + 255) / 256, 256>>>(Co.p, m->OT, m->K, m->S, m->Kc);
         FARNN_HIP_TRY(hipGetLastError());
         FARNN_HIP_TRY(hipDeviceSynchronize());
         w.o = m->o;

@@ -29,27 +29,28 @@ __global__ void colsum_kernel(const float *src, float *dst, int rows, int cols) 
 // Mf[v][s][jp] = (T[v][s][j] + W[s][j]) * mask[s][j];  Mb[v][j][sp] = the same value transposed.
 // grid = (ceil(S*SP/256), V)
 __global__ void premix_kernel(const float *T, const float *W, const float *mask, float *Mf, float *Mb,
-                              int S, int SP) {
+                              int S, int SP, int SR) {
     const long long v = blockIdx.y;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * SP) return;
+    if (idx >= SR * SP) return;
     int r = idx / SP, cpad = idx - r * SP;
     const float *Tv = T + v * S * S;
     float f = 0.0f, bwd = 0.0f;
-    if (cpad < S) {
+    if (cpad < S && r < S) {
         f = Tv[r * S + cpad] + W[r * S + cpad];
         if (mask) f *= mask[r * S + cpad];
         bwd = Tv[cpad * S + r] + W[cpad * S + r];
         if (mask) bwd *= mask[cpad * S + r];
     }
-    Mf[v * S * SP + idx] = f;
-    if (Mb) Mb[v * S * SP + idx] = bwd;
+    Mf[v * SR * SP + idx] = f;
+    if (Mb) Mb[v * SR * SP + idx] = bwd;
 }
 
+// SR >= S: rows allocated per block (extra rows zero-filled; see chain.hip.h)
 inline int launch_premix(const float *T, const float *W, const float *mask, float *Mf, float *Mb,
-                         int V, int S, int SP) {
-    dim3 grid((S * SP + 255) / 256, V);
-    premix_kernel<<<grid, 256>>>(T, W, mask, Mf, Mb, S, SP);
+                         int V, int S, int SP, int SR) {
+    dim3 grid((SR * SP + 255) / 256, V);
+    premix_kernel<<<grid, 256>>>(T, W, mask, Mf, Mb, S, SP, SR);
     FARNN_HIP_TRY(hipGetLastError());
     FARNN_HIP_TRY(hipDeviceSynchronize());
     return FARNN_OK;
@@ -60,11 +61,16 @@ inline int launch_premix(const float *T, const float *W, const float *mask, floa
 //   A4[v][c] = T4[v][c] + W4[c]                 -> scoring stream, rows padded
 // grid = (ceil(S*SP/256), V)
 __global__ void premix_fst4_kernel(const float *T4, const float *W4, float *Mf, float *Mb, float *A4,
-                                   int C, int S, int SP) {
+                                   int C, int S, int SP, int SR) {
     const long long v = blockIdx.y;
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= S * SP) return;
+    if (idx >= SR * SP) return;
     int r = idx / SP, cpad = idx - r * SP;
+    if (r >= S) {                       // zero-filled padding rows of the chain blocks
+        Mf[v * SR * SP + idx] = 0.0f;
+        Mb[v * SR * SP + idx] = 0.0f;
+        return;
+    }
     const long long SS = (long long)S * S;
     float tsum = 0.0f, wsum = 0.0f, tsum_b = 0.0f, wsum_b = 0.0f;
     for (int c = 0; c < C; c++) {
@@ -78,14 +84,14 @@ __global__ void premix_fst4_kernel(const float *T4, const float *W4, float *Mf, 
         }
         A4[((v * C + c) * S) * SP + idx] = a;
     }
-    Mf[v * S * SP + idx] = tsum + wsum;
-    Mb[v * S * SP + idx] = tsum_b + wsum_b;
+    Mf[v * SR * SP + idx] = tsum + wsum;
+    Mb[v * SR * SP + idx] = tsum_b + wsum_b;
 }
 
 inline int launch_premix_fst4(const float *T4, const float *W4, float *Mf, float *Mb, float *A4,
-                              int V, int C, int S, int SP) {
-    dim3 grid((S * SP + 255) / 256, V);
-    premix_fst4_kernel<<<grid, 256>>>(T4, W4, Mf, Mb, A4, C, S, SP);
+                              int V, int C, int S, int SP, int SR) {
+    dim3 grid((SR * SP + 255) / 256, V);
+    premix_fst4_kernel<<<grid, 256>>>(T4, W4, Mf, Mb, A4, C, S, SP, SR);
     FARNN_HIP_TRY(hipGetLastError());
     FARNN_HIP_TRY(hipDeviceSynchronize());
     return FARNN_OK;

@@ -1,0 +1,8 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+true
+pr() { python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d['roofline']; print('$1 tok/s %.3g ms/step %.4f chain_us %.1f frac %.3f score_us %.1f' % (d['value'], d['ms_per_step'], r['kernel_avg_us'], r['frac'], r['score_decode_avg_us']))"; }
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline 2>/dev/null | pr ragged
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --full-length 2>/dev/null | pr full
+python bench.py --steps 100 --warmup 10 --no-cpu-baseline --full-length --batch 64 2>/dev/null | pr b64
