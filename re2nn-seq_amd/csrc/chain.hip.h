@@ -60,46 +60,6 @@ constexpr int CHAIN_MAX_THREADS = 512;     // NW compute + NLD loader + 1 writer
 constexpr int CHAIN_MAX_NP = 20;           // partial vectors per step (NW * G)
 constexpr int CHAIN_MAX_G = 4;
 
-// One LDS-DMA piece: 64 lanes x 16 bytes from (base + voff) land at LDS byte address `lds`
-// (wave-uniform) + lane*16.  M0 carries the LDS base and is compiler-reserved, so it is saved and
-// restored inside the statement (cdna_hip_programming.md 5.7).  The leading s_nop covers the
-// SGPR-write -> VMEM-read wait states of operands fresh from v_readfirstlane / SALU.
-__device__ __forceinline__ void lds_dma16(unsigned voff, const char *base, unsigned lds) {
-    unsigned keep;
-    asm volatile("s_nop 4\n\t"
-                 "s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %3\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(lds)
-                 : "memory");
-}
-
-// Workgroup barrier that orders LDS traffic only (lgkmcnt), never the vector-memory counter.
-__device__ __forceinline__ void wg_barrier_lds() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
-__device__ __forceinline__ void wait_vmcnt(int n) {
-#define FARNN_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
-    switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
-        FARNN_VMC(0) FARNN_VMC(1) FARNN_VMC(2) FARNN_VMC(3) FARNN_VMC(4) FARNN_VMC(5) FARNN_VMC(6) FARNN_VMC(7)
-        FARNN_VMC(8) FARNN_VMC(9) FARNN_VMC(10) FARNN_VMC(11) FARNN_VMC(12) FARNN_VMC(13) FARNN_VMC(14)
-        FARNN_VMC(15) FARNN_VMC(16) FARNN_VMC(17) FARNN_VMC(18) FARNN_VMC(19) FARNN_VMC(20) FARNN_VMC(21)
-        FARNN_VMC(22) FARNN_VMC(23) FARNN_VMC(24) FARNN_VMC(25) FARNN_VMC(26) FARNN_VMC(27) FARNN_VMC(28)
-        FARNN_VMC(29) FARNN_VMC(30) FARNN_VMC(31) FARNN_VMC(32) FARNN_VMC(33) FARNN_VMC(34) FARNN_VMC(35)
-        FARNN_VMC(36) FARNN_VMC(37) FARNN_VMC(38) FARNN_VMC(39) FARNN_VMC(40) FARNN_VMC(41) FARNN_VMC(42)
-        FARNN_VMC(43) FARNN_VMC(44) FARNN_VMC(45) FARNN_VMC(46) FARNN_VMC(47) FARNN_VMC(48) FARNN_VMC(49)
-        FARNN_VMC(50) FARNN_VMC(51) FARNN_VMC(52) FARNN_VMC(53) FARNN_VMC(54) FARNN_VMC(55) FARNN_VMC(56)
-        FARNN_VMC(57) FARNN_VMC(58) FARNN_VMC(59) FARNN_VMC(60) FARNN_VMC(61) FARNN_VMC(62)
-        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
-    }
-#undef FARNN_VMC
-}
-
 template <int NCH, bool MAXSR>
 __global__ void __launch_bounds__(CHAIN_MAX_THREADS)
 chain_kernel(const ChainParams p) {

@@ -62,4 +62,75 @@ __device__ __forceinline__ void wave_argmax(float &v, int &i) {
     }
 }
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from (base + voff) land at LDS byte address `lds`
+// (wave-uniform) + lane*16.  M0 carries the LDS base and is compiler-reserved, so it is saved and
+// restored inside the statement (cdna_hip_programming.md 5.7).  The leading s_nop covers the
+// SGPR-write -> VMEM-read wait states of operands fresh from v_readfirstlane / SALU.
+__device__ __forceinline__ void lds_dma16(unsigned voff, const char *base, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %3\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds)
+                 : "memory");
+}
+
+// Workgroup barrier that orders LDS traffic only (lgkmcnt), never the vector-memory counter.
+__device__ __forceinline__ void wg_barrier_lds() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform runtime n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define FARNN_VMC(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
+        FARNN_VMC(0) FARNN_VMC(1) FARNN_VMC(2) FARNN_VMC(3) FARNN_VMC(4) FARNN_VMC(5) FARNN_VMC(6) FARNN_VMC(7)
+        FARNN_VMC(8) FARNN_VMC(9) FARNN_VMC(10) FARNN_VMC(11) FARNN_VMC(12) FARNN_VMC(13) FARNN_VMC(14)
+        FARNN_VMC(15) FARNN_VMC(16) FARNN_VMC(17) FARNN_VMC(18) FARNN_VMC(19) FARNN_VMC(20) FARNN_VMC(21)
+        FARNN_VMC(22) FARNN_VMC(23) FARNN_VMC(24) FARNN_VMC(25) FARNN_VMC(26) FARNN_VMC(27) FARNN_VMC(28)
+        FARNN_VMC(29) FARNN_VMC(30) FARNN_VMC(31) FARNN_VMC(32) FARNN_VMC(33) FARNN_VMC(34) FARNN_VMC(35)
+        FARNN_VMC(36) FARNN_VMC(37) FARNN_VMC(38) FARNN_VMC(39) FARNN_VMC(40) FARNN_VMC(41) FARNN_VMC(42)
+        FARNN_VMC(43) FARNN_VMC(44) FARNN_VMC(45) FARNN_VMC(46) FARNN_VMC(47) FARNN_VMC(48) FARNN_VMC(49)
+        FARNN_VMC(50) FARNN_VMC(51) FARNN_VMC(52) FARNN_VMC(53) FARNN_VMC(54) FARNN_VMC(55) FARNN_VMC(56)
+        FARNN_VMC(57) FARNN_VMC(58) FARNN_VMC(59) FARNN_VMC(60) FARNN_VMC(61) FARNN_VMC(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef FARNN_VMC
+}
+
+
+// ---- wave-level first-index argmax on the DPP network (no LDS round trips) ---------------------
+// torch.max tie-breaking = (value desc, index asc).  Both are folded into one 64-bit key:
+// hi = order-preserving u32 image of the float, lo = ~index (smaller index -> larger key), and the
+// key is max-scanned with row_shr 1/2/4/8 + row_bcast 15/31; lane 63 ends up with the wave total.
+__device__ __forceinline__ unsigned float_order_key(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void dpp_max_step(unsigned &hi, unsigned &lo) {
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xf, false);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xf, false);
+    const bool take = ohi > hi || (ohi == hi && olo > lo);
+    hi = take ? ohi : hi;
+    lo = take ? olo : lo;
+}
+
+// returns the winning index in every lane (wave-uniform); `idx` must be < 0x7fffffff
+__device__ __forceinline__ int wave_argmax_dpp(float v, int idx) {
+    unsigned hi = float_order_key(v), lo = ~(unsigned)idx;
+    dpp_max_step<0x111, 0xf>(hi, lo);      // row_shr:1
+    dpp_max_step<0x112, 0xf>(hi, lo);      // row_shr:2
+    dpp_max_step<0x114, 0xf>(hi, lo);      // row_shr:4
+    dpp_max_step<0x118, 0xf>(hi, lo);      // row_shr:8
+    dpp_max_step<0x142, 0xa>(hi, lo);      // row_bcast:15 into rows 1 and 3
+    dpp_max_step<0x143, 0xc>(hi, lo);      // row_bcast:31 into rows 2 and 3
+    return (int)~(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
 }  // namespace farnn

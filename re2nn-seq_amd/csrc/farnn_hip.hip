@@ -40,7 +40,7 @@ struct farnn_model {
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     DecompWeights dw;                       // decomposed model weights
     // workspace
-    float *A = nullptr, *Bk = nullptr;
+    float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
     int64_t *offs = nullptr;
     int wsB = 0, wsL = 0;
     ChainGeom geom;
@@ -189,9 +189,9 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
         TmpDev O;
         if ((rc = O.init(d->O, (size_t)m->C * m->S, od))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
-        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kc * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, round_up_sz((size_t)m->S * m->Kc * 4, 1024)))) return bail(rc);
         FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
-        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kc * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, round_up_sz((size_t)m->S * m->Kc * 4, 1024)));
         colsum_kernel<<<(m->S + 255) / 256, 256>>>(O.p, m->o, m->C, m->S);
         int n = m->C * m->S;
         transpose_pad_kernel<<<(n + 255) / 256, 256>>>(O.p, m->OT, m->C, m->S, m->Kc);
@@ -222,12 +222,18 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     if (B <= m->wsB && L <= m->wsL) return FARNN_OK;
     FARNN_HIP_TRY(hipSetDevice(m->device));
     int nB = B > m->wsB ? B : m->wsB, nL = L > m->wsL ? L : m->wsL;
-    if (m->A) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); }
-    m->A = m->Bk = nullptr; m->offs = nullptr; m->wsB = m->wsL = 0;
+    if (m->A) {
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+        (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs);
+        if (m->crf_scores) (void)hipFree(m->crf_scores);
+    }
+    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->wsB = m->wsL = 0;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
+    if (m->use_crf)
+        FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float)));
     FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
     FARNN_HIP_TRY(hipMemset(m->Bk, 0, stash));
     FARNN_HIP_TRY(hipDeviceSynchronize());
@@ -345,29 +351,36 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
     ScoreParams p;
     p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
     p.offs = flat ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
+    p.crf_scores = m->crf_scores;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
-    // LDS residency of the shared tables, largest benefit first
-    const size_t cap = 156 * 1024;
     const int hasP = m->P ? 1 : 0;
-    int ot = 0, tr = 0;
-    if (score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, m->use_crf, hasP, 1, 0) <= cap) ot = 1;
-    if (m->use_crf && score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, 1, hasP, ot, 1) <= cap) tr = 1;
-    const size_t lds = score_lds_bytes(m->S, m->SP, m->K, m->Kp, m->Kc, p.L, m->use_crf, hasP, ot, tr);
+    const int ot = score_lds_bytes(m->S, m->SP, m->Kc, hasP, 1) <= 150 * 1024 ? 1 : 0;
+    const size_t lds = score_lds_bytes(m->S, m->SP, m->Kc, hasP, ot);
+    const dim3 grid((p.L + SCORE_TT - 1) / SCORE_TT, B), block(SCORE_WAVES * 64);
     int rc;
-#define FARNN_LAUNCH_SCORE(OT_, TR_)                                                          \
-    do {                                                                                      \
-        if ((rc = raise_lds_limit(score_decode_kernel<OT_, TR_>, lds))) return rc;            \
-        score_decode_kernel<OT_, TR_><<<dim3(B), dim3(SCORE_WAVES * 64), lds, s>>>(p);        \
-    } while (0)
     KernelTimer kt(m, KERN_SCORE, s);
-    if (ot && tr) FARNN_LAUNCH_SCORE(true, true);
-    else if (ot) FARNN_LAUNCH_SCORE(true, false);
-    else if (tr) FARNN_LAUNCH_SCORE(false, true);
-    else FARNN_LAUNCH_SCORE(false, false);
-#undef FARNN_LAUNCH_SCORE
+    if (ot) {
+        if ((rc = raise_lds_limit(score_tile_kernel<true>, lds))) return rc;
+        score_tile_kernel<true><<<grid, block, lds, s>>>(p);
+    } else {
+        if ((rc = raise_lds_limit(score_tile_kernel<false>, lds))) return rc;
+        score_tile_kernel<false><<<grid, block, lds, s>>>(p);
+    }
     FARNN_HIP_TRY(hipGetLastError());
+    if (m->use_crf) {
+        const int tr = viterbi_lds_bytes(m->K, m->Kp, p.L, 1) <= 150 * 1024 ? 1 : 0;
+        const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L, tr);
+        if (tr) {
+            if ((rc = raise_lds_limit(viterbi_kernel<true>, vlds))) return rc;
+            viterbi_kernel<true><<<dim3(B), dim3(VITERBI_THREADS), vlds, s>>>(p);
+        } else {
+            if ((rc = raise_lds_limit(viterbi_kernel<false>, vlds))) return rc;
+            viterbi_kernel<false><<<dim3(B), dim3(VITERBI_THREADS), vlds, s>>>(p);
+        }
+        FARNN_HIP_TRY(hipGetLastError());
+    }
     return FARNN_OK;
 }
 
@@ -570,9 +583,9 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
         TmpDev Co;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->o, (size_t)m->SP * 4))) return bail(rc);
-        if ((rc = dev_alloc(m, (void **)&m->OT, (size_t)m->S * m->Kc * 4))) return bail(rc);
+        if ((rc = dev_alloc(m, (void **)&m->OT, round_up_sz((size_t)m->S * m->Kc * 4, 1024)))) return bail(rc);
         FARNN_HIP_TRY(hipMemset(m->o, 0, (size_t)m->SP * 4));
-        FARNN_HIP_TRY(hipMemset(m->OT, 0, (size_t)m->S * m->Kc * 4));
+        FARNN_HIP_TRY(hipMemset(m->OT, 0, round_up_sz((size_t)m->S * m->Kc * 4, 1024)));
         colsum_kernel<<<(m->S + 255) / 256, 256>>>(Co.p, m->o, m->K, m->S);
         int n = m->K * m->S;
         transpose_pad_kernel<<<(n + 255) / 256, 256>>>(Co.p, m->OT, m->K, m->S, m->Kc);
@@ -598,6 +611,7 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->A) (void)hipFree(m->A);
     if (m->Bk) (void)hipFree(m->Bk);
     if (m->offs) (void)hipFree(m->offs);
+    if (m->crf_scores) (void)hipFree(m->crf_scores);
     delete m;
 }
 

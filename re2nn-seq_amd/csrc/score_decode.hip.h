@@ -5,14 +5,17 @@
 //   decomposed model_decompose_single.py:202-205, :263-269    (same form with C_output_mat)
 //   decode    model_decompose.py:339-371 (argmax or CRF) ; crf.py:102-195 (Viterbi)
 //
-// One workgroup (8 wavefronts) per sequence; per sequence this is a small GEMM
-// [tokens x S] . [S x K] whose right operand (the transposed output matrix) is shared by every
-// token, so it is made LDS-resident once per workgroup and register-blocked: a wavefront scores
-// 4 tokens at a time, a lane owns label columns {lane, lane+64, ...}; the a*b products of a
-// 32-token tile are staged in LDS with coalesced 16-byte loads.  Scores never go to HBM unless
-// the caller asks for them: threshold clamp, first-index argmax and the `oo -> o_idx` mapping --
-// or the whole Viterbi DP with transitions, partitions and back-pointers in LDS -- run in the
-// same kernel.
+// score_tile_kernel: one workgroup (8 wavefronts) per (sequence, 32-token tile).  Per tile this is
+// a small GEMM [32 x S] . [S x K] whose right operand (the transposed output matrix) is shared by
+// every token of every sequence: it is pulled into LDS by LDS-DMA while the a*b products of the
+// tile are formed, then the GEMM is register-blocked (a wavefront scores 4 tokens at a time, a lane
+// owns label columns {lane, lane+64, ...}).  Scores never go to HBM unless the caller asks for
+// them: threshold clamp, first-index argmax (on the DPP network, no LDS round trips) and the
+// `oo -> o_idx` mapping run in the same kernel.
+//
+// viterbi_kernel (use_crf=1): one workgroup per sequence runs the max-plus DP with the transition
+// table, the partitions and the back-pointers in LDS; it reads the clamped scores the tile kernel
+// left in the workspace (B*L*K floats, ~1% of the chain kernel's traffic).
 #pragma once
 #include "common.hip.h"
 
@@ -20,14 +23,15 @@ namespace farnn {
 
 struct ScoreParams {
     const float *A, *Bk;    // stash [B][L+1][SP]
-    const float *OT;        // [S][Kc] transposed output matrix, columns >= K zero
+    const float *OT;        // [S][Kc] transposed output matrix, columns >= K zero (alloc padded to 1 KiB)
     const float *P;         // [K][Kc] priority matrix or nullptr
     const float *trT;       // [K][Kp] TRANSPOSED CRF transitions trT[j][i] = tr[i][j], or nullptr
     const int64_t *len;     // [B]
     const int64_t *offs;    // [B+1] exclusive prefix of lengths (flat output) or nullptr
     int32_t *tags;          // [B][L] or nullptr
     int64_t *flat;          // [sum len] or nullptr
-    float *scores;          // [B][L][K] or nullptr
+    float *scores;          // [B][L][K] or nullptr (unclamped, what forward_score returns)
+    float *crf_scores;      // [B][L][Kp] workspace: clamped scores for the Viterbi kernel
     int B, L, S, SP, K, Kp, Kc, kch;
     int full, use_crf, o_idx;
     float threshold;
@@ -35,171 +39,206 @@ struct ScoreParams {
 
 constexpr int SCORE_KCH = 4;       // label columns per lane: K <= 256
 constexpr int SCORE_WAVES = 8;
-constexpr int SCORE_TT = 32;       // tokens per LDS tile (4 per wavefront)
+constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 
-template <bool OT_LDS, bool TR_LDS>
+template <bool OT_LDS>
 __global__ void __launch_bounds__(SCORE_WAVES * 64)
-score_decode_kernel(const ScoreParams p) {
+score_tile_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = SCORE_WAVES * 64;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, t0 = blockIdx.x * SCORE_TT;
     const int len = (int)p.len[b];
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, K = p.K, Kp = p.Kp, Kc = p.Kc, kch = p.kch;
+    const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc, kch = p.kch;
+    const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
+    const int ntL = min(SCORE_TT, p.L - t0);             // tokens of this tile that exist
+
+    if (nt <= 0) {      // a tile of pads only (LOCAL mode)
+        for (int i = t0 + w; i < t0 + ntL; i += SCORE_WAVES) {
+            if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
+            if (p.scores)
+                for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
+        }
+        return;
+    }
 
     // ---- LDS carve ---------------------------------------------------------------------------
     float *ab = smem;                                    // [TT][SP]  alpha*beta of the tile
     float *cur = ab + SCORE_TT * SP;
     float *scw = nullptr;                                // [waves][Kc] one score row per wave (P)
     if (p.P) { scw = cur; cur += SCORE_WAVES * Kc; }
-    float *otl = nullptr;
+    float *otl = cur;                                    // [S][Kc] rounded up to whole DMA pieces
     if (OT_LDS) {
-        otl = cur; cur += S * Kc;
-        for (int i = tid * 4; i < S * Kc; i += nthreads * 4) st4(otl + i, ld4(p.OT + i));
-    }
-    float *sc_all = nullptr, *part = nullptr, *trl = nullptr;
-    unsigned short *bp = nullptr;
-    if (p.use_crf) {
-        sc_all = cur; cur += (size_t)p.L * Kp;           // [L][Kp] clamped scores of this sequence
-        part = cur; cur += 2 * Kp;                       // [2][Kp]
-        if (TR_LDS) {
-            trl = cur; cur += K * Kp;
-            for (int i = tid * 4; i < K * Kp; i += nthreads * 4) st4(trl + i, ld4(p.trT + i));
-        }
-        bp = reinterpret_cast<unsigned short *>(cur);    // [L][Kp] back-pointers
+        // LDS-DMA: 1 KiB pieces, round-robin over the wavefronts; lands while phase 1 runs
+        const unsigned ot_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)otl);
+        const int pieces = (S * Kc * 4 + 1023) / 1024;
+        const char *obase = reinterpret_cast<const char *>(p.OT);
+        for (int k = w; k < pieces; k += SCORE_WAVES)
+            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, obase, ot_lds + (unsigned)k * 1024u);
     }
 
     const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
     const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
-    const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
-    const long long foff = p.offs ? p.offs[b] : 0;
     const int SP4 = SP >> 2;
-
-    for (int t0 = 0; t0 < nsteps; t0 += SCORE_TT) {
-        const int nt = min(SCORE_TT, nsteps - t0);
-        // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
-        // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
-        for (int idx = tid; idx < SCORE_TT * SP4; idx += nthreads) {
-            const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
+    // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
+    for (int idx0 = 0; idx0 < SCORE_TT * SP4; idx0 += 2 * nthreads) {
+        float4 a4[2], b4[2];
+        int tokv[2], s4v[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int idx = idx0 + r * nthreads + tid;
+            const int tok = idx / SP4;
+            tokv[r] = tok; s4v[r] = (idx - tok * SP4) * 4;
+            a4[r] = make_float4(0.f, 0.f, 0.f, 0.f); b4[r] = a4[r];
             if (tok < nt) {
                 const int i = t0 + tok;
                 const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
-                const float4 a4 = ld4(Ab + (long long)(i + 1) * SP + s4);
-                const float4 b4 = ld4(Bb + (long long)bidx * SP + s4);
-                v = make_float4(a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w);
+                a4[r] = ld4(Ab + (long long)(i + 1) * SP + s4v[r]);
+                b4[r] = ld4(Bb + (long long)bidx * SP + s4v[r]);
             }
-            st4(ab + tok * SP + s4, v);
         }
-        __syncthreads();
-        // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ------
-        const int tg = w * 4;
-        if (tg < nt) {
-            float acc[4][SCORE_KCH];
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+        for (int r = 0; r < 2; r++)
+            if (tokv[r] < SCORE_TT)
+                st4(ab + tokv[r] * SP + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
+                                                             a4[r].z * b4[r].z, a4[r].w * b4[r].w));
+    }
+    if (OT_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's DMA pieces landed
+    __syncthreads();
+
+    // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ----------
+    const int tg = w * 4;
+    if (tg >= nt && tg >= ntL) return;
+    const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
+    const long long foff = p.offs ? p.offs[b] : 0;
+    float acc[4][SCORE_KCH];
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++) acc[j][k] = 0.0f;
-            const float *abw = ab + tg * SP;
-            for (int s0 = 0; s0 < S; s0 += 4) {
-                float av[4][4];
+    for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float4 a4 = ld4(abw + j * SP + s0);          // LDS broadcast
-                    av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (s0 + u < S) {
-                        const float *orow = (OT_LDS ? otl : p.OT) + (long long)(s0 + u) * Kc + lane;
-#pragma unroll
-                        for (int k = 0; k < SCORE_KCH; k++) {
-                            if (k < kch) {
-                                const float ov = orow[64 * k];
-#pragma unroll
-                                for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov, acc[j][k]);
-                            }
-                        }
-                    }
-                }
-            }
+        for (int k = 0; k < SCORE_KCH; k++) acc[j][k] = 0.0f;
+    if (tg < nt) {
+        const float *abw = ab + tg * SP;
+        const float *otb = (OT_LDS ? otl : p.OT) + lane;
+        for (int s0 = 0; s0 < S; s0 += 4) {
+            float av[4][4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int i = t0 + tg + j;
-                if (tg + j < nt) {
-                    float sc[SCORE_KCH];
+                const float4 a4 = ld4(abw + j * SP + s0);              // LDS broadcast
+                av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
+            }
+            float ov[4][SCORE_KCH];
 #pragma unroll
-                    for (int k = 0; k < SCORE_KCH; k++) sc[k] = acc[j][k];
-                    if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
-                        float *sr = scw + w * Kc;
+            for (int u = 0; u < 4; u++) {
+                const int srow = (s0 + u < S) ? s0 + u : S - 1;        // ab pad columns are zero
 #pragma unroll
-                        for (int k = 0; k < SCORE_KCH; k++) if (k < kch) sr[lane + 64 * k] = sc[k];
-                        __builtin_amdgcn_wave_barrier();
+                for (int k = 0; k < SCORE_KCH; k++)
+                    ov[u][k] = (k < kch) ? otb[(long long)srow * Kc + 64 * k] : 0.0f;
+            }
 #pragma unroll
-                        for (int k = 0; k < SCORE_KCH; k++) sc[k] = 0.0f;
-                        for (int cc = 0; cc < K; cc++) {
-                            const float sv = sr[cc];
-                            const float *prow = p.P + (long long)cc * Kc + lane;
+            for (int u = 0; u < 4; u++)
 #pragma unroll
-                            for (int k = 0; k < SCORE_KCH; k++)
-                                if (k < kch) sc[k] = fmaf(sv, prow[64 * k], sc[k]);
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    if (p.scores) {
-                        float *so = p.scores + ((long long)b * p.L + i) * K;
+                for (int k = 0; k < SCORE_KCH; k++)
 #pragma unroll
-                        for (int k = 0; k < SCORE_KCH; k++) {
-                            const int col = lane + 64 * k;
-                            if (k < kch && col < K) so[col] = sc[k];
-                        }
-                    }
-                    // threshold clamp of the `oo` column, then decode
-                    float bv = -INFINITY; int bi = 0x7fffffff;
+                    for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov[u][k], acc[j][k]);
+        }
+    }
 #pragma unroll
-                    for (int k = 0; k < SCORE_KCH; k++) {
-                        const int col = lane + 64 * k;
-                        if (k < kch && col < K) {
-                            float v = sc[k];
-                            if (col == clamp_col) v = fminf(v, p.threshold);
-                            if (p.use_crf) sc_all[(long long)i * Kp + col] = v;
-                            if (v > bv) { bv = v; bi = col; }
-                        }
-                    }
-                    if (!p.use_crf) {
-                        wave_argmax(bv, bi);
-                        if (lane == 0) {
-                            if (bi >= K) bi = 0;                    // all-NaN row: torch returns 0
-                            const int tag = (bi == K - 1) ? p.o_idx : bi;
-                            if (p.tags) p.tags[(long long)b * p.L + i] = tag;
-                            if (p.flat && i < len) p.flat[foff + i] = tag;
-                        }
-                    }
+    for (int j = 0; j < 4; j++) {
+        const int i = t0 + tg + j;
+        if (tg + j < nt) {
+            float sc[SCORE_KCH];
+#pragma unroll
+            for (int k = 0; k < SCORE_KCH; k++) sc[k] = acc[j][k];
+            if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
+                float *sr = scw + w * Kc;
+#pragma unroll
+                for (int k = 0; k < SCORE_KCH; k++) if (k < kch) sr[lane + 64 * k] = sc[k];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < SCORE_KCH; k++) sc[k] = 0.0f;
+                for (int cc = 0; cc < K; cc++) {
+                    const float sv = sr[cc];
+                    const float *prow = p.P + (long long)cc * Kc + lane;
+#pragma unroll
+                    for (int k = 0; k < SCORE_KCH; k++)
+                        if (k < kch) sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (p.scores) {
+                float *so = p.scores + ((long long)b * p.L + i) * K;
+#pragma unroll
+                for (int k = 0; k < SCORE_KCH; k++) {
+                    const int col = lane + 64 * k;
+                    if (k < kch && col < K) so[col] = sc[k];
                 }
             }
+            // threshold clamp of the `oo` column, then decode
+            float bv = -INFINITY; int bi = 0x7ffffffe;
+#pragma unroll
+            for (int k = 0; k < SCORE_KCH; k++) {
+                const int col = lane + 64 * k;
+                if (k < kch && col < K) {
+                    float v = sc[k] + 0.0f;                      // -0.0 -> +0.0 (torch: -0 == +0)
+                    if (col == clamp_col) v = fminf(v, p.threshold);
+                    if (p.use_crf) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
+                    if (v > bv) { bv = v; bi = col; }
+                }
+            }
+            if (!p.use_crf) {
+                bi = wave_argmax_dpp(bv, bi);
+                if (lane == 0) {
+                    if (bi >= K) bi = 0;                        // all-NaN row: torch returns 0
+                    const int tag = (bi == K - 1) ? p.o_idx : bi;
+                    if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                    if (p.flat && i < len) p.flat[foff + i] = tag;
+                }
+            }
+        } else if (tg + j < ntL) {      // pad position inside a partly valid tile (LOCAL mode)
+            if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
+            if (p.scores)
+                for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
         }
-        __syncthreads();
     }
+}
 
-    // positions the recurrence did not visit (LOCAL mode pads)
-    for (int i = nsteps + w; i < p.L; i += SCORE_WAVES) {
-        if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
-        if (p.scores)
-            for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
-    }
+inline size_t score_lds_bytes(int S, int SP, int Kc, int has_P, int ot_in_lds) {
+    size_t bytes = (size_t)SCORE_TT * SP * 4;
+    if (has_P) bytes += (size_t)SCORE_WAVES * Kc * 4;
+    if (ot_in_lds) bytes += ((size_t)S * Kc * 4 + 1023) / 1024 * 1024;
+    return bytes;
+}
 
-    if (!p.use_crf) return;
+// ---- Viterbi (crf.py:102-195) over the valid positions, one workgroup per sequence ------------
+// A quad of lanes shares one destination tag j and splits the source tags i; the quad is combined
+// with (value desc, index asc), which is torch.max's first-index rule.
+constexpr int VITERBI_THREADS = 512;
 
-    // ---- Viterbi (crf.py:102-195) over the valid positions, per sequence ----------------------
-    // A quad of lanes shares one destination tag j and splits the source tags i; the quad is
-    // combined with (value desc, index asc), which is torch.max's first-index rule.
-    __syncthreads();
+template <bool TR_LDS>
+__global__ void __launch_bounds__(VITERBI_THREADS)
+viterbi_kernel(const ScoreParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int nthreads = VITERBI_THREADS;
+    const int b = blockIdx.x;
+    const int n = (int)p.len[b];
+    const int nsteps = p.full ? p.L : n;
+    const int K = p.K, Kp = p.Kp;
+    float *part = smem;                                  // [2][Kp]
+    float *trl = part + 2 * Kp;                          // [K][Kp] when TR_LDS
+    unsigned short *bp = reinterpret_cast<unsigned short *>(TR_LDS ? trl + (size_t)K * Kp : trl);  // [L][Kp]
+    if (TR_LDS)
+        for (int i = tid * 4; i < K * Kp; i += nthreads * 4) st4(trl + i, ld4(p.trT + i));
     const float *trT = TR_LDS ? trl : p.trT;
+    const float *sc = p.crf_scores + (long long)b * p.L * Kp;
+    const long long foff = p.offs ? p.offs[b] : 0;
     const int START = K - 2, STOP = K - 1;
-    const int n = len;
+    __syncthreads();
     for (int j = tid; j < K; j += nthreads)
-        part[j] = sc_all[j] + trT[(long long)j * Kp + START];                 // crf.py:135
+        part[j] = sc[j] + trT[(long long)j * Kp + START];                     // crf.py:135
     __syncthreads();
     int pc = 0;
     const int q = tid & 3;
@@ -210,7 +249,7 @@ score_decode_kernel(const ScoreParams p) {
             const int j = j0 + (tid >> 2);
             float best = -INFINITY; int bi = 0x7fffffff;
             if (j < K) {
-                const float f = sc_all[(long long)t * Kp + j];
+                const float f = sc[(long long)t * Kp + j];
                 const float *trow = trT + (long long)j * Kp;
                 for (int i = q; i < K; i += 4) {
                     const float v = (f + trow[i]) + pin[i];                   // crf.py:123,145
@@ -255,17 +294,10 @@ score_decode_kernel(const ScoreParams p) {
         for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
 }
 
-inline size_t score_lds_bytes(int S, int SP, int K, int Kp, int Kc, int L, int use_crf, int has_P,
-                              int ot_in_lds, int tr_in_lds) {
-    size_t f = (size_t)SCORE_TT * SP;
-    if (has_P) f += (size_t)SCORE_WAVES * Kc;
-    if (ot_in_lds) f += (size_t)S * Kc;
-    size_t bytes = f * 4;
-    if (use_crf) {
-        bytes += ((size_t)L * Kp + 2 * Kp) * 4;
-        if (tr_in_lds) bytes += (size_t)K * Kp * 4;
-        bytes += (size_t)L * Kp * 2;
-    }
+inline size_t viterbi_lds_bytes(int K, int Kp, int L, int tr_in_lds) {
+    size_t bytes = (size_t)2 * Kp * 4;
+    if (tr_in_lds) bytes += (size_t)K * Kp * 4;
+    bytes += (size_t)L * Kp * 2;
     return bytes;
 }
 

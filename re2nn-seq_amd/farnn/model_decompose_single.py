@@ -1,0 +1,170 @@
+"""Host mirror of the reference's decomposed i-FST tagger ``FARNN_S_D_W_I_S``
+(src_seq/farnn/model_decompose_single.py:12-304; shared pieces from model_decompose.py).
+
+The constructor keeps the reference's argument list and builds the same parameter set
+(state padding with ``additional_states``, the pseudo-inverse word-embedding bridge, optional
+GRU-style gates, optional CRF) with torch CPU ops; inference runs in the HIP library.  Because the
+weights are frozen on the tagging path, the per-token ``get_generalized_v_embed_vec``
+(model_decompose.py:222-241) is folded once into a table ``Vgen[V,R]`` when the device handle is
+built -- the reference recomputes it twice per time step.
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+from ._native import NativeTagger
+from .priority import expand_priority
+
+_GATE_KEYS = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
+_PARAM_KEYS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_output_mat', 'wildcard_mat',
+               'wildcard_output_vector', 'h0', 'hT', 'beta_vec') + _GATE_KEYS
+
+
+def crf_default_transitions(tagset_size):
+    """CRF.__init__ of the reference (baselines/crf.py:31-46)."""
+    K = tagset_size + 2
+    tr = torch.zeros(K, K)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    return tr
+
+
+class FARNN_S_D_W_I_S(NativeTagger):
+    local_uses_max_len = True        # forward_local iterates lengths.max() positions (ref :221)
+
+    def __init__(self, V=None, S1=None, S2=None, C_output_mat=None, wildcard_mat=None,
+                 wildcard_output_vector=None, final_vector=None, start_vector=None,
+                 pretrained_word_embed=None, priority_mat=None, args=None, o_idx=0, is_cuda=True):
+        super().__init__(args, o_idx)
+        self.additional_states = int(args.additional_states)
+        self.embedding = torch.from_numpy(np.asarray(pretrained_word_embed)).float()       # V x D
+        self.C = C_output_mat.shape[0]
+        self.S, self.R = S1.shape
+        self.use_crf = bool(args.use_crf)
+        self.crf_transitions = None
+        if self.use_crf:
+            self.crf_transitions = crf_default_transitions(self.C)
+            self.C += 2
+        self.priority_full = expand_priority(self.C, priority_mat)
+        self.random = bool(args.random)
+        self.h0 = self.pad_additional_states(torch.from_numpy(np.asarray(start_vector)).float())
+        self.hT = self.pad_additional_states(torch.from_numpy(np.asarray(final_vector)).float())
+        self._init_forward_parameters(S1, S2, V, C_output_mat, wildcard_mat, wildcard_output_vector)
+        self.beta = args.beta
+        self.beta_vec = torch.tensor([self.beta] * self.R).float()
+
+    # ---- parameter construction (ref model_decompose_single.py:68-136) ------------------------
+    def get_random(self, sizes):
+        """ref model_decompose.py:189-199"""
+        f = self.args.random_pad_func
+        if f == 'uniform':
+            return torch.rand(sizes)
+        if f == 'normal':
+            return torch.randn(sizes)
+        a = torch.randn(sizes)
+        torch.nn.init.xavier_normal_(a)
+        return a
+
+    def pad_additional_states(self, obj):
+        """ref model_decompose.py:201-220: EVERY dimension equal to S grows by additional_states;
+        new entries are rand * rand_constant (zeros for vectors)."""
+        shape = tuple(obj.shape)
+        padded = tuple(d if d != self.S else d + self.additional_states for d in shape)
+        if len(shape) == 1:
+            out = torch.zeros(padded)
+        else:
+            out = self.get_random(padded) * self.args.rand_constant
+        out[tuple(slice(0, d) for d in shape)] = obj
+        return out
+
+    def _init_forward_parameters(self, S1, S2, V, C_o, W, W_o):
+        a = self.args
+        t = lambda x: torch.from_numpy(np.asarray(x)).float()      # noqa: E731
+        self.S1 = self.pad_additional_states(t(S1))
+        self.S2 = self.pad_additional_states(t(S2))
+        self.V_embed = t(V)
+        self.embed_r_generalized = torch.matmul(self.embedding.pinverse(), self.V_embed)   # D x R (:73-76)
+        C_o = np.asarray(C_o)
+        if a.use_crf == 1:       # two extra rows for START/STOP (:78-79)
+            C_o = np.concatenate((C_o, self.get_random((2, self.S)).numpy() * a.rand_constant), axis=0)
+        self.C_output_mat = self.pad_additional_states(t(C_o))
+        self.wildcard_mat = self.pad_additional_states(t(W))
+        self.wildcard_output_vector = self.pad_additional_states(t(W_o))
+        Sp = self.S + self.additional_states
+        if a.farnn in (1, 2):    # gate parameters (:93-123)
+            self.Wss1 = torch.randn((Sp, Sp)).float()
+            self.Wrs1 = torch.randn((self.R, Sp)).float()
+            self.bs1 = torch.ones((1, Sp)).float() * a.bias_init
+            if a.farnn == 2:
+                self.Wss2 = torch.randn((Sp, Sp)).float()
+                self.Wrs2 = torch.randn((self.R, Sp)).float()
+                self.bs2 = torch.ones((1, Sp)).float() * a.bias_init
+            if a.xavier:
+                for name in _GATE_KEYS:
+                    if hasattr(self, name) and not name.startswith('bs'):
+                        torch.nn.init.xavier_normal_(getattr(self, name))
+                if a.farnn == 1:
+                    torch.nn.init.xavier_normal_(self.bs1)
+        if self.random:          # (:125-136)
+            for name in ('S1', 'S2', 'V_embed', 'C_output_mat', 'embed_r_generalized', 'wildcard_mat'):
+                torch.nn.init.xavier_normal_(getattr(self, name))
+            torch.nn.init.normal_(self.h0)
+            torch.nn.init.normal_(self.hT)
+
+    # ---- state dict compatible with the reference's key names ---------------------------------
+    def state_dict(self):
+        sd = {k: getattr(self, k) for k in _PARAM_KEYS if hasattr(self, k)}
+        sd['embedding.weight'] = self.embedding
+        sd['priority_layer.priority_mat'] = torch.from_numpy(self.priority_full)
+        if self.use_crf:
+            sd['crf.transitions'] = self.crf_transitions
+        return sd
+
+    def load_state_dict(self, sd, strict=False):
+        for k, v in sd.items():
+            v = torch.as_tensor(np.asarray(v)).float() if not torch.is_tensor(v) else v.detach().float().cpu()
+            if k in _PARAM_KEYS:
+                setattr(self, k, v)
+            elif k == 'embedding.weight':
+                self.embedding = v
+            elif k == 'priority_layer.priority_mat':
+                self.priority_full = v.numpy()
+            elif k == 'crf.transitions':
+                self.crf_transitions = v
+        self.invalidate()
+        return self
+
+    # ---- device handle ------------------------------------------------------------------------
+    def generalized_vocab_table(self):
+        """get_generalized_v_embed_vec for every word id at once (ref model_decompose.py:222-241)."""
+        gen = torch.matmul(self.embedding, self.embed_r_generalized)
+        nl = self.args.additional_nonlinear
+        if nl == 'relu':
+            gen = torch.relu(gen)
+        elif nl == 'tanh':
+            gen = torch.tanh(gen)
+        elif nl == 'sigmoid':
+            gen = torch.sigmoid(gen)
+        elif nl == 'relutanh':
+            gen = torch.tanh(torch.relu(gen))
+        return self.V_embed * self.beta_vec + gen * (1 - self.beta_vec)
+
+    def _build_handle(self):
+        a = self.args
+        if a.local_loss_func != 'CE1':
+            raise NotImplementedError('only CE1 is reachable from main.py (:127)')
+        gates = {k: getattr(self, k).reshape(-1) if k.startswith('bs') else getattr(self, k)
+                 for k in _GATE_KEYS if hasattr(self, k)}
+        gates = {k: v.numpy() for k, v in gates.items()}
+        return _lib.create_decomp_ifst(
+            self.generalized_vocab_table().numpy(), self.S1.numpy(), self.S2.numpy(),
+            self.wildcard_mat.numpy(), self.C_output_mat.numpy(), self.h0.numpy(), self.hT.numpy(),
+            P=self.priority_full if a.use_priority else None, farnn=a.farnn, gates=gates,
+            sigmoid_exponent=a.sigmoid_exponent, nl=a.update_nonlinear,
+            semiring='max' if a.train_mode == 'max' else 'sum', threshold=a.threshold,
+            o_idx=self.o_idx, use_crf=self.use_crf,
+            crf_trans=None if self.crf_transitions is None else self.crf_transitions.numpy(),
+            device=self.device_index)
+
+    def forward_RE(self, input, label, lengths, train=False):
+        raise NotImplementedError('forward_RE exists only on the onehot models (ref model_onehot.py:148)')

@@ -1,0 +1,116 @@
+"""GPU parity of the decomposed i-FST path (FARNN_S_D_W_I_S mirror -> C-ABI -> HIP) and of the
+fused Viterbi decode, against the reference fixtures and the oracle.  Float path: scores within
+1e-4 (north_star); tags equal."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import farnn_oracle as fo
+from util import ns, load_golden, GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+def _configs():
+    with open(os.path.join(GOLDEN, 'decomp_small.json')) as f:
+        return json.load(f)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _build(g, k, cfg, meta):
+    from re2nn_seq_amd.farnn.model_decompose_single import FARNN_S_D_W_I_S
+    a = ns(independent=2, threshold=meta['threshold'], **cfg)
+    torch.manual_seed(0)
+    m = FARNN_S_D_W_I_S(V=g['V_in'], S1=g['S1_in'], S2=g['S2_in'], C_output_mat=g['O_in'],
+                        wildcard_mat=g['W_in'], wildcard_output_vector=g['Ow_in'],
+                        final_vector=g['final_in'], start_vector=g['start_in'],
+                        pretrained_word_embed=g['E_in'], priority_mat=g['priority_in'], args=a,
+                        o_idx=meta['o_idx'])
+    # exact parameters of the captured reference model (random pads / gates / CRF transitions)
+    pre = 'c{}.'.format(k)
+    sd = {}
+    for key in g.files:
+        if key.startswith(pre) and key not in (pre + 'scores', pre + 'flat_pred'):
+            name = key[len(pre):]
+            name = {'embedding': 'embedding.weight', 'priority_mat': 'priority_layer.priority_mat',
+                    'crf_transitions': 'crf.transitions'}.get(name, name)
+            sd[name] = g[key]
+    m.load_state_dict(sd)
+    return m
+
+
+@pytest.mark.parametrize('k', range(len(_configs()['configs'])))
+def test_decomposed_small_vs_reference(k):
+    from re2nn_seq_amd import _lib
+    meta = _configs()
+    cfg = meta['configs'][k]
+    g = load_golden('decomp_small')
+    x, lengths = g['x'], g['lengths']
+    m = _build(g, k, cfg, meta)
+    pre = 'c{}.'.format(k)
+    ref_scores = g[pre + 'scores']
+    Lmax = int(lengths.max())
+    assert ref_scores.shape[1] == Lmax
+    # FULL mode over the first Lmax columns = the reference's padded loop (ref :221, :236-249)
+    r = m.run(_t(x[:, :Lmax]), _t(lengths), _lib.MODE_FULL, want_scores=True)
+    np.testing.assert_allclose(r['scores'].cpu().numpy(), ref_scores, rtol=1e-4, atol=1e-4)
+    _, pred, true = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    assert pred.dtype == torch.int64
+    assert np.array_equal(pred.numpy(), g[pre + 'flat_pred'])
+    assert true.shape == pred.shape
+
+
+def test_decomposed_constructor_matches_reference_shapes():
+    """The mirror's own constructor (no state loading) builds the reference's parameter set."""
+    meta = _configs()
+    g = load_golden('decomp_small')
+    for k, cfg in enumerate(meta['configs']):
+        m = _build(g, k, cfg, meta)
+        a = ns(independent=2, **cfg)
+        S = g['S1_in'].shape[0] + a.additional_states
+        K = g['O_in'].shape[0] + (2 if a.use_crf else 0)
+        assert tuple(m.S1.shape) == (S, g['S1_in'].shape[1])
+        assert tuple(m.C_output_mat.shape) == (K, S)
+        assert tuple(m.wildcard_mat.shape) == (S, S)
+        assert m.handle.num_columns() == K
+
+
+@pytest.mark.parametrize('tr_kind', ['default', 'random'])
+def test_onehot_ifst_with_fused_viterbi(tr_kind):
+    """BASELINE config 4 (onehot + use_crf=1): the composition SURVEY.md 8a-note defines, checked
+    against the oracle's restatement of the reference's CRF decode chain."""
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    g = load_golden('ifst_small')
+    S, C = g['T'].shape[1], g['O'].shape[0]
+    x, lengths, o_idx = g['x'], g['lengths'], int(g['o_idx'])
+    rng = np.random.RandomState(17)
+    tr = fo.crf_default_transitions(C)
+    if tr_kind == 'random':
+        tr = tr + rng.randn(C + 2, C + 2).astype(np.float32) * 0.5
+    m = FARNN_S_O_I_S(g['T'], g['O'], g['W'], np.zeros(S), g['hT'], g['h0'], None, ns(), o_idx=o_idx)
+    m.enable_crf(tr)
+    _, pred, _ = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    sc = fo.onehot_crf_extension_scores(fo.onehot_ifst_scores(g['T'], g['W'], g['O'], g['h0'], g['hT'], x, lengths))
+    ref = fo.forward_local_tags(sc, lengths, 0.5, o_idx, crf_tr=tr)
+    assert np.array_equal(pred.numpy(), ref)
+
+
+def test_viterbi_atis_scale_vs_oracle():
+    """K=130 tags, L=64, B=64: the Viterbi kernel with its transition table in LDS."""
+    from re2nn_seq_amd import synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(5)
+    V, S, C, B, L = 300, 71, 128, 64, 64
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=8.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    tr = fo.crf_default_transitions(C) + rng.randn(C + 2, C + 2).astype(np.float32)
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, None, ns(), o_idx=3).enable_crf(tr)
+    _, pred, _ = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    sc = fo.onehot_crf_extension_scores(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths))
+    assert np.array_equal(pred.numpy(), fo.forward_local_tags(sc, lengths, 0.5, 3, crf_tr=tr))
