@@ -60,7 +60,10 @@ constexpr int CHAIN_MAX_THREADS = 512;     // NW compute + NLD loader + 1 writer
 constexpr int CHAIN_MAX_NP = 20;           // partial vectors per step (NW * G)
 constexpr int CHAIN_MAX_G = 4;
 
-template <int NCH, bool MAXSR>
+// FQ > 0: fast path for one-phase steps of exactly FQ chunks per compute wavefront (small S): the
+// next step's block share is read from the ring into registers BEFORE the reduce of the current
+// step, so those LDS reads overlap the reduce instead of following it.  FQ == 0: generic loop.
+template <int NCH, bool MAXSR, int FQ>
 __global__ void __launch_bounds__(CHAIN_MAX_THREADS)
 chain_kernel(const ChainParams p) {
     constexpr int PER = 4 * NCH;                 // DMA pieces (1 KiB each) per 4-row chunk
@@ -105,12 +108,13 @@ chain_kernel(const ChainParams p) {
         }
         hp[idx] = v;
     }
-    for (int j = tid; j < SP; j += nthreads) {
-        stash[j] = (j < S) ? hinit[j] : 0.0f;
-        ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
+    for (int j = tid; j < SP; j += nthreads) ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
+    if (nsteps == 0) {
+        for (int j = tid; j < SP; j += nthreads) stash[j] = (j < S) ? hinit[j] : 0.0f;
+        return;
     }
-    __syncthreads();
-    if (nsteps == 0) return;
+    // no barrier yet: the loaders start their DMA below while the other wavefronts finish the
+    // set-up; everybody meets at B_{-1}.
 
     // ---- lane -> (row group, column chunk); the loaders reproduce the compute lanes' mapping ---
     int g = lane / p.LPR;
@@ -133,6 +137,7 @@ chain_kernel(const ChainParams p) {
     // writer wavefront
     // =========================================================================================
     if (w == NW + NLD) {
+        for (int j = lane; j < SP; j += WAVE) stash[j] = (j < S) ? hinit[j] : 0.0f;   // state 0
         wg_barrier_lds();                                            // B_{-1}
         for (int f = (p.dbg & 4) ? NF : 0; f <= NF; f++) {
             wg_barrier_lds();                                        // B_f (f == NF: the final one)
@@ -157,11 +162,10 @@ chain_kernel(const ChainParams p) {
         int mine = 0;                                                // DMA pieces per phase, this loader
         for (int ch = l; ch < nchunks; ch += NLD) mine += PER;
 
-        auto issue_phase = [&](int f) {
-            int t = f / PPS;
+        auto issue_phase = [&](int f, int tokv) {
+            const int t = f / PPS;
             const int ph = f - t * PPS;
-            t = t < nsteps ? t : nsteps - 1;                         // past the end: dummy refills
-            const char *blkp = Mbase + (long long)__builtin_amdgcn_readfirstlane(tok[t]) * blk_bytes;
+            const char *blkp = Mbase + (long long)tokv * blk_bytes;
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(size_t)blkp);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((size_t)blkp >> 32));
             const char *base = reinterpret_cast<const char *>(((size_t)hi << 32) | lo);
@@ -179,20 +183,39 @@ chain_kernel(const ChainParams p) {
                         lds_dma16(lane_off[m] + goff + u * rowb, base, dst + (u * NCH + m) * 1024u);
             }
         };
-
+        // phases in flight after the loader has issued everything up to phase `upto` (exclusive)
+        // and needs phase `need` landed: (upto - 1 - need) phases of `mine` pieces each.
+        const int first = NF < KS ? NF : KS;
         if (!(p.dbg & 1)) {
-            for (int f = 0; f < KS; f++) issue_phase(f);
-            wait_vmcnt((KS - 1) * mine);                             // phase 0 has landed
+            // The first KS phases start before the workgroup's set-up barrier: their token ids come
+            // straight from global memory (all loaded before the first DMA so that the compiler's
+            // wait for them cannot drain DMA already in flight).
+            int tk[8];
+#pragma unroll
+            for (int f = 0; f < 8; f++) {
+                int t = f / PPS;
+                t = t < nsteps ? t : nsteps - 1;
+                const int idx = (dir == 0) ? t : (t < len ? len - 1 - t : t);
+                tk[f] = (f < first) ? (int)p.x[(long long)b * p.L + idx] : 0;
+            }
+#pragma unroll
+            for (int f = 0; f < 8; f++)
+                if (f < first) issue_phase(f, __builtin_amdgcn_readfirstlane(tk[f]));
+            wait_vmcnt((first - 1) * mine);                          // phase 0 has landed
         }
         wg_barrier_lds();                                            // B_{-1}
         if (!(p.dbg & 4)) {
             for (int f = 0; f < NF; f++) {
-                if (!(p.dbg & 1)) wait_vmcnt((KS - 2) * mine);       // phase f+1 has landed
+                if (!(p.dbg & 1)) {
+                    const int issued = (f + KS < NF) ? f + KS : NF;  // phases issued so far
+                    const int inflight_ok = issued - (f + 2);        // those newer than phase f+1
+                    wait_vmcnt((inflight_ok > 0 ? inflight_ok : 0) * mine);
+                }
                 wg_barrier_lds();                                    // B_f: slot f%KS is free again
-                if (!(p.dbg & 1)) issue_phase(f + KS);
+                if (!(p.dbg & 1) && f + KS < NF)
+                    issue_phase(f + KS, __builtin_amdgcn_readfirstlane(tok[(f + KS) / PPS]));
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // dummies land before LDS is freed
         wg_barrier_lds();                                            // final barrier
         return;
     }
@@ -207,66 +230,14 @@ chain_kernel(const ChainParams p) {
     const char *myring = ring + (unsigned)(w * NQP) * (PER * 1024u) + lane * 16;
     const float *myhp = hp + gid * RPGp;
     const int rows_w = p.G * RPG;
+
+    wg_barrier_lds();                                                // B_{-1}: set-up done, phase 0 in LDS
+    int pb = 0;
     // the output-sum entry of the row this lane finishes (rows_w <= 64 in the common geometries)
     const float my_o = (lane < rows_w && w * rows_w + lane < S) ? ol[w * rows_w + lane] : 1.0f;
 
-    wg_barrier_lds();                                                // B_{-1}: phase 0 is in LDS
-    int pb = 0, f = 0;
-    for (int t = 0; t < nsteps && !(p.dbg & 4); t++) {
-#pragma unroll
-        for (int m = 0; m < NCH; m++) acc[m] = MAXSR ? make_float4(ninf, ninf, ninf, ninf)
-                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-        float *pp = part + (long long)pb * NP * SP;
-        for (int ph = 0; ph < PPS; ph++, f++) {
-            const char *src = myring + (unsigned)(f % KS) * phase_bytes;
-            if (!(p.dbg & 2)) {
-                for (int qq = 0; qq < NQP; qq++) {
-                    const int q = ph * NQP + qq;
-                    if (q >= NQ) break;
-                    const float4 hv4 = ld4(myhp + q * 4);
-                    float4 v[4][NCH];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-#pragma unroll
-                        for (int m = 0; m < NCH; m++)
-                            v[u][m] = *reinterpret_cast<const float4 *>(src + (qq * PER + u * NCH + m) * 1024);
-                    const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        bool ok = true;
-                        if (MAXSR) {
-                            const int i = q * 4 + u;
-                            ok = i < RPG && (row0 + i) < S;
-                        }
-#pragma unroll
-                        for (int m = 0; m < NCH; m++) {
-                            if (MAXSR) {
-                                acc[m].x = fmaxf(acc[m].x, ok ? hv[u] * v[u][m].x : ninf);
-                                acc[m].y = fmaxf(acc[m].y, ok ? hv[u] * v[u][m].y : ninf);
-                                acc[m].z = fmaxf(acc[m].z, ok ? hv[u] * v[u][m].z : ninf);
-                                acc[m].w = fmaxf(acc[m].w, ok ? hv[u] * v[u][m].w : ninf);
-                            } else {
-                                acc[m].x = fmaf(hv[u], v[u][m].x, acc[m].x);
-                                acc[m].y = fmaf(hv[u], v[u][m].y, acc[m].y);
-                                acc[m].z = fmaf(hv[u], v[u][m].z, acc[m].z);
-                                acc[m].w = fmaf(hv[u], v[u][m].w, acc[m].w);
-                            }
-                        }
-                    }
-                }
-            }
-            if (ph == PPS - 1 && active) {          // step end: partial sums meet in LDS
-#pragma unroll
-                for (int m = 0; m < NCH; m++) {
-                    const int cc = c + 64 * m;
-                    if (cc < p.CPR) st4(pp + gid * SP + cc * 4, acc[m]);
-                }
-            }
-            wg_barrier_lds();                                        // B_f
-        }
-        pb ^= 1;
-        if (p.dbg & 8) continue;
-        // each compute wavefront finishes exactly the rows it consumes next step
+    // finish the rows this wavefront consumes next step (called right after B_t)
+    auto reduce_rows = [&](int t, const float *pp) {
         float *srow = hfull + (t & 1) * SP;                          // picked up by the writer
         for (int li = lane; li < rows_w; li += WAVE) {
             const int row = w * rows_w + li;
@@ -286,6 +257,105 @@ chain_kernel(const ChainParams p) {
                 const int gi = li / RPG, ii = li - gi * RPG;
                 hp[(w * p.G + gi) * RPGp + ii] = hnext;
             }
+        }
+    };
+    auto fma_chunk = [&](int q, const float4 &hv4, const float4 (&v)[4][NCH]) {
+        const float hv[4] = {hv4.x, hv4.y, hv4.z, hv4.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bool ok = true;
+            if (MAXSR) {
+                const int i = q * 4 + u;
+                ok = i < RPG && (row0 + i) < S;
+            }
+#pragma unroll
+            for (int m = 0; m < NCH; m++) {
+                if (MAXSR) {
+                    acc[m].x = fmaxf(acc[m].x, ok ? hv[u] * v[u][m].x : ninf);
+                    acc[m].y = fmaxf(acc[m].y, ok ? hv[u] * v[u][m].y : ninf);
+                    acc[m].z = fmaxf(acc[m].z, ok ? hv[u] * v[u][m].z : ninf);
+                    acc[m].w = fmaxf(acc[m].w, ok ? hv[u] * v[u][m].w : ninf);
+                } else {
+                    acc[m].x = fmaf(hv[u], v[u][m].x, acc[m].x);
+                    acc[m].y = fmaf(hv[u], v[u][m].y, acc[m].y);
+                    acc[m].z = fmaf(hv[u], v[u][m].z, acc[m].z);
+                    acc[m].w = fmaf(hv[u], v[u][m].w, acc[m].w);
+                }
+            }
+        }
+    };
+    auto write_partials = [&](float *pp) {
+        if (active) {
+#pragma unroll
+            for (int m = 0; m < NCH; m++) {
+                const int cc = c + 64 * m;
+                if (cc < p.CPR) st4(pp + gid * SP + cc * 4, acc[m]);
+            }
+        }
+    };
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int m = 0; m < NCH; m++) acc[m] = MAXSR ? make_float4(ninf, ninf, ninf, ninf)
+                                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+
+    if constexpr (FQ > 0) {
+        // ---- fast path: PPS == 1, NQ == NQP == FQ ---------------------------------------------
+        float4 v[FQ][4][NCH];
+        auto load_step = [&](int t) {
+            const char *src = myring + (unsigned)(t % KS) * phase_bytes;
+#pragma unroll
+            for (int q = 0; q < FQ; q++)
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int m = 0; m < NCH; m++)
+                        v[q][u][m] = *reinterpret_cast<const float4 *>(src + (q * PER + u * NCH + m) * 1024);
+        };
+        load_step(0);
+        for (int t = 0; t < nsteps && !(p.dbg & 4); t++) {
+            reset_acc();
+            float4 hv4[FQ];
+#pragma unroll
+            for (int q = 0; q < FQ; q++) hv4[q] = ld4(myhp + q * 4);
+            if (!(p.dbg & 2)) {
+#pragma unroll
+                for (int q = 0; q < FQ; q++) fma_chunk(q, hv4[q], v[q]);
+            }
+            float *pp = part + (long long)pb * NP * SP;
+            write_partials(pp);
+            wg_barrier_lds();                                        // B_t: step t+1 is in the ring
+            pb ^= 1;
+            if (t + 1 < nsteps) load_step(t + 1);                    // overlaps the reduce below
+            if (!(p.dbg & 8)) reduce_rows(t, pp);
+        }
+    } else {
+        // ---- generic path: PPS phases of up to NQP chunks per step ------------------------------
+        int f = 0;
+        for (int t = 0; t < nsteps && !(p.dbg & 4); t++) {
+            reset_acc();
+            float *pp = part + (long long)pb * NP * SP;
+            for (int ph = 0; ph < PPS; ph++, f++) {
+                const char *src = myring + (unsigned)(f % KS) * phase_bytes;
+                if (!(p.dbg & 2)) {
+                    for (int qq = 0; qq < NQP; qq++) {
+                        const int q = ph * NQP + qq;
+                        if (q >= NQ) break;
+                        const float4 hv4 = ld4(myhp + q * 4);
+                        float4 v[4][NCH];
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+#pragma unroll
+                            for (int m = 0; m < NCH; m++)
+                                v[u][m] = *reinterpret_cast<const float4 *>(src + (qq * PER + u * NCH + m) * 1024);
+                        fma_chunk(q, hv4, v);
+                    }
+                }
+                if (ph == PPS - 1) write_partials(pp);   // step end: partial sums meet in LDS
+                wg_barrier_lds();                                    // B_f
+            }
+            pb ^= 1;
+            if (!(p.dbg & 8)) reduce_rows(t, pp);
         }
     }
     wg_barrier_lds();                                                // final: last state -> writer

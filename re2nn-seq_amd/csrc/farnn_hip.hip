@@ -328,17 +328,22 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     const dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);   // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
-#define FARNN_LAUNCH_CHAIN(NCH, MX)                                                           \
+#define FARNN_LAUNCH_CHAIN(NCH, MX, FQ)                                                       \
     do {                                                                                      \
-        if ((rc = raise_lds_limit(chain_kernel<NCH, MX>, lds))) return rc;                    \
-        chain_kernel<NCH, MX><<<grid, block, lds, s>>>(p);                                    \
+        if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ>, lds))) return rc;                \
+        chain_kernel<NCH, MX, FQ><<<grid, block, lds, s>>>(p);                                \
     } while (0)
-#define FARNN_LAUNCH_CHAIN_MX(NCH)                                                            \
-    do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true); else FARNN_LAUNCH_CHAIN(NCH, false); } while (0)
+#define FARNN_LAUNCH_CHAIN_MX(NCH, FQ)                                                        \
+    do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true, FQ); else FARNN_LAUNCH_CHAIN(NCH, false, FQ); } while (0)
     KernelTimer kt(m, KERN_CHAIN, s);
-    if (g.NCH == 1) FARNN_LAUNCH_CHAIN_MX(1);
-    else if (g.NCH == 2) FARNN_LAUNCH_CHAIN_MX(2);
-    else if (g.NCH <= 4) FARNN_LAUNCH_CHAIN_MX(4);
+    const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= 3 && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
+    if (g.NCH == 1) {
+        if (fq == 1) FARNN_LAUNCH_CHAIN_MX(1, 1);
+        else if (fq == 2) FARNN_LAUNCH_CHAIN_MX(1, 2);
+        else if (fq == 3) FARNN_LAUNCH_CHAIN_MX(1, 3);
+        else FARNN_LAUNCH_CHAIN_MX(1, 0);
+    } else if (g.NCH == 2) FARNN_LAUNCH_CHAIN_MX(2, 0);
+    else if (g.NCH <= 4) FARNN_LAUNCH_CHAIN_MX(4, 0);
     else return fail(FARNN_ERANGE, "unsupported state count%s%s");
 #undef FARNN_LAUNCH_CHAIN_MX
 #undef FARNN_LAUNCH_CHAIN

@@ -1,0 +1,81 @@
+"""Decomposed-automaton pickle -> initial parameters (reference src_seq/init_params.py:221-320,
+``get_init_params_seq_independent_single``: the ``--independent 2`` loader).
+
+Pickle schema (writer: reference wfa/decompose_automata.py:373-431):
+    {'automata': dict,
+     seed: [ {rank: {'V':[V,R], 'S1':[S,R], 'S2':[S,R], 'wildcard_mat':[S,S]}},
+             {'output_mat':[C,S],   'output_wildcard_vector':[S]},      # non-CE1
+             {'output_mat':[C+1,S], 'output_wildcard_vector':[S]} ]}    # CE1
+Quirks kept: `[args.rank]` indexes only the factor dict (:239-240); CE1 picks entry [2]
+(:234-235); a zero pad row is appended to V_embed and to the word embeddings (:280-281);
+start/final vectors are indexed with raw state ids.  numpy-2 note: the reference's `np.float`
+is spelled `np.float64` here.
+"""
+import os
+
+import numpy as np
+
+from .create_logic_mat_bias import create_mat_priority
+from .data import load_fasttext_embed, load_glove_embed
+from .utils import get_average, load_pkl, xavier_normal
+
+
+def get_init_params_seq_independent_single(args, s2i, t2i, data_dir='../data/'):
+    print("Start getting initial decompsoed parameters V C S1 S2...")
+    dpath = os.path.join(data_dir, args.dataset)
+    loader = load_glove_embed if args.embed_type == 'glove' else load_fasttext_embed
+    pretrained_embed = loader(dpath, args.embed_dim)
+    if args.random_embed:
+        pretrained_embed = np.random.random(pretrained_embed.shape)
+
+    automata_dicts = load_pkl(args.automata_path)
+    print("Loading automata: {}".format(args.automata_path))
+    per_seed = automata_dicts[args.seed]
+    factor_dicts = per_seed[0][args.rank]
+    factor_output_dicts = per_seed[2] if args.local_loss_func == 'CE1' else per_seed[1]
+    automata = automata_dicts['automata']
+
+    V_embed, S1, S2 = factor_dicts['V'], factor_dicts['S1'], factor_dicts['S2']
+    wildcard_mat = factor_dicts['wildcard_mat']
+    C_output_mat = factor_output_dicts['output_mat']
+    wildcard_output_vector = factor_output_dicts['output_wildcard_vector']
+
+    corrupt = 1e5          # the reference only reports these counts (:249-262)
+    print('Invalid Positive Values: {}'.format(
+        int(np.sum(V_embed > corrupt) + np.sum(S1 > corrupt) + np.sum(S2 > corrupt))))
+    print('Invalid Negative Values: {}'.format(
+        int(np.sum(V_embed < -corrupt) + np.sum(S1 < -corrupt) + np.sum(S2 < -corrupt))))
+
+    n_state, rank = S1.shape
+    final_vector = np.zeros(n_state)
+    final_vector[automata['finalstates']] = 1
+    start_vector = np.zeros(n_state)
+    start_vector[automata['startstate']] = 1
+    print("DFA states: {}".format(n_state))
+
+    pretrain_embed_extend = np.append(pretrained_embed, np.zeros((1, args.embed_dim), dtype=np.float64), axis=0)
+    V_embed_extend = np.append(V_embed, np.zeros((1, rank), dtype=np.float64), axis=0)
+    priority_mat = create_mat_priority(s2i, args)
+
+    if args.normalize_automata != 'none':       # (:285-297)
+        print('Normalize automata decomposed parameters...')
+        v_avg = get_average(V_embed_extend, args.normalize_automata)
+        s1_avg = get_average(S1, args.normalize_automata)
+        s2_avg = get_average(S2, args.normalize_automata)
+        factor = np.float_power(v_avg * s1_avg * s2_avg, 1 / 3)
+        S1 = S1 * (factor / s1_avg)
+        S2 = S2 * (factor / s2_avg)
+        V_embed_extend = V_embed_extend * (factor / v_avg)
+
+    if args.random == 1:                         # (:299-308)
+        V_embed_extend, S1, S2 = xavier_normal(V_embed_extend), xavier_normal(S1), xavier_normal(S2)
+        wildcard_mat = xavier_normal(wildcard_mat)
+        wildcard_output_vector = xavier_normal(wildcard_output_vector)
+        final_vector, start_vector = xavier_normal(final_vector), xavier_normal(start_vector)
+        C_output_mat = xavier_normal(C_output_mat)
+        assert args.use_priority == 0
+
+    if bool(getattr(args, 'use_bert', 0)):
+        raise NotImplementedError('the BERT front-end is outside the forward tagging path (SURVEY.md 2, row 23)')
+    return (V_embed_extend, S1, S2, pretrain_embed_extend, wildcard_mat, wildcard_output_vector,
+            final_vector, start_vector, priority_mat, C_output_mat, None)

@@ -297,3 +297,38 @@ def random_decomposed_params(V, S, C, R, D, rng, scale=None):
     p['start_vector'] = h0
     p['final_vector'] = hT
     return p
+
+
+# --------------------------------------------------------------------------- on-disk trees
+def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n_states=20, seed=0,
+                       n_train=48, n_dev=24, n_test=24, max_len=16, embed_dim=16, ranks=(100,)):
+    """Write a complete, schema-identical data directory for the CLI drivers:
+        <root>/<dataset>/dataset.pkl
+        <root>/<dataset>/glove.<dim>.emb
+        <root>/<dataset>/automata/synthetic.ID{0,1,2}           (automaton dict, one per --independent)
+        <root>/<dataset>/automata/IIID.automata.synthetic.pkl   (decomposed i-FST)
+    Returns a dict of the paths and the generated objects."""
+    import os
+    import pickle
+    rng = np.random.RandomState(seed + 1000)
+    dset, automaton, rules = make_dataset(n_words, n_entity_types, n_states, seed,
+                                          n_train=n_train, n_dev=n_dev, n_test=n_test, max_len=max_len)
+    ddir = os.path.join(root, dataset)
+    adir = os.path.join(ddir, 'automata')
+    os.makedirs(adir, exist_ok=True)
+    with open(os.path.join(ddir, 'dataset.pkl'), 'wb') as f:
+        pickle.dump(dset, f)
+    with open(os.path.join(ddir, 'glove.{}.emb'.format(embed_dim)), 'wb') as f:
+        pickle.dump(rng.randn(len(dset['t2i']), embed_dim) * 0.5, f)
+    paths = {'data_dir': root + ('' if root.endswith('/') else '/'), 'dataset_dir': ddir}
+    for ind in (0, 1, 2):
+        p = os.path.join(adir, 'synthetic.ID{}'.format(ind))
+        with open(p, 'wb') as f:
+            pickle.dump({'automata': automaton} if ind == 2 else automaton, f)   # both wrappers occur
+        paths['ID{}'.format(ind)] = p
+    iiid = make_iiid_pickle_dict(automaton, dset['t2i'], dset['s2i'], ranks=list(ranks), rng=rng)
+    p = os.path.join(adir, 'IIID.automata.synthetic.pkl')
+    with open(p, 'wb') as f:
+        pickle.dump(iiid, f)
+    paths['IIID'] = p
+    return {'paths': paths, 'dset': dset, 'automaton': automaton, 'rules': rules}

@@ -344,6 +344,24 @@ def gen_metrics(dset, s2i):
     print('wrote tests/golden/metrics_small.json')
 
 
+def gen_cli_flags():
+    """Flag names / types / defaults of the reference CLI, parsed from its argparse calls (the
+    module itself cannot be imported here: it pulls in fasttext/pydash via data.py).  Also copies
+    one of the reference's shipped example result files (a data file) as the --args_path fixture."""
+    import re
+    import shutil
+    src = open('/root/reference/src_seq/main.py').read()
+    flags = []
+    for m in re.finditer(r"parser\.add_argument\('--(\w+)',\s*type=(\w+),\s*default=([^,]+?),\s*help", src):
+        flags.append([m.group(1), m.group(2), eval(m.group(3).strip())])
+    with open(os.path.join(HERE, 'cli_flags.json'), 'w') as f:
+        json.dump({'flags': flags}, f, indent=0)
+    shutil.copy('/root/reference/model_seq/example/ATIS-ZH.FSTRNN.0%.softmax.7503.res',
+                os.path.join(HERE, 'example_ATIS-ZH_0pct.res'))
+    print('wrote tests/golden/cli_flags.json ({} flags) and example_ATIS-ZH_0pct.res'.format(len(flags)))
+
+
+
 if __name__ == '__main__':
     dset, automaton, t2i, s2i = gen_loader()
     x, lengths = gen_onehot(dset, automaton, t2i, s2i)
@@ -351,3 +369,4 @@ if __name__ == '__main__':
     gen_crf()
     gen_atis_scale()
     gen_metrics(dset, s2i)
+    gen_cli_flags()

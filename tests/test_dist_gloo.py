@@ -1,0 +1,71 @@
+"""The N>1 path on CPU: world_size-2 gloo.  Every rank tags its contiguous slice of the batch and
+one all-gather returns the tag ids (re2nn_seq_amd/dist.py); the per-shard tagger here is the CPU
+oracle (this is a test), the collective and the sharding arithmetic are the product code."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, B, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from oracle import farnn_oracle as fo
+    from re2nn_seq_amd import dist as fdist, synth
+    rng = np.random.RandomState(11)                      # same weights and batch on every rank
+    V, S, C, L = 40, 9, 6, 10
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=5.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+
+    def tag_fn(xs, ls):
+        if xs.shape[0] == 0:
+            return torch.zeros((0, L), dtype=torch.int32)
+        sc = fo.onehot_ifst_scores(T, W, O, h0, hT, xs.numpy(), ls.numpy())
+        return torch.from_numpy(fo.decode_argmax(sc, 0.5, 0).astype(np.int32))
+
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    lo, hi = fdist.shard_bounds(B, rank, world)
+    assert fdist.shard_batch(xt, lt)[2] == (lo, hi)
+    tags = fdist.tag_sharded(tag_fn, xt, lt)
+    full = fo.decode_argmax(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths), 0.5, 0)
+    ok = tags.shape == (B, L) and np.array_equal(tags.numpy().astype(np.int64), full)
+    with open(os.path.join(out_dir, 'rank{}.txt'.format(rank)), 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('B', [8, 7, 1])
+def test_sharded_tagging_two_ranks_gloo(tmp_path, B):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / 'rank{}.txt'.format(r)).read_text() == 'ok'
+
+
+def test_shard_bounds_cover_the_batch():
+    from re2nn_seq_amd.dist import shard_bounds
+    for n in (0, 1, 7, 8, 256, 8192):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
