@@ -1,0 +1,17 @@
+# Round profile: bench line + rocprofv3 kernel trace + PMC passes (FETCH_SIZE / WRITE_SIZE / L2 hit) in
+# separate runs, as MI355X_MICROARCH.md prescribes (counters never combined with trace domains).
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/prof_r01
+rm -rf $O; mkdir -p $O
+python bench.py 2>/dev/null > $O/bench_ifst.json
+python bench.py --full-length --no-cpu-baseline 2>/dev/null > $O/bench_ifst_full.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_write.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $O/pmc_l2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_full -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --full-length > $O/pmc_fetch_full.log 2>&1
+find $O -name '*.csv' | head -30
+# keep only the small summaries (kernel_stats + counter collection), drop per-dispatch traces > 5 MB
+find $O -name '*.csv' -size +5M -delete
+du -sh $O
