@@ -165,9 +165,11 @@ int  farnn_num_columns(const farnn_model *m);              /* K of the scores te
 /* algorithmic HBM bytes of one farnn_tag() call with `valid_tokens` tagged tokens
  * (SURVEY.md 8d / DESIGN.md: per-token figure x tokens), for the roofline line of bench.py */
 double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_tokens);
-/* per-kernel timing with HIP events recorded on the launch stream.  enable=1 starts
- * collecting; farnn_kernel_time() synchronises, then reports the accumulated milliseconds
- * and launch count of kernel `which` (0 = recurrence chain, 1 = score+decode, 2 = prep). */
+/* per-kernel timing with HIP events recorded on the launch stream.  enable=N>0 starts collecting
+ * on every N-th farnn_tag() call (N=1: every call; event records cost a few microseconds of
+ * launch latency each, so a stride keeps the timed region honest); enable=0 stops.
+ * farnn_kernel_time() synchronises, then reports the accumulated milliseconds and the number of
+ * timed launches of kernel `which` (0 = recurrence chain, 1 = score+decode, 2 = prep). */
 int  farnn_set_profiling(farnn_model *m, int32_t enable);
 int  farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms, int64_t *launches);
 const char *farnn_kernel_name(const farnn_model *m, int32_t which);

@@ -157,8 +157,9 @@ class Handle:
     def algorithmic_bytes(self, valid_tokens):
         return load().farnn_algorithmic_bytes(self.raw, int(valid_tokens))
 
-    def set_profiling(self, on):
-        check(load().farnn_set_profiling(self.raw, 1 if on else 0), 'farnn_set_profiling')
+    def set_profiling(self, every):
+        """every=0 off; every=N: time every N-th farnn_tag call with HIP events."""
+        check(load().farnn_set_profiling(self.raw, int(every)), 'farnn_set_profiling')
 
     def kernel_time(self, which):
         ms, n = C.c_double(0), C.c_int64(0)

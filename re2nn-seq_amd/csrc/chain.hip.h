@@ -176,11 +176,13 @@ chain_kernel(const ChainParams p) {
                 q = q < NQ ? q : NQ - 1;                             // ragged last phase: harmless re-read
                 const unsigned goff = (unsigned)w2 * wave_stride + (unsigned)(q * 4) * rowb;
                 const unsigned dst = dst0 + (unsigned)ch * (PER * 1024u);
+                // the chunk's PER pieces are consecutive in LDS in (u, m) order: 4 per statement
+                unsigned vo[PER];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int k = 0; k < PER; k++) vo[k] = lane_off[k % NCH] + goff + (unsigned)(k / NCH) * rowb;
 #pragma unroll
-                    for (int m = 0; m < NCH; m++)
-                        lds_dma16(lane_off[m] + goff + u * rowb, base, dst + (u * NCH + m) * 1024u);
+                for (int k = 0; k < PER; k += 4)
+                    lds_dma16x4(vo[k], vo[k + 1], vo[k + 2], vo[k + 3], base, dst + (unsigned)k * 1024u);
             }
         };
         // phases in flight after the loader has issued everything up to phase `upto` (exclusive)
@@ -236,23 +238,41 @@ chain_kernel(const ChainParams p) {
     // the output-sum entry of the row this lane finishes (rows_w <= 64 in the common geometries)
     const float my_o = (lane < rows_w && w * rows_w + lane < S) ? ol[w * rows_w + lane] : 1.0f;
 
-    // finish the rows this wavefront consumes next step (called right after B_t)
+    // finish the rows this wavefront consumes next step (called right after B_t).  Lane li owns
+    // row w*rows_w + li; everything that does not depend on the step is hoisted out of the loop.
+    const int my_row = w * rows_w + lane;
+    const bool my_valid = lane < rows_w && my_row < S;
+    const int my_hp = my_valid ? (w * p.G + lane / RPG) * RPGp + lane % RPG : 0;
+    const int nl_mode = p.nl;
+    auto finish = [&](float s, float ov, float &hn, float &hnext) {
+        if (dir == 0) { hn = apply_nl(s * ov, nl_mode); hnext = hn; }      // (:377-386)
+        else          { hn = apply_nl(s, nl_mode);      hnext = hn * ov; } // (:393-402)
+    };
     auto reduce_rows = [&](int t, const float *pp) {
         float *srow = hfull + (t & 1) * SP;                          // picked up by the writer
-        for (int li = lane; li < rows_w; li += WAVE) {
+        if (my_valid) {
+            const float *col = pp + my_row;
+            float s = col[0];
+#pragma unroll 4
+            for (int q2 = 1; q2 < NP; q2++) {
+                const float v = col[q2 * SP];
+                s = MAXSR ? fmaxf(s, v) : s + v;
+            }
+            float hn, hnext;
+            finish(s, my_o, hn, hnext);
+            srow[my_row] = hn;
+            hp[my_hp] = hnext;
+        }
+        for (int li = lane + WAVE; li < rows_w; li += WAVE) {        // only when a wave owns > 64 rows
             const int row = w * rows_w + li;
             if (row < S) {
-                float pv[CHAIN_MAX_NP];
-#pragma unroll
-                for (int q2 = 0; q2 < CHAIN_MAX_NP; q2++) pv[q2] = (q2 < NP) ? pp[q2 * SP + row] : 0.0f;
-                float s = pv[0];
-#pragma unroll
-                for (int q2 = 1; q2 < CHAIN_MAX_NP; q2++)
-                    if (q2 < NP) s = MAXSR ? fmaxf(s, pv[q2]) : s + pv[q2];
-                const float ov = (li == lane) ? my_o : ol[row];
+                float s = pp[row];
+                for (int q2 = 1; q2 < NP; q2++) {
+                    const float v = pp[q2 * SP + row];
+                    s = MAXSR ? fmaxf(s, v) : s + v;
+                }
                 float hn, hnext;
-                if (dir == 0) { hn = apply_nl(s * ov, p.nl); hnext = hn; }      // (:377-386)
-                else          { hn = apply_nl(s, p.nl);      hnext = hn * ov; } // (:393-402)
+                finish(s, ol[row], hn, hnext);
                 srow[row] = hn;
                 const int gi = li / RPG, ii = li - gi * RPG;
                 hp[(w * p.G + gi) * RPGp + ii] = hnext;
@@ -408,7 +428,7 @@ inline ChainGeom chain_geometry_nw(int S, int nw, int nld) {
 }
 
 inline ChainGeom chain_geometry(int S, int rows_per_group_target, int nld, int L_hint = 128) {
-    nld = nld < 1 ? 1 : (nld > 3 ? 3 : nld);
+    nld = nld < 1 ? 1 : (nld > 4 ? 4 : nld);
     const int nw_max = CHAIN_MAX_THREADS / 64 - 1 - nld;
     ChainGeom g0 = chain_geometry_nw(S, 1, nld);
     int groups = (S + rows_per_group_target - 1) / rows_per_group_target;

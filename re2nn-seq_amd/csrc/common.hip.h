@@ -79,6 +79,32 @@ __device__ __forceinline__ void lds_dma16(unsigned voff, const char *base, unsig
                  : "memory");
 }
 
+// Four consecutive pieces (LDS destinations lds, lds+1K, lds+2K, lds+3K) in one statement: M0 is
+// saved/restored once and advanced with s_add between the loads, which trims the scalar overhead
+// the loaders pay per piece (the DMA issue itself costs ~60-100 cycles).
+__device__ __forceinline__ void lds_dma16x4(unsigned v0, unsigned v1, unsigned v2, unsigned v3,
+                                            const char *base, unsigned lds) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %6\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %3, %5\n\t"
+                 "s_add_u32 m0, m0, 0x400\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %4, %5\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(base), "s"(lds)
+                 : "memory", "scc");
+}
+
 // Workgroup barrier that orders LDS traffic only (lgkmcnt), never the vector-memory counter.
 __device__ __forceinline__ void wg_barrier_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

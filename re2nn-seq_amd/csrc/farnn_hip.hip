@@ -45,7 +45,9 @@ struct farnn_model {
     int wsB = 0, wsL = 0;
     ChainGeom geom;
     int chain_ks = 3;
-    int profiling = 0;
+    int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
+    long long calls = 0;
+    int prof_this_call = 0;
     Prof prof;
     std::vector<void *> owned;              // everything to hipFree at destroy
 };
@@ -166,7 +168,7 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
     m->K = d->C + (m->use_crf ? 2 : 0);
     m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -245,7 +247,7 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
 struct KernelTimer {
     farnn_model *m; int which; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
     KernelTimer(farnn_model *m_, int w, hipStream_t s_) : m(m_), which(w), s(s_) {
-        if (m->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
+        if (m->prof_this_call && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
             (void)hipEventRecord(e0, s);
     }
     ~KernelTimer() {
@@ -276,7 +278,8 @@ extern "C" int farnn_set_profiling(farnn_model *m, int32_t enable) {
     if (!m) return fail(FARNN_EINVAL, "null model%s%s");
     prof_fold(m);
     if (enable) for (int k = 0; k < KERN_COUNT; k++) { m->prof.ms[k] = 0; m->prof.n[k] = 0; }
-    m->profiling = enable ? 1 : 0;
+    m->profiling = enable > 0 ? enable : 0;
+    m->calls = 0;
     return FARNN_OK;
 }
 
@@ -405,6 +408,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
         if ((rc = farnn_reserve(m, B > keepB ? B : keepB, L))) return rc;
     }
     const int full = mode == FARNN_MODE_FULL;
+    m->prof_this_call = m->profiling > 0 && (m->calls++ % m->profiling) == 0;
     if (flat_tags) {
         KernelTimer kt(m, KERN_PREP, s);
         lengths_scan_kernel<<<1, 1024, 0, s>>>(lengths, m->offs, B);
@@ -456,7 +460,7 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
     m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -497,7 +501,7 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     m->mask_by_output = d->mask_by_output;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 2));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
