@@ -95,6 +95,13 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length):
     if full_length:
         lengths[:] = L
         x, _ = synth.random_batch(V, B, L, brng, min_len=L)
+    order = os.environ.get('FARNN_BENCH_ORDER')
+    if order:        # experiment: input permutations that change which sequences share a CU
+        idx = np.argsort(-lengths, kind='stable')
+        if order == 'fold':
+            half = B // 2
+            idx = np.concatenate([idx[:half], idx[half:][::-1]])
+        x, lengths = x[idx], lengths[idx]
     return h, x, lengths, extras
 
 

@@ -48,6 +48,7 @@ struct ChainParams {
     const float *h0, *hT;   // [S]
     const int64_t *x;       // [B][L]
     const int64_t *len;     // [B]
+    const int *order;       // [B] launch order (batch_prep_kernel) or nullptr
     float *A, *Bk;          // stash [B][L+1][SP]: forward / backward states by step count
     int B, L, S, SP, CPR;   // CPR = SP/4 column chunks per row
     int NW, NLD, G, LPR, RPG, RPGp, NQ, KS;
@@ -72,7 +73,7 @@ chain_kernel(const ChainParams p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int nthreads = blockDim.x;
     const int item = blockIdx.x;
-    const int b = item >> 1, dir = item & 1;
+    const int b = p.order ? p.order[item >> 1] : (item >> 1), dir = item & 1;
     const int len = (int)p.len[b];
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ, KS = p.KS;

@@ -42,9 +42,11 @@ struct farnn_model {
     // workspace
     float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
     int64_t *offs = nullptr;
+    int *order = nullptr;
     int wsB = 0, wsL = 0;
     ChainGeom geom;
     int chain_ks = 3;
+    bool order_valid = false;
     int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
     long long calls = 0;
     int prof_this_call = 0;
@@ -226,14 +228,15 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     int nB = B > m->wsB ? B : m->wsB, nL = L > m->wsL ? L : m->wsL;
     if (m->A) {
         FARNN_HIP_TRY(hipDeviceSynchronize());
-        (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs);
+        (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); (void)hipFree(m->order);
         if (m->crf_scores) (void)hipFree(m->crf_scores);
     }
-    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->wsB = m->wsL = 0;
+    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->wsB = m->wsL = 0;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
+    FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float)));
     FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
@@ -297,7 +300,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
         case KERN_CHAIN: return m->kind == KIND_DECOMP ? "decomp_chain_kernel" : "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel" : "score_decode_kernel");
-        case KERN_PREP:  return "lengths_scan_kernel";
+        case KERN_PREP:  return "batch_prep_kernel";
         default: return "";
     }
 }
@@ -318,6 +321,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     ChainParams p;
     p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
+    p.order = m->order_valid ? m->order : nullptr;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
     p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
@@ -409,9 +413,14 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     }
     const int full = mode == FARNN_MODE_FULL;
     m->prof_this_call = m->profiling > 0 && (m->calls++ % m->profiling) == 0;
-    if (flat_tags) {
+    // batch preparation: flat-output offsets and the length-sorted launch order (full mode runs
+    // every sequence for L steps, so there is nothing to balance)
+    const bool want_order = !full && B > 2 && !env_int("FARNN_NOSORT", 0);
+    m->order_valid = want_order;
+    if (flat_tags || want_order) {
         KernelTimer kt(m, KERN_PREP, s);
-        lengths_scan_kernel<<<1, 1024, 0, s>>>(lengths, m->offs, B);
+        batch_prep_kernel<<<1, 1024, (size_t)(L + 2) * sizeof(int), s>>>(
+            lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L);
         FARNN_HIP_TRY(hipGetLastError());
     }
     switch (m->kind) {
@@ -620,6 +629,7 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->A) (void)hipFree(m->A);
     if (m->Bk) (void)hipFree(m->Bk);
     if (m->offs) (void)hipFree(m->offs);
+    if (m->order) (void)hipFree(m->order);
     if (m->crf_scores) (void)hipFree(m->crf_scores);
     delete m;
 }

@@ -301,26 +301,58 @@ inline size_t viterbi_lds_bytes(int K, int Kp, int L, int tr_in_lds) {
     return bytes;
 }
 
-// exclusive prefix sum of lengths -> offs[B+1] (one workgroup; B is a batch size, not a corpus)
+// Batch preparation (one workgroup; B is a batch size, not a corpus):
+//   offs[B+1]  exclusive prefix sum of lengths -> where each sequence starts in the flat output
+//   order[B]   launch order of the chain kernel: sequences sorted by length (descending, counting
+//              sort) and folded so that block i and block i + B/2 pair a long with a short one.
+//              Workgroups that share a CU share its memory path; on a ragged batch the unsorted
+//              order left the longest chains co-located (58 us vs 44 us for the same work).
 __global__ void __launch_bounds__(1024)
-lengths_scan_kernel(const int64_t *len, int64_t *offs, int B) {
+batch_prep_kernel(const int64_t *len, int64_t *offs, int *order, int B, int L) {
+    extern __shared__ __align__(16) int prep_smem[];
     __shared__ long long sums[1024];
     const int tid = threadIdx.x;
-    const int per = (B + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, B);
-    long long s = 0;
-    for (int i = lo; i < hi; i++) s += len[i];
-    sums[tid] = s;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        long long v = (tid >= off) ? sums[tid - off] : 0;
+    if (offs) {
+        const int per = (B + 1023) / 1024;
+        const int lo = tid * per, hi = min(lo + per, B);
+        long long s = 0;
+        for (int i = lo; i < hi; i++) s += len[i];
+        sums[tid] = s;
         __syncthreads();
-        sums[tid] += v;
-        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            long long v = (tid >= off) ? sums[tid - off] : 0;
+            __syncthreads();
+            sums[tid] += v;
+            __syncthreads();
+        }
+        long long run = (tid == 0) ? 0 : sums[tid - 1];
+        for (int i = lo; i < hi; i++) { offs[i] = run; run += len[i]; }
+        if (tid == 1023) offs[B] = sums[1023];
     }
-    long long run = (tid == 0) ? 0 : sums[tid - 1];
-    for (int i = lo; i < hi; i++) { offs[i] = run; run += len[i]; }
-    if (tid == 1023) offs[B] = sums[1023];
+    if (order) {
+        int *cnt = prep_smem;                 // [L+2] histogram, then bucket cursors
+        for (int i = tid; i < L + 2; i += 1024) cnt[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < B; i += 1024) {
+            int n = (int)len[i];
+            n = n < 0 ? 0 : (n > L ? L : n);
+            atomicAdd(&cnt[n], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {                       // descending lengths: bucket L first
+            int run = 0;
+            for (int n = L; n >= 0; n--) { int c = cnt[n]; cnt[n] = run; run += c; }
+        }
+        __syncthreads();
+        const int half = B / 2;
+        for (int i = tid; i < B; i += 1024) {
+            int n = (int)len[i];
+            n = n < 0 ? 0 : (n > L ? L : n);
+            const int pos = atomicAdd(&cnt[n], 1);                    // rank in descending order
+            const int slot = pos < half ? pos : half + (B - 1 - pos);  // fold the shorter half
+            order[slot] = i;
+        }
+    }
 }
 
 }  // namespace farnn
