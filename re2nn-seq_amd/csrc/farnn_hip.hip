@@ -367,19 +367,30 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
+    p.dbg = env_int("FARNN_DBG", 0);
     const int hasP = m->P ? 1 : 0;
     const int ot = score_lds_bytes(m->S, m->SP, m->Kc, hasP, 1) <= 150 * 1024 ? 1 : 0;
     const size_t lds = score_lds_bytes(m->S, m->SP, m->Kc, hasP, ot);
     const dim3 grid((p.L + SCORE_TT - 1) / SCORE_TT, B), block(SCORE_WAVES * 64);
     int rc;
     KernelTimer kt(m, KERN_SCORE, s);
-    if (ot) {
-        if ((rc = raise_lds_limit(score_tile_kernel<true>, lds))) return rc;
-        score_tile_kernel<true><<<grid, block, lds, s>>>(p);
-    } else {
-        if ((rc = raise_lds_limit(score_tile_kernel<false>, lds))) return rc;
-        score_tile_kernel<false><<<grid, block, lds, s>>>(p);
-    }
+#define FARNN_LAUNCH_SCORE(OT_, KCH_)                                                         \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(score_tile_kernel<OT_, KCH_>, lds))) return rc;             \
+        score_tile_kernel<OT_, KCH_><<<grid, block, lds, s>>>(p);                             \
+    } while (0)
+#define FARNN_LAUNCH_SCORE_K(OT_)                                                             \
+    do {                                                                                      \
+        switch (p.kch) {                                                                      \
+            case 1: FARNN_LAUNCH_SCORE(OT_, 1); break;                                        \
+            case 2: FARNN_LAUNCH_SCORE(OT_, 2); break;                                        \
+            case 3: FARNN_LAUNCH_SCORE(OT_, 3); break;                                        \
+            default: FARNN_LAUNCH_SCORE(OT_, 4); break;                                       \
+        }                                                                                     \
+    } while (0)
+    if (ot) FARNN_LAUNCH_SCORE_K(true); else FARNN_LAUNCH_SCORE_K(false);
+#undef FARNN_LAUNCH_SCORE_K
+#undef FARNN_LAUNCH_SCORE
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf) {
         const int tr = viterbi_lds_bytes(m->K, m->Kp, p.L, 1) <= 150 * 1024 ? 1 : 0;

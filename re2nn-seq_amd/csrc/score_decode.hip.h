@@ -35,13 +35,17 @@ struct ScoreParams {
     int B, L, S, SP, K, Kp, Kc, kch;
     int full, use_crf, o_idx;
     float threshold;
+    int dbg;                // diagnostic ablation mask (FARNN_DBG bits 16/32/64); 0 in production
 };
 
 constexpr int SCORE_KCH = 4;       // label columns per lane: K <= 256
 constexpr int SCORE_WAVES = 8;
 constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 
-template <bool OT_LDS>
+// KCH = label columns per lane (K <= 64*KCH): compile-time so that the register-blocked loops are
+// fully unrolled with no per-column guards (with a runtime bound hipcc emitted one scalar branch
+// per column and the GEMM loop ran 3x slower).
+template <bool OT_LDS, int KCH>
 __global__ void __launch_bounds__(SCORE_WAVES * 64)
 score_tile_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -51,7 +55,7 @@ score_tile_kernel(const ScoreParams p) {
     const int b = blockIdx.y, t0 = blockIdx.x * SCORE_TT;
     const int len = (int)p.len[b];
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc, kch = p.kch;
+    const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc;
     const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
     const int ntL = min(SCORE_TT, p.L - t0);             // tokens of this tile that exist
 
@@ -70,7 +74,7 @@ score_tile_kernel(const ScoreParams p) {
     float *scw = nullptr;                                // [waves][Kc] one score row per wave (P)
     if (p.P) { scw = cur; cur += SCORE_WAVES * Kc; }
     float *otl = cur;                                    // [S][Kc] rounded up to whole DMA pieces
-    if (OT_LDS) {
+    if (OT_LDS && !(p.dbg & 16)) {
         // LDS-DMA: 1 KiB pieces, round-robin over the wavefronts; lands while phase 1 runs
         const unsigned ot_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)otl);
         const int pieces = (S * Kc * 4 + 1023) / 1024;
@@ -114,12 +118,12 @@ score_tile_kernel(const ScoreParams p) {
     if (tg >= nt && tg >= ntL) return;
     const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
     const long long foff = p.offs ? p.offs[b] : 0;
-    float acc[4][SCORE_KCH];
+    float acc[4][KCH];
 #pragma unroll
     for (int j = 0; j < 4; j++)
 #pragma unroll
-        for (int k = 0; k < SCORE_KCH; k++) acc[j][k] = 0.0f;
-    if (tg < nt) {
+        for (int k = 0; k < KCH; k++) acc[j][k] = 0.0f;
+    if (tg < nt && !(p.dbg & 32)) {
         const float *abw = ab + tg * SP;
         const float *otb = (OT_LDS ? otl : p.OT) + lane;
         for (int s0 = 0; s0 < S; s0 += 4) {
@@ -129,18 +133,18 @@ score_tile_kernel(const ScoreParams p) {
                 const float4 a4 = ld4(abw + j * SP + s0);              // LDS broadcast
                 av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
             }
-            float ov[4][SCORE_KCH];
+            float ov[4][KCH];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const int srow = (s0 + u < S) ? s0 + u : S - 1;        // ab pad columns are zero
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++)
-                    ov[u][k] = (k < kch) ? otb[(long long)srow * Kc + 64 * k] : 0.0f;
+                for (int k = 0; k < KCH; k++)
+                    ov[u][k] = otb[(long long)srow * Kc + 64 * k];
             }
 #pragma unroll
             for (int u = 0; u < 4; u++)
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++)
+                for (int k = 0; k < KCH; k++)
 #pragma unroll
                     for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov[u][k], acc[j][k]);
         }
@@ -149,39 +153,39 @@ score_tile_kernel(const ScoreParams p) {
     for (int j = 0; j < 4; j++) {
         const int i = t0 + tg + j;
         if (tg + j < nt) {
-            float sc[SCORE_KCH];
+            float sc[KCH];
 #pragma unroll
-            for (int k = 0; k < SCORE_KCH; k++) sc[k] = acc[j][k];
+            for (int k = 0; k < KCH; k++) sc[k] = acc[j][k];
             if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
                 float *sr = scw + w * Kc;
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++) if (k < kch) sr[lane + 64 * k] = sc[k];
+                for (int k = 0; k < KCH; k++) sr[lane + 64 * k] = sc[k];
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++) sc[k] = 0.0f;
+                for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
                 for (int cc = 0; cc < K; cc++) {
                     const float sv = sr[cc];
                     const float *prow = p.P + (long long)cc * Kc + lane;
 #pragma unroll
-                    for (int k = 0; k < SCORE_KCH; k++)
-                        if (k < kch) sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                    for (int k = 0; k < KCH; k++)
+                        sc[k] = fmaf(sv, prow[64 * k], sc[k]);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             if (p.scores) {
                 float *so = p.scores + ((long long)b * p.L + i) * K;
 #pragma unroll
-                for (int k = 0; k < SCORE_KCH; k++) {
+                for (int k = 0; k < KCH; k++) {
                     const int col = lane + 64 * k;
-                    if (k < kch && col < K) so[col] = sc[k];
+                    if (col < K) so[col] = sc[k];
                 }
             }
             // threshold clamp of the `oo` column, then decode
             float bv = -INFINITY; int bi = 0x7ffffffe;
 #pragma unroll
-            for (int k = 0; k < SCORE_KCH; k++) {
+            for (int k = 0; k < KCH; k++) {
                 const int col = lane + 64 * k;
-                if (k < kch && col < K) {
+                if (col < K) {
                     float v = sc[k] + 0.0f;                      // -0.0 -> +0.0 (torch: -0 == +0)
                     if (col == clamp_col) v = fminf(v, p.threshold);
                     if (p.use_crf) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
@@ -189,7 +193,7 @@ score_tile_kernel(const ScoreParams p) {
                 }
             }
             if (!p.use_crf) {
-                bi = wave_argmax_dpp(bv, bi);
+                if (!(p.dbg & 64)) bi = wave_argmax_dpp(bv, bi);
                 if (lane == 0) {
                     if (bi >= K) bi = 0;                        // all-NaN row: torch returns 0
                     const int tag = (bi == K - 1) ? p.o_idx : bi;
@@ -339,9 +343,24 @@ batch_prep_kernel(const int64_t *len, int64_t *offs, int *order, int B, int L) {
             atomicAdd(&cnt[n], 1);
         }
         __syncthreads();
-        if (tid == 0) {                       // descending lengths: bucket L first
-            int run = 0;
-            for (int n = L; n >= 0; n--) { int c = cnt[n]; cnt[n] = run; run += c; }
+        // exclusive scan over the buckets in DESCENDING length order (bucket L first); thread `tid`
+        // owns `per` consecutive positions of that order
+        {
+            const int nb = L + 1, per = (nb + 1023) / 1024;
+            const int lo = tid * per, hi = min(lo + per, nb);
+            long long s2 = 0;
+            for (int r = lo; r < hi; r++) s2 += cnt[L - r];
+            __syncthreads();
+            sums[tid] = s2;
+            __syncthreads();
+            for (int off = 1; off < 1024; off <<= 1) {
+                long long v = (tid >= off) ? sums[tid - off] : 0;
+                __syncthreads();
+                sums[tid] += v;
+                __syncthreads();
+            }
+            int run = (tid == 0) ? 0 : (int)sums[tid - 1];
+            for (int r = lo; r < hi; r++) { const int c2 = cnt[L - r]; cnt[L - r] = run; run += c2; }
         }
         __syncthreads();
         const int half = B / 2;
