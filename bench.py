@@ -39,6 +39,9 @@ WORKLOADS = {
     'ifst_crf': ('ATIS-BIO-sized onehot i-FST + fused Viterbi decode (use_crf=1)', 950, 71, 128),
     'fst4': ('ATIS-BIO-sized onehot FST, dense T[V,C,S,S] (--independent 0)', 950, 71, 128),
     'decomp': ('SNIPS-BIO-sized decomposed i-FST (--method decompose --independent 2)', 11000, 104, 73),
+    # BASELINE configs[4], one GPU's shard: i-FST layout only (the 4-D layout would be 5.5 PB)
+    'synth512': ('synthetic onehot i-FST V=20k S=512 C=256 (T = 21 GB fp32 per GPU, + transposed copy)',
+                 20000, 512, 256),
 }
 
 
@@ -54,6 +57,10 @@ def parse():
     ap.add_argument('--full-length', action='store_true', help='all sequences at full length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--streams', type=int, default=1,
+                    help='in-flight batches: steps alternate over this many HIP streams, each with its '
+                         'own model handle and workspace, so the score/decode kernel of one batch '
+                         'overlaps the recurrence of the next')
     ap.add_argument('--event-stride', type=int, default=8,
                     help='time the kernels of every N-th step with HIP events (0 = never)')
     return ap.parse_args()
@@ -68,7 +75,25 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length):
     brng = np.random.RandomState(4321 + rank_id)
     dev = torch.cuda.current_device()
     extras = {}
-    if name in ('ifst', 'ifst_crf'):
+    if name == 'synth512':
+        # generated on the device (21 GB would take minutes on the host): automaton-like 0/1 tensor,
+        # ~2 successors per (word, from-state) row on average, zero pad row
+        g = torch.Generator(device='cuda'); g.manual_seed(1234)
+        dv = torch.device('cuda', dev)
+        T = torch.empty((V, S, S), dtype=torch.float32, device=dv)
+        for v0 in range(0, V, 500):
+            T[v0:v0 + 500] = (torch.rand((min(500, V - v0), S, S), device=dv, generator=g) < 2.0 / S).float()
+        T[V - 1] = 0
+        W = torch.zeros((S, S), device=dv); W[0, 0] = 1; W[S - 1, S - 1] = 1
+        O = torch.zeros((C, S), device=dv)
+        O[torch.randint(0, C - 1, (S,), device=dv, generator=g), torch.arange(S, device=dv)] = 1
+        O[:, 0] = 0; O[:, S - 1] = 0; O[C - 1, 0] = 1; O[C - 1, S - 1] = 1
+        h0 = torch.zeros(S, device=dv); h0[0] = 1
+        hT = torch.zeros(S, device=dv); hT[0] = 1; hT[S - 1] = 1
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl='tanh', device=dev)   # tanh keeps states bounded
+        del T
+        torch.cuda.empty_cache()
+    elif name in ('ifst', 'ifst_crf'):
         T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
         crf = name == 'ifst_crf'
         tr = None
@@ -154,24 +179,36 @@ def main():
 
     B, L = a.batch, a.seqlen
     h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length)
+    handles = [h] + [build_workload(a.workload, B, L, rank, a.rank, a.full_length)[0]
+                     for _ in range(max(1, a.streams) - 1)]
     xd = torch.from_numpy(x).to(dev)
     ld = torch.from_numpy(lengths).to(dev)
-    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    tags_bufs = [torch.empty((B, L), dtype=torch.int32, device=dev) for _ in handles]
+    tags = tags_bufs[0]
     gathered = torch.empty((world * B, L), dtype=torch.int32, device=dev) if world > 1 else None
-    h.reserve(B, L)
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    for hh in handles:
+        hh.reserve(B, L)
+    main_stream = torch.cuda.current_stream(dev)
+    streams = [main_stream] + [torch.cuda.Stream(dev) for _ in handles[1:]]
+    counter = [0]
 
     def step():
-        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None, stream)
+        k = counter[0] % len(handles)
+        counter[0] += 1
+        st = streams[k]
+        handles[k].tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[k].data_ptr(),
+                       None, None, st.cuda_stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, tags)       # RCCL gather of tag ids over xGMI
+            with torch.cuda.stream(st):
+                dist.all_gather_into_tensor(gathered, tags_bufs[k])   # RCCL gather of tag ids over xGMI
 
     for _ in range(a.warmup):
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
-    h.set_profiling(a.event_stride)            # HIP events around the kernels of every N-th step
+    for hh in handles:
+        hh.set_profiling(a.event_stride)       # HIP events around the kernels of every N-th step
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -181,9 +218,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    chain_ms, chain_n = h.kernel_time(_lib.KERN_CHAIN)
-    score_ms, score_n = h.kernel_time(_lib.KERN_SCORE)
-    h.set_profiling(0)
+    chain_ms = chain_n = score_ms = score_n = 0
+    for hh in handles:
+        ms, n = hh.kernel_time(_lib.KERN_CHAIN); chain_ms += ms; chain_n += n
+        ms, n = hh.kernel_time(_lib.KERN_SCORE); score_ms += ms; score_n += n
+        hh.set_profiling(0)
 
     tok_local = int(lengths.sum())
     if world > 1:
@@ -218,8 +257,9 @@ def main():
                                    .format(desc, V, S, C, B, L,
                                            'all {}'.format(L) if a.full_length else 'U[5,{}]'.format(L)),
                        'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
-                       'parallelism': 'batch-sharded x{} (weights replicated{})'.format(
-                           world, ', RCCL all_gather of tag ids' if world > 1 else '')},
+                       'parallelism': 'batch-sharded x{} (weights replicated{}){}'.format(
+                           world, ', RCCL all_gather of tag ids' if world > 1 else '',
+                           ', {} batches in flight per GPU'.format(len(handles)) if len(handles) > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': h.kernel_name(_lib.KERN_CHAIN),
                          'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,

@@ -177,8 +177,25 @@ def _create(fn_name, desc, device, keep):
     return Handle(out, keep)
 
 
+def _dev_ptr(t):
+    return C.cast(C.c_void_p(t.data_ptr()), _f32p)
+
+
 def create_onehot_ifst(T, W, O, h0, hT, P=None, nl='none', semiring='sum', threshold=0.5, o_idx=0,
                        use_crf=False, crf_trans=None, device=0):
+    """Weights as numpy arrays (host, copied by the library) or -- all of them -- as float32
+    torch tensors already on the target device (weights_on_device=1; nothing crosses PCIe)."""
+    import torch
+    if torch.is_tensor(T):
+        arrs = [a for a in (T, W, O, h0, hT, P, crf_trans) if a is not None]
+        assert all(torch.is_tensor(a) and a.is_cuda and a.dtype == torch.float32 and a.is_contiguous()
+                   for a in arrs), 'device weights must all be contiguous float32 CUDA tensors'
+        V, S, _ = T.shape
+        d = OnehotIfstDesc(V, S, O.shape[0], _dev_ptr(T), _dev_ptr(W), _dev_ptr(O), _dev_ptr(h0), _dev_ptr(hT),
+                           None if P is None else _dev_ptr(P), NL[nl], SEMIRING[semiring], float(threshold),
+                           int(o_idx), int(bool(use_crf)), None if crf_trans is None else _dev_ptr(crf_trans), 1)
+        torch.cuda.synchronize(T.device)
+        return _create('farnn_onehot_ifst_create', d, device, tuple(arrs))
     T, W, O, h0, hT = f32(T), f32(W), f32(O), f32(h0), f32(hT)
     P = None if P is None else f32(P)
     crf_trans = None if crf_trans is None else f32(crf_trans)

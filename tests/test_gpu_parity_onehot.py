@@ -108,7 +108,8 @@ def test_atis_scale_ifst_vs_reference():
 
 
 @pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (64, 9, 17, 5), (65, 130, 9, 3),
-                                     (130, 70, 12, 4), (257, 40, 6, 3), (300, 256, 5, 2)])
+                                     (130, 70, 12, 4), (257, 40, 6, 3), (300, 256, 5, 2), (512, 256, 7, 3),
+                                     (1024, 6, 4, 2)])
 @pytest.mark.parametrize('mode', ['sum', 'max'])
 def test_ifst_shapes_vs_oracle(S, C, L, B, mode):
     """Ragged / edge geometries of the chain kernel (row groups, column-chunk passes, workgroup
@@ -128,3 +129,43 @@ def test_ifst_shapes_vs_oracle(S, C, L, B, mode):
     assert np.array_equal(scores, ref)
     assert np.array_equal(flat, fo.forward_local_tags(ref, lengths, 0.5, 1 % C))
     assert np.array_equal(re_pred, fo.decode_argmax(ref, 0.5, 1 % C))
+
+
+def test_device_resident_weights_match_host_weights():
+    """weights_on_device=1 (torch tensors already in HBM, nothing crosses PCIe): same results."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(3)
+    V, S, C, B, L = 50, 37, 11, 9, 10
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=8.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    dev = torch.device('cuda', 0)
+    dt = [torch.from_numpy(a).to(dev).contiguous() for a in (T, W, O, h0, hT)]
+    h = _lib.create_onehot_ifst(*dt, device=0)
+    xd, ld = _t(x).to(dev), _t(lengths).to(dev)
+    scores = torch.empty((B, L, C), dtype=torch.float32, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_FULL, tags.data_ptr(), None, scores.data_ptr(),
+          torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+    assert np.array_equal(scores.cpu().numpy(), ref)
+    assert np.array_equal(tags.cpu().numpy().astype(np.int64), fo.decode_argmax(ref, 0.5, 0))
+
+
+def test_error_codes_through_the_abi():
+    """Bad arguments come back as negative codes + message, never as a crash."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(1)
+    T, W, O, h0, hT = synth.random_ifst_tensors(20, 5, 4, rng)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, device=0)
+    with pytest.raises(_lib.FarnnError, match='B and L must be positive'):
+        h.tag(1, 1, 0, 4, _lib.MODE_LOCAL)
+    with pytest.raises(_lib.FarnnError, match='null'):
+        h.tag(None, None, 2, 4, _lib.MODE_LOCAL)
+    with pytest.raises(_lib.FarnnError, match='bad mode'):
+        h.tag(1, 1, 2, 4, 7)
+    with pytest.raises(_lib.FarnnError, match='256 label columns'):
+        _lib.create_onehot_ifst(T, W, np.zeros((300, 5), np.float32), h0, hT, device=0)
+    h.close()
+    with pytest.raises(_lib.FarnnError, match='destroyed'):
+        h.num_columns()
