@@ -165,6 +165,8 @@ int  farnn_num_columns(const farnn_model *m);              /* K of the scores te
 /* algorithmic HBM bytes of one farnn_tag() call with `valid_tokens` tagged tokens
  * (SURVEY.md 8d / DESIGN.md: per-token figure x tokens), for the roofline line of bench.py */
 double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_tokens);
+/* the share of that figure read/written by kernel `which` (0 = recurrence chain, 1 = score+decode) */
+double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t which, int64_t valid_tokens);
 /* per-kernel timing with HIP events recorded on the launch stream.  enable=N>0 starts collecting
  * on every N-th farnn_tag() call (N=1: every call; event records cost a few microseconds of
  * launch latency each, so a stride keeps the timed region honest); enable=0 stops.

@@ -73,6 +73,7 @@ SIGNATURES = {
     'farnn_last_error': (C.c_char_p, []),
     'farnn_num_columns': (C.c_int, [_vp]),
     'farnn_algorithmic_bytes': (C.c_double, [_vp, C.c_int64]),
+    'farnn_kernel_algorithmic_bytes': (C.c_double, [_vp, C.c_int32, C.c_int64]),
     'farnn_set_profiling': (C.c_int, [_vp, C.c_int32]),
     'farnn_kernel_time': (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'farnn_kernel_name': (C.c_char_p, [_vp, C.c_int32]),
@@ -156,6 +157,9 @@ class Handle:
 
     def algorithmic_bytes(self, valid_tokens):
         return load().farnn_algorithmic_bytes(self.raw, int(valid_tokens))
+
+    def kernel_algorithmic_bytes(self, which, valid_tokens):
+        return load().farnn_kernel_algorithmic_bytes(self.raw, int(which), int(valid_tokens))
 
     def set_profiling(self, every):
         """every=0 off; every=N: time every N-th farnn_tag call with HIP events."""

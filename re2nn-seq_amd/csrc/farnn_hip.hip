@@ -393,15 +393,21 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
 #undef FARNN_LAUNCH_SCORE
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf) {
-        const int tr = viterbi_lds_bytes(m->K, m->Kp, p.L, 1) <= 150 * 1024 ? 1 : 0;
-        const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L, tr);
-        if (tr) {
-            if ((rc = raise_lds_limit(viterbi_kernel<true>, vlds))) return rc;
-            viterbi_kernel<true><<<dim3(B), dim3(VITERBI_THREADS), vlds, s>>>(p);
-        } else {
-            if ((rc = raise_lds_limit(viterbi_kernel<false>, vlds))) return rc;
-            viterbi_kernel<false><<<dim3(B), dim3(VITERBI_THREADS), vlds, s>>>(p);
-        }
+        const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
+        int threads = round_up(4 * m->K, 64);
+        if (threads > 1024) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
+        const int ib4 = viterbi_ib4(m->K);
+#define FARNN_LAUNCH_VIT(N)                                                                   \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                       \
+        viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                            \
+    } while (0)
+        if (ib4 == 2) FARNN_LAUNCH_VIT(2);            // K <= 32
+        else if (ib4 == 4) FARNN_LAUNCH_VIT(4);       // K <= 64
+        else if (ib4 == 9) FARNN_LAUNCH_VIT(9);       // K <= 144
+        else if (ib4 == 13) FARNN_LAUNCH_VIT(13);     // K <= 208
+        else FARNN_LAUNCH_VIT(16);                    // K <= 256
+#undef FARNN_LAUNCH_VIT
         FARNN_HIP_TRY(hipGetLastError());
     }
     return FARNN_OK;
@@ -673,3 +679,21 @@ extern "C" double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_to
     }
     return per_tok * (double)valid_tokens + once;
 }
+
+extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t which, int64_t valid_tokens) {
+    if (!m) return 0.0;
+    const double S = m->S, C = m->C, R = m->R, K = m->K, n = (double)valid_tokens;
+    if (which == KERN_CHAIN) {
+        if (m->kind == KIND_DECOMP) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
+        return (2.0 * S * S * 4 + 8) * n;                 // one block per direction + the token id
+    }
+    if (which == KERN_SCORE) {
+        switch (m->kind) {
+            case KIND_FST4: return (C * S * S * 4 + 4) * n;             // the 4-D scoring stream
+            case KIND_IND1: return (S * S * 4 + 4) * n + C * S * S * 4;
+            default: return 4 * n + K * S * 4;                          // tags out (+ the output matrix once)
+        }
+    }
+    return 0.0;
+}
+

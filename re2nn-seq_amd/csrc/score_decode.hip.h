@@ -217,69 +217,80 @@ inline size_t score_lds_bytes(int S, int SP, int Kc, int has_P, int ot_in_lds) {
 }
 
 // ---- Viterbi (crf.py:102-195) over the valid positions, one workgroup per sequence ------------
-// A quad of lanes shares one destination tag j and splits the source tags i; the quad is combined
-// with (value desc, index asc), which is torch.max's first-index rule.
-constexpr int VITERBI_THREADS = 512;
-
-template <bool TR_LDS>
-__global__ void __launch_bounds__(VITERBI_THREADS)
+// A quad of lanes shares one destination tag j; lane q of the quad owns the CONTIGUOUS block of
+// source tags i in [q*IB, (q+1)*IB).  The transition column trT[j][block] never changes over time,
+// so it lives in registers for the whole sequence; per step a lane reads its block of the previous
+// partition with 16-byte LDS reads, and the quad is combined with (value desc, index asc) --
+// torch.max's first-index rule (lane-local strict `>` keeps the first index inside a block).
+// The sequence's clamped scores and the back-pointers stay in LDS.  IB4 = IB/4 is compile-time.
+template <int IB4>
+__global__ void __launch_bounds__(1024)
 viterbi_kernel(const ScoreParams p) {
+    constexpr int IB = IB4 * 4;
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int nthreads = VITERBI_THREADS;
+    const int nthreads = blockDim.x;
     const int b = blockIdx.x;
     const int n = (int)p.len[b];
     const int nsteps = p.full ? p.L : n;
     const int K = p.K, Kp = p.Kp;
-    float *part = smem;                                  // [2][Kp]
-    float *trl = part + 2 * Kp;                          // [K][Kp] when TR_LDS
-    unsigned short *bp = reinterpret_cast<unsigned short *>(TR_LDS ? trl + (size_t)K * Kp : trl);  // [L][Kp]
-    if (TR_LDS)
-        for (int i = tid * 4; i < K * Kp; i += nthreads * 4) st4(trl + i, ld4(p.trT + i));
-    const float *trT = TR_LDS ? trl : p.trT;
+    const int PW = 4 * IB;                               // padded partition width (>= K)
+    float *part = smem;                                  // [2][PW], pad entries -inf
+    float *scl = part + 2 * PW;                          // [L][Kp] clamped scores of this sequence
+    unsigned short *bp = reinterpret_cast<unsigned short *>(scl + (size_t)p.L * Kp);   // [L][Kp]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
     const long long foff = p.offs ? p.offs[b] : 0;
     const int START = K - 2, STOP = K - 1;
+    const float ninf = -INFINITY;
+
+    for (int i = tid * 4; i < n * Kp; i += nthreads * 4) st4(scl + i, ld4(sc + i));
+    for (int i = tid; i < 2 * PW; i += nthreads) part[i] = ninf;
+    const int j = tid >> 2, q = tid & 3;
+    const bool owner = j < K;
+    float trr[IB];                                       // tr[i][j] for this lane's block of i
+#pragma unroll
+    for (int k = 0; k < IB; k++) {
+        const int i = q * IB + k;
+        trr[k] = (owner && i < K) ? p.trT[(long long)j * Kp + i] : ninf;
+    }
     __syncthreads();
-    for (int j = tid; j < K; j += nthreads)
-        part[j] = sc[j] + trT[(long long)j * Kp + START];                     // crf.py:135
+    for (int jj = tid; jj < K; jj += nthreads)
+        part[jj] = scl[jj] + p.trT[(long long)jj * Kp + START];              // crf.py:135
     __syncthreads();
     int pc = 0;
-    const int q = tid & 3;
     for (int t = 1; t < n; t++) {
-        const float *pin = part + pc * Kp;
-        float *pout = part + (pc ^ 1) * Kp;
-        for (int j0 = 0; j0 < K; j0 += nthreads >> 2) {
-            const int j = j0 + (tid >> 2);
-            float best = -INFINITY; int bi = 0x7fffffff;
-            if (j < K) {
-                const float f = sc[(long long)t * Kp + j];
-                const float *trow = trT + (long long)j * Kp;
-                for (int i = q; i < K; i += 4) {
-                    const float v = (f + trow[i]) + pin[i];                   // crf.py:123,145
-                    if (v > best) { best = v; bi = i; }
-                }
-            }
+        const float *pin = part + pc * PW + q * IB;
+        float *pout = part + (pc ^ 1) * PW;
+        const float f = owner ? scl[(long long)t * Kp + j] : 0.0f;
+        float best = ninf; int bi = 0x7fffffff;
 #pragma unroll
-            for (int off = 1; off <= 2; off <<= 1) {
-                const float ov = __shfl_xor(best, off, WAVE);
-                const int oi = __shfl_xor(bi, off, WAVE);
-                argmax_combine(best, bi, ov, oi);
+        for (int k4 = 0; k4 < IB4; k4++) {
+            const float4 p4 = ld4(pin + k4 * 4);
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const float v = (f + trr[k4 * 4 + u]) + pv[u];                // crf.py:123,145
+                if (v > best) { best = v; bi = q * IB + k4 * 4 + u; }
             }
-            if (j < K && q == 0) {
-                pout[j] = best;
-                bp[(long long)t * Kp + j] = (unsigned short)(bi >= K ? 0 : bi);
-            }
+        }
+#pragma unroll
+        for (int off = 1; off <= 2; off <<= 1) {
+            const float ov = __shfl_xor(best, off, WAVE);
+            const int oi = __shfl_xor(bi, off, WAVE);
+            argmax_combine(best, bi, ov, oi);
+        }
+        if (owner && q == 0) {
+            pout[j] = best;
+            bp[(long long)t * Kp + j] = (unsigned short)(bi >= K ? 0 : bi);
         }
         __syncthreads();
         pc ^= 1;
     }
     if (w == 0) {
-        const float *pin = part + pc * Kp;
-        const float *tstop = trT + (long long)STOP * Kp;
-        float bv = -INFINITY; int bi = 0x7fffffff;
+        const float *pin = part + pc * PW;
+        float bv = ninf; int bi = 0x7fffffff;
         for (int i = lane; i < K; i += WAVE) {
-            const float v = pin[i] + tstop[i];                                // crf.py:168-169
+            const float v = pin[i] + p.trT[(long long)STOP * Kp + i];          // crf.py:168-169
             if (v > bv) { bv = v; bi = i; }
         }
         wave_argmax(bv, bi);
@@ -298,11 +309,13 @@ viterbi_kernel(const ScoreParams p) {
         for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
 }
 
-inline size_t viterbi_lds_bytes(int K, int Kp, int L, int tr_in_lds) {
-    size_t bytes = (size_t)2 * Kp * 4;
-    if (tr_in_lds) bytes += (size_t)K * Kp * 4;
-    bytes += (size_t)L * Kp * 2;
-    return bytes;
+// the instantiated block size (in float4s) for K tags: ceil(ceil(K/4)/4) rounded up to a built one
+inline int viterbi_ib4(int K) {
+    const int need = ((K + 3) / 4 + 3) / 4;
+    return need <= 2 ? 2 : need <= 4 ? 4 : need <= 9 ? 9 : need <= 13 ? 13 : 16;
+}
+inline size_t viterbi_lds_bytes(int K, int Kp, int L) {
+    return (size_t)2 * 16 * viterbi_ib4(K) * 4 + (size_t)L * Kp * 4 + (size_t)L * Kp * 2;
 }
 
 // Batch preparation (one workgroup; B is a batch size, not a corpus):
