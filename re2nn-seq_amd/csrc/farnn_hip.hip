@@ -56,7 +56,8 @@ struct farnn_model {
 
 // ---- small helpers ---------------------------------------------------------------------------
 static int dev_alloc(farnn_model *m, void **p, size_t bytes) {
-    FARNN_HIP_TRY(hipMalloc(p, bytes ? bytes : 16));
+    // +1 KiB slack: LDS-DMA moves whole 1 KiB pieces, the last piece of a table may run past its end
+    FARNN_HIP_TRY(hipMalloc(p, bytes + 1024));
     m->owned.push_back(*p);
     return FARNN_OK;
 }
@@ -306,12 +307,17 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
 }
 
 // ---- the hot path ----------------------------------------------------------------------------
+// Raise a kernel's dynamic-LDS limit (needed above 48 KiB).  The attribute is sticky, so it is set
+// only when a kernel needs more than it was last given (a host API call per launch otherwise).
 template <typename KernelT>
 static int raise_lds_limit(KernelT kern, size_t bytes) {
+    static thread_local size_t granted = 0;          // one instance per kernel type
     if (bytes > 160 * 1024) return fail(FARNN_ERANGE, "kernel needs more than 160 KiB of LDS%s%s");
-    if (bytes > 48 * 1024)
+    if (bytes > 48 * 1024 && bytes > granted) {
         FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        granted = bytes;
+    }
     return FARNN_OK;
 }
 
@@ -463,7 +469,8 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
         case KIND_DECOMP: {
             {
                 KernelTimer kt(m, KERN_CHAIN, s);
-                if ((rc = launch_decomp_chain(m->dw, x, lengths, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+                if ((rc = launch_decomp_chain(m->dw, x, lengths, m->order_valid ? m->order : nullptr, m->A, m->Bk, B,
+                                              m->wsL, full, s))) return rc;
             }
             return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
         }
@@ -604,6 +611,15 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if ((rc = upload_transposed(m, &tmp, d->S2, m->S, m->R, m->SP, od))) return bail(rc); w.S2T = tmp;
     if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.W = tmp;
     if ((rc = upload_transposed(m, &tmp, d->W, m->S, m->S, m->SP, od))) return bail(rc); w.WT = tmp;
+    // fast-path copies with odd 16-byte row strides (see decomp_chain.hip.h)
+    w.SPo = m->SP + (((m->SP / 4) & 1) ? 0 : 4);
+    w.Rpo = m->Rp + (((m->Rp / 4) & 1) ? 0 : 4);
+    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, w.Rpo, od))) return bail(rc); w.fS1 = tmp;
+    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, w.Rpo, od))) return bail(rc); w.fS2 = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->S1, m->S, m->R, w.SPo, od))) return bail(rc); w.fS1T = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->S2, m->S, m->R, w.SPo, od))) return bail(rc); w.fS2T = tmp;
+    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, w.SPo, od))) return bail(rc); w.fW = tmp;
+    if ((rc = upload_transposed(m, &tmp, d->W, m->S, m->S, w.SPo, od))) return bail(rc); w.fWT = tmp;
     if (d->farnn >= 1) {
         if ((rc = upload_padded(m, &tmp, d->Wss1, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss1 = tmp;
         if ((rc = upload_padded(m, &tmp, d->Wrs1, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs1 = tmp;
