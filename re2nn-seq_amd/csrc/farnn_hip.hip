@@ -2,7 +2,9 @@
 // gfx950 only; no CPU fallback lives here (the CPU oracle is test infrastructure under oracle/).
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <map>
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "common.hip.h"
@@ -311,12 +313,16 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
 // only when a kernel needs more than it was last given (a host API call per launch otherwise).
 template <typename KernelT>
 static int raise_lds_limit(KernelT kern, size_t bytes) {
-    static thread_local size_t granted = 0;          // one instance per kernel type
+    static std::map<std::pair<int, const void *>, size_t> granted;    // (device, kernel) -> bytes
     if (bytes > 160 * 1024) return fail(FARNN_ERANGE, "kernel needs more than 160 KiB of LDS%s%s");
-    if (bytes > 48 * 1024 && bytes > granted) {
-        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        granted = bytes;
+    if (bytes <= 48 * 1024) return FARNN_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const void *fn = reinterpret_cast<const void *>(kern);
+    size_t &g = granted[{dev, fn}];
+    if (bytes > g) {
+        FARNN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        g = bytes;
     }
     return FARNN_OK;
 }
