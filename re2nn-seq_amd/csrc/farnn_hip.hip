@@ -448,8 +448,15 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     m->order_valid = want_order;
     if (flat_tags || want_order) {
         KernelTimer kt(m, KERN_PREP, s);
-        batch_prep_kernel<<<1, 1024, (size_t)(L + 2) * sizeof(int), s>>>(
-            lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L);
+        if (B <= 1024) {
+            int G = 1;
+            while (G < 16 && B * G * 2 <= 1024) G *= 2;               // lanes per sequence
+            batch_prep_small_kernel<<<1, round_up(B * G, 64), 0, s>>>(
+                lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L, G);
+        }
+        else
+            batch_prep_kernel<<<1, 1024, (size_t)(L + 2) * sizeof(int), s>>>(
+                lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L);
         FARNN_HIP_TRY(hipGetLastError());
     }
     switch (m->kind) {

@@ -387,4 +387,56 @@ batch_prep_kernel(const int64_t *len, int64_t *offs, int *order, int B, int L) {
     }
 }
 
+// Small-batch variant (B <= 1024): one pass, one barrier.  Thread i ranks its own sequence against
+// all others by (length desc, index asc) and sums the lengths before it, reading the B lengths as
+// LDS broadcasts -- O(B) per thread instead of two block scans with ~40 barriers (4.6 us -> ~1 us
+// at B = 256, and this kernel sits in front of the chain kernel on every call).
+__global__ void __launch_bounds__(1024)
+batch_prep_small_kernel(const int64_t *len, int64_t *offs, int *order, int B, int L, int G) {
+    // G (power of two, 1..16) adjacent lanes share one sequence and split the j range
+    __shared__ __align__(16) int ls[1024];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < 1024; k += blockDim.x) {
+        int v = -1;                                  // padding entries: shorter than anything
+        if (k < B) {
+            const int n = (int)len[k];
+            v = n < 0 ? 0 : (n > L ? L : n);
+        }
+        ls[k] = v;
+    }
+    __syncthreads();
+    const int i = tid / G, part = tid - i * G;
+    const bool live = i < B;
+    const int mine = live ? ls[i] : -1;
+    int rank = 0;
+    unsigned before = 0;                             // B * L < 2^31 for any batch this kernel sees
+    const int4 *ls4 = reinterpret_cast<const int4 *>(ls);
+    const int n4 = (B + 3) >> 2;
+    const int per = (n4 + G - 1) / G, lo = part * per, hi = min(lo + per, n4);
+#pragma unroll 4
+    for (int j4 = lo; j4 < hi; j4++) {
+        const int4 v = ls4[j4];                      // 4 lengths per LDS read
+        const int lj[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j4 * 4 + u;
+            rank += (lj[u] > mine) || (lj[u] == mine && j < i);
+            before += (j < i && lj[u] > 0) ? (unsigned)lj[u] : 0u;
+        }
+    }
+    for (int off = 1; off < G; off <<= 1) {          // combine the G partial results
+        rank += __shfl_xor(rank, off, WAVE);
+        before += __shfl_xor(before, off, WAVE);
+    }
+    if (!live || part != 0) return;
+    if (offs) {
+        offs[i] = (long long)before;
+        if (i == B - 1) offs[B] = (long long)before + mine;
+    }
+    if (order) {
+        const int half = B / 2;
+        order[rank < half ? rank : half + (B - 1 - rank)] = i;          // fold the shorter half
+    }
+}
+
 }  // namespace farnn

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Fold gpurun_out/prof_rNN (bench lines, rocprofv3 kernel stats, PMC passes) into the small,
+committed summaries under profiles/.  Usage: python scripts/summarize_profile.py r01"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else 'r01'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
+dst = os.path.join(ROOT, 'profiles')
+os.makedirs(dst, exist_ok=True)
+
+for f in glob.glob(os.path.join(src, 'bench_*.json')):
+    if os.path.getsize(f) > 0:
+        shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
+ks = sorted(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
+if ks:
+    shutil.copy(ks[-1], os.path.join(dst, tag + '_ifst_kernel_stats.csv'))
+
+
+def agg(path):
+    d = collections.defaultdict(lambda: [0.0, 0])
+    files = sorted(glob.glob(os.path.join(src, path, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+    if not files:
+        return {}
+    for row in csv.DictReader(open(files[-1])):       # gpurun merges runs: take the newest
+
+        k = (row['Kernel_Name'].split('(')[0].replace('void ', ''), row['Counter_Name'])
+        d[k][0] += float(row['Counter_Value'])
+        d[k][1] += 1
+    return {k: (s / n, n) for k, (s, n) in d.items()}
+
+
+rows = []
+runs = [('pmc_fetch', 'ifst ragged U[5,64]'), ('pmc_write', 'ifst ragged U[5,64]'), ('pmc_l2', 'ifst ragged U[5,64]'),
+        ('pmc_fetch_full', 'ifst full-length'), ('pmc_fetch_synth512', 'synth512 B1024 L128'),
+        ('pmc_fetch_fst4', 'fst4')]
+for run, label in runs:
+    for (k, c), (mean, n) in sorted(agg(run).items()):
+        if 'farnn::' in k and any(t in k for t in ('chain', 'score', 'viterbi')):
+            rows.append([label, k, c, '%.1f' % mean, n])
+with open(os.path.join(dst, tag + '_pmc_summary.csv'), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['workload', 'kernel', 'counter', 'mean_per_dispatch', 'dispatches'])
+    w.writerows(rows)
+
+
+def pick(label, kernel, counter):
+    for r in rows:
+        if r[0] == label and kernel in r[1] and r[2] == counter:
+            return float(r[3])
+    return None
+
+
+traffic = {}
+note = ('(2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch from separate rocprofv3 --pmc passes; on gfx950 '
+        'FETCH_SIZE tallies 128-B requests at 64 B for 16-B/lane streams, hence the factor 2 '
+        '(MI355X_MICROARCH.md, HBM section)')
+f_, w_ = pick('ifst ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64]', 'chain', 'WRITE_SIZE')
+if f_ is not None:
+    traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_kernel', 'source': note}
+f_ = pick('synth512 B1024 L128', 'chain', 'FETCH_SIZE')
+if f_ is not None:
+    traffic['synth512'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'chain_kernel', 'source': note + ' (reads only)'}
+f_ = pick('fst4', 'fst4_score', 'FETCH_SIZE')
+if f_ is not None:
+    traffic['fst4'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'fst4_score_kernel', 'source': note + ' (reads only)'}
+with open(os.path.join(dst, 'traffic.json'), 'w') as f:
+    json.dump(traffic, f, indent=1)
+for r in rows:
+    print(r)
+print(json.dumps(traffic, indent=1))

@@ -169,3 +169,20 @@ def test_error_codes_through_the_abi():
     h.close()
     with pytest.raises(_lib.FarnnError, match='destroyed'):
         h.num_columns()
+
+
+@pytest.mark.parametrize('B', [3, 257, 1500])
+def test_batch_prep_paths_flat_order(B):
+    """Both batch-prep kernels (B <= 1024: rank kernel; larger: counting sort): the flat output
+    must come out in the reference's batch-major order whatever the internal launch order."""
+    from re2nn_seq_amd import synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(B)
+    V, S, C, L = 30, 6, 5, 9
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, None, ns(), o_idx=2)
+    xt, lt = _t(x), _t(lengths)
+    _, pred, _ = m.forward_local(xt, torch.zeros_like(xt), lt, train=False)
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+    assert np.array_equal(pred.numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
