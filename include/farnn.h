@@ -132,6 +132,32 @@ typedef struct farnn_decomp_ifst_desc {
 
 int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *desc, int device, farnn_model **out);
 
+/* ---- decomposed independent=1: FARNN_S_D_W_I (reference model_decompose_independent.py:11-300) ---- */
+typedef struct farnn_decomp_ind1_desc {
+    int32_t V, S, R, RO, K;     /* S incl. additional_states; RO = rank of the output factors        */
+    const float *Vgen;          /* [V,R]  generalized word table (model_decompose.py:222-241)        */
+    const float *S1, *S2;       /* [S,R]                                                              */
+    const float *W;             /* [S,S]  wildcard_mat                                                */
+    const float *Cout;          /* [K,RO] C_output (:82-83)                                           */
+    const float *S1o, *S2o;     /* [S,RO] S1_output / S2_output (:85-89)                              */
+    const float *Wo;            /* [S,S]  wildcard_output, added to the output sum unless CE1; NULL   */
+    const float *h0, *hT;       /* [S]                                                                */
+    const float *P;             /* [K,K] or NULL                                                      */
+    int32_t farnn;
+    const float *Wss1, *Wrs1, *bs1;
+    const float *Wss2, *Wrs2, *bs2;
+    float   sigmoid_exponent;
+    int32_t nl;
+    int32_t semiring;
+    float   threshold;
+    int32_t o_idx;
+    int32_t use_crf;
+    const float *crf_trans;     /* [K,K] when use_crf                                                 */
+    int32_t weights_on_device;
+} farnn_decomp_ind1_desc;
+
+int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *desc, int device, farnn_model **out);
+
 /* ---- the hot path ------------------------------------------------------------------- */
 /*
  * farnn_tag: model.forward_local / forward_RE / forward_score of the reference

@@ -353,3 +353,75 @@ def onehot_crf_extension_scores(scores):
     model_decompose_single.py:78-79), then the CRF decode of model_decompose.py:349-356."""
     B, L, C = scores.shape
     return np.concatenate([scores, np.zeros((B, L, 2), F32)], axis=2)
+
+
+# --------------------------------------------------------------------------- decomposed independent=1
+def decomp_ind1_output_sum(p):
+    """FARNN_S_D_W_I.get_output_tensor_sum, model_decompose_independent.py:210-217 (CE1: no
+    wildcard_output).  Returns Osum[from, to]."""
+    csum = p['Cout'].sum(0).astype(F32)                               # [R_O]
+    temp = (csum[None, :] * p['S1o']).astype(F32)                     # [S,R_O]
+    Tr = np.einsum('sr,jr->js', p['S2o'], temp).astype(F32)
+    if p.get('Wo') is not None:
+        Tr = Tr + p['Wo']
+    return Tr
+
+
+def decomp_ind1_step(h, v, h_init, Osum, p, fwd):
+    """FARNN_S_D_W_I.get_forward_score, model_decompose_independent.py:148-197: the per-step
+    transition matrix is materialised from the factors and masked by the output sum."""
+    farnn = p['farnn']
+    if farnn == 0:
+        hb = h
+    else:
+        z = _sig(h @ p['Wss1'] + v @ p['Wrs1'] + p['bs1'], p['sig_k'])
+        if farnn == 2:
+            r = _sig(h @ p['Wss2'] + v @ p['Wrs2'] + p['bs2'], p['sig_k'])
+            hb = ((F32(1) - r) * h_init + r * h).astype(F32)
+        else:
+            hb = h
+    tmp = np.einsum('br,sr->bsr', v, p['S1'])
+    Tr = np.einsum('sr,bjr->bjs', p['S2'], tmp).astype(F32)           # [b, from, to]
+    Tr = (Tr + p['W']) * Osum                                          # :167-168
+    nx = semiring_vm(hb, Tr if fwd else Tr.transpose(0, 2, 1), p['semiring'])
+    nx = _nl(nx.astype(F32), p['nl'])
+    if farnn == 0:
+        return nx
+    return ((F32(1) - z) * h + z * nx).astype(F32)
+
+
+def decomp_ind1_scores(p, x, lengths, P=None):
+    """FARNN_S_D_W_I.forward_local score part, model_decompose_independent.py:219-274.
+    p keys: Vgen [V,R], S1,S2 [S,R], W [S,S], Cout [K,R_O], S1o,S2o [S,R_O], Wo (or None),
+    h0,hT, farnn, nl, semiring, gate params, sig_k.  alpha = state BEFORE token i (:262)."""
+    q = {k: (np.asarray(v, F32) if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    B = x.shape[0]
+    L = int(np.max(lengths))
+    h0, hT, Vgen = q['h0'], q['hT'], q['Vgen']
+    S = h0.shape[0]
+    Osum = decomp_ind1_output_sum(q)
+    xb = reverse_prefix(x, lengths)
+    h0b = np.repeat(h0[None], B, 0); hTb = np.repeat(hT[None], B, 0)
+    hf, hb = h0b.copy(), hTb.copy()
+    fw = np.zeros((B, L + 1, S), F32); fw[:, 0] = h0
+    bw = np.zeros((B, L + 1, S), F32); bw[:, 0] = hT
+    for i in range(L):
+        hf = decomp_ind1_step(hf, Vgen[x[:, i]], h0b, Osum, q, True)
+        fw[:, i + 1] = hf
+        hb = decomp_ind1_step(hb, Vgen[xb[:, i]], hTb, Osum, q, False)
+        bw[:, i + 1] = hb
+    rb = reverse_prefix(bw, np.asarray(lengths) + 1)
+    s1_s2 = np.einsum('ir,jr->ijr', q['S1'], q['S2'])
+    s1_s2_out = np.einsum('ir,jr->rij', q['S1o'], q['S2o'])
+    K = q['Cout'].shape[0]
+    scores = np.zeros((B, L, K), F32)
+    for i in range(L):
+        v = Vgen[x[:, i]]
+        bss = np.einsum('ijr,br->bij', s1_s2, v).astype(F32) + q['W']            # :201
+        ab = fw[:, i][:, :, None] * rb[:, i + 1][:, None, :]                      # :202
+        abw = ab * bss                                                            # :203
+        br = np.einsum('bij,rij->br', abw, s1_s2_out).astype(F32)                 # :204
+        scores[:, i] = br @ q['Cout'].T                                           # :205
+    if P is not None:
+        scores = priority(scores, P)
+    return scores

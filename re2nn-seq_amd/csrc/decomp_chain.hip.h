@@ -28,6 +28,8 @@ struct DecompWeights {
     const float *Wss1 = nullptr, *Wrs1 = nullptr, *bs1 = nullptr;   // [S][SP], [R][SP], [SP]
     const float *Wss2 = nullptr, *Wrs2 = nullptr, *bs2 = nullptr;
     const float *o = nullptr, *h0 = nullptr, *hT = nullptr;         // [SP]
+    const float *mask = nullptr;    // [S][SP] independent=1: output sum multiplied into the per-step
+                                    // transition matrix (model_decompose_independent.py:167-168)
     // fast-path copies, row strides SPo / Rpo chosen so that (stride/4) is odd: a lane that walks
     // one ROW with 16-byte LDS reads is then bank-conflict-free against its 15 group neighbours
     const float *fS1 = nullptr, *fS2 = nullptr;     // [S][Rpo]
@@ -79,6 +81,7 @@ decomp_chain_kernel(const DecompParams p) {
     const float *SbT = dir == 0 ? w.S2T : w.S1T;     // (.) . Sb^T         [R][SP]
     const float *Wd = dir == 0 ? w.W : w.WT;         // hb . W  or hb . W^T [S][SP]
     const bool maxsr = w.semiring == FARNN_SEMIRING_MAX;
+    const bool materialise = maxsr || w.mask != nullptr;     // build Tr[s][j] from the factors per step
 
     for (int t = 0; t < nsteps; t++) {
         const float *vg = w.Vgen + (long long)tok[t] * Rp;
@@ -111,7 +114,7 @@ decomp_chain_kernel(const DecompParams p) {
         }
         __syncthreads();
         float *srow = stash + (long long)(t + 1) * SP;
-        if (!maxsr) {
+        if (!materialise) {
             // ---- rr = (hb . Sa) * v  (:169-170 / :174-175) ------------------------------------
             for (int r = tid; r < R; r += nt) {
                 float a = 0.0f;
@@ -132,9 +135,11 @@ decomp_chain_kernel(const DecompParams p) {
                 h[j] = hn;                 // only thread j reads h[j] in this phase
             }
         } else {
-            // ---- max-times semiring (:159-166): Tr[s][j] = sum_r v_r S1[s][r] S2[j][r] + W[s][j]
+            // ---- materialised transition (max-times semiring, model_decompose_single.py:159-166, and
+            // the independent=1 model, model_decompose_independent.py:165-173):
+            //     Tr[s][j] = (sum_r v_r S1[s][r] S2[j][r] + W[s][j]) * mask[s][j]
             for (int j = tid; j < S; j += nt) {
-                float best = -INFINITY;
+                float best = maxsr ? -INFINITY : 0.0f;
                 for (int s = 0; s < S; s++) {
                     // forward uses Tr[s][j]; backward uses Tr^T, i.e. Tr[j][s]
                     const int fr = dir == 0 ? s : j, to = dir == 0 ? j : s;
@@ -142,7 +147,8 @@ decomp_chain_kernel(const DecompParams p) {
                     for (int r = 0; r < R; r++)
                         tr = fmaf(v[r] * w.S1[(long long)fr * Rp + r], w.S2[(long long)to * Rp + r], tr);
                     tr += w.W[(long long)fr * SP + to];
-                    best = fmaxf(best, hb[s] * tr);
+                    if (w.mask) tr *= w.mask[(long long)fr * SP + to];
+                    best = maxsr ? fmaxf(best, hb[s] * tr) : fmaf(hb[s], tr, best);
                 }
                 float nx = best;
                 if (dir == 0) nx *= w.o[j];
@@ -301,7 +307,7 @@ inline size_t decomp_fast_lds_bytes(const DecompWeights &w, int L) {
 
 inline int launch_decomp_chain(const DecompWeights &w, const int64_t *x, const int64_t *len,
                                const int *order, float *A, float *Bk, int B, int L, int full, hipStream_t s) {
-    const bool fast_ok = w.farnn == 0 && w.semiring == FARNN_SEMIRING_SUM &&
+    const bool fast_ok = w.farnn == 0 && w.semiring == FARNN_SEMIRING_SUM && !w.mask &&
                          decomp_fast_lds_bytes(w, L) <= 150 * 1024 && !getenv("FARNN_DECOMP_GENERIC");
     if (fast_ok) {
         DecompFastParams p;

@@ -13,13 +13,14 @@
 #include "layout.hip.h"
 #include "fst4_score.hip.h"
 #include "decomp_chain.hip.h"
+#include "decomp1_score.hip.h"
 
 namespace farnn {
 thread_local char g_err[512] = "";
 }
 using namespace farnn;
 
-enum { KIND_IFST = 2, KIND_IND1 = 1, KIND_FST4 = 0, KIND_DECOMP = 12 };
+enum { KIND_IFST = 2, KIND_IND1 = 1, KIND_FST4 = 0, KIND_DECOMP = 12, KIND_DECOMP1 = 11 };
 enum { KERN_CHAIN = 0, KERN_SCORE = 1, KERN_PREP = 2, KERN_COUNT = 3 };
 
 struct Prof {
@@ -41,6 +42,8 @@ struct farnn_model {
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     DecompWeights dw;                       // decomposed model weights
+    int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
+    float *d1_S1o = nullptr, *d1_S2o = nullptr, *d1_CoutT = nullptr;
     // workspace
     float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
     int64_t *offs = nullptr;
@@ -300,9 +303,10 @@ extern "C" int farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms
 extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
-        case KERN_CHAIN: return m->kind == KIND_DECOMP ? "decomp_chain_kernel" : "chain_kernel";
+        case KERN_CHAIN: return (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1) ? "decomp_chain_kernel" : "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
-                              : (m->kind == KIND_IND1 ? "ind1_score_kernel" : "score_decode_kernel");
+                              : (m->kind == KIND_IND1 ? "ind1_score_kernel"
+                              : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel" : "score_decode_kernel"));
         case KERN_PREP:  return "batch_prep_kernel";
         default: return "";
     }
@@ -370,6 +374,54 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     return FARNN_OK;
 }
 
+static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s) {
+    int rc;
+    const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
+    int threads = round_up(4 * m->K, 64);
+    if (threads > 1024) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
+    const int ib4 = viterbi_ib4(m->K);
+#define FARNN_LAUNCH_VIT(N)                                                                   \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                       \
+        viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                            \
+    } while (0)
+    if (ib4 == 2) FARNN_LAUNCH_VIT(2);            // K <= 32
+    else if (ib4 == 4) FARNN_LAUNCH_VIT(4);       // K <= 64
+    else if (ib4 == 9) FARNN_LAUNCH_VIT(9);       // K <= 144
+    else if (ib4 == 13) FARNN_LAUNCH_VIT(13);     // K <= 208
+    else FARNN_LAUNCH_VIT(16);                    // K <= 256
+#undef FARNN_LAUNCH_VIT
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t *len, int B, int full,
+                                int32_t *tags, int64_t *flat, float *scores, hipStream_t s) {
+    Decomp1ScoreParams p;
+    p.A = m->A; p.Bk = m->Bk; p.Vgen = m->dw.Vgen; p.S1 = m->dw.S1; p.S2 = m->dw.S2; p.W = m->dw.W;
+    p.S1o = m->d1_S1o; p.S2o = m->d1_S2o; p.CoutT = m->d1_CoutT; p.P = m->P;
+    p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
+    p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RO = m->RO; p.ROp = m->ROp;
+    p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
+    p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
+    const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
+    int rc;
+    if ((rc = raise_lds_limit(decomp1_score_kernel, lds))) return rc;
+    KernelTimer kt(m, KERN_SCORE, s);
+    decomp1_score_kernel<<<dim3(p.L, B), dim3(256), lds, s>>>(p);
+    FARNN_HIP_TRY(hipGetLastError());
+    if (m->use_crf) {
+        ScoreParams v;
+        memset(&v, 0, sizeof(v));
+        v.trT = m->tr; v.len = len; v.offs = flat ? m->offs : nullptr; v.tags = tags; v.flat = flat;
+        v.crf_scores = m->crf_scores; v.B = B; v.L = m->wsL; v.K = m->K; v.Kp = m->Kp;
+        v.full = full; v.use_crf = 1; v.o_idx = m->o_idx; v.threshold = m->threshold;
+        if ((rc = launch_viterbi(m, v, B, s))) return rc;
+    }
+    return FARNN_OK;
+}
+
 static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
                                int64_t *flat, float *scores, hipStream_t s) {
     ScoreParams p;
@@ -404,24 +456,7 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
 #undef FARNN_LAUNCH_SCORE_K
 #undef FARNN_LAUNCH_SCORE
     FARNN_HIP_TRY(hipGetLastError());
-    if (m->use_crf) {
-        const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
-        int threads = round_up(4 * m->K, 64);
-        if (threads > 1024) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
-        const int ib4 = viterbi_ib4(m->K);
-#define FARNN_LAUNCH_VIT(N)                                                                   \
-    do {                                                                                      \
-        if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                       \
-        viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                            \
-    } while (0)
-        if (ib4 == 2) FARNN_LAUNCH_VIT(2);            // K <= 32
-        else if (ib4 == 4) FARNN_LAUNCH_VIT(4);       // K <= 64
-        else if (ib4 == 9) FARNN_LAUNCH_VIT(9);       // K <= 144
-        else if (ib4 == 13) FARNN_LAUNCH_VIT(13);     // K <= 208
-        else FARNN_LAUNCH_VIT(16);                    // K <= 256
-#undef FARNN_LAUNCH_VIT
-        FARNN_HIP_TRY(hipGetLastError());
-    }
+    if (m->use_crf && (rc = launch_viterbi(m, p, B, s))) return rc;
     return FARNN_OK;
 }
 
@@ -486,6 +521,13 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                                               m->wsL, full, s))) return rc;
             }
             return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+        }
+        case KIND_DECOMP1: {
+            {
+                KernelTimer kt(m, KERN_CHAIN, s);
+                if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+            }
+            return launch_decomp1_score(m, x, lengths, B, full, tags, flat_tags, scores, s);
         }
         default:
             return fail(FARNN_EINVAL, "tag: unknown model kind%s%s");
@@ -666,6 +708,82 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     return FARNN_OK;
 }
 
+// ---- create: decomposed independent=1 ----------------------------------------------------------
+extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->RO <= 0 || d->K <= 0 || !d->Vgen || !d->S1 || !d->S2 ||
+        !d->W || !d->Cout || !d->S1o || !d->S2o || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "decomp_ind1: sizes must be positive and factor pointers non-null%s%s");
+    if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "decomp_ind1: farnn must be 0, 1 or 2%s%s");
+    if (d->farnn >= 1 && (!d->Wss1 || !d->Wrs1 || !d->bs1))
+        return fail(FARNN_EINVAL, "decomp_ind1: farnn>=1 needs Wss1/Wrs1/bs1%s%s");
+    if (d->farnn == 2 && (!d->Wss2 || !d->Wrs2 || !d->bs2))
+        return fail(FARNN_EINVAL, "decomp_ind1: farnn==2 needs Wss2/Wrs2/bs2%s%s");
+    if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "decomp_ind1: bad nl%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_DECOMP1; m->device = device;
+    m->V = d->V; m->S = d->S; m->R = d->R; m->RO = d->RO; m->K = d->K;
+    m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);
+    m->C = d->use_crf ? d->K - 2 : d->K;
+    m->SP = round_up(d->S, 4); m->Rp = round_up(d->R, 4); m->ROp = round_up(d->RO, 4);
+    m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->use_crf = d->use_crf ? 1 : 0; m->farnn_gate = d->farnn; m->sig_k = d->sigmoid_exponent;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 256) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
+    if (decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc) > 160 * 1024)
+        return bail(fail(FARNN_ERANGE, "decomp_ind1: S*S*4 bytes of LDS needed per token (S too large)%s%s"));
+    DecompWeights &w = m->dw;
+    w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
+    w.farnn = d->farnn; w.nl = d->nl; w.semiring = d->semiring; w.sig_k = d->sigmoid_exponent;
+    float *tmp = nullptr;
+    if ((rc = upload_padded(m, &tmp, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc); w.Vgen = tmp;
+    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S1 = tmp;
+    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S2 = tmp;
+    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.W = tmp;
+    if (d->farnn >= 1) {
+        if ((rc = upload_padded(m, &tmp, d->Wss1, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss1 = tmp;
+        if ((rc = upload_padded(m, &tmp, d->Wrs1, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs1 = tmp;
+        if ((rc = dev_upload(m, &tmp, d->bs1, m->S, m->SP, od))) return bail(rc); w.bs1 = tmp;
+    }
+    if (d->farnn == 2) {
+        if ((rc = upload_padded(m, &tmp, d->Wss2, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss2 = tmp;
+        if ((rc = upload_padded(m, &tmp, d->Wrs2, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs2 = tmp;
+        if ((rc = dev_upload(m, &tmp, d->bs2, m->S, m->SP, od))) return bail(rc); w.bs2 = tmp;
+    }
+    {   // no per-state output scaling in this model: o = 1; the output sum masks the transitions instead
+        std::vector<float> ones((size_t)m->SP, 1.0f);
+        if ((rc = dev_upload(m, &m->o, ones.data(), m->SP, m->SP, 0))) return bail(rc);
+        w.o = m->o;
+        TmpDev Co, S1o, S2o, Wo;
+        if ((rc = Co.init(d->Cout, (size_t)m->K * m->RO, od))) return bail(rc);
+        if ((rc = S1o.init(d->S1o, (size_t)m->S * m->RO, od))) return bail(rc);
+        if ((rc = S2o.init(d->S2o, (size_t)m->S * m->RO, od))) return bail(rc);
+        if ((rc = Wo.init(d->Wo, (size_t)m->S * m->S, od))) return bail(rc);
+        float *osum = nullptr;
+        if ((rc = dev_alloc(m, (void **)&osum, (size_t)m->S * m->SP * 4))) return bail(rc);
+        FARNN_HIP_TRY(hipMemset(osum, 0, (size_t)m->S * m->SP * 4));
+        output_sum_kernel<<<(m->S * m->S + 255) / 256, 256>>>(Co.p, S1o.p, S2o.p, Wo.p, osum, m->K, m->S, m->SP, m->RO);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+        w.mask = osum;
+    }
+    if ((rc = upload_padded(m, &m->d1_S1o, d->S1o, m->S, m->RO, m->S, m->ROp, od))) return bail(rc);
+    if ((rc = upload_padded(m, &m->d1_S2o, d->S2o, m->S, m->RO, m->S, m->ROp, od))) return bail(rc);
+    if ((rc = upload_transposed(m, &m->d1_CoutT, d->Cout, m->K, m->RO, m->Kc, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    w.h0 = m->h0; w.hT = m->hT;
+    if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
 extern "C" void farnn_destroy(farnn_model *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
@@ -701,6 +819,7 @@ extern "C" double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_to
         case KIND_IFST: per_tok = 2.0 * S * S * 4 + 12; break;
         case KIND_IND1: per_tok = 3.0 * S * S * 4 + 12; once = C * S * S * 4; break;
         case KIND_FST4: per_tok = (C + 2.0) * S * S * 4 + 12; break;
+        case KIND_DECOMP1:
         case KIND_DECOMP:
             per_tok = R * 4 + 12;
             once = (2.0 * S * R + S * S + K * S) * 4;
@@ -713,7 +832,7 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     if (!m) return 0.0;
     const double S = m->S, C = m->C, R = m->R, K = m->K, n = (double)valid_tokens;
     if (which == KERN_CHAIN) {
-        if (m->kind == KIND_DECOMP) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
+        if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
         return (2.0 * S * S * 4 + 8) * n;                 // one block per direction + the token id
     }
     if (which == KERN_SCORE) {

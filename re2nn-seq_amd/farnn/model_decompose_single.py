@@ -30,6 +30,7 @@ def crf_default_transitions(tagset_size):
 
 
 class FARNN_S_D_W_I_S(NativeTagger):
+    _param_keys = _PARAM_KEYS
     local_uses_max_len = True        # forward_local iterates lengths.max() positions (ref :221)
 
     def __init__(self, V=None, S1=None, S2=None, C_output_mat=None, wildcard_mat=None,
@@ -113,7 +114,7 @@ class FARNN_S_D_W_I_S(NativeTagger):
 
     # ---- state dict compatible with the reference's key names ---------------------------------
     def state_dict(self):
-        sd = {k: getattr(self, k) for k in _PARAM_KEYS if hasattr(self, k)}
+        sd = {k: getattr(self, k) for k in self._param_keys if hasattr(self, k)}
         sd['embedding.weight'] = self.embedding
         sd['priority_layer.priority_mat'] = torch.from_numpy(self.priority_full)
         if self.use_crf:
@@ -123,7 +124,7 @@ class FARNN_S_D_W_I_S(NativeTagger):
     def load_state_dict(self, sd, strict=False):
         for k, v in sd.items():
             v = torch.as_tensor(np.asarray(v)).float() if not torch.is_tensor(v) else v.detach().float().cpu()
-            if k in _PARAM_KEYS:
+            if k in self._param_keys:
                 setattr(self, k, v)
             elif k == 'embedding.weight':
                 self.embedding = v

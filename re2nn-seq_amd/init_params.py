@@ -1,5 +1,6 @@
 """Decomposed-automaton pickle -> initial parameters (reference src_seq/init_params.py:221-320,
-``get_init_params_seq_independent_single``: the ``--independent 2`` loader).
+``get_init_params_seq_independent_single``: the ``--independent 2`` loader; :123-218,
+``get_init_params_seq_independent``: the ``--independent 1`` loader, schema in its docstring).
 
 Pickle schema (writer: reference wfa/decompose_automata.py:373-431):
     {'automata': dict,
@@ -79,3 +80,68 @@ def get_init_params_seq_independent_single(args, s2i, t2i, data_dir='../data/'):
         raise NotImplementedError('the BERT front-end is outside the forward tagging path (SURVEY.md 2, row 23)')
     return (V_embed_extend, S1, S2, pretrain_embed_extend, wildcard_mat, wildcard_output_vector,
             final_vector, start_vector, priority_mat, C_output_mat, None)
+
+
+def get_init_params_seq_independent(args, s2i, t2i, data_dir='../data/'):
+    """``--independent 1`` loader (reference init_params.py:123-218).  Pickle schema (writer:
+    decompose_automata.py:148-300):
+        seed: [ {rank: {'V','S1','S2','wildcard_mat'}},
+                {rank_wildcard: {'C_output'[C,RO],'S1_output','S2_output'[S,RO],'wildcard_output'[S,S]}},
+                {rank_wildcard: {'C_output'[C+1,RO], ..., 'wildcard_output': None}} ]        # CE1
+    Quirks kept: the output factors are indexed by ``args.rank_wildcard`` (:144); BOTH factor
+    triples are normalised (:191-215); no ``args.random`` branch here (the model re-initialises)."""
+    print("Start getting initial decompsoed parameters V C S1 S2...")
+    dpath = os.path.join(data_dir, args.dataset)
+    loader = load_glove_embed if args.embed_type == 'glove' else load_fasttext_embed
+    pretrained_embed = loader(dpath, args.embed_dim)
+    if args.random_embed:
+        pretrained_embed = np.random.random(pretrained_embed.shape)
+
+    automata_dicts = load_pkl(args.automata_path)
+    print("Loading automata: {}".format(args.automata_path))
+    per_seed = automata_dicts[args.seed]
+    factor_dicts = per_seed[0][args.rank]
+    factor_output_dicts = (per_seed[2] if args.local_loss_func == 'CE1' else per_seed[1])[args.rank_wildcard]
+    automata = automata_dicts['automata']
+
+    V_embed, S1, S2 = factor_dicts['V'], factor_dicts['S1'], factor_dicts['S2']
+    wildcard_mat = factor_dicts['wildcard_mat']
+    C_output, S1_output, S2_output = (factor_output_dicts[k] for k in ('C_output', 'S1_output', 'S2_output'))
+    wildcard_output = factor_output_dicts['wildcard_output']
+
+    corrupt = 1000         # only reported (:155-170)
+    print('Invalid Positive Values: {}'.format(
+        int(np.sum(V_embed > corrupt) + np.sum(S1 > corrupt) + np.sum(S2 > corrupt))))
+    print('Invalid Negative Values: {}'.format(
+        int(np.sum(V_embed < -corrupt) + np.sum(S1 < -corrupt) + np.sum(S2 < -corrupt))))
+
+    n_state, rank = S1.shape
+    final_vector = np.zeros(n_state)
+    final_vector[automata['finalstates']] = 1
+    start_vector = np.zeros(n_state)
+    start_vector[automata['startstate']] = 1
+    print("DFA states: {}".format(n_state))
+
+    pretrain_embed_extend = np.append(pretrained_embed, np.zeros((1, args.embed_dim), dtype=np.float64), axis=0)
+    V_embed_extend = np.append(V_embed, np.zeros((1, rank), dtype=np.float64), axis=0)
+    priority_mat = create_mat_priority(s2i, args)
+
+    if args.normalize_automata != 'none':       # (:191-215)
+        print('Normalize automata decomposed parameters...')
+        v_avg = get_average(V_embed_extend, args.normalize_automata)
+        s1_avg = get_average(S1, args.normalize_automata)
+        s2_avg = get_average(S2, args.normalize_automata)
+        factor = np.float_power(v_avg * s1_avg * s2_avg, 1 / 3)
+        S1 = S1 * (factor / s1_avg)
+        S2 = S2 * (factor / s2_avg)
+        V_embed_extend = V_embed_extend * (factor / v_avg)
+        c_avg = get_average(C_output, args.normalize_automata)
+        s1o_avg = get_average(S1_output, args.normalize_automata)
+        s2o_avg = get_average(S2_output, args.normalize_automata)
+        factor = np.float_power(c_avg * s1o_avg * s2o_avg, 1 / 3)
+        C_output = C_output * (factor / c_avg)
+        S1_output = S1_output * (factor / s1o_avg)
+        S2_output = S2_output * (factor / s2o_avg)
+
+    return (V_embed_extend, S1, S2, pretrain_embed_extend, wildcard_mat, wildcard_output,
+            final_vector, start_vector, priority_mat, C_output, S1_output, S2_output)

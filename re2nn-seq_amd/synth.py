@@ -277,6 +277,32 @@ def make_iiid_pickle_dict(automaton, t2i, s2i, ranks, rng, noise=0.01, n_seeds=4
     return out
 
 
+def make_iid_pickle_dict(automaton, t2i, s2i, ranks, output_ranks, rng, noise=0.01, n_seeds=4,
+                         dataset='MITR-BIO'):
+    """A dict with the schema of ``IID.automata.*.pkl`` written by decompose_automata_independent
+    (decompose_automata.py:148-300):
+    {'automata': dict, seed: [ {rank: {'V','S1','S2','wildcard_mat'}},
+                               {rank_o: {'C_output'[C,RO], 'S1_output','S2_output'[S,RO], 'wildcard_output'[S,S]}},
+                               {rank_o: {'C_output'[C+1,RO], ..., 'wildcard_output': None}} ]}   # CE1."""
+    from .wfa.fsa_to_tensor import dfa_to_tensor_slot_independent_wildcard
+    lang, _, wild, out_ten, _, _, _, _ = dfa_to_tensor_slot_independent_wildcard(
+        automaton, t2i, s2i, dataset=dataset)
+    out = {'automata': automaton}
+    for seed in range(n_seeds):
+        per_rank, per_ro, per_ro_w = {}, {}, {}
+        for R in ranks:
+            Vf, S1, S2 = exact_cp_factors(lang, rank=R, rng=rng, noise=noise)
+            per_rank[R] = {'V': Vf, 'S1': S1, 'S2': S2, 'wildcard_mat': wild.copy()}
+        for RO in output_ranks:
+            Cf, S1o, S2o = exact_cp_factors(out_ten[:-1], rank=RO, rng=rng, noise=noise)
+            per_ro[RO] = {'C_output': Cf, 'S1_output': S1o, 'S2_output': S2o,
+                          'wildcard_output': out_ten[-1].copy()}
+            Cf, S1o, S2o = exact_cp_factors(out_ten, rank=RO, rng=rng, noise=noise)
+            per_ro_w[RO] = {'C_output': Cf, 'S1_output': S1o, 'S2_output': S2o, 'wildcard_output': None}
+        out[seed] = [per_rank, per_ro, per_ro_w]
+    return out
+
+
 def random_decomposed_params(V, S, C, R, D, rng, scale=None):
     """Dense gaussian factors for size/throughput runs of the decomposed path."""
     if scale is None:
@@ -301,12 +327,14 @@ def random_decomposed_params(V, S, C, R, D, rng, scale=None):
 
 # --------------------------------------------------------------------------- on-disk trees
 def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n_states=20, seed=0,
-                       n_train=48, n_dev=24, n_test=24, max_len=16, embed_dim=16, ranks=(100,)):
+                       n_train=48, n_dev=24, n_test=24, max_len=16, embed_dim=16, ranks=(100,),
+                       output_ranks=(70,)):
     """Write a complete, schema-identical data directory for the CLI drivers:
         <root>/<dataset>/dataset.pkl
         <root>/<dataset>/glove.<dim>.emb
         <root>/<dataset>/automata/synthetic.ID{0,1,2}           (automaton dict, one per --independent)
         <root>/<dataset>/automata/IIID.automata.synthetic.pkl   (decomposed i-FST)
+        <root>/<dataset>/automata/IID.automata.synthetic.pkl    (decomposed independent=1)
     Returns a dict of the paths and the generated objects."""
     import os
     import pickle
@@ -331,4 +359,10 @@ def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n
     with open(p, 'wb') as f:
         pickle.dump(iiid, f)
     paths['IIID'] = p
+    iid = make_iid_pickle_dict(automaton, dset['t2i'], dset['s2i'], ranks=list(ranks),
+                               output_ranks=list(output_ranks), rng=rng)
+    p = os.path.join(adir, 'IID.automata.synthetic.pkl')
+    with open(p, 'wb') as f:
+        pickle.dump(iid, f)
+    paths['IID'] = p
     return {'paths': paths, 'dset': dset, 'automaton': automaton, 'rules': rules}

@@ -39,6 +39,7 @@ import torch  # noqa: E402
 from re2nn_seq_amd import synth  # noqa: E402
 from src_seq.farnn.model_onehot import FARNN_S_O, FARNN_S_O_I, FARNN_S_O_I_S  # noqa: E402
 from src_seq.farnn.model_decompose_single import FARNN_S_D_W_I_S  # noqa: E402
+from src_seq.farnn.model_decompose_independent import FARNN_S_D_W_I  # noqa: E402
 from src_seq.baselines.crf import CRF  # noqa: E402
 from src_seq.wfa import fsa_to_tensor as ref_f2t  # noqa: E402
 from src_seq.metrics.metrics import eval_seq_token, get_ner_fmeasure  # noqa: E402
@@ -268,6 +269,93 @@ def gen_decomposed(dset, automaton, t2i, s2i, x, lengths):
          Ow_in=Ow, final_in=fin, start_in=sta, E_in=E, priority_in=pri, **blob)
 
 
+# ----------------------------------------------------------------------------- decomposed independent=1
+IND1_KEYS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_output', 'S1_output', 'S2_output',
+             'wildcard_mat', 'h0', 'hT', 'beta_vec', 'Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
+
+
+def exact_output_factors(Oten, rank, rng, noise):
+    """Oten[c,s,j] = sum_q C[c,q] S1o[s,q] S2o[j,q]: one term per (s,j) pair that carries a label."""
+    C, S, _ = Oten.shape
+    pairs = np.argwhere(Oten.sum(0) > 0)
+    assert rank >= len(pairs)
+    Cf = np.zeros((C, rank)); S1o = np.zeros((S, rank)); S2o = np.zeros((S, rank))
+    for q, (s, j) in enumerate(pairs):
+        Cf[:, q] = Oten[:, s, j]
+        S1o[s, q] = 1.0
+        S2o[j, q] = 1.0
+    Cf += noise * rng.randn(*Cf.shape); S1o += noise * rng.randn(*S1o.shape); S2o += noise * rng.randn(*S2o.shape)
+    return Cf, S1o, S2o
+
+
+def gen_decomposed_ind1(dset, automaton, t2i, s2i, x, lengths):
+    o_idx = s2i['o']
+    V = len(t2i)
+    rng = np.random.RandomState(19)
+    t2i_nopad = {w: i for w, i in t2i.items() if w != '<pad>'}
+    T, _, W, Oten, _, fin, sta, _ = quiet(ref_f2t.dfa_to_tensor_slot_independent_wildcard,
+                                          automaton, t2i_nopad, s2i)
+    R = int((T.sum(0) > 0).sum()) + 6
+    Vf, S1, S2 = synth.exact_cp_factors(T, rank=R, rng=rng, noise=0.02)
+    Vf = np.append(Vf, np.zeros((1, R)), axis=0)
+    RO = int((Oten.sum(0) > 0).sum()) + 3
+    Cf, S1o, S2o = exact_output_factors(Oten, RO, rng, 0.02)
+    D = 8
+    E = np.append(rng.randn(V - 1, D) * 0.5, np.zeros((1, D)), axis=0)
+    pri = np.eye(len(s2i))
+    for s_, i_ in s2i.items():
+        if s_.startswith('b-') and ('i-' + s_[2:]) in s2i:
+            pri[s2i['i-' + s_[2:]]][i_] = -1
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    label = torch.zeros_like(xt)
+    configs = [
+        dict(farnn=0, use_crf=0, update_nonlinear='tanh', beta=0.7),
+        dict(farnn=0, use_crf=1, update_nonlinear='none', beta=1.0),
+        dict(farnn=1, use_crf=0, update_nonlinear='relu', beta=0.5, additional_nonlinear='tanh'),
+        dict(farnn=2, use_crf=1, update_nonlinear='tanh', beta=0.6, use_priority=1),
+        dict(farnn=0, use_crf=0, update_nonlinear='tanh', beta=0.8, train_mode='max'),
+        dict(farnn=2, use_crf=0, update_nonlinear='relutanh', beta=0.4, additional_states=2, rand_constant=1e-3),
+    ]
+    blob, meta = {}, []
+    for k, cfg in enumerate(configs):
+        torch.manual_seed(300 + k)
+        a = ns(independent=1, **cfg)
+        m = quiet(FARNN_S_D_W_I, V=Vf, S1=S1, S2=S2, C_output=Cf, S1_output=S1o, S2_output=S2o,
+                  wildcard_mat=W, wildcard_output=None, final_vector=fin, start_vector=sta,
+                  pretrained_word_embed=E, priority_mat=pri, args=a, o_idx=o_idx)
+        m.is_cuda = False
+        m.initialize()
+        if a.use_crf:
+            with torch.no_grad():
+                m.crf.transitions += torch.randn_like(m.crf.transitions) * 0.3
+        sd = {kk: vv.detach().numpy() for kk, vv in m.state_dict().items()}
+        pre = 'c{}.'.format(k)
+        for kk in IND1_KEYS:
+            if kk in sd:
+                blob[pre + kk] = sd[kk]
+        blob[pre + 'embedding'] = sd['embedding.weight']
+        blob[pre + 'priority_mat'] = sd['priority_layer.priority_mat']
+        if a.use_crf:
+            blob[pre + 'crf_transitions'] = sd['crf.transitions']
+        captured = {}
+        orig_decode = m.decode
+
+        def spy(all_scores, flat, mask, lens, _c=captured, _o=orig_decode):
+            _c['scores'] = all_scores.detach().numpy().copy()
+            return _o(all_scores, flat, mask, lens)
+        m.decode = spy
+        with torch.no_grad():
+            _, pred, _ = m.forward_local(xt, label, lt, train=False)
+        blob[pre + 'scores'] = captured['scores']
+        blob[pre + 'flat_pred'] = pred.numpy()
+        meta.append(cfg)
+    with open(os.path.join(HERE, 'decomp_ind1_small.json'), 'w') as f:
+        json.dump({'configs': meta, 'o_idx': int(o_idx), 'threshold': 0.5}, f, sort_keys=True)
+    save('decomp_ind1_small', x=x, lengths=lengths, V_in=Vf, S1_in=S1, S2_in=S2, C_in=Cf, S1o_in=S1o,
+         S2o_in=S2o, W_in=W, final_in=fin, start_in=sta, E_in=E, priority_in=pri, **blob)
+
+
+
 # ----------------------------------------------------------------------------- CRF alone
 def gen_crf():
     rng = np.random.RandomState(21)
@@ -366,6 +454,7 @@ if __name__ == '__main__':
     dset, automaton, t2i, s2i = gen_loader()
     x, lengths = gen_onehot(dset, automaton, t2i, s2i)
     gen_decomposed(dset, automaton, t2i, s2i, x, lengths)
+    gen_decomposed_ind1(dset, automaton, t2i, s2i, x, lengths)
     gen_crf()
     gen_atis_scale()
     gen_metrics(dset, s2i)

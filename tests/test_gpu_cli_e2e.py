@@ -88,6 +88,28 @@ def test_decompose_cli_matches_oracle(tree, tmp_path):
     assert results['test']['token-level'][3] > 0.3
 
 
+def test_decompose_independent1_cli_matches_oracle(tree, tmp_path):
+    """--method decompose --independent 1 (FARNN_S_D_W_I): IID pickle -> loader -> mirror -> HIP."""
+    L = 12
+    argv = ['--dataset', 'ATIS-BIO', '--method', 'decompose', '--independent', '1',
+            '--automata_path', tree['paths']['IID'], '--rank', '100', '--rank_wildcard', '70', '--seed', '1',
+            '--beta', '1.0', '--embed_dim', '16', '--normalize_automata', 'none', '--rand_constant', '0',
+            '--update_nonlinear', 'none', '--bz', '9', '--seq_max_len', str(L), '--epoch', '0',
+            '--train_portion', '0', '--data_dir', tree['paths']['data_dir'], '--model_dir', str(tmp_path)]
+    results, stats, _ = cli.main(argv)
+    automaton = tree['automaton']
+
+    # beta=1 and (nearly) exact CP factors of both tensors: the onehot independent=1 tags
+    def score_fn(t2i, s2i, x, lengths):
+        T, _, W, Oten, _, fin, sta, _ = f2t.dfa_to_tensor_slot_independent_wildcard(automaton, t2i, s2i)
+        return fo.onehot_ind1_scores(T, W, Oten, sta, fin, x, lengths)
+
+    tok, ent = _expected(tree, 'test', L, score_fn)
+    assert abs(results['test']['token-level'][3] - tok[3]) < 0.05
+    assert results['test']['token-level'][3] > 0.3
+    assert stats['test']['tokens'] > 0
+
+
 def test_predict_by_RE_scores_and_cache(tree, tmp_path):
     """RE.predict_by_RE: unflattened predictions + scores incl. pad positions, 0.99 -> 1.0 fix-up,
     cached as <automata_path>.re.score (reference RE.py:77-192)."""

@@ -114,3 +114,84 @@ def test_viterbi_atis_scale_vs_oracle():
     _, pred, _ = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
     sc = fo.onehot_crf_extension_scores(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths))
     assert np.array_equal(pred.numpy(), fo.forward_local_tags(sc, lengths, 0.5, 3, crf_tr=tr))
+
+
+# ---------------------------------------------------------------- decomposed independent=1 (a15)
+def _ind1_configs():
+    with open(os.path.join(GOLDEN, 'decomp_ind1_small.json')) as f:
+        return json.load(f)
+
+
+def _build_ind1(g, k, cfg, meta):
+    from re2nn_seq_amd.farnn.model_decompose_independent import FARNN_S_D_W_I
+    a = ns(independent=1, threshold=meta['threshold'], **cfg)
+    torch.manual_seed(0)
+    m = FARNN_S_D_W_I(V=g['V_in'], S1=g['S1_in'], S2=g['S2_in'], C_output=g['C_in'],
+                      S1_output=g['S1o_in'], S2_output=g['S2o_in'], wildcard_mat=g['W_in'],
+                      wildcard_output=None, final_vector=g['final_in'], start_vector=g['start_in'],
+                      pretrained_word_embed=g['E_in'], priority_mat=g['priority_in'], args=a,
+                      o_idx=meta['o_idx'])
+    pre = 'c{}.'.format(k)
+    sd = {}
+    for key in g.files:
+        if key.startswith(pre) and key not in (pre + 'scores', pre + 'flat_pred'):
+            name = key[len(pre):]
+            name = {'embedding': 'embedding.weight', 'priority_mat': 'priority_layer.priority_mat',
+                    'crf_transitions': 'crf.transitions'}.get(name, name)
+            sd[name] = g[key]
+    shapes = {n: tuple(getattr(m, n).shape) for n in ('S1', 'S2', 'C_output', 'S1_output', 'S2_output',
+                                                      'wildcard_mat', 'h0', 'hT')}
+    m.load_state_dict(sd)
+    for n, shp in shapes.items():      # the mirror's constructor built the reference's shapes
+        assert tuple(getattr(m, n).shape) == shp, n
+    return m
+
+
+@pytest.mark.parametrize('k', range(len(_ind1_configs()['configs'])))
+def test_decomposed_independent1_vs_reference(k):
+    """FARNN_S_D_W_I (--independent 1): scores within 1e-4 of the captured reference, tags equal."""
+    from re2nn_seq_amd import _lib
+    meta = _ind1_configs()
+    cfg = meta['configs'][k]
+    g = load_golden('decomp_ind1_small')
+    x, lengths = g['x'], g['lengths']
+    m = _build_ind1(g, k, cfg, meta)
+    pre = 'c{}.'.format(k)
+    ref_scores = g[pre + 'scores']
+    Lmax = int(lengths.max())
+    r = m.run(_t(x[:, :Lmax]), _t(lengths), _lib.MODE_FULL, want_scores=True)
+    np.testing.assert_allclose(r['scores'].cpu().numpy(), ref_scores, rtol=1e-4, atol=1e-4)
+    _, pred, true = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    assert np.array_equal(pred.numpy(), g[pre + 'flat_pred'])
+    assert true.shape == pred.shape
+
+
+def test_decomposed_independent1_ragged_vs_oracle():
+    """A larger ragged batch (B=48, L=24, S=23, R=40, RO=30), LOCAL mode, against the oracle."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(11)
+    V, S, R, RO, K, B, L = 90, 23, 40, 30, 9, 48, 24
+    p = {'Vgen': (rng.randn(V, R) * 0.4).astype(np.float32), 'S1': (rng.randn(S, R) * 0.4).astype(np.float32),
+         'S2': (rng.randn(S, R) * 0.4).astype(np.float32), 'W': (rng.rand(S, S) < 0.1).astype(np.float32) * 0.5,
+         'Cout': (rng.randn(K, RO) * 0.5).astype(np.float32), 'S1o': (rng.randn(S, RO) * 0.2).astype(np.float32),
+         'S2o': (rng.randn(S, RO) * 0.2).astype(np.float32), 'Wo': None,     # contractive recurrence
+         'h0': np.eye(S, dtype=np.float32)[0], 'hT': (rng.rand(S) < 0.3).astype(np.float32),
+         'farnn': 0, 'nl': fo.NL_CODES['tanh'], 'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    h = _lib.create_decomp_ind1(p['Vgen'], p['S1'], p['S2'], p['W'], p['Cout'], p['S1o'], p['S2o'],
+                                p['h0'], p['hT'], nl='tanh', threshold=0.5, o_idx=2)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(),
+          scores.data_ptr())
+    torch.cuda.synchronize()
+    Lmax = int(lengths.max())
+    ref = fo.decomp_ind1_scores(p, x, lengths)
+    got = scores.cpu().numpy()[:, :Lmax]
+    mask = np.arange(Lmax)[None, :] < lengths[:, None]
+    np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
+    t = tags.cpu().numpy()
+    assert (t[:, :Lmax][~mask] == -1).all()

@@ -110,3 +110,43 @@ def test_decomposed_pickle_loader(tmp_path):
     np.testing.assert_allclose(avgs[0][nz], avgs[1][nz], rtol=1e-9)
     np.testing.assert_allclose(avgs[1][nz], avgs[2][nz], rtol=1e-9)
     assert bert is None and n_pairs > 0
+
+
+def test_decomposed_independent1_pickle_loader(tmp_path):
+    """IID pickle -> get_init_params_seq_independent (reference init_params.py:123-218)."""
+    from re2nn_seq_amd.init_params import get_init_params_seq_independent
+    from re2nn_seq_amd.utils import get_average
+    rng = np.random.RandomState(0)
+    dset, automaton, _ = synth.make_dataset(40, 3, 12, seed=5)
+    t2i, s2i = dset['t2i'], dset['s2i']
+    blob = synth.make_iid_pickle_dict(automaton, t2i, s2i, ranks=[100], output_ranks=[70], rng=rng)
+    # the exact factors reproduce the C+1 output tensor of the reference's CE1 layout
+    Oten = f2t.dfa_to_tensor_slot_independent_wildcard(automaton, t2i, s2i)[3]
+    o = blob[1][2][70]
+    np.testing.assert_allclose(np.einsum('cq,iq,jq->cij', o['C_output'], o['S1_output'], o['S2_output']),
+                               Oten, atol=0.2)
+    assert o['wildcard_output'] is None and blob[1][1][70]['wildcard_output'].shape == Oten.shape[1:]
+    ddir = tmp_path / 'ATIS-BIO'
+    ddir.mkdir()
+    apath = ddir / 'IID.automata.synthetic.pkl'
+    with open(apath, 'wb') as f:
+        pickle.dump(blob, f)
+    D = 16
+    with open(ddir / 'glove.{}.emb'.format(D), 'wb') as f:
+        pickle.dump(rng.randn(len(t2i), D), f)
+    for loss, C in (('CE1', len(s2i) + 1), ('CE', len(s2i))):
+        a = ns(dataset='ATIS-BIO', embed_type='glove', embed_dim=D, random_embed=0, automata_path=str(apath),
+               seed=1, rank=100, rank_wildcard=70, normalize_automata='l2-rank', use_bert=0,
+               local_loss_func=loss)
+        out = get_init_params_seq_independent(a, s2i, t2i, data_dir=str(tmp_path) + '/')
+        V_ext, S1, S2, E_ext, W, Wo, fin, sta, pri, Cout, S1o, S2o = out
+        assert V_ext.shape == (len(t2i) + 1, 100) and np.all(V_ext[-1] == 0)
+        assert E_ext.shape == (len(t2i) + 1, D) and np.all(E_ext[-1] == 0)
+        assert Cout.shape == (C, 70) and S1o.shape == (12, 70) and S2o.shape == (12, 70)
+        assert (Wo is None) == (loss == 'CE1')
+        assert fin.sum() == len(automaton['finalstates']) and sta[0] == 1
+        for trip in ((V_ext, S1, S2), (Cout, S1o, S2o)):      # both triples are normalised (:191-215)
+            avgs = [get_average(m, 'l2-rank') for m in trip]
+            nz = avgs[0] > 0
+            np.testing.assert_allclose(avgs[0][nz], avgs[1][nz], rtol=1e-9)
+            np.testing.assert_allclose(avgs[1][nz], avgs[2][nz], rtol=1e-9)

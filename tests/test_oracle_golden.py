@@ -155,3 +155,46 @@ def test_atis_scale_ifst():
     assert np.array_equal(fo.decode_argmax(sc, 0.5, 0), g['tags'].astype(np.int64))
     assert np.array_equal(fo.forward_local_tags(sc, l, 0.5, 0), g['flat_pred'].astype(np.int64))
     assert int((g['flat_pred'] != 0).sum()) > 100          # rules do fire in this fixture
+
+
+def decomp_ind1_params_from_fixture(g, k, cfg):
+    pre = 'c{}.'.format(k)
+    p = {
+        'S1': g[pre + 'S1'], 'S2': g[pre + 'S2'], 'W': g[pre + 'wildcard_mat'],
+        'Cout': g[pre + 'C_output'], 'S1o': g[pre + 'S1_output'], 'S2o': g[pre + 'S2_output'], 'Wo': None,
+        'h0': g[pre + 'h0'], 'hT': g[pre + 'hT'],
+        'farnn': cfg.get('farnn', 0), 'nl': fo.NL_CODES[cfg.get('update_nonlinear', 'none')],
+        'semiring': fo.SEMIRING_MAX if cfg.get('train_mode', 'sum') == 'max' else fo.SEMIRING_SUM,
+        'sig_k': cfg.get('sigmoid_exponent', 5),
+    }
+    p['Vgen'] = fo.generalized_vocab_table(
+        g[pre + 'V_embed'], g[pre + 'embedding'], g[pre + 'embed_r_generalized'],
+        g[pre + 'beta_vec'], fo.NL_CODES[cfg.get('additional_nonlinear', 'none')])
+    for kk in ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2'):
+        if pre + kk in g.files:
+            p[kk] = g[pre + kk]
+    return p
+
+
+def _ind1_configs():
+    with open(os.path.join(GOLDEN, 'decomp_ind1_small.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('k', range(len(_ind1_configs()['configs'])))
+def test_decomposed_independent1_small(k):
+    """FARNN_S_D_W_I (--method decompose --independent 1), SURVEY.md 8a row a15."""
+    meta = _ind1_configs()
+    cfg = meta['configs'][k]
+    g = _load('decomp_ind1_small')
+    x, l = g['x'], g['lengths']
+    pre = 'c{}.'.format(k)
+    p = decomp_ind1_params_from_fixture(g, k, cfg)
+    P = g[pre + 'priority_mat'] if cfg.get('use_priority', 0) else None
+    sc = fo.decomp_ind1_scores(p, x, l, P)
+    ref = g[pre + 'scores']
+    assert sc.shape == ref.shape
+    np.testing.assert_allclose(sc, ref, rtol=1e-4, atol=1e-4)
+    tr = g[pre + 'crf_transitions'] if cfg.get('use_crf', 0) else None
+    tags = fo.forward_local_tags(sc, l, meta['threshold'], meta['o_idx'], tr)
+    assert np.array_equal(tags, g[pre + 'flat_pred'])
