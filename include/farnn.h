@@ -158,6 +158,32 @@ typedef struct farnn_decomp_ind1_desc {
 
 int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *desc, int device, farnn_model **out);
 
+/* ---- decomposed independent=0: FARNN_S_D_W (reference model_decompose.py:10-459) ------------------ */
+typedef struct farnn_decomp_fst_desc {
+    int32_t V, S, R, RW, K;     /* S incl. additional_states; RW = rank of the wildcard factors       */
+    const float *Vgen;          /* [V,R]  generalized word table (model_decompose.py:222-241)        */
+    const float *C;             /* [K,R]  C_embed (:125); the recurrence sees Vgen * sum_c C (:253)   */
+    const float *S1, *S2;       /* [S,R]                                                              */
+    const float *Cw;            /* [K,RW] C_wildcard (:122-123)                                       */
+    const float *S1w, *S2w;     /* [S,RW] S1_wildcard / S2_wildcard (:127-131)                        */
+    const float *WW;            /* [S,S]  wildcard_wildcard (:133-135)                                */
+    const float *h0, *hT;       /* [S]                                                                */
+    const float *P;             /* [K,K] or NULL                                                      */
+    int32_t farnn;
+    const float *Wss1, *Wrs1, *bs1;
+    const float *Wss2, *Wrs2, *bs2;
+    float   sigmoid_exponent;
+    int32_t nl;
+    int32_t semiring;
+    float   threshold;
+    int32_t o_idx;
+    int32_t use_crf;
+    const float *crf_trans;     /* [K,K] when use_crf                                                 */
+    int32_t weights_on_device;
+} farnn_decomp_fst_desc;
+
+int farnn_decomp_fst_create(const farnn_decomp_fst_desc *desc, int device, farnn_model **out);
+
 /* ---- the hot path ------------------------------------------------------------------- */
 /*
  * farnn_tag: model.forward_local / forward_RE / forward_score of the reference

@@ -268,7 +268,8 @@ def generalized_vocab_table(V_embed, E, G, beta_vec, add_nl=NL_NONE):
 
 
 def _sig(v, k):
-    return (F32(1) / (F32(1) + np.exp(-(v * F32(k))))).astype(F32)
+    with np.errstate(over='ignore'):        # exp(+big) -> inf -> 1/(1+inf) = 0, as torch.sigmoid saturates
+        return (F32(1) / (F32(1) + np.exp(-(v * F32(k))))).astype(F32)
 
 
 def decomp_ifst_step(h, v, h_init, o, p, fwd):
@@ -422,6 +423,81 @@ def decomp_ind1_scores(p, x, lengths, P=None):
         abw = ab * bss                                                            # :203
         br = np.einsum('bij,rij->br', abw, s1_s2_out).astype(F32)                 # :204
         scores[:, i] = br @ q['Cout'].T                                           # :205
+    if P is not None:
+        scores = priority(scores, P)
+    return scores
+
+
+# --------------------------------------------------------------------------- decomposed independent=0
+def decomp_fst_wildcard_sum(p):
+    """FARNN_S_D_W.get_wildcard_tensor_origin_sum_forward, model_decompose.py:319-324.
+    Returns Wsum[from, to] = sum_q (sum_c Cw[c,q]) S1w[from,q] S2w[to,q] + WW[from,to]."""
+    cw = p['Cw'].sum(0).astype(F32)                                   # [R_W]
+    temp = (cw[:, None] * p['S1w'].T).astype(F32)                     # 'r,sr->rs'
+    res = np.einsum('sr,rj->js', p['S2w'], temp).astype(F32)
+    return (res + p['WW']).astype(F32)
+
+
+def decomp_fst_step(h, v, h_init, csum, Wsum, p, fwd):
+    """FARNN_S_D_W.get_forward_score, model_decompose.py:243-307.  v = generalized word vector;
+    the recurrence (and the gates) see _R = v * sum_c C_embed[c]  (:253)."""
+    farnn = p['farnn']
+    _R = (v * csum).astype(F32)
+    if farnn == 0:
+        hb = h
+    else:
+        z = _sig(h @ p['Wss1'] + _R @ p['Wrs1'] + p['bs1'], p['sig_k'])
+        if farnn == 2:
+            r = _sig(h @ p['Wss2'] + _R @ p['Wrs2'] + p['bs2'], p['sig_k'])
+            hb = ((F32(1) - r) * h_init + r * h).astype(F32)
+        else:
+            hb = h
+    S1, S2 = p['S1'], p['S2']
+    if p['semiring'] == SEMIRING_MAX:                                  # :269-276
+        tmp = np.einsum('br,sr->bsr', _R, S1)
+        Tr = np.einsum('sr,bjr->bjs', S2, tmp).astype(F32) + Wsum
+        nx = semiring_vm(hb, Tr if fwd else Tr.transpose(0, 2, 1), SEMIRING_MAX)
+    elif fwd:                                                          # :279-284
+        nx = ((((hb @ S1) * _R) @ S2.T) + hb @ Wsum).astype(F32)
+    else:                                                              # :285-290
+        nx = ((((hb @ S2) * _R) @ S1.T) + hb @ Wsum.T).astype(F32)
+    nx = _nl(nx.astype(F32), p['nl'])
+    if farnn == 0:
+        return nx
+    return ((F32(1) - z) * h + z * nx).astype(F32)
+
+
+def decomp_fst_scores(p, x, lengths, P=None):
+    """FARNN_S_D_W.forward_local score part, model_decompose.py:373-432 with get_final_score
+    (:309-323).  p keys: Vgen [V,R], C [K,R], S1,S2 [S,R], Cw [K,R_W], S1w,S2w [S,R_W], WW [S,S],
+    h0,hT, farnn, nl, semiring, gate params, sig_k.  alpha = state BEFORE token i (:418)."""
+    q = {k: (np.asarray(v, F32) if isinstance(v, np.ndarray) else v) for k, v in p.items()}
+    B = x.shape[0]
+    L = int(np.max(lengths))
+    h0, hT, Vgen = q['h0'], q['hT'], q['Vgen']
+    S = h0.shape[0]
+    Wsum = decomp_fst_wildcard_sum(q)
+    csum = q['C'].sum(0).astype(F32)                                   # :393
+    xb = reverse_prefix(x, lengths)
+    h0b = np.repeat(h0[None], B, 0); hTb = np.repeat(hT[None], B, 0)
+    hf, hb = h0b.copy(), hTb.copy()
+    fw = np.zeros((B, L + 1, S), F32); fw[:, 0] = h0
+    bw = np.zeros((B, L + 1, S), F32); bw[:, 0] = hT
+    for i in range(L):
+        hf = decomp_fst_step(hf, Vgen[x[:, i]], h0b, csum, Wsum, q, True)
+        fw[:, i + 1] = hf
+        hb = decomp_fst_step(hb, Vgen[xb[:, i]], hTb, csum, Wsum, q, False)
+        bw[:, i + 1] = hb
+    rb = reverse_prefix(bw, np.asarray(lengths) + 1)
+    K = q['C'].shape[0]
+    scores = np.zeros((B, L, K), F32)
+    for i in range(L):
+        v = Vgen[x[:, i]]
+        al, be = fw[:, i], rb[:, i + 1]
+        ab = ((al @ q['S1']) * (be @ q['S2'])).astype(F32)                            # :314-316
+        sc = np.einsum('bcr,br->bc', np.einsum('br,cr->bcr', v, q['C']), ab)          # :313,:317
+        abw = ((al @ q['S1w']) * (be @ q['S2w'])).astype(F32)                         # :318-320
+        scores[:, i] = (sc + abw @ q['Cw'].T).astype(F32)                             # :321-322
     if P is not None:
         scores = priority(scores, P)
     return scores

@@ -71,6 +71,19 @@ class DecompInd1Desc(C.Structure):
                 ('crf_trans', _f32p), ('weights_on_device', C.c_int32)]
 
 
+class DecompFstDesc(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('RW', C.c_int32), ('K', C.c_int32),
+                ('Vgen', _f32p), ('C', _f32p), ('S1', _f32p), ('S2', _f32p), ('Cw', _f32p),
+                ('S1w', _f32p), ('S2w', _f32p), ('WW', _f32p),
+                ('h0', _f32p), ('hT', _f32p), ('P', _f32p),
+                ('farnn', C.c_int32),
+                ('Wss1', _f32p), ('Wrs1', _f32p), ('bs1', _f32p),
+                ('Wss2', _f32p), ('Wrs2', _f32p), ('bs2', _f32p),
+                ('sigmoid_exponent', C.c_float), ('nl', C.c_int32), ('semiring', C.c_int32),
+                ('threshold', C.c_float), ('o_idx', C.c_int32), ('use_crf', C.c_int32),
+                ('crf_trans', _f32p), ('weights_on_device', C.c_int32)]
+
+
 # every symbol include/farnn.h declares, with its ctypes signature (tests check the exports)
 _vp = C.c_void_p
 SIGNATURES = {
@@ -79,6 +92,7 @@ SIGNATURES = {
     'farnn_onehot_ind1_create': (C.c_int, [C.POINTER(OnehotInd1Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_ifst_create': (C.c_int, [C.POINTER(DecompIfstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_ind1_create': (C.c_int, [C.POINTER(DecompInd1Desc), C.c_int, C.POINTER(_vp)]),
+    'farnn_decomp_fst_create': (C.c_int, [C.POINTER(DecompFstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_tag': (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     'farnn_reserve': (C.c_int, [_vp, C.c_int32, C.c_int32]),
     'farnn_destroy': (None, [_vp]),
@@ -278,3 +292,25 @@ def create_decomp_ind1(Vgen, S1, S2, W, Cout, S1o, S2o, h0, hT, Wo=None, P=None,
                        int(bool(use_crf)), ptr(crf_trans), 0)
     return _create('farnn_decomp_ind1_create', d, device,
                    (Vgen, S1, S2, W, Cout, S1o, S2o, Wo, h0, hT, P, crf_trans, g))
+
+
+def create_decomp_fst(Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P=None, farnn=0, gates=None,
+                      sigmoid_exponent=5, nl='none', semiring='sum', threshold=0.5, o_idx=0, use_crf=False,
+                      crf_trans=None, device=0):
+    Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT = (
+        f32(a) for a in (Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT))
+    P = None if P is None else f32(P)
+    crf_trans = None if crf_trans is None else f32(crf_trans)
+    g = {k: f32(v) for k, v in (gates or {}).items()}
+    S, R = S1.shape
+    K, RW = Cw.shape
+    if Cemb.shape != (K, R):
+        raise FarnnError('C_embed must be [K,R] = {}, got {}'.format((K, R), Cemb.shape))
+    d = DecompFstDesc(Vgen.shape[0], S, R, RW, K, ptr(Vgen), ptr(Cemb), ptr(S1), ptr(S2), ptr(Cw),
+                      ptr(S1w), ptr(S2w), ptr(WW), ptr(h0), ptr(hT), ptr(P), int(farnn),
+                      ptr(g.get('Wss1')), ptr(g.get('Wrs1')), ptr(g.get('bs1')),
+                      ptr(g.get('Wss2')), ptr(g.get('Wrs2')), ptr(g.get('bs2')),
+                      float(sigmoid_exponent), NL[nl], SEMIRING[semiring], float(threshold), int(o_idx),
+                      int(bool(use_crf)), ptr(crf_trans), 0)
+    return _create('farnn_decomp_fst_create', d, device,
+                   (Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P, crf_trans, g))

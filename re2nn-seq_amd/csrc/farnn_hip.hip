@@ -20,7 +20,7 @@ thread_local char g_err[512] = "";
 }
 using namespace farnn;
 
-enum { KIND_IFST = 2, KIND_IND1 = 1, KIND_FST4 = 0, KIND_DECOMP = 12, KIND_DECOMP1 = 11 };
+enum { KIND_IFST = 2, KIND_IND1 = 1, KIND_FST4 = 0, KIND_DECOMP = 12, KIND_DECOMP1 = 11, KIND_DECOMP0 = 10 };
 enum { KERN_CHAIN = 0, KERN_SCORE = 1, KERN_PREP = 2, KERN_COUNT = 3 };
 
 struct Prof {
@@ -44,6 +44,8 @@ struct farnn_model {
     DecompWeights dw;                       // decomposed model weights
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
     float *d1_S1o = nullptr, *d1_S2o = nullptr, *d1_CoutT = nullptr;
+    int RW = 0, RWp = 0;                    // decomposed independent=0: wildcard factors + label factor
+    float *d0_Vgen = nullptr, *d0_CT = nullptr, *d0_S1w = nullptr, *d0_S2w = nullptr, *d0_CwT = nullptr;
     // workspace
     float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
     int64_t *offs = nullptr;
@@ -303,10 +305,11 @@ extern "C" int farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms
 extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
-        case KERN_CHAIN: return (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1) ? "decomp_chain_kernel" : "chain_kernel";
+        case KERN_CHAIN: return (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0) ? "decomp_chain_kernel" : "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
-                              : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel" : "score_decode_kernel"));
+                              : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel"
+                              : (m->kind == KIND_DECOMP0 ? "decomp0_score_kernel" : "score_decode_kernel")));
         case KERN_PREP:  return "batch_prep_kernel";
         default: return "";
     }
@@ -422,6 +425,33 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     return FARNN_OK;
 }
 
+static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t *len, int B, int full,
+                                int32_t *tags, int64_t *flat, float *scores, hipStream_t s) {
+    Decomp0ScoreParams p;
+    p.A = m->A; p.Bk = m->Bk; p.Vgen = m->d0_Vgen; p.S1 = m->dw.S1; p.S2 = m->dw.S2; p.CT = m->d0_CT;
+    p.S1w = m->d0_S1w; p.S2w = m->d0_S2w; p.CwT = m->d0_CwT; p.P = m->P;
+    p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
+    p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RW = m->RW; p.RWp = m->RWp;
+    p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
+    p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
+    const size_t lds = decomp0_score_lds_bytes(m->SP, m->Rp, m->RWp, m->Kc);
+    int rc;
+    if ((rc = raise_lds_limit(decomp0_score_kernel, lds))) return rc;
+    KernelTimer kt(m, KERN_SCORE, s);
+    decomp0_score_kernel<<<dim3(p.L, B), dim3(256), lds, s>>>(p);
+    FARNN_HIP_TRY(hipGetLastError());
+    if (m->use_crf) {
+        ScoreParams v;
+        memset(&v, 0, sizeof(v));
+        v.trT = m->tr; v.len = len; v.offs = flat ? m->offs : nullptr; v.tags = tags; v.flat = flat;
+        v.crf_scores = m->crf_scores; v.B = B; v.L = m->wsL; v.K = m->K; v.Kp = m->Kp;
+        v.full = full; v.use_crf = 1; v.o_idx = m->o_idx; v.threshold = m->threshold;
+        if ((rc = launch_viterbi(m, v, B, s))) return rc;
+    }
+    return FARNN_OK;
+}
+
 static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
                                int64_t *flat, float *scores, hipStream_t s) {
     ScoreParams p;
@@ -521,6 +551,13 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                                               m->wsL, full, s))) return rc;
             }
             return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+        }
+        case KIND_DECOMP0: {
+            {
+                KernelTimer kt(m, KERN_CHAIN, s);
+                if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+            }
+            return launch_decomp0_score(m, x, lengths, B, full, tags, flat_tags, scores, s);
         }
         case KIND_DECOMP1: {
             {
@@ -628,6 +665,65 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     return FARNN_OK;
 }
 
+// ---- shared by the three decomposed creates: factor tables of the recurrence ---------------------
+struct GateSrc { int farnn; const float *Wss1, *Wrs1, *bs1, *Wss2, *Wrs2, *bs2; };
+
+static int check_gates(const GateSrc &g, const char *who) {
+    if (g.farnn < 0 || g.farnn > 2) return fail(FARNN_EINVAL, "%s: farnn must be 0, 1 or 2%s", who, "");
+    if (g.farnn >= 1 && (!g.Wss1 || !g.Wrs1 || !g.bs1))
+        return fail(FARNN_EINVAL, "%s: farnn>=1 needs Wss1/Wrs1/bs1%s", who, "");
+    if (g.farnn == 2 && (!g.Wss2 || !g.Wrs2 || !g.bs2))
+        return fail(FARNN_EINVAL, "%s: farnn==2 needs Wss2/Wrs2/bs2%s", who, "");
+    return FARNN_OK;
+}
+
+// Vgen [V,R], S1/S2 [S,R], W [S,S] dense row-major; each with its own host|device flag.
+// `fast` also uploads the odd-stride copies the LDS-resident fast path wants.
+static int upload_chain_factors(farnn_model *m, const float *Vgen, int odV, const float *S1, const float *S2,
+                                int odS, const float *W, int odW, const GateSrc &g, int odG, bool fast) {
+    DecompWeights &w = m->dw;
+    int rc;
+    w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
+    w.farnn = g.farnn; w.nl = m->nl; w.semiring = m->semiring; w.sig_k = m->sig_k;
+    float *tmp = nullptr;
+    if ((rc = upload_padded(m, &tmp, Vgen, m->V, m->R, m->V, m->Rp, odV))) return rc; w.Vgen = tmp;
+    if ((rc = upload_padded(m, &tmp, S1, m->S, m->R, m->S, m->Rp, odS))) return rc; w.S1 = tmp;
+    if ((rc = upload_padded(m, &tmp, S2, m->S, m->R, m->S, m->Rp, odS))) return rc; w.S2 = tmp;
+    if ((rc = upload_transposed(m, &tmp, S1, m->S, m->R, m->SP, odS))) return rc; w.S1T = tmp;
+    if ((rc = upload_transposed(m, &tmp, S2, m->S, m->R, m->SP, odS))) return rc; w.S2T = tmp;
+    if ((rc = upload_padded(m, &tmp, W, m->S, m->S, m->S, m->SP, odW))) return rc; w.W = tmp;
+    if ((rc = upload_transposed(m, &tmp, W, m->S, m->S, m->SP, odW))) return rc; w.WT = tmp;
+    if (fast) {   // odd 16-byte row strides (see decomp_chain.hip.h)
+        w.SPo = m->SP + (((m->SP / 4) & 1) ? 0 : 4);
+        w.Rpo = m->Rp + (((m->Rp / 4) & 1) ? 0 : 4);
+        if ((rc = upload_padded(m, &tmp, S1, m->S, m->R, m->S, w.Rpo, odS))) return rc; w.fS1 = tmp;
+        if ((rc = upload_padded(m, &tmp, S2, m->S, m->R, m->S, w.Rpo, odS))) return rc; w.fS2 = tmp;
+        if ((rc = upload_transposed(m, &tmp, S1, m->S, m->R, w.SPo, odS))) return rc; w.fS1T = tmp;
+        if ((rc = upload_transposed(m, &tmp, S2, m->S, m->R, w.SPo, odS))) return rc; w.fS2T = tmp;
+        if ((rc = upload_padded(m, &tmp, W, m->S, m->S, m->S, w.SPo, odW))) return rc; w.fW = tmp;
+        if ((rc = upload_transposed(m, &tmp, W, m->S, m->S, w.SPo, odW))) return rc; w.fWT = tmp;
+    }
+    if (g.farnn >= 1) {
+        if ((rc = upload_padded(m, &tmp, g.Wss1, m->S, m->S, m->S, m->SP, odG))) return rc; w.Wss1 = tmp;
+        if ((rc = upload_padded(m, &tmp, g.Wrs1, m->R, m->S, m->R, m->SP, odG))) return rc; w.Wrs1 = tmp;
+        if ((rc = dev_upload(m, &tmp, g.bs1, m->S, m->SP, odG))) return rc; w.bs1 = tmp;
+    }
+    if (g.farnn == 2) {
+        if ((rc = upload_padded(m, &tmp, g.Wss2, m->S, m->S, m->S, m->SP, odG))) return rc; w.Wss2 = tmp;
+        if ((rc = upload_padded(m, &tmp, g.Wrs2, m->R, m->S, m->R, m->SP, odG))) return rc; w.Wrs2 = tmp;
+        if ((rc = dev_upload(m, &tmp, g.bs2, m->S, m->SP, odG))) return rc; w.bs2 = tmp;
+    }
+    return FARNN_OK;
+}
+
+static int upload_ones_o(farnn_model *m) {
+    std::vector<float> ones((size_t)m->SP, 1.0f);
+    int rc = dev_upload(m, &m->o, ones.data(), m->SP, m->SP, 0);
+    if (rc) return rc;
+    m->dw.o = m->o;
+    return FARNN_OK;
+}
+
 // ---- create: decomposed i-FST ------------------------------------------------------------------
 extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int device, farnn_model **out) {
     if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
@@ -635,11 +731,8 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0 || !d->Vgen || !d->S1 || !d->S2 || !d->W ||
         !d->Cout || !d->h0 || !d->hT)
         return fail(FARNN_EINVAL, "decomp_ifst: sizes must be positive and factor pointers non-null%s%s");
-    if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "decomp_ifst: farnn must be 0, 1 or 2%s%s");
-    if (d->farnn >= 1 && (!d->Wss1 || !d->Wrs1 || !d->bs1))
-        return fail(FARNN_EINVAL, "decomp_ifst: farnn>=1 needs Wss1/Wrs1/bs1%s%s");
-    if (d->farnn == 2 && (!d->Wss2 || !d->Wrs2 || !d->bs2))
-        return fail(FARNN_EINVAL, "decomp_ifst: farnn==2 needs Wss2/Wrs2/bs2%s%s");
+    const GateSrc gates{d->farnn, d->Wss1, d->Wrs1, d->bs1, d->Wss2, d->Wrs2, d->bs2};
+    if (int grc = check_gates(gates, "decomp_ifst")) return grc;
     if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "decomp_ifst: bad nl%s%s");
     int rc = select_device(device);
     if (rc) return rc;
@@ -656,35 +749,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
     if (m->S > 1024 || m->R > 4096) return bail(fail(FARNN_ERANGE, "decomp_ifst: S<=1024, R<=4096%s%s"));
     DecompWeights &w = m->dw;
-    w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
-    w.farnn = d->farnn; w.nl = d->nl; w.semiring = d->semiring; w.sig_k = d->sigmoid_exponent;
-    float *tmp = nullptr;
-    if ((rc = upload_padded(m, &tmp, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc); w.Vgen = tmp;
-    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S1 = tmp;
-    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S2 = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->S1, m->S, m->R, m->SP, od))) return bail(rc); w.S1T = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->S2, m->S, m->R, m->SP, od))) return bail(rc); w.S2T = tmp;
-    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.W = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->W, m->S, m->S, m->SP, od))) return bail(rc); w.WT = tmp;
-    // fast-path copies with odd 16-byte row strides (see decomp_chain.hip.h)
-    w.SPo = m->SP + (((m->SP / 4) & 1) ? 0 : 4);
-    w.Rpo = m->Rp + (((m->Rp / 4) & 1) ? 0 : 4);
-    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, w.Rpo, od))) return bail(rc); w.fS1 = tmp;
-    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, w.Rpo, od))) return bail(rc); w.fS2 = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->S1, m->S, m->R, w.SPo, od))) return bail(rc); w.fS1T = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->S2, m->S, m->R, w.SPo, od))) return bail(rc); w.fS2T = tmp;
-    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, w.SPo, od))) return bail(rc); w.fW = tmp;
-    if ((rc = upload_transposed(m, &tmp, d->W, m->S, m->S, w.SPo, od))) return bail(rc); w.fWT = tmp;
-    if (d->farnn >= 1) {
-        if ((rc = upload_padded(m, &tmp, d->Wss1, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss1 = tmp;
-        if ((rc = upload_padded(m, &tmp, d->Wrs1, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs1 = tmp;
-        if ((rc = dev_upload(m, &tmp, d->bs1, m->S, m->SP, od))) return bail(rc); w.bs1 = tmp;
-    }
-    if (d->farnn == 2) {
-        if ((rc = upload_padded(m, &tmp, d->Wss2, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss2 = tmp;
-        if ((rc = upload_padded(m, &tmp, d->Wrs2, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs2 = tmp;
-        if ((rc = dev_upload(m, &tmp, d->bs2, m->S, m->SP, od))) return bail(rc); w.bs2 = tmp;
-    }
+    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od, true))) return bail(rc);
     {   // o = sum_k Cout[k,:] (CE1, model_decompose_single.py:232); OT = Cout^T
         TmpDev Co;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
@@ -715,11 +780,8 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->RO <= 0 || d->K <= 0 || !d->Vgen || !d->S1 || !d->S2 ||
         !d->W || !d->Cout || !d->S1o || !d->S2o || !d->h0 || !d->hT)
         return fail(FARNN_EINVAL, "decomp_ind1: sizes must be positive and factor pointers non-null%s%s");
-    if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "decomp_ind1: farnn must be 0, 1 or 2%s%s");
-    if (d->farnn >= 1 && (!d->Wss1 || !d->Wrs1 || !d->bs1))
-        return fail(FARNN_EINVAL, "decomp_ind1: farnn>=1 needs Wss1/Wrs1/bs1%s%s");
-    if (d->farnn == 2 && (!d->Wss2 || !d->Wrs2 || !d->bs2))
-        return fail(FARNN_EINVAL, "decomp_ind1: farnn==2 needs Wss2/Wrs2/bs2%s%s");
+    const GateSrc gates{d->farnn, d->Wss1, d->Wrs1, d->bs1, d->Wss2, d->Wrs2, d->bs2};
+    if (int grc = check_gates(gates, "decomp_ind1")) return grc;
     if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "decomp_ind1: bad nl%s%s");
     int rc = select_device(device);
     if (rc) return rc;
@@ -738,27 +800,9 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     if (decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc) > 160 * 1024)
         return bail(fail(FARNN_ERANGE, "decomp_ind1: S*S*4 bytes of LDS needed per token (S too large)%s%s"));
     DecompWeights &w = m->dw;
-    w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
-    w.farnn = d->farnn; w.nl = d->nl; w.semiring = d->semiring; w.sig_k = d->sigmoid_exponent;
-    float *tmp = nullptr;
-    if ((rc = upload_padded(m, &tmp, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc); w.Vgen = tmp;
-    if ((rc = upload_padded(m, &tmp, d->S1, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S1 = tmp;
-    if ((rc = upload_padded(m, &tmp, d->S2, m->S, m->R, m->S, m->Rp, od))) return bail(rc); w.S2 = tmp;
-    if ((rc = upload_padded(m, &tmp, d->W, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.W = tmp;
-    if (d->farnn >= 1) {
-        if ((rc = upload_padded(m, &tmp, d->Wss1, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss1 = tmp;
-        if ((rc = upload_padded(m, &tmp, d->Wrs1, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs1 = tmp;
-        if ((rc = dev_upload(m, &tmp, d->bs1, m->S, m->SP, od))) return bail(rc); w.bs1 = tmp;
-    }
-    if (d->farnn == 2) {
-        if ((rc = upload_padded(m, &tmp, d->Wss2, m->S, m->S, m->S, m->SP, od))) return bail(rc); w.Wss2 = tmp;
-        if ((rc = upload_padded(m, &tmp, d->Wrs2, m->R, m->S, m->R, m->SP, od))) return bail(rc); w.Wrs2 = tmp;
-        if ((rc = dev_upload(m, &tmp, d->bs2, m->S, m->SP, od))) return bail(rc); w.bs2 = tmp;
-    }
+    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od, false))) return bail(rc);
     {   // no per-state output scaling in this model: o = 1; the output sum masks the transitions instead
-        std::vector<float> ones((size_t)m->SP, 1.0f);
-        if ((rc = dev_upload(m, &m->o, ones.data(), m->SP, m->SP, 0))) return bail(rc);
-        w.o = m->o;
+        if ((rc = upload_ones_o(m))) return bail(rc);
         TmpDev Co, S1o, S2o, Wo;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->RO, od))) return bail(rc);
         if ((rc = S1o.init(d->S1o, (size_t)m->S * m->RO, od))) return bail(rc);
@@ -778,6 +822,69 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
     if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
     w.h0 = m->h0; w.hT = m->hT;
+    if ((rc = setup_priority(m, d->P, od))) return bail(rc);
+    if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    *out = m;
+    return FARNN_OK;
+}
+
+// ---- create: decomposed independent=0 ----------------------------------------------------------
+extern "C" int farnn_decomp_fst_create(const farnn_decomp_fst_desc *d, int device, farnn_model **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->RW <= 0 || d->K <= 0 || !d->Vgen || !d->C || !d->S1 ||
+        !d->S2 || !d->Cw || !d->S1w || !d->S2w || !d->WW || !d->h0 || !d->hT)
+        return fail(FARNN_EINVAL, "decomp_fst: sizes must be positive and factor pointers non-null%s%s");
+    const GateSrc gates{d->farnn, d->Wss1, d->Wrs1, d->bs1, d->Wss2, d->Wrs2, d->bs2};
+    if (int grc = check_gates(gates, "decomp_fst")) return grc;
+    if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "decomp_fst: bad nl%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    farnn_model *m = new (std::nothrow) farnn_model();
+    if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    m->kind = KIND_DECOMP0; m->device = device;
+    m->V = d->V; m->S = d->S; m->R = d->R; m->RW = d->RW; m->K = d->K;
+    m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);
+    m->C = d->use_crf ? d->K - 2 : d->K;
+    m->SP = round_up(d->S, 4); m->Rp = round_up(d->R, 4); m->RWp = round_up(d->RW, 4);
+    m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
+    m->use_crf = d->use_crf ? 1 : 0; m->farnn_gate = d->farnn; m->sig_k = d->sigmoid_exponent;
+    const int od = d->weights_on_device;
+    auto bail = [&](int code) { farnn_destroy(m); return code; };
+    if (m->K > 256) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
+    if (m->S > 1024 || m->R > 4096 || m->RW > 4096)
+        return bail(fail(FARNN_ERANGE, "decomp_fst: S<=1024, R<=4096, RW<=4096%s%s"));
+    {
+        // recurrence inputs: table = Vgen * sum_c C (:253), W = sum_q (sum_c Cw) S1w S2w + WW (:319-324)
+        TmpDev Cd, Cwd, S1wd, S2wd, WWd;
+        if ((rc = Cd.init(d->C, (size_t)m->K * m->R, od))) return bail(rc);
+        if ((rc = Cwd.init(d->Cw, (size_t)m->K * m->RW, od))) return bail(rc);
+        if ((rc = S1wd.init(d->S1w, (size_t)m->S * m->RW, od))) return bail(rc);
+        if ((rc = S2wd.init(d->S2w, (size_t)m->S * m->RW, od))) return bail(rc);
+        if ((rc = WWd.init(d->WW, (size_t)m->S * m->S, od))) return bail(rc);
+        float *table = nullptr, *wsum = nullptr;
+        FARNN_HIP_TRY(hipMalloc((void **)&table, (size_t)m->V * m->R * 4));
+        struct Free { float *&p; ~Free() { if (p) (void)hipFree(p); } } f1{table};
+        FARNN_HIP_TRY(hipMalloc((void **)&wsum, (size_t)m->S * m->S * 4));
+        Free f2{wsum};
+        FARNN_HIP_TRY(hipMemcpy(table, d->Vgen, (size_t)m->V * m->R * 4,
+                                od ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        const long long n = (long long)m->V * m->R;
+        scale_by_colsum_kernel<<<(unsigned)((n + 255) / 256), 256>>>(table, Cd.p, m->V, m->R, m->K);
+        output_sum_kernel<<<(m->S * m->S + 255) / 256, 256>>>(Cwd.p, S1wd.p, S2wd.p, WWd.p, wsum, m->K, m->S, m->S, m->RW);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+        if ((rc = upload_chain_factors(m, table, 1, d->S1, d->S2, od, wsum, 1, gates, od, true))) return bail(rc);
+    }
+    if ((rc = upload_ones_o(m))) return bail(rc);
+    if ((rc = upload_padded(m, &m->d0_Vgen, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc);
+    if ((rc = upload_transposed(m, &m->d0_CT, d->C, m->K, m->R, m->Kc, od))) return bail(rc);
+    if ((rc = upload_padded(m, &m->d0_S1w, d->S1w, m->S, m->RW, m->S, m->RWp, od))) return bail(rc);
+    if ((rc = upload_padded(m, &m->d0_S2w, d->S2w, m->S, m->RW, m->S, m->RWp, od))) return bail(rc);
+    if ((rc = upload_transposed(m, &m->d0_CwT, d->Cw, m->K, m->RW, m->Kc, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
+    if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
+    m->dw.h0 = m->h0; m->dw.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
     *out = m;
@@ -819,6 +926,7 @@ extern "C" double farnn_algorithmic_bytes(const farnn_model *m, int64_t valid_to
         case KIND_IFST: per_tok = 2.0 * S * S * 4 + 12; break;
         case KIND_IND1: per_tok = 3.0 * S * S * 4 + 12; once = C * S * S * 4; break;
         case KIND_FST4: per_tok = (C + 2.0) * S * S * 4 + 12; break;
+        case KIND_DECOMP0:
         case KIND_DECOMP1:
         case KIND_DECOMP:
             per_tok = R * 4 + 12;
@@ -832,7 +940,7 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     if (!m) return 0.0;
     const double S = m->S, C = m->C, R = m->R, K = m->K, n = (double)valid_tokens;
     if (which == KERN_CHAIN) {
-        if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
+        if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
         return (2.0 * S * S * 4 + 8) * n;                 // one block per direction + the token id
     }
     if (which == KERN_SCORE) {

@@ -277,6 +277,45 @@ def make_iiid_pickle_dict(automaton, t2i, s2i, ranks, rng, noise=0.01, n_seeds=4
     return out
 
 
+def exact_cp_factors_4d(T4, rank=None, rng=None, noise=0.0):
+    """Exact CP factors of a 0/1 4th-order language tensor, one rank-1 term per labelled edge:
+    ``T4[w,c,s,j] = sum_r V[w,r] C[c,r] S1[s,r] S2[j,r]``."""
+    Vn, C, S, _ = T4.shape
+    trip = np.argwhere(T4.sum(0) > 0)
+    R = len(trip) if rank is None else int(rank)
+    assert R >= len(trip), "rank {} < number of labelled edges {}".format(R, len(trip))
+    Vf = np.zeros((Vn, R)); Cf = np.zeros((C, R)); S1 = np.zeros((S, R)); S2 = np.zeros((S, R))
+    for r, (c, s, j) in enumerate(trip):
+        Vf[:, r] = T4[:, c, s, j]
+        Cf[c, r] = 1.0; S1[s, r] = 1.0; S2[j, r] = 1.0
+    if noise and rng is not None:
+        for a in (Vf, Cf, S1, S2):
+            a += noise * rng.randn(*a.shape)
+    return Vf, Cf, S1, S2
+
+
+def make_d_pickle_dict(automaton, t2i, s2i, ranks, wildcard_ranks, rng, noise=0.01, n_seeds=4,
+                       dataset='MITR-BIO'):
+    """A dict with the schema of ``D.automata.*.pkl`` written by decompose_automata
+    (decompose_automata.py:30-146):
+    {'automata': dict, seed: [ {rank: {'V','C','S1','S2','wildcard_tensor','wildcard_wildcard_tensor'}},
+                               {rank_w: {'C_wildcard'[C,RW], 'S1_wildcard','S2_wildcard'[S,RW]}} ]}."""
+    from .wfa.fsa_to_tensor import dfa_to_tensor_slot_new_wildcard
+    T4, _, W4, WW, _, _, _ = dfa_to_tensor_slot_new_wildcard(automaton, t2i, s2i, dataset=dataset)
+    out = {'automata': automaton}
+    for seed in range(n_seeds):
+        per_rank, per_rw = {}, {}
+        for R in ranks:
+            Vf, Cf, S1, S2 = exact_cp_factors_4d(T4, rank=R, rng=rng, noise=noise)
+            per_rank[R] = {'V': Vf, 'C': Cf, 'S1': S1, 'S2': S2, 'wildcard_tensor': W4.copy(),
+                           'wildcard_wildcard_tensor': WW.copy()}
+        for RW in wildcard_ranks:
+            Cw, S1w, S2w = exact_cp_factors(W4, rank=RW, rng=rng, noise=noise)
+            per_rw[RW] = {'C_wildcard': Cw, 'S1_wildcard': S1w, 'S2_wildcard': S2w}
+        out[seed] = [per_rank, per_rw]
+    return out
+
+
 def make_iid_pickle_dict(automaton, t2i, s2i, ranks, output_ranks, rng, noise=0.01, n_seeds=4,
                          dataset='MITR-BIO'):
     """A dict with the schema of ``IID.automata.*.pkl`` written by decompose_automata_independent
@@ -335,6 +374,7 @@ def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n
         <root>/<dataset>/automata/synthetic.ID{0,1,2}           (automaton dict, one per --independent)
         <root>/<dataset>/automata/IIID.automata.synthetic.pkl   (decomposed i-FST)
         <root>/<dataset>/automata/IID.automata.synthetic.pkl    (decomposed independent=1)
+        <root>/<dataset>/automata/D.automata.synthetic.pkl      (decomposed independent=0)
     Returns a dict of the paths and the generated objects."""
     import os
     import pickle
@@ -365,4 +405,10 @@ def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n
     with open(p, 'wb') as f:
         pickle.dump(iid, f)
     paths['IID'] = p
+    dd = make_d_pickle_dict(automaton, dset['t2i'], dset['s2i'], ranks=list(ranks),
+                            wildcard_ranks=list(output_ranks), rng=rng)
+    p = os.path.join(adir, 'D.automata.synthetic.pkl')
+    with open(p, 'wb') as f:
+        pickle.dump(dd, f)
+    paths['D'] = p
     return {'paths': paths, 'dset': dset, 'automaton': automaton, 'rules': rules}

@@ -40,6 +40,7 @@ from re2nn_seq_amd import synth  # noqa: E402
 from src_seq.farnn.model_onehot import FARNN_S_O, FARNN_S_O_I, FARNN_S_O_I_S  # noqa: E402
 from src_seq.farnn.model_decompose_single import FARNN_S_D_W_I_S  # noqa: E402
 from src_seq.farnn.model_decompose_independent import FARNN_S_D_W_I  # noqa: E402
+from src_seq.farnn.model_decompose import FARNN_S_D_W  # noqa: E402
 from src_seq.baselines.crf import CRF  # noqa: E402
 from src_seq.wfa import fsa_to_tensor as ref_f2t  # noqa: E402
 from src_seq.metrics.metrics import eval_seq_token, get_ner_fmeasure  # noqa: E402
@@ -356,6 +357,95 @@ def gen_decomposed_ind1(dset, automaton, t2i, s2i, x, lengths):
 
 
 
+# ----------------------------------------------------------------------------- decomposed independent=0
+FST_KEYS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_embed', 'C_wildcard', 'S1_wildcard',
+            'S2_wildcard', 'wildcard_wildcard', 'h0', 'hT', 'beta_vec',
+            'Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
+
+
+def exact_4d_factors(T4, rank, rng, noise):
+    """T4[v,c,s,j] = sum_r V[v,r] C[c,r] S1[s,r] S2[j,r]: one term per labelled (c,s,j) edge."""
+    Vn, C, S, _ = T4.shape
+    trip = np.argwhere(T4.sum(0) > 0)
+    assert rank >= len(trip)
+    Vf = np.zeros((Vn, rank)); Cf = np.zeros((C, rank)); S1 = np.zeros((S, rank)); S2 = np.zeros((S, rank))
+    for r, (c, s, j) in enumerate(trip):
+        Vf[:, r] = T4[:, c, s, j]
+        Cf[c, r] = 1.0; S1[s, r] = 1.0; S2[j, r] = 1.0
+    for a in (Vf, Cf, S1, S2):
+        a += noise * rng.randn(*a.shape)
+    return Vf, Cf, S1, S2
+
+
+def gen_decomposed_fst(dset, automaton, t2i, s2i, x, lengths):
+    """FARNN_S_D_W (independent=0 decomposed): SURVEY.md 8a row a15, model_decompose.py:10-459."""
+    o_idx = s2i['o']
+    V = len(t2i)
+    rng = np.random.RandomState(23)
+    t2i_nopad = {w: i for w, i in t2i.items() if w != '<pad>'}
+    T4, _, W4, WW, fin, sta, _ = quiet(ref_f2t.dfa_to_tensor_slot_new_wildcard, automaton, t2i_nopad, s2i)
+    S = T4.shape[2]
+    R = int((T4.sum(0) > 0).sum()) + 5
+    RW = int((W4.sum(0) > 0).sum()) + 4
+    assert S not in (R, RW, T4.shape[1])
+    Vf, Cf, S1, S2 = exact_4d_factors(T4, R, rng, 0.02)
+    Vf = np.append(Vf, np.zeros((1, R)), axis=0)
+    Cw, S1w, S2w = exact_output_factors(W4, RW, rng, 0.02)
+    D = 8
+    E = np.append(rng.randn(V - 1, D) * 0.5, np.zeros((1, D)), axis=0)
+    pri = np.eye(len(s2i))
+    for s_, i_ in s2i.items():
+        if s_.startswith('b-') and ('i-' + s_[2:]) in s2i:
+            pri[s2i['i-' + s_[2:]]][i_] = -1
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    label = torch.zeros_like(xt)
+    configs = [
+        dict(farnn=0, use_crf=0, update_nonlinear='tanh', beta=0.7),
+        dict(farnn=0, use_crf=1, update_nonlinear='none', beta=1.0),
+        dict(farnn=1, use_crf=0, update_nonlinear='relu', beta=0.5, additional_nonlinear='tanh'),
+        dict(farnn=2, use_crf=1, update_nonlinear='tanh', beta=0.6, use_priority=1),
+        dict(farnn=0, use_crf=0, update_nonlinear='tanh', beta=0.8, train_mode='max'),
+        dict(farnn=2, use_crf=0, update_nonlinear='relutanh', beta=0.4, additional_states=2, rand_constant=1e-3),
+    ]
+    blob, meta = {}, []
+    for k, cfg in enumerate(configs):
+        torch.manual_seed(400 + k)
+        a = ns(independent=0, **cfg)
+        m = quiet(FARNN_S_D_W, V=Vf, C=Cf, S1=S1, S2=S2, C_wildcard=Cw, S1_wildcard=S1w, S2_wildcard=S2w,
+                  wildcard_wildcard=WW, final_vector=fin, start_vector=sta, pretrained_word_embed=E,
+                  priority_mat=pri, args=a, o_idx=o_idx)
+        m.is_cuda = False
+        m.initialize()
+        if a.use_crf:
+            with torch.no_grad():
+                m.crf.transitions += torch.randn_like(m.crf.transitions) * 0.3
+        sd = {kk: vv.detach().numpy() for kk, vv in m.state_dict().items()}
+        pre = 'c{}.'.format(k)
+        for kk in FST_KEYS:
+            if kk in sd:
+                blob[pre + kk] = sd[kk]
+        blob[pre + 'embedding'] = sd['embedding.weight']
+        blob[pre + 'priority_mat'] = sd['priority_layer.priority_mat']
+        if a.use_crf:
+            blob[pre + 'crf_transitions'] = sd['crf.transitions']
+        captured = {}
+        orig_decode = m.decode
+
+        def spy(all_scores, flat, mask, lens, _c=captured, _o=orig_decode):
+            _c['scores'] = all_scores.detach().numpy().copy()
+            return _o(all_scores, flat, mask, lens)
+        m.decode = spy
+        with torch.no_grad():
+            _, pred, _ = m.forward_local(xt, label, lt, train=False)
+        blob[pre + 'scores'] = captured['scores']
+        blob[pre + 'flat_pred'] = pred.numpy()
+        meta.append(cfg)
+    with open(os.path.join(HERE, 'decomp_fst_small.json'), 'w') as f:
+        json.dump({'configs': meta, 'o_idx': int(o_idx), 'threshold': 0.5}, f, sort_keys=True)
+    save('decomp_fst_small', x=x, lengths=lengths, V_in=Vf, C_in=Cf, S1_in=S1, S2_in=S2, Cw_in=Cw,
+         S1w_in=S1w, S2w_in=S2w, WW_in=WW, final_in=fin, start_in=sta, E_in=E, priority_in=pri, **blob)
+
+
 # ----------------------------------------------------------------------------- CRF alone
 def gen_crf():
     rng = np.random.RandomState(21)
@@ -455,6 +545,7 @@ if __name__ == '__main__':
     x, lengths = gen_onehot(dset, automaton, t2i, s2i)
     gen_decomposed(dset, automaton, t2i, s2i, x, lengths)
     gen_decomposed_ind1(dset, automaton, t2i, s2i, x, lengths)
+    gen_decomposed_fst(dset, automaton, t2i, s2i, x, lengths)
     gen_crf()
     gen_atis_scale()
     gen_metrics(dset, s2i)

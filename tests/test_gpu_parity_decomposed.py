@@ -195,3 +195,82 @@ def test_decomposed_independent1_ragged_vs_oracle():
     assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
     t = tags.cpu().numpy()
     assert (t[:, :Lmax][~mask] == -1).all()
+
+
+# ---------------------------------------------------------------- decomposed independent=0 (a15)
+def _fst_configs():
+    with open(os.path.join(GOLDEN, 'decomp_fst_small.json')) as f:
+        return json.load(f)
+
+
+def _build_fst(g, k, cfg, meta):
+    from re2nn_seq_amd.farnn.model_decompose import FARNN_S_D_W
+    a = ns(independent=0, threshold=meta['threshold'], **cfg)
+    torch.manual_seed(0)
+    m = FARNN_S_D_W(V=g['V_in'], C=g['C_in'], S1=g['S1_in'], S2=g['S2_in'], C_wildcard=g['Cw_in'],
+                    S1_wildcard=g['S1w_in'], S2_wildcard=g['S2w_in'], wildcard_wildcard=g['WW_in'],
+                    final_vector=g['final_in'], start_vector=g['start_in'],
+                    pretrained_word_embed=g['E_in'], priority_mat=g['priority_in'], args=a,
+                    o_idx=meta['o_idx'])
+    pre = 'c{}.'.format(k)
+    sd = {}
+    for key in g.files:
+        if key.startswith(pre) and key not in (pre + 'scores', pre + 'flat_pred'):
+            name = key[len(pre):]
+            name = {'embedding': 'embedding.weight', 'priority_mat': 'priority_layer.priority_mat',
+                    'crf_transitions': 'crf.transitions'}.get(name, name)
+            sd[name] = g[key]
+    names = ('S1', 'S2', 'C_embed', 'C_wildcard', 'S1_wildcard', 'S2_wildcard', 'wildcard_wildcard', 'h0', 'hT')
+    shapes = {n: tuple(getattr(m, n).shape) for n in names}
+    m.load_state_dict(sd)
+    for n, shp in shapes.items():      # the mirror's constructor built the reference's shapes
+        assert tuple(getattr(m, n).shape) == shp, n
+    return m
+
+
+@pytest.mark.parametrize('k', range(len(_fst_configs()['configs'])))
+def test_decomposed_independent0_vs_reference(k):
+    """FARNN_S_D_W (--independent 0): scores within 1e-4 of the captured reference, tags equal."""
+    from re2nn_seq_amd import _lib
+    meta = _fst_configs()
+    cfg = meta['configs'][k]
+    g = load_golden('decomp_fst_small')
+    x, lengths = g['x'], g['lengths']
+    m = _build_fst(g, k, cfg, meta)
+    pre = 'c{}.'.format(k)
+    ref_scores = g[pre + 'scores']
+    Lmax = int(lengths.max())
+    r = m.run(_t(x[:, :Lmax]), _t(lengths), _lib.MODE_FULL, want_scores=True)
+    np.testing.assert_allclose(r['scores'].cpu().numpy(), ref_scores, rtol=1e-4, atol=1e-4)
+    _, pred, true = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    assert np.array_equal(pred.numpy(), g[pre + 'flat_pred'])
+    assert true.shape == pred.shape
+
+
+def test_decomposed_independent0_ragged_vs_oracle():
+    """A larger ragged batch (B=48, L=24, S=23, R=60, RW=20), LOCAL mode (fast chain path)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(12)
+    V, S, R, RW, K, B, L = 90, 23, 60, 20, 9, 48, 24
+    f = lambda *shape, sc=0.3: (rng.randn(*shape) * sc).astype(np.float32)      # noqa: E731
+    p = {'Vgen': f(V, R), 'C': f(K, R), 'S1': f(S, R), 'S2': f(S, R), 'Cw': f(K, RW, sc=0.2),
+         'S1w': f(S, RW, sc=0.2), 'S2w': f(S, RW, sc=0.2), 'WW': (rng.rand(S, S) < 0.1).astype(np.float32) * 0.3,
+         'h0': np.eye(S, dtype=np.float32)[0], 'hT': (rng.rand(S) < 0.3).astype(np.float32),
+         'farnn': 0, 'nl': fo.NL_CODES['tanh'], 'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    h = _lib.create_decomp_fst(p['Vgen'], p['C'], p['S1'], p['S2'], p['Cw'], p['S1w'], p['S2w'], p['WW'],
+                               p['h0'], p['hT'], nl='tanh', threshold=0.5, o_idx=2)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(),
+          scores.data_ptr())
+    torch.cuda.synchronize()
+    Lmax = int(lengths.max())
+    ref = fo.decomp_fst_scores(p, x, lengths)
+    got = scores.cpu().numpy()[:, :Lmax]
+    mask = np.arange(Lmax)[None, :] < lengths[:, None]
+    np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
+    assert (tags.cpu().numpy()[:, :Lmax][~mask] == -1).all()

@@ -150,3 +150,42 @@ def test_decomposed_independent1_pickle_loader(tmp_path):
             nz = avgs[0] > 0
             np.testing.assert_allclose(avgs[0][nz], avgs[1][nz], rtol=1e-9)
             np.testing.assert_allclose(avgs[1][nz], avgs[2][nz], rtol=1e-9)
+
+
+def test_decomposed_independent0_pickle_loader(tmp_path):
+    """D pickle -> get_init_params_seq (reference init_params.py:10-121)."""
+    from re2nn_seq_amd.init_params import get_init_params_seq
+    from re2nn_seq_amd.utils import get_average
+    rng = np.random.RandomState(0)
+    dset, automaton, _ = synth.make_dataset(40, 3, 12, seed=5)
+    t2i, s2i = dset['t2i'], dset['s2i']
+    blob = synth.make_d_pickle_dict(automaton, t2i, s2i, ranks=[100], wildcard_ranks=[70], rng=rng)
+    T4, _, W4, WW, _, _, _ = f2t.dfa_to_tensor_slot_new_wildcard(automaton, t2i, s2i)
+    d = blob[1][0][100]
+    np.testing.assert_allclose(np.einsum('vr,cr,sr,jr->vcsj', d['V'], d['C'], d['S1'], d['S2']), T4, atol=0.2)
+    ddir = tmp_path / 'ATIS-BIO'
+    ddir.mkdir()
+    apath = ddir / 'D.automata.synthetic.pkl'
+    with open(apath, 'wb') as f:
+        pickle.dump(blob, f)
+    D = 16
+    with open(ddir / 'glove.{}.emb'.format(D), 'wb') as f:
+        pickle.dump(rng.randn(len(t2i), D), f)
+    a = ns(dataset='ATIS-BIO', embed_type='glove', embed_dim=D, random_embed=0, automata_path=str(apath),
+           seed=1, rank=100, rank_wildcard=70, normalize_automata='l2-rank', use_bert=0, local_loss_func='CE1')
+    out = get_init_params_seq(a, s2i, data_dir=str(tmp_path) + '/')
+    V_ext, Cemb, S1, S2, E_ext, Wt, WWt, fin, sta, pri, Cw, S1w, S2w = out
+    assert V_ext.shape == (len(t2i) + 1, 100) and np.all(V_ext[-1] == 0)
+    assert Cemb.shape == (len(s2i) + 1, 100) and Cw.shape == (len(s2i) + 1, 70)
+    assert Wt.shape == W4.shape and WWt.shape == WW.shape
+    assert S1w.shape == (12, 70) and S2w.shape == (12, 70)
+    avgs = [get_average(m, 'l2-rank') for m in (V_ext, Cemb, S1, S2)]      # 4th-root normalisation (:91-107)
+    nz = avgs[0] > 0
+    for other in avgs[1:]:
+        np.testing.assert_allclose(avgs[0][nz], other[nz], rtol=1e-9)
+    # values beyond +-100 are clipped to +-1 by this loader only (:50-65)
+    blob[1][0][100]['S1'][0, 0] = 1e4
+    with open(apath, 'wb') as f:
+        pickle.dump(blob, f)
+    a.normalize_automata = 'none'
+    assert get_init_params_seq(a, s2i, data_dir=str(tmp_path) + '/')[2][0, 0] == 1

@@ -198,3 +198,46 @@ def test_decomposed_independent1_small(k):
     tr = g[pre + 'crf_transitions'] if cfg.get('use_crf', 0) else None
     tags = fo.forward_local_tags(sc, l, meta['threshold'], meta['o_idx'], tr)
     assert np.array_equal(tags, g[pre + 'flat_pred'])
+
+
+def decomp_fst_params_from_fixture(g, k, cfg):
+    pre = 'c{}.'.format(k)
+    p = {
+        'S1': g[pre + 'S1'], 'S2': g[pre + 'S2'], 'C': g[pre + 'C_embed'], 'Cw': g[pre + 'C_wildcard'],
+        'S1w': g[pre + 'S1_wildcard'], 'S2w': g[pre + 'S2_wildcard'], 'WW': g[pre + 'wildcard_wildcard'],
+        'h0': g[pre + 'h0'], 'hT': g[pre + 'hT'],
+        'farnn': cfg.get('farnn', 0), 'nl': fo.NL_CODES[cfg.get('update_nonlinear', 'none')],
+        'semiring': fo.SEMIRING_MAX if cfg.get('train_mode', 'sum') == 'max' else fo.SEMIRING_SUM,
+        'sig_k': cfg.get('sigmoid_exponent', 5),
+    }
+    p['Vgen'] = fo.generalized_vocab_table(
+        g[pre + 'V_embed'], g[pre + 'embedding'], g[pre + 'embed_r_generalized'],
+        g[pre + 'beta_vec'], fo.NL_CODES[cfg.get('additional_nonlinear', 'none')])
+    for kk in ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2'):
+        if pre + kk in g.files:
+            p[kk] = g[pre + kk]
+    return p
+
+
+def _fst_configs():
+    with open(os.path.join(GOLDEN, 'decomp_fst_small.json')) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize('k', range(len(_fst_configs()['configs'])))
+def test_decomposed_independent0_small(k):
+    """FARNN_S_D_W (--method decompose --independent 0), SURVEY.md 8a row a15."""
+    meta = _fst_configs()
+    cfg = meta['configs'][k]
+    g = _load('decomp_fst_small')
+    x, l = g['x'], g['lengths']
+    pre = 'c{}.'.format(k)
+    p = decomp_fst_params_from_fixture(g, k, cfg)
+    P = g[pre + 'priority_mat'] if cfg.get('use_priority', 0) else None
+    sc = fo.decomp_fst_scores(p, x, l, P)
+    ref = g[pre + 'scores']
+    assert sc.shape == ref.shape
+    np.testing.assert_allclose(sc, ref, rtol=1e-4, atol=1e-4)
+    tr = g[pre + 'crf_transitions'] if cfg.get('use_crf', 0) else None
+    tags = fo.forward_local_tags(sc, l, meta['threshold'], meta['o_idx'], tr)
+    assert np.array_equal(tags, g[pre + 'flat_pred'])
