@@ -30,7 +30,7 @@ def up_to_date():
 def build_hip(force=False, verbose=True):
     if not force and up_to_date():
         return OUT
-    cmd = [HIPCC] + FLAGS + ['-o', OUT, SRC]
+    cmd = [HIPCC] + FLAGS + os.environ.get('FARNN_EXTRA_FLAGS', '').split() + ['-o', OUT, SRC]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)

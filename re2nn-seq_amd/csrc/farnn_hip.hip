@@ -14,6 +14,7 @@
 #include "fst4_score.hip.h"
 #include "decomp_chain.hip.h"
 #include "decomp1_score.hip.h"
+#include "decomp_rows.hip.h"
 
 namespace farnn {
 thread_local char g_err[512] = "";
@@ -42,6 +43,7 @@ struct farnn_model {
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     DecompWeights dw;                       // decomposed model weights
+    DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
     float *d1_S1o = nullptr, *d1_S2o = nullptr, *d1_CoutT = nullptr;
     int RW = 0, RWp = 0;                    // decomposed independent=0: wildcard factors + label factor
@@ -305,7 +307,10 @@ extern "C" int farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms
 extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
-        case KERN_CHAIN: return (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0) ? "decomp_chain_kernel" : "chain_kernel";
+        case KERN_CHAIN:
+            if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
+                return m->rows.ok ? "decomp_rows_kernel" : "decomp_chain_kernel";
+            return "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
                               : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel"
@@ -375,6 +380,61 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 #undef FARNN_LAUNCH_CHAIN
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
+}
+
+// ---- packed rows + gate tables for decomp_rows_kernel (create time) ------------------------------
+static int build_rows_pack(farnn_model *m) {
+    DecompWeights &w = m->dw;
+    DecompRowsPack &k = m->rows;
+    k.ok = false;
+    if (w.semiring != FARNN_SEMIRING_SUM || w.mask || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
+    const RowsCfg c2 = rows_cfg(m->S), c3 = rows_cfg(m->Rp + m->S);
+    if (!c2.LPR || !c3.LPR) return FARNN_OK;              // wider than 1024 columns: generic kernel
+    const int tvl = m->Rp + (w.farnn >= 1 ? m->SP : 0) + (w.farnn == 2 ? m->SP : 0);
+    if (tvl > DR_MAX_PF * DR_THREADS) return FARNN_OK;
+    k.lpr2 = c2.LPR; k.m2 = c2.M; k.lpr3 = c3.LPR; k.m3 = c3.M;
+    k.ld2 = c2.LPR * c2.M * 4; k.ld3 = c3.LPR * c3.M * 4;
+    k.vbs = k.ld3 - m->Rp > k.ld2 ? k.ld3 - m->Rp : k.ld2;       // floats of one hb vector
+    k.n1 = w.farnn == 2 ? 2 * m->S : 0;
+    k.n2 = m->R + (w.farnn == 1 ? m->S : 0);
+    k.n3 = m->S;
+    PackSrc q;
+    q.S1 = w.S1; q.S2 = w.S2; q.W = w.W; q.Wss1 = w.Wss1; q.Wss2 = w.Wss2; q.o = w.o;
+    q.S = m->S; q.SP = m->SP; q.R = m->R; q.Rp = m->Rp; q.farnn = w.farnn;
+    int rc;
+    auto blocks = [](long long n) { return (unsigned)((n + 255) / 256); };
+    for (int dir = 0; dir < 2; dir++) {
+        if ((rc = dev_alloc(m, (void **)&k.P2[dir], (size_t)k.n2 * k.ld2 * 4))) return rc;
+        if ((rc = dev_alloc(m, (void **)&k.P3[dir], (size_t)k.n3 * k.ld3 * 4))) return rc;
+        pack_p2_kernel<<<blocks((long long)k.n2 * k.ld2), 256>>>(q, k.P2[dir], k.n2, k.ld2, dir);
+        pack_p3_kernel<<<blocks((long long)k.n3 * k.ld3), 256>>>(q, k.P3[dir], k.ld3, dir);
+    }
+    if (k.n1) {
+        if ((rc = dev_alloc(m, (void **)&k.P1, (size_t)k.n1 * k.ld2 * 4))) return rc;
+        pack_p1_kernel<<<blocks((long long)k.n1 * k.ld2), 256>>>(q, k.P1, k.ld2);
+    }
+    if (w.farnn >= 1) {
+        if ((rc = dev_alloc(m, (void **)&k.Gz, (size_t)m->V * m->SP * 4))) return rc;
+        gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs1, w.bs1, k.Gz, m->V, m->R, m->Rp, m->S, m->SP);
+    }
+    if (w.farnn == 2) {
+        if ((rc = dev_alloc(m, (void **)&k.Gr, (size_t)m->V * m->SP * 4))) return rc;
+        gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs2, w.bs2, k.Gr, m->V, m->R, m->Rp, m->S, m->SP);
+    }
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    k.ok = true;
+    return FARNN_OK;
+}
+
+// the recurrence of the three decomposed kinds: rows kernel when packed, else the older kernels
+static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int64_t *lengths, int B, int full,
+                                    hipStream_t s) {
+    const int *order = m->order_valid ? m->order : nullptr;
+    RowsPlan pl;
+    if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->wsL, pl))
+        return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
+    return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
 }
 
 static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s) {
@@ -547,15 +607,14 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
         case KIND_DECOMP: {
             {
                 KernelTimer kt(m, KERN_CHAIN, s);
-                if ((rc = launch_decomp_chain(m->dw, x, lengths, m->order_valid ? m->order : nullptr, m->A, m->Bk, B,
-                                              m->wsL, full, s))) return rc;
+                if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
             }
             return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
         }
         case KIND_DECOMP0: {
             {
                 KernelTimer kt(m, KERN_CHAIN, s);
-                if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+                if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
             }
             return launch_decomp0_score(m, x, lengths, B, full, tags, flat_tags, scores, s);
         }
@@ -769,6 +828,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    if ((rc = build_rows_pack(m))) return bail(rc);
     *out = m;
     return FARNN_OK;
 }
@@ -887,6 +947,7 @@ extern "C" int farnn_decomp_fst_create(const farnn_decomp_fst_desc *d, int devic
     m->dw.h0 = m->h0; m->dw.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    if ((rc = build_rows_pack(m))) return bail(rc);
     *out = m;
     return FARNN_OK;
 }
