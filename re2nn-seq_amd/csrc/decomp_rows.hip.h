@@ -16,37 +16,45 @@
 // tagging path), like Vgen.  The o scaling (:156-157 input side backward, :180-181 output side
 // forward) is folded into the packed rows.
 //
-// Every product is a set of ROW dot products.  A workgroup of 16 wavefronts owns NSEQ sequences of
-// one direction; LPR adjacent lanes share a row and split its columns, so a lane keeps its column
-// slice of the NSEQ input vectors in registers for the whole phase and every 16-byte weight read is
-// used NSEQ times.  Partial sums meet on the DPP network (row_shr / row_bcast), never in LDS.  The
-// packed rows live in LDS as far as the 160 KiB go (a rank-50 model fits whole: ~105 KiB); the rest
-// is streamed from L2 every step (a rank-250 gated model: ~390 KiB of rows per step, shared by the
-// NSEQ sequences).  Bound: LDS / L2->CU bandwidth per step, not HBM: the weights are a few hundred
-// KiB for the whole batch ("decomposed path: not HBM-bound").
+// Every product is a set of ROW dot products.  A workgroup of 8 wavefronts owns NSEQ sequences of one
+// direction; four adjacent lanes share a row and split its columns in 32-column chunks, every 16-byte
+// weight read is used for the NSEQ sequences, the math is packed f32 (v_pk_fma_f32) and the quad's
+// partial sums meet on the DPP network (quad_perm), never in LDS; 128 rows per pass make a phase of
+// S <= 128 rows one pass.  The packed rows live in LDS as far as the 160 KiB go (a rank-50 model fits
+// whole: ~105 KiB); the rest is streamed from L2 every step (a gated rank-250 model: ~390 KiB of rows
+// per step).  Element-wise work (gates, non-linearity, stash) runs on the few wavefronts that own
+// state entries, between raw LDS barriers.  Bound: LDS-array cycles and VALU issue per step, not HBM:
+// the weights are a few hundred KiB for the whole batch ("decomposed path: not HBM-bound").
 //
-// Measured (profiles/): the previous one-wavefront-per-sequence kernel ran 2 wavefronts per CU and
-// was LDS-latency bound at 3.5 us per step (R=50); gated or rank>=150 models fell back to the
-// generic kernel.
+// Measured history (B=256, L=64, S=104, MI355X):
+//   * one wavefront per sequence, factors in LDS: 3.5 us/step at R=50 (LDS-latency bound, 2 waves/CU);
+//     gated or rank >= 150 models fell back to a generic kernel at ~90 us/step.
+//   * 16 waves, 16..64 lanes per row, epilogue inside the row loop: 3.3 us/step -- every wavefront
+//     executed the tanh/gate/store epilogue for its 1-4 rows at 6% lane utilisation.
+//   * the same with row sums parked in LDS and element-wise phases on 4 waves: 2.2 us/step.
+//   * the products on v_mfma_f32_4x4x1_16b_f32 (scripts/probe/): parity-green but 3.0 us/step; the
+//     16-block form issues 256 MACs per 32 cycles per SIMD, a quarter of the f32 VALU rate.
+//   * this version: 2.2 us/step at NSEQ=2, 1.0 us/step per sequence at NSEQ=1 (0.66 us of it the
+//     barrier/element-wise skeleton); whole farnn_tag 145 us at R=50 (was 237), 374 us for the gated
+//     rank-250 model (was 5960).
 #pragma once
 #include "common.hip.h"
 #include "decomp_chain.hip.h"
 
 namespace farnn {
 
-#ifndef FARNN_DR_THREADS
-#define FARNN_DR_THREADS 1024
-#endif
-constexpr int DR_THREADS = FARNN_DR_THREADS;
-constexpr int DR_MAX_PF = 2;          // prefetch registers per thread for the per-token vectors
+constexpr int DR_THREADS = 512;       // 8 wavefronts: 256 VGPRs each, cheap barriers
+constexpr int DR_LPR = 4;             // lanes per row
+constexpr int DR_RPP = DR_THREADS / DR_LPR;   // rows per pass (128)
+constexpr int DR_CHUNK = 32;          // floats of a row one quad covers per chunk (2 x 16 bytes per lane)
+constexpr int DR_MAX_PF = 4;          // prefetch registers per thread for the per-token vectors
 
 struct DecompRowsParams {
     const float *P1;              // [2S][ld2]   gate rows (farnn==2) or nullptr
     const float *P2[2];           // [n2][ld2]   per direction
     const float *P3[2];           // [S][ld3]    per direction
-    int n1, n2, n3, ld2, ld3, lpr2, m2, lpr3, m3;
+    int n1, n2, n3, ld2, ld3, nch2, nch3;
     int res1, res2, res3;         // leading rows of each matrix kept in LDS
-    int vbs;                      // floats per [rr | hb] vector
     const float *Vgen, *Gz, *Gr;  // [V][Rp], [V][SP], [V][SP]
     const float *h0, *hT;
     const int64_t *x, *len;
@@ -57,126 +65,80 @@ struct DecompRowsParams {
     int dbg;                      // diagnostic ablation mask (FARNN_DBG); 0 in production
 };
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_add(float x) {
-    // lanes without a source (row start / rows outside ROW_MASK) add 0
-    return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
-}
-
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-    v = dpp_add<0x111, 0xf>(v);                      // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);                      // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);                      // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);                      // row_shr:8
-    if (LPR >= 32) v = dpp_add<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
-    if (LPR >= 64) v = dpp_add<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3
-    return v;        // complete in the last lane of every LPR-lane group
-}
-
-// out[row] = <M[row, :], vec_s> for s < NSEQ; epi(row, acc) runs in the last lane of the row's group.
-// Rows [0, nres) are read from LDS, the rest from global memory (L2); the two parts are separate
-// loops over pointers of explicit address spaces -- one loop over a selected generic pointer
-// compiles to flat_load + a full vmcnt/lgkmcnt drain per row pass.
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef __attribute__((address_space(3))) const v4f lds_cv4f;
 typedef __attribute__((address_space(1))) const v4f glb_cv4f;
 
-template <int LPR, int M, int NSEQ, typename Vec, typename Epi>
-__device__ __forceinline__ void rowdots_v(const float *ml, const float *mg, int nres, int nrows, int ld,
-                                          Vec &&vecf, int tid, Epi &&epi) {
-    constexpr int RPP = DR_THREADS / LPR;
-    const int k = tid & (LPR - 1), rloc = tid / LPR;
-    float4 xv[NSEQ][M];
+// sum over the 4 lanes of a quad, result in all four (two DPP butterflies, no LDS)
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    return v;
+}
+
+// out[row] = <M[row, :], x_s> for s < NSEQ.  Four adjacent lanes share a row; per chunk of 32 columns a
+// lane reads two 16-byte pieces of the row and of every x_s and does packed f32 FMAs (v_pk_fma_f32), so
+// the instruction stream is mostly math; the quad's partial sums meet on the DPP network.  With 128
+// rows per pass a phase of S <= 128 rows is ONE pass.  Rows [0, nres) come from LDS, the rest from
+// global memory (L2): two loops over pointers of explicit address spaces -- a loop over one selected
+// generic pointer compiles to flat_load + a full vmcnt/lgkmcnt drain per pass.
+template <int NSEQ, typename Epi>
+__device__ __forceinline__ void rowdots(const float *ml, const float *mg, int nres, int nrows, int ld, int nch,
+                                        const float *X, int xs, int tid, Epi &&epi) {
+    const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+    lds_cfloat *xl = (lds_cfloat *)X + k * 4;
+    auto body = [&](auto src, int row, bool ok) {
+        v2f tl[NSEQ], th[NSEQ];
 #pragma unroll
-    for (int s = 0; s < NSEQ; s++)
+        for (int s = 0; s < NSEQ; s++) { tl[s] = v2f{0.f, 0.f}; th[s] = v2f{0.f, 0.f}; }
+#pragma unroll 2
+        for (int c = 0; c < nch; c++) {
+            const v4f a0 = src[c * 8], a1 = src[c * 8 + 4];
 #pragma unroll
-        for (int m = 0; m < M; m++) xv[s][m] = vecf(s, (m * LPR + k) * 4);
-    auto finish = [&](int row, bool ok, const float4 (&a)[M]) {
+            for (int s = 0; s < NSEQ; s++) {
+                lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * DR_CHUNK);
+                const v4f x0 = xp[0], x1 = xp[4];
+                tl[s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tl[s]);
+                th[s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, th[s]);
+                tl[s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tl[s]);
+                th[s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[s]);
+            }
+        }
         float acc[NSEQ];
 #pragma unroll
-        for (int s = 0; s < NSEQ; s++) {
-            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int m = 0; m < M; m++) {
-                t.x = fmaf(a[m].x, xv[s][m].x, t.x); t.y = fmaf(a[m].y, xv[s][m].y, t.y);
-                t.z = fmaf(a[m].z, xv[s][m].z, t.z); t.w = fmaf(a[m].w, xv[s][m].w, t.w);
-            }
-            acc[s] = group_sum<LPR>((t.x + t.y) + (t.z + t.w));
-        }
-        if (k == LPR - 1 && ok) epi(row, acc);
+        for (int s = 0; s < NSEQ; s++) { const v2f t = tl[s] + th[s]; acc[s] = quad_sum(t.x + t.y); }
+        if (k == 0 && ok) epi(row, acc);
     };
     int row0 = 0;
-    {   // ---- LDS-resident rows ---------------------------------------------------------------------
-        lds_cfloat *mlds = (lds_cfloat *)ml;
-        for (; row0 < nres; row0 += RPP) {
-            const int row = row0 + rloc;
-            const bool ok = row < nrows;
-            const int rc = ok ? row : nrows - 1;
-            lds_cv4f *src = (lds_cv4f *)(mlds + rc * ld + k * 4);
-            float4 a[M];
-#pragma unroll
-            for (int m = 0; m < M; m++) { const v4f q = src[m * LPR]; a[m] = make_float4(q.x, q.y, q.z, q.w); }
-            finish(row, ok, a);
-        }
+    for (; row0 < nres; row0 += DR_RPP) {
+        const int row = row0 + rloc;
+        const bool ok = row < nrows;
+        body((lds_cv4f *)((lds_cfloat *)ml + (ok ? row : nrows - 1) * ld + k * 4), row, ok);
     }
-    if (row0 < nrows) {   // ---- streamed rows: the next pass is in flight while this one is reduced -----
-        auto load = [&](int r0, float4 (&a)[M]) {
-            const int row = r0 + rloc;
-            const int rc = row < nrows ? row : nrows - 1;
-            glb_cv4f *src = (glb_cv4f *)(mg + (long long)rc * ld + k * 4);
-#pragma unroll
-            for (int m = 0; m < M; m++) { const v4f q = src[m * LPR]; a[m] = make_float4(q.x, q.y, q.z, q.w); }
-        };
-        float4 a[M], an[M];
-        load(row0, a);
-        for (; row0 < nrows; row0 += RPP) {
-            const bool more = row0 + RPP < nrows;
-            if (more) load(row0 + RPP, an);
-            finish(row0 + rloc, row0 + rloc < nrows, a);
-            if (more) {
-#pragma unroll
-                for (int m = 0; m < M; m++) a[m] = an[m];
-            }
-        }
+    for (; row0 < nrows; row0 += DR_RPP) {
+        const int row = row0 + rloc;
+        const bool ok = row < nrows;
+        body((glb_cv4f *)(mg + (long long)(ok ? row : nrows - 1) * ld + k * 4), row, ok);
     }
 }
 
-template <int LPR, int M, int NSEQ, typename Epi>
-__device__ __forceinline__ void rowdots(const float *ml, const float *mg, int nres, int nrows, int ld,
-                                        const float *vec, int vstride, int tid, Epi &&epi) {
-    rowdots_v<LPR, M, NSEQ>(ml, mg, nres, nrows, ld,
-                            [&](int s, int c) -> float4 { return ld4(vec + s * vstride + c); }, tid, epi);
+__device__ __forceinline__ float gate_sigmoid(float x, float k) { return 1.0f / (1.0f + __expf(-(x * k))); }
+
+// update non-linearity on the hardware exponential: |error| ~1e-7 against the 1e-4 parity bar
+__device__ __forceinline__ float dr_tanh(float x) {
+    const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow for any x
+    return copysignf((1.0f - e) / (1.0f + e), x);
 }
-
-#define FARNN_ROWS_CASE(LPRV, MV, ...)                                                         \
-    case (LPRV) * 8 + (MV): rowdots<LPRV, MV, NSEQ>(__VA_ARGS__); break;
-#define FARNN_ROWS_DISPATCH(lpr, mm, ...)                                                      \
-    switch ((lpr) * 8 + (mm)) {                                                                \
-        FARNN_ROWS_CASE(16, 1, __VA_ARGS__) FARNN_ROWS_CASE(16, 2, __VA_ARGS__)                \
-        FARNN_ROWS_CASE(16, 3, __VA_ARGS__)                                                    \
-        FARNN_ROWS_CASE(32, 1, __VA_ARGS__) FARNN_ROWS_CASE(32, 2, __VA_ARGS__)                \
-        FARNN_ROWS_CASE(32, 3, __VA_ARGS__)                                                    \
-        FARNN_ROWS_CASE(64, 1, __VA_ARGS__) FARNN_ROWS_CASE(64, 2, __VA_ARGS__)                \
-        FARNN_ROWS_CASE(64, 3, __VA_ARGS__)                                                    \
-        default: break;                                                                        \
+__device__ __forceinline__ float dr_nl(float x, int nl) {
+    switch (nl) {
+        case FARNN_NL_RELU: return fmaxf(x, 0.0f);
+        case FARNN_NL_TANH: return dr_tanh(x);
+        case FARNN_NL_RELUTANH: return dr_tanh(fmaxf(x, 0.0f));
+        default: return x;
     }
-
-#define FARNN_ROWS_CASE_V(LPRV, MV, ...)                                                       \
-    case (LPRV) * 8 + (MV): rowdots_v<LPRV, MV, NSEQ>(__VA_ARGS__); break;
-#define FARNN_ROWS_DISPATCH_V(lpr, mm, ...)                                                    \
-    switch ((lpr) * 8 + (mm)) {                                                                \
-        FARNN_ROWS_CASE_V(16, 1, __VA_ARGS__) FARNN_ROWS_CASE_V(16, 2, __VA_ARGS__)            \
-        FARNN_ROWS_CASE_V(16, 3, __VA_ARGS__)                                                  \
-        FARNN_ROWS_CASE_V(32, 1, __VA_ARGS__) FARNN_ROWS_CASE_V(32, 2, __VA_ARGS__)            \
-        FARNN_ROWS_CASE_V(32, 3, __VA_ARGS__)                                                  \
-        FARNN_ROWS_CASE_V(64, 1, __VA_ARGS__) FARNN_ROWS_CASE_V(64, 2, __VA_ARGS__)            \
-        FARNN_ROWS_CASE_V(64, 3, __VA_ARGS__)                                                  \
-        default: break;                                                                        \
-    }
-
-__device__ __forceinline__ float gate_sigmoid(float x, float k) { return 1.0f / (1.0f + expf(-(x * k))); }
+}
 
 template <int NSEQ>
 __global__ void __launch_bounds__(DR_THREADS)
@@ -184,21 +146,21 @@ decomp_rows_kernel(const DecompRowsParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x;
     const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
-    const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, ld2 = p.ld2, ld3 = p.ld3, vbs = p.vbs;
+    const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, ld2 = p.ld2, ld3 = p.ld3;
+    const int c2p = p.nch2 * DR_CHUNK, c3p = p.nch3 * DR_CHUNK;      // floats of the input vectors
     const int farnn = p.farnn;
     const int Lr = (p.L + 3) & ~3;
     const int tvl = Rp + (farnn >= 1 ? SP : 0) + (farnn == 2 ? SP : 0);
-    const int s2l = Rp + SP;                                  // floats per SUM2 vector
 
     // ---- LDS carve (every block a multiple of 16 bytes) ----------------------------------------
     int *tok = reinterpret_cast<int *>(smem);                 // [NSEQ][Lr]
-    float *Hinit = smem + NSEQ * Lr;                          // [ld2]
-    float *H = Hinit + ld2;                                   // [NSEQ][ld2]   state (farnn==2 only)
-    float *HB = H + NSEQ * ld2;                               // [NSEQ][vbs]   hb: what the factors see
-    float *Z = HB + NSEQ * vbs;                               // [NSEQ][SP]    update gate (farnn==2)
+    float *Hinit = smem + NSEQ * Lr;                          // [SP]
+    float *H = Hinit + SP;                                    // [NSEQ][c2p]   state h (input of P1)
+    float *HB = H + NSEQ * c2p;                               // [NSEQ][c2p]   hb: input of P2
+    float *X3 = HB + NSEQ * c2p;                              // [NSEQ][c3p]   rr | hb: input of P3
+    float *Z = X3 + NSEQ * c3p;                               // [NSEQ][SP]    update gate
     float *SUM1 = Z + NSEQ * SP;                              // [NSEQ][2*SP]  P1 row sums: z | r
-    float *SUM2 = SUM1 + NSEQ * 2 * SP;                       // [NSEQ][s2l]   P2 row sums: rr | z (farnn==1)
-    float *SUM3 = SUM2 + NSEQ * s2l;                          // [NSEQ][SP]    P3 row sums
+    float *SUM3 = SUM1 + NSEQ * 2 * SP;                       // [NSEQ][SP]    P3 row sums
     float *TV = SUM3 + NSEQ * SP;                             // [2][NSEQ][tvl]  per-token vectors
     float *L1 = TV + 2 * NSEQ * tvl;                          // resident rows
     float *L2 = L1 + (long long)p.res1 * ld2;
@@ -224,6 +186,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
     }
     const float *hinit = dir == 0 ? p.h0 : p.hT;
     float *stash_base = dir == 0 ? p.A : p.Bk;
+    auto pick = [&](const int (&arr)[NSEQ], int s) { int v = arr[0];
+#pragma unroll
+        for (int q = 1; q < NSEQ; q++) v = s == q ? arr[q] : v;
+        return v; };
 
     // ---- set-up ------------------------------------------------------------------------------------
     for (int i = tid; i < (int)(TV - Hinit); i += DR_THREADS) Hinit[i] = 0.0f;
@@ -248,8 +214,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) {
             if (nst[s] < 0) continue;
-            H[s * ld2 + j] = hv;
-            HB[s * vbs + j] = hv;
+            H[s * c2p + j] = hv;
+            HB[s * c2p + j] = hv;
+            X3[s * c3p + Rp + j] = hv;
             stash_base[(long long)bseq[s] * (p.L + 1) * SP + j] = hv;
         }
     }
@@ -260,8 +227,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
 
     // per-token vectors: element e of sequence s at step t
     auto tv_load = [&](int s, int e, int t) -> float {
-        if (nst[s] <= 0) return 0.0f;
-        const int tk = tok[s * Lr + (t < nst[s] ? t : nst[s] - 1)];
+        const int n = pick(nst, s);
+        if (n <= 0) return 0.0f;
+        const int tk = tok[s * Lr + (t < n ? t : n - 1)];
         if (e < Rp) return p.Vgen[(long long)tk * Rp + e];
         if (e < Rp + SP) return p.Gz[(long long)tk * SP + (e - Rp)];
         return p.Gr[(long long)tk * SP + (e - Rp - SP)];
@@ -276,20 +244,17 @@ decomp_rows_kernel(const DecompRowsParams p) {
     }
     for (int i = 0; i < DR_MAX_PF; i++)
         if (pf_e[i] >= 0) TV[tid + i * DR_THREADS] = tv_load(pf_s[i], pf_e[i], 0);
-    // element-wise phases: thread (es, ej) owns state entry ej of sequence es
-    const int es = tid < NSEQ * S ? tid / S : 0, ej = tid < NSEQ * S ? tid % S : -1;
-    int e_nst = -1;
-    long long e_stash = 0;
-#pragma unroll
-    for (int s = 0; s < NSEQ; s++)
-        if (s == es) { e_nst = nst[s]; e_stash = (long long)bseq[s] * (p.L + 1) * SP; }
     __syncthreads();
 
     const float sig_k = p.sig_k;
     const int nl_mode = p.nl;
+    // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
     for (int t = 0; t < nmax; t++) {
         const int cur = t & 1, nxt = cur ^ 1;
         const float *TVc = TV + cur * ntv;
+        int act[NSEQ];
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) act[s] = t < nst[s];
         // next step's per-token vectors: loads issued now, parked in registers until after P3
         float pf[DR_MAX_PF];
 #pragma unroll
@@ -302,40 +267,38 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) SUM1[s * 2 * SP + o] = acc[s];
             };
-            FARNN_ROWS_DISPATCH(p.lpr2, p.m2, L1, p.P1, p.res1, p.n1, ld2, H, ld2, tid, epi1)
+            if (!(p.dbg & 1)) rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             wg_barrier_lds();
             // ---- E1: z, r; hb = (1-r) h_init + r h  (:149-151) ---------------------------------------
-            if (ej >= 0 && t < e_nst) {
-                const float *tv = TVc + es * tvl;
-                Z[es * SP + ej] = gate_sigmoid(SUM1[es * 2 * SP + ej] + tv[Rp + ej], sig_k);
-                const float rg = gate_sigmoid(SUM1[es * 2 * SP + SP + ej] + tv[Rp + SP + ej], sig_k);
-                HB[es * vbs + ej] = (1.0f - rg) * Hinit[ej] + rg * H[es * ld2 + ej];
+            for (int e = tid; e < NSEQ * S; e += DR_THREADS) {
+                const int s = e % NSEQ, j = e / NSEQ;
+                if (!pick(act, s)) continue;
+                const float *tv = TVc + s * tvl;
+                Z[s * SP + j] = gate_sigmoid(SUM1[s * 2 * SP + j] + tv[Rp + j], sig_k);
+                const float rg = gate_sigmoid(SUM1[s * 2 * SP + SP + j] + tv[Rp + SP + j], sig_k);
+                const float hb = (1.0f - rg) * Hinit[j] + rg * H[s * c2p + j];
+                HB[s * c2p + j] = hb;
+                X3[s * c3p + Rp + j] = hb;
             }
             wg_barrier_lds();
         }
-        {   // ---- P2: Sa^T . hb  (:169 / :174); farnn==1: the z pre-activation from the same h -----------
+        {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: the z pre-activation too -----
             auto epi2 = [&](int row, const float (&acc)[NSEQ]) {
-                const int o = row < R ? row : Rp + (row - R);
 #pragma unroll
-                for (int s = 0; s < NSEQ; s++) SUM2[s * s2l + o] = acc[s];
+                for (int s = 0; s < NSEQ; s++) {
+                    if (row < R) X3[s * c3p + row] = acc[s] * TVc[s * tvl + row];
+                    else SUM1[s * 2 * SP + (row - R)] = acc[s];
+                }
             };
-            if (!(p.dbg & 1)) FARNN_ROWS_DISPATCH(p.lpr2, p.m2, L2, p.P2[dir], p.res2, p.n2, ld2, HB, vbs, tid, epi2)
+            if (!(p.dbg & 1)) rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HB, c2p, tid, epi2);
             wg_barrier_lds();
         }
-        {   // ---- P3: nx = Sb . (v * sums) + W(^T) . hb  (:170-173 / :175-178) ---------------------------
+        {   // ---- P3: nx = Sb . rr + W(^T) . hb  (:171-173 / :176-178) -------------------------------------
             auto epi3 = [&](int row, const float (&acc)[NSEQ]) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) SUM3[s * SP + row] = acc[s];
             };
-            // the input vector [rr | hb] is formed on the fly: rr = v * (P2 sums)
-            auto vec3 = [&](int s, int c) -> float4 {
-                if (c < Rp) {
-                    const float4 a = ld4(SUM2 + s * s2l + c), v = ld4(TVc + s * tvl + c);
-                    return make_float4(a.x * v.x, a.y * v.y, a.z * v.z, a.w * v.w);
-                }
-                return ld4(HB + s * vbs + (c - Rp));
-            };
-            if (!(p.dbg & 1)) FARNN_ROWS_DISPATCH_V(p.lpr3, p.m3, L3, p.P3[dir], p.res3, p.n3, ld3, vec3, tid, epi3)
+            if (!(p.dbg & 1)) rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3, c3p, tid, epi3);
         }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
@@ -346,21 +309,25 @@ decomp_rows_kernel(const DecompRowsParams p) {
         }
         wg_barrier_lds();
         // ---- E3: non-linearity, gate mix, stash  (:183-196) ------------------------------------------
-        if (ej >= 0 && t < e_nst) {
-            const float nx = (p.dbg & 2) ? SUM3[es * SP + ej] : apply_nl(SUM3[es * SP + ej], nl_mode);
+        for (int e = tid; e < NSEQ * S; e += DR_THREADS) {
+            const int s = e % NSEQ, j = e / NSEQ;
+            if (!pick(act, s)) continue;
+            const float nx = (p.dbg & 2) ? SUM3[s * SP + j] : dr_nl(SUM3[s * SP + j], nl_mode);
             float hn = nx;
             if (farnn == 2) {
-                const float z = Z[es * SP + ej];
-                hn = (1.0f - z) * H[es * ld2 + ej] + z * nx;
-                H[es * ld2 + ej] = hn;
-            } else if (farnn == 1) {
-                const float z = gate_sigmoid(SUM2[es * s2l + Rp + ej] + TVc[es * tvl + Rp + ej], sig_k);
-                hn = (1.0f - z) * HB[es * vbs + ej] + z * nx;
-                HB[es * vbs + ej] = hn;
+                const float z = Z[s * SP + j];
+                hn = (1.0f - z) * H[s * c2p + j] + z * nx;
+                H[s * c2p + j] = hn;
             } else {
-                HB[es * vbs + ej] = hn;
+                if (farnn == 1) {
+                    const float z = gate_sigmoid(SUM1[s * 2 * SP + j] + TVc[s * tvl + Rp + j], sig_k);
+                    hn = (1.0f - z) * HB[s * c2p + j] + z * nx;
+                }
+                HB[s * c2p + j] = hn;
+                X3[s * c3p + Rp + j] = hn;
             }
-            if (!(p.dbg & 4)) stash_base[e_stash + (long long)(t + 1) * SP + ej] = hn;
+            if (!(p.dbg & 4))
+                stash_base[((long long)pick(bseq, s) * (p.L + 1) + t + 1) * SP + j] = hn;
         }
         wg_barrier_lds();
     }
@@ -427,25 +394,16 @@ __global__ void gate_table_kernel(const float *Vgen, const float *Wrs, const flo
     G[idx] = acc;
 }
 
-struct RowsCfg { int LPR, M; };
-inline RowsCfg rows_cfg(int cols) {
-    const int c4 = (cols + 3) / 4;
-    RowsCfg best{0, 0};
-    int bestsz = 1 << 30;
-    const int lprs[3] = {16, 32, 64};
-    for (int i = 0; i < 3; i++) {
-        const int mm = (c4 + lprs[i] - 1) / lprs[i];
-        if (mm <= 3 && lprs[i] * mm < bestsz) { best = RowsCfg{lprs[i], mm}; bestsz = lprs[i] * mm; }
-    }
-    return best;
-}
-
 // everything the launcher needs, filled by build_rows_pack() in farnn_hip.hip
 struct DecompRowsPack {
     bool ok = false;
     float *P1 = nullptr, *P2[2] = {nullptr, nullptr}, *P3[2] = {nullptr, nullptr}, *Gz = nullptr, *Gr = nullptr;
-    int n1 = 0, n2 = 0, n3 = 0, ld2 = 0, ld3 = 0, lpr2 = 0, m2 = 0, lpr3 = 0, m3 = 0, vbs = 0;
+    int n1 = 0, n2 = 0, n3 = 0, ld2 = 0, ld3 = 0, nch2 = 0, nch3 = 0;
 };
+
+// row length in floats for `cols` columns: whole 32-column chunks, +16 so that the four rows a 16-lane
+// LDS access group touches (64 contiguous bytes each) start in different quarters of the 64 banks
+inline int rows_ld(int cols) { return (cols + DR_CHUNK - 1) / DR_CHUNK * DR_CHUNK + 16; }
 
 struct RowsPlan { int nseq, res1, res2, res3; size_t lds; };
 
@@ -453,27 +411,28 @@ inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, in
     const int Lr = (L + 3) & ~3;
     const int tvl = w.Rp + (w.farnn >= 1 ? w.SP : 0) + (w.farnn == 2 ? w.SP : 0);
     int nseq = 1;
-    while (nseq < 4 && 2 * ((B + nseq - 1) / nseq) > 256) nseq *= 2;       // about one workgroup per CU
+    // measured (B=256, S=104): one sequence per workgroup in two rounds beats two per workgroup in one
+    // (145 vs 168 us at R=50, 374 vs 450 us gated R=250): the x reads and FMAs scale with NSEQ, only the
+    // weight reads are shared
+    while (nseq < 4 && 2 * ((B + nseq - 1) / nseq) > 512 * nseq) nseq *= 2;
     if (const char *e = getenv("FARNN_ROWS_NSEQ")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nseq = v; }
-    if (nseq == 4 && (k.m2 > 2 || k.m3 > 2)) nseq = 2;      // 4 x 3 float4 of vector slices would spill
     for (; nseq >= 1; nseq /= 2) {
         if (nseq * tvl > DR_MAX_PF * DR_THREADS) continue;
-        const size_t fixed = 4 * ((size_t)nseq * Lr + k.ld2 + (size_t)nseq * k.ld2 + (size_t)nseq * k.vbs +
-                                  (size_t)nseq * (w.SP + 2 * w.SP + (w.Rp + w.SP) + w.SP) + 2ull * nseq * tvl);
+        const size_t fixed = 4 * ((size_t)nseq * Lr + w.SP + 2ull * nseq * k.nch2 * DR_CHUNK +
+                                  (size_t)nseq * k.nch3 * DR_CHUNK + (size_t)nseq * 4 * w.SP + 2ull * nseq * tvl);
         const size_t cap = 159 * 1024;
         if (fixed + 16 * 1024 > cap) continue;               // leave room for at least some resident rows
         size_t left = cap - fixed;
-        auto take = [&](int nrows, int ld, int lpr) {
+        auto take = [&](int nrows, int ld) {
             if (nrows == 0) return 0;
-            const int rpp = DR_THREADS / lpr;
             long long fit = (long long)(left / ((size_t)ld * 4));
-            int res = fit >= nrows ? nrows : (int)(fit / rpp) * rpp;
+            int res = fit >= nrows ? nrows : (int)(fit / DR_RPP) * DR_RPP;
             left -= (size_t)res * ld * 4;
             return res;
         };
-        pl.res3 = take(k.n3, k.ld3, k.lpr3);
-        pl.res2 = take(k.n2, k.ld2, k.lpr2);
-        pl.res1 = take(k.n1, k.ld2, k.lpr2);
+        pl.res3 = take(k.n3, k.ld3);
+        pl.res2 = take(k.n2, k.ld2);
+        pl.res1 = take(k.n1, k.ld2);
         pl.nseq = nseq;
         pl.lds = cap - left;
         return true;
@@ -499,9 +458,8 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
                               int B, int L, int full, hipStream_t s) {
     DecompRowsParams p;
     p.P1 = k.P1; p.P2[0] = k.P2[0]; p.P2[1] = k.P2[1]; p.P3[0] = k.P3[0]; p.P3[1] = k.P3[1];
-    p.n1 = k.n1; p.n2 = k.n2; p.n3 = k.n3; p.ld2 = k.ld2; p.ld3 = k.ld3;
-    p.lpr2 = k.lpr2; p.m2 = k.m2; p.lpr3 = k.lpr3; p.m3 = k.m3;
-    p.res1 = pl.res1; p.res2 = pl.res2; p.res3 = pl.res3; p.vbs = k.vbs;
+    p.n1 = k.n1; p.n2 = k.n2; p.n3 = k.n3; p.ld2 = k.ld2; p.ld3 = k.ld3; p.nch2 = k.nch2; p.nch3 = k.nch3;
+    p.res1 = pl.res1; p.res2 = pl.res2; p.res3 = pl.res3;
     p.Vgen = w.Vgen; p.Gz = k.Gz; p.Gr = k.Gr; p.h0 = w.h0; p.hT = w.hT;
     p.x = x; p.len = len; p.order = order; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;

@@ -388,13 +388,10 @@ static int build_rows_pack(farnn_model *m) {
     DecompRowsPack &k = m->rows;
     k.ok = false;
     if (w.semiring != FARNN_SEMIRING_SUM || w.mask || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
-    const RowsCfg c2 = rows_cfg(m->S), c3 = rows_cfg(m->Rp + m->S);
-    if (!c2.LPR || !c3.LPR) return FARNN_OK;              // wider than 1024 columns: generic kernel
     const int tvl = m->Rp + (w.farnn >= 1 ? m->SP : 0) + (w.farnn == 2 ? m->SP : 0);
     if (tvl > DR_MAX_PF * DR_THREADS) return FARNN_OK;
-    k.lpr2 = c2.LPR; k.m2 = c2.M; k.lpr3 = c3.LPR; k.m3 = c3.M;
-    k.ld2 = c2.LPR * c2.M * 4; k.ld3 = c3.LPR * c3.M * 4;
-    k.vbs = k.ld3 - m->Rp > k.ld2 ? k.ld3 - m->Rp : k.ld2;       // floats of one hb vector
+    k.nch2 = (m->S + DR_CHUNK - 1) / DR_CHUNK; k.nch3 = (m->Rp + m->S + DR_CHUNK - 1) / DR_CHUNK;
+    k.ld2 = rows_ld(m->S); k.ld3 = rows_ld(m->Rp + m->S);
     k.n1 = w.farnn == 2 ? 2 * m->S : 0;
     k.n2 = m->R + (w.farnn == 1 ? m->S : 0);
     k.n3 = m->S;
