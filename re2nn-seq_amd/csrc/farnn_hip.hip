@@ -248,7 +248,7 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
     if (m->use_crf)
-        FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float)));
+        FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
     FARNN_HIP_TRY(hipMemset(m->Bk, 0, stash));
     FARNN_HIP_TRY(hipDeviceSynchronize());
@@ -440,10 +440,17 @@ static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream
     int threads = round_up(4 * m->K, 64);
     if (threads > 1024) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
     const int ib4 = viterbi_ib4(m->K);
+    const size_t hlds = viterbi_hist_lds_bytes(m->K, m->Kp, p.L);
+    const bool hist = hlds <= 158 * 1024 && !env_int("FARNN_VITERBI_BP", 0);
 #define FARNN_LAUNCH_VIT(N)                                                                   \
     do {                                                                                      \
-        if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                       \
-        viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                            \
+        if (hist) {                                                                           \
+            if ((rc = raise_lds_limit(viterbi_hist_kernel<N>, hlds))) return rc;              \
+            viterbi_hist_kernel<N><<<dim3(B), dim3(threads), hlds, s>>>(p);                   \
+        } else {                                                                              \
+            if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                   \
+            viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                        \
+        }                                                                                     \
     } while (0)
     if (ib4 == 2) FARNN_LAUNCH_VIT(2);            // K <= 32
     else if (ib4 == 4) FARNN_LAUNCH_VIT(4);       // K <= 64

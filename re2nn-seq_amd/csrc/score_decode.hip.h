@@ -309,6 +309,122 @@ viterbi_kernel(const ScoreParams p) {
         for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
 }
 
+// History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
+// VALUES of every step (2 adds + 1 max per (i, j) instead of 2 adds + compare + 2 selects, and the
+// four lanes of a tag combine on the DPP network instead of two ds_bpermute round trips); the
+// back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE path the
+// backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
+// expression on the same values, so the path is bit-identical.  The transposed transition table
+// stays in LDS for that second pass.
+template <int IB4>
+__global__ void __launch_bounds__(1024)
+viterbi_hist_kernel(const ScoreParams p) {
+    constexpr int IB = IB4 * 4;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nthreads = blockDim.x;
+    const int b = blockIdx.x;
+    const int n = (int)p.len[b];
+    const int nsteps = p.full ? p.L : n;
+    const int K = p.K, Kp = p.Kp;
+    const int PW = 4 * IB;                               // padded partition width (>= K)
+    float *hist = smem;                                  // [L][PW] partitions of every step, pads -inf
+    const int sc_pieces = (p.L * Kp * 4 + 1023) / 1024, tr_pieces = (K * Kp * 4 + 1023) / 1024;
+    float *scl = hist + (size_t)p.L * PW;                // [L][Kp] clamped scores of this sequence (whole KiB)
+    float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
+    const float *sc = p.crf_scores + (long long)b * p.L * Kp;
+    const long long foff = p.offs ? p.offs[b] : 0;
+    const int START = K - 2, STOP = K - 1;
+    const float ninf = -INFINITY;
+    const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
+
+    // set-up without a register round trip: the scores and (behind them) the transition table stream
+    // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
+    // during the forward pass (counted vmcnt: this wavefront's table pieces are its youngest operations)
+    {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)scl);
+        const int need = (n * Kp * 4 + 1023) / 1024;
+        for (int k = wu; k < need; k += nwaves)
+            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(sc), lds0 + (unsigned)k * 1024u);
+    }
+    const int j = tid >> 2, q = tid & 3;
+    const bool owner = j < K;
+    float trr[IB];                                       // tr[i][j] for this lane's block of i
+    {
+        const float *row = p.trT + (long long)(owner ? j : 0) * Kp + q * IB;   // 16-byte aligned; may run into
+#pragma unroll                                                                  // the next row: masked below
+        for (int k4 = 0; k4 < IB4; k4++) {
+            const float4 v = ld4(row + k4 * 4);
+            trr[k4 * 4 + 0] = v.x; trr[k4 * 4 + 1] = v.y; trr[k4 * 4 + 2] = v.z; trr[k4 * 4 + 3] = v.w;
+        }
+    }
+    const float t_start = (owner && q == 0) ? p.trT[(long long)j * Kp + START] : 0.0f;   // before the table DMA
+    int my_tr = 0;
+    {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
+        for (int k = wu; k < tr_pieces; k += nwaves, my_tr++)
+            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.trT), lds0 + (unsigned)k * 1024u);
+    }
+    if (PW > K)
+        for (int i = tid; i < n * (PW - K); i += nthreads) hist[(i / (PW - K)) * PW + K + i % (PW - K)] = ninf;
+    wait_vmcnt(my_tr);                                   // scores + this lane's transition block landed
+#pragma unroll
+    for (int k = 0; k < IB; k++) trr[k] = (owner && q * IB + k < K) ? trr[k] : ninf;
+    wg_barrier_lds();                                    // (a __syncthreads would drain the table DMA)
+    if (owner && q == 0) hist[j] = scl[j] + t_start;                          // crf.py:135
+    wg_barrier_lds();
+    for (int t = 1; t < n; t++) {
+        const float *pin = hist + (size_t)(t - 1) * PW + q * IB;
+        const float f = owner ? scl[(long long)t * Kp + j] : 0.0f;
+        float best = ninf;
+#pragma unroll
+        for (int k4 = 0; k4 < IB4; k4++) {
+            const float4 p4 = ld4(pin + k4 * 4);
+            const float v0 = (f + trr[k4 * 4 + 0]) + p4.x, v1 = (f + trr[k4 * 4 + 1]) + p4.y;   // crf.py:123,145
+            const float v2 = (f + trr[k4 * 4 + 2]) + p4.z, v3 = (f + trr[k4 * 4 + 3]) + p4.w;
+            best = fmaxf(fmaxf(best, v0), v1);
+            best = fmaxf(fmaxf(best, v2), v3);
+        }
+        best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), 0xB1, 0xf, 0xf, false)));
+        best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), 0x4E, 0xf, 0xf, false)));
+        if (owner && q == 0) hist[(size_t)t * PW + j] = best;
+        wg_barrier_lds();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transition table is in LDS
+    __syncthreads();
+    if (w == 0 && n > 0) {
+        const float *pin = hist + (size_t)(n - 1) * PW;
+        float bv = ninf; int bi = 0x7ffffffe;
+        for (int i = lane; i < K; i += WAVE) {
+            const float v = pin[i] + trl[(long long)STOP * Kp + i];            // crf.py:168-169
+            if (v > bv) { bv = v; bi = i; }
+        }
+        int ptr = wave_argmax_dpp(bv, bi);
+        if (ptr >= K) ptr = 0;
+        for (int t = n - 1; t >= 0; t--) {
+            if (lane == 0) {
+                const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
+                if (p.tags) p.tags[(long long)b * p.L + t] = tag;
+                if (p.flat) p.flat[foff + t] = tag;
+            }
+            if (t > 0) {      // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed
+                const float f = scl[(long long)t * Kp + ptr];
+                const float *pp = hist + (size_t)(t - 1) * PW;
+                const float *tr = trl + (long long)ptr * Kp;
+                float v = ninf; int vi = 0x7ffffffe;
+                for (int i = lane; i < K; i += WAVE) {
+                    const float c = (f + tr[i]) + pp[i];
+                    if (c > v) { v = c; vi = i; }
+                }
+                ptr = wave_argmax_dpp(v, vi);
+                if (ptr >= K) ptr = 0;
+            }
+        }
+    }
+    if (p.tags)
+        for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
+}
+
 // the instantiated block size (in float4s) for K tags: ceil(ceil(K/4)/4) rounded up to a built one
 inline int viterbi_ib4(int K) {
     const int need = ((K + 3) / 4 + 3) / 4;
@@ -316,6 +432,10 @@ inline int viterbi_ib4(int K) {
 }
 inline size_t viterbi_lds_bytes(int K, int Kp, int L) {
     return (size_t)2 * 16 * viterbi_ib4(K) * 4 + (size_t)L * Kp * 4 + (size_t)L * Kp * 2;
+}
+inline size_t viterbi_hist_lds_bytes(int K, int Kp, int L) {
+    return (size_t)L * 16 * viterbi_ib4(K) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +
+           ((size_t)K * Kp * 4 + 1023) / 1024 * 1024;
 }
 
 // Batch preparation (one workgroup; B is a batch size, not a corpus):

@@ -101,8 +101,11 @@ def test_onehot_ifst_with_fused_viterbi(tr_kind):
     assert np.array_equal(pred.numpy(), ref)
 
 
-def test_viterbi_atis_scale_vs_oracle():
-    """K=130 tags, L=64, B=64: the Viterbi kernel with its transition table in LDS."""
+@pytest.mark.parametrize('variant', ['history', 'backpointers'])
+def test_viterbi_atis_scale_vs_oracle(variant, monkeypatch):
+    """K=130 tags, L=64, B=64: both Viterbi kernels (partition history + lazy back-pointers, and the
+    stored-back-pointer fallback for tag sets whose history does not fit the LDS)."""
+    monkeypatch.setenv('FARNN_VITERBI_BP', '1' if variant == 'backpointers' else '0')
     from re2nn_seq_amd import synth
     from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
     rng = np.random.RandomState(5)
