@@ -741,9 +741,8 @@ static int check_gates(const GateSrc &g, const char *who) {
 }
 
 // Vgen [V,R], S1/S2 [S,R], W [S,S] dense row-major; each with its own host|device flag.
-// `fast` also uploads the odd-stride copies the LDS-resident fast path wants.
 static int upload_chain_factors(farnn_model *m, const float *Vgen, int odV, const float *S1, const float *S2,
-                                int odS, const float *W, int odW, const GateSrc &g, int odG, bool fast) {
+                                int odS, const float *W, int odW, const GateSrc &g, int odG) {
     DecompWeights &w = m->dw;
     int rc;
     w.S = m->S; w.SP = m->SP; w.R = m->R; w.Rp = m->Rp; w.V = m->V;
@@ -756,16 +755,6 @@ static int upload_chain_factors(farnn_model *m, const float *Vgen, int odV, cons
     if ((rc = upload_transposed(m, &tmp, S2, m->S, m->R, m->SP, odS))) return rc; w.S2T = tmp;
     if ((rc = upload_padded(m, &tmp, W, m->S, m->S, m->S, m->SP, odW))) return rc; w.W = tmp;
     if ((rc = upload_transposed(m, &tmp, W, m->S, m->S, m->SP, odW))) return rc; w.WT = tmp;
-    if (fast) {   // odd 16-byte row strides (see decomp_chain.hip.h)
-        w.SPo = m->SP + (((m->SP / 4) & 1) ? 0 : 4);
-        w.Rpo = m->Rp + (((m->Rp / 4) & 1) ? 0 : 4);
-        if ((rc = upload_padded(m, &tmp, S1, m->S, m->R, m->S, w.Rpo, odS))) return rc; w.fS1 = tmp;
-        if ((rc = upload_padded(m, &tmp, S2, m->S, m->R, m->S, w.Rpo, odS))) return rc; w.fS2 = tmp;
-        if ((rc = upload_transposed(m, &tmp, S1, m->S, m->R, w.SPo, odS))) return rc; w.fS1T = tmp;
-        if ((rc = upload_transposed(m, &tmp, S2, m->S, m->R, w.SPo, odS))) return rc; w.fS2T = tmp;
-        if ((rc = upload_padded(m, &tmp, W, m->S, m->S, m->S, w.SPo, odW))) return rc; w.fW = tmp;
-        if ((rc = upload_transposed(m, &tmp, W, m->S, m->S, w.SPo, odW))) return rc; w.fWT = tmp;
-    }
     if (g.farnn >= 1) {
         if ((rc = upload_padded(m, &tmp, g.Wss1, m->S, m->S, m->S, m->SP, odG))) return rc; w.Wss1 = tmp;
         if ((rc = upload_padded(m, &tmp, g.Wrs1, m->R, m->S, m->R, m->SP, odG))) return rc; w.Wrs1 = tmp;
@@ -812,7 +801,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
     if (m->S > 1024 || m->R > 4096) return bail(fail(FARNN_ERANGE, "decomp_ifst: S<=1024, R<=4096%s%s"));
     DecompWeights &w = m->dw;
-    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od, true))) return bail(rc);
+    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od))) return bail(rc);
     {   // o = sum_k Cout[k,:] (CE1, model_decompose_single.py:232); OT = Cout^T
         TmpDev Co;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
@@ -864,7 +853,7 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     if (decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc) > 160 * 1024)
         return bail(fail(FARNN_ERANGE, "decomp_ind1: S*S*4 bytes of LDS needed per token (S too large)%s%s"));
     DecompWeights &w = m->dw;
-    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od, false))) return bail(rc);
+    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od))) return bail(rc);
     {   // no per-state output scaling in this model: o = 1; the output sum masks the transitions instead
         if ((rc = upload_ones_o(m))) return bail(rc);
         TmpDev Co, S1o, S2o, Wo;
@@ -938,7 +927,7 @@ extern "C" int farnn_decomp_fst_create(const farnn_decomp_fst_desc *d, int devic
         output_sum_kernel<<<(m->S * m->S + 255) / 256, 256>>>(Cwd.p, S1wd.p, S2wd.p, WWd.p, wsum, m->K, m->S, m->S, m->RW);
         FARNN_HIP_TRY(hipGetLastError());
         FARNN_HIP_TRY(hipDeviceSynchronize());
-        if ((rc = upload_chain_factors(m, table, 1, d->S1, d->S2, od, wsum, 1, gates, od, true))) return bail(rc);
+        if ((rc = upload_chain_factors(m, table, 1, d->S1, d->S2, od, wsum, 1, gates, od))) return bail(rc);
     }
     if ((rc = upload_ones_o(m))) return bail(rc);
     if ((rc = upload_padded(m, &m->d0_Vgen, d->Vgen, m->V, m->R, m->V, m->Rp, od))) return bail(rc);
