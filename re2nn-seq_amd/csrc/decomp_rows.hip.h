@@ -156,12 +156,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
     int *tok = reinterpret_cast<int *>(smem);                 // [NSEQ][Lr]
     float *Hinit = smem + NSEQ * Lr;                          // [SP]
     float *H = Hinit + SP;                                    // [NSEQ][c2p]   state h (input of P1)
-    float *HB = H + NSEQ * c2p;                               // [NSEQ][c2p]   hb: input of P2
-    float *X3 = HB + NSEQ * c2p;                              // [NSEQ][c3p]   rr | hb: input of P3
-    float *Z = X3 + NSEQ * c3p;                               // [NSEQ][SP]    update gate
-    float *SUM1 = Z + NSEQ * SP;                              // [NSEQ][2*SP]  P1 row sums: z | r
-    float *SUM3 = SUM1 + NSEQ * 2 * SP;                       // [NSEQ][SP]    P3 row sums
-    float *TV = SUM3 + NSEQ * SP;                             // [2][NSEQ][tvl]  per-token vectors
+    float *HB = H + NSEQ * c2p;                               // [2][NSEQ][c2p]  hb: input of P2 (ping-pong)
+    float *X3 = HB + 2 * NSEQ * c2p;                          // [2][NSEQ][c3p]  rr | hb: input of P3
+    float *Z = X3 + 2 * NSEQ * c3p;                           // [NSEQ][SP]    update gate
+    float *TV = Z + NSEQ * SP;                                // [2][NSEQ][tvl]  per-token vectors
     float *L1 = TV + 2 * NSEQ * tvl;                          // resident rows
     float *L2 = L1 + (long long)p.res1 * ld2;
     float *L3 = L2 + (long long)p.res2 * ld2;
@@ -215,7 +213,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int s = 0; s < NSEQ; s++) {
             if (nst[s] < 0) continue;
             H[s * c2p + j] = hv;
-            HB[s * c2p + j] = hv;
+            HB[s * c2p + j] = hv;                              // buffer 0 = step 0's "cur"
             X3[s * c3p + Rp + j] = hv;
             stash_base[(long long)bseq[s] * (p.L + 1) * SP + j] = hv;
         }
@@ -260,45 +258,42 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
         for (int i = 0; i < DR_MAX_PF; i++)
             pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(pf_s[i], pf_e[i], t + 1) : 0.0f;
+        // The element-wise work rides in the row epilogues: the lane that finishes a row sum turns it into
+        // a gate, an rr entry or the new state right away, so a step is 2 barriers (3 with farnn==2).
+        // hb and [rr | hb] ping-pong because P3's epilogue writes the next step's hb while other
+        // wavefronts still read this step's.
+        float *HBc = HB + cur * NSEQ * c2p, *HBn = HB + nxt * NSEQ * c2p;
+        float *X3c = X3 + cur * NSEQ * c3p, *X3n = X3 + nxt * NSEQ * c3p;
         if (farnn == 2) {
-            // ---- P1: both gate pre-activations from h  (:143-148) -----------------------------------
+            // ---- P1: z, r from h; hb = (1-r) h_init + r h  (:143-151) -----------------------------------
             auto epi1 = [&](int row, const float (&acc)[NSEQ]) {
-                const int o = row < S ? row : SP + (row - S);
 #pragma unroll
-                for (int s = 0; s < NSEQ; s++) SUM1[s * 2 * SP + o] = acc[s];
+                for (int s = 0; s < NSEQ; s++) {
+                    if (!act[s]) continue;
+                    const float *tv = TVc + s * tvl;
+                    if (row < S) {
+                        Z[s * SP + row] = gate_sigmoid(acc[s] + tv[Rp + row], sig_k);
+                    } else {
+                        const int j = row - S;
+                        const float rg = gate_sigmoid(acc[s] + tv[Rp + SP + j], sig_k);
+                        const float hb = (1.0f - rg) * Hinit[j] + rg * H[s * c2p + j];
+                        HBc[s * c2p + j] = hb;
+                        X3c[s * c3p + Rp + j] = hb;
+                    }
+                }
             };
             if (!(p.dbg & 1)) rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             wg_barrier_lds();
-            // ---- E1: z, r; hb = (1-r) h_init + r h  (:149-151) ---------------------------------------
-            for (int e = tid; e < NSEQ * S; e += DR_THREADS) {
-                const int s = e % NSEQ, j = e / NSEQ;
-                if (!pick(act, s)) continue;
-                const float *tv = TVc + s * tvl;
-                Z[s * SP + j] = gate_sigmoid(SUM1[s * 2 * SP + j] + tv[Rp + j], sig_k);
-                const float rg = gate_sigmoid(SUM1[s * 2 * SP + SP + j] + tv[Rp + SP + j], sig_k);
-                const float hb = (1.0f - rg) * Hinit[j] + rg * H[s * c2p + j];
-                HB[s * c2p + j] = hb;
-                X3[s * c3p + Rp + j] = hb;
-            }
-            wg_barrier_lds();
         }
-        {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: the z pre-activation too -----
+        {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: z from the same h ------------
             auto epi2 = [&](int row, const float (&acc)[NSEQ]) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
-                    if (row < R) X3[s * c3p + row] = acc[s] * TVc[s * tvl + row];
-                    else SUM1[s * 2 * SP + (row - R)] = acc[s];
+                    if (row < R) X3c[s * c3p + row] = acc[s] * TVc[s * tvl + row];
+                    else Z[s * SP + (row - R)] = gate_sigmoid(acc[s] + TVc[s * tvl + Rp + (row - R)], sig_k);
                 }
             };
-            if (!(p.dbg & 1)) rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HB, c2p, tid, epi2);
-            wg_barrier_lds();
-        }
-        {   // ---- P3: nx = Sb . rr + W(^T) . hb  (:171-173 / :176-178) -------------------------------------
-            auto epi3 = [&](int row, const float (&acc)[NSEQ]) {
-#pragma unroll
-                for (int s = 0; s < NSEQ; s++) SUM3[s * SP + row] = acc[s];
-            };
-            if (!(p.dbg & 1)) rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3, c3p, tid, epi3);
+            if (!(p.dbg & 1)) rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
         }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
@@ -308,26 +303,29 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 if (pf_e[i] >= 0) TVn[tid + i * DR_THREADS] = pf[i];
         }
         wg_barrier_lds();
-        // ---- E3: non-linearity, gate mix, stash  (:183-196) ------------------------------------------
-        for (int e = tid; e < NSEQ * S; e += DR_THREADS) {
-            const int s = e % NSEQ, j = e / NSEQ;
-            if (!pick(act, s)) continue;
-            const float nx = (p.dbg & 2) ? SUM3[s * SP + j] : dr_nl(SUM3[s * SP + j], nl_mode);
-            float hn = nx;
-            if (farnn == 2) {
-                const float z = Z[s * SP + j];
-                hn = (1.0f - z) * H[s * c2p + j] + z * nx;
-                H[s * c2p + j] = hn;
-            } else {
-                if (farnn == 1) {
-                    const float z = gate_sigmoid(SUM1[s * 2 * SP + j] + TVc[s * tvl + Rp + j], sig_k);
-                    hn = (1.0f - z) * HB[s * c2p + j] + z * nx;
+        {   // ---- P3: nx = Sb . rr + W(^T) . hb, non-linearity, gate mix, stash  (:171-196) -----------------
+            auto epi3 = [&](int row, const float (&acc)[NSEQ]) {
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) {
+                    if (!act[s]) continue;
+                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl(acc[s], nl_mode);
+                    float hn = nx;
+                    if (farnn == 2) {
+                        const float z = Z[s * SP + row];
+                        hn = (1.0f - z) * H[s * c2p + row] + z * nx;
+                        H[s * c2p + row] = hn;
+                    } else {
+                        if (farnn == 1) {
+                            const float z = Z[s * SP + row];
+                            hn = (1.0f - z) * HBc[s * c2p + row] + z * nx;
+                        }
+                        HBn[s * c2p + row] = hn;
+                        X3n[s * c3p + Rp + row] = hn;
+                    }
+                    if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
-                HB[s * c2p + j] = hn;
-                X3[s * c3p + Rp + j] = hn;
-            }
-            if (!(p.dbg & 4))
-                stash_base[((long long)pick(bseq, s) * (p.L + 1) + t + 1) * SP + j] = hn;
+            };
+            if (!(p.dbg & 1)) rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
         }
         wg_barrier_lds();
     }
@@ -418,8 +416,8 @@ inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, in
     if (const char *e = getenv("FARNN_ROWS_NSEQ")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nseq = v; }
     for (; nseq >= 1; nseq /= 2) {
         if (nseq * tvl > DR_MAX_PF * DR_THREADS) continue;
-        const size_t fixed = 4 * ((size_t)nseq * Lr + w.SP + 2ull * nseq * k.nch2 * DR_CHUNK +
-                                  (size_t)nseq * k.nch3 * DR_CHUNK + (size_t)nseq * 4 * w.SP + 2ull * nseq * tvl);
+        const size_t fixed = 4 * ((size_t)nseq * Lr + w.SP + 3ull * nseq * k.nch2 * DR_CHUNK +
+                                  2ull * nseq * k.nch3 * DR_CHUNK + (size_t)nseq * w.SP + 2ull * nseq * tvl);
         const size_t cap = 159 * 1024;
         if (fixed + 16 * 1024 > cap) continue;               // leave room for at least some resident rows
         size_t left = cap - fixed;
