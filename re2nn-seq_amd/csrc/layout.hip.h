@@ -97,4 +97,18 @@ inline int launch_premix_fst4(const float *T4, const float *W4, float *Mf, float
     return FARNN_OK;
 }
 
+// ---- automaton edge list -> dense device tensors (fsa_to_tensor.py:546-615 without the host tensor) ----
+__global__ void scatter_edges_kernel(const int32_t *word, const int32_t *from, const int32_t *to,
+                                     const int32_t *label, const float *val, long long n,
+                                     float *T, float *W, float *O, int V, int S, int C, int *bad) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int w = word[e], f = from[e], t = to[e], l = label ? label[e] : -1;
+    if (w >= V || f < 0 || f >= S || t < 0 || t >= S || l >= C) { atomicExch(bad, 1); return; }
+    const float v = val ? val[e] : 1.0f;
+    if (w >= 0) T[((long long)w * S + f) * S + t] = v;
+    else if (w == -1) W[(long long)f * S + t] = v;          // w < -1: label only
+    if (l >= 0) O[(long long)l * S + t] = 1.0f;
+}
+
 }  // namespace farnn

@@ -54,6 +54,40 @@ class FARNN_S_O_I_S(_OnehotBase):
         self.use_crf = False          # the reference's onehot models never read use_crf
         self.crf_transitions = None
 
+    @classmethod
+    def from_automaton(cls, automata, word2idx, slot2idx, priority_mat=None, args=None, o_idx=0,
+                       dataset='MITR-BIO'):
+        """The same tagger built WITHOUT the dense host tensors: the automaton's edges go
+        to the device as int32 lists and are scattered in HBM (farnn_onehot_ifst_create_from_edges).
+        Only for rand_constant == 0 (the noise of utils.add_random_noise is dense by nature)."""
+        from ..wfa.fsa_to_tensor import dfa_to_edges_slot_single_wildcard
+        if args.rand_constant:
+            raise ValueError('from_automaton needs rand_constant == 0')
+        word, frm, to, label, fin, sta, _ = dfa_to_edges_slot_single_wildcard(automata, word2idx, slot2idx, dataset)
+        self = cls.__new__(cls)
+        C, S = len(slot2idx) + 1, len(automata['states'])
+        _OnehotBase.__init__(self, args, o_idx, C, priority_mat, False)
+        self.S, self.V = S, len(word2idx)
+        self.h0, self.hT = _noisy(sta, 0), _noisy(fin, 0)
+        self.edges = (word, frm, to, label)
+        self.use_crf = False
+        self.crf_transitions = None
+        return self
+
+    def _dense(self):
+        """language_tensor / wildcard_mat / output_mat of an edge-built model, on demand (state_dict)."""
+        word, frm, to, label = self.edges
+        C = self.C
+        T = np.zeros((self.V, self.S, self.S), np.float32)
+        W = np.zeros((self.S, self.S), np.float32)
+        O = np.zeros((C, self.S), np.float32)
+        lang = word >= 0
+        T[word[lang], frm[lang], to[lang]] = 1
+        wild = word == -1
+        W[frm[wild], to[wild]] = 1
+        O[label, to] = 1
+        return T, W, O
+
     def enable_crf(self, transitions=None):
         """BASELINE config 4 (onehot + fused Viterbi): the composition SURVEY.md 8a-note defines --
         scores + two zero columns -> clamp column C'-3 -> CRF._viterbi_decode -> C'-3 -> o_idx."""
@@ -66,13 +100,21 @@ class FARNN_S_O_I_S(_OnehotBase):
         a = self.args
         if a.local_loss_func != 'CE1':
             raise NotImplementedError('only CE1 is reachable from main.py (:127)')
-        return _lib.create_onehot_ifst(
-            self.language_tensor, self.wildcard_mat, self.output_mat, self.h0, self.hT, P=self._P(),
-            nl=a.update_nonlinear, semiring='max' if a.train_mode == 'max' else 'sum',
-            threshold=a.threshold, o_idx=self.o_idx, use_crf=self.use_crf,
-            crf_trans=self.crf_transitions, device=self.device_index)
+        kw = dict(P=self._P(), nl=a.update_nonlinear, semiring='max' if a.train_mode == 'max' else 'sum',
+                  threshold=a.threshold, o_idx=self.o_idx, use_crf=self.use_crf,
+                  crf_trans=self.crf_transitions, device=self.device_index)
+        if getattr(self, 'edges', None) is not None:
+            word, frm, to, label = self.edges
+            return _lib.create_onehot_ifst_from_edges(self.V, self.S, self.C, word, frm, to, label,
+                                                      self.h0, self.hT, **kw)
+        return _lib.create_onehot_ifst(self.language_tensor, self.wildcard_mat, self.output_mat, self.h0,
+                                       self.hT, **kw)
 
     def state_dict(self):
+        if getattr(self, 'edges', None) is not None:
+            T, W, O = self._dense()
+            return {'h0': self.h0, 'hT': self.hT, 'language_tensor': T, 'wildcard_mat': W, 'output_mat': O,
+                    'output_wildcard_vector': np.zeros(self.S, np.float32)}
         return {'h0': self.h0, 'hT': self.hT, 'language_tensor': self.language_tensor,
                 'wildcard_mat': self.wildcard_mat, 'output_mat': self.output_mat,
                 'output_wildcard_vector': self.output_wildcard_vector}

@@ -186,3 +186,34 @@ def test_batch_prep_paths_flat_order(B):
     _, pred, _ = m.forward_local(xt, torch.zeros_like(xt), lt, train=False)
     ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
     assert np.array_equal(pred.numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
+
+
+def test_ifst_built_on_device_from_edges_matches_dense_upload():
+    """farnn_onehot_ifst_create_from_edges: same scores and tags, bit for bit, as the
+    handle built from the host's dense tensors; bad indices come back as EINVAL."""
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.wfa import fsa_to_tensor as f2t
+    dset, automaton, _ = synth.make_dataset(60, 4, 20, seed=9, max_len=14)
+    t2i = dict(dset['t2i']); t2i['<pad>'] = len(t2i)
+    s2i = dset['s2i']
+    T, _, W, O, _, fin, sta, _ = f2t.dfa_to_tensor_slot_single_wildcard(automaton, t2i, s2i, dataset='ATIS-BIO')
+    word, frm, to, label, fin2, sta2, _ = f2t.dfa_to_edges_slot_single_wildcard(automaton, t2i, s2i, dataset='ATIS-BIO')
+    V, S, C = T.shape[0], T.shape[1], O.shape[0]
+    x, lengths = synth.pad_batch(dset['query_test'][:20], 14, t2i['<pad>'])
+    B, L = x.shape
+    outs = []
+    for h in (_lib.create_onehot_ifst(T, W, O, sta, fin, o_idx=s2i['o']),
+              _lib.create_onehot_ifst_from_edges(V, S, C, word, frm, to, label, sta2, fin2, o_idx=s2i['o'])):
+        xd, ld = _t(x).cuda(), _t(lengths).cuda()
+        scores = torch.empty((B, L, C), dtype=torch.float32, device='cuda')
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_FULL, tags.data_ptr(), None, scores.data_ptr())
+        torch.cuda.synchronize()
+        outs.append((scores.cpu().numpy(), tags.cpu().numpy()))
+        h.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[1][0], fo.onehot_ifst_scores(T, W, O, sta, fin, x, lengths))
+    assert (outs[1][1] != s2i['o']).sum() > 10
+    bad = word.copy(); bad[0] = V + 5
+    with pytest.raises(_lib.FarnnError, match='out of range'):
+        _lib.create_onehot_ifst_from_edges(V, S, C, bad, frm, to, label, sta2, fin2)

@@ -189,3 +189,24 @@ def test_decomposed_independent0_pickle_loader(tmp_path):
         pickle.dump(blob, f)
     a.normalize_automata = 'none'
     assert get_init_params_seq(a, s2i, data_dir=str(tmp_path) + '/')[2][0, 0] == 1
+
+
+def test_edge_list_reproduces_the_dense_ifst_tensors():
+    """dfa_to_edges_slot_single_wildcard: scattering its entries gives exactly the tensors of
+    dfa_to_tensor_slot_single_wildcard (what farnn_onehot_ifst_create_from_edges does on the device)."""
+    for ds in ('MITR-BIO', 'ATIS-BIO'):
+        dset, automaton, _ = synth.make_dataset(40, 3, 12, seed=5)
+        t2i = dict(dset['t2i']); t2i['<pad>'] = len(t2i)
+        s2i = dset['s2i']
+        T, _, W, O, _, fin, sta, _ = f2t.dfa_to_tensor_slot_single_wildcard(automaton, t2i, s2i, dataset=ds)
+        word, frm, to, label, fin2, sta2, _ = f2t.dfa_to_edges_slot_single_wildcard(automaton, t2i, s2i, dataset=ds)
+        assert word.dtype == np.int32 and len(word) == len(frm) == len(to) == len(label)
+        T2, W2, O2 = np.zeros_like(T), np.zeros_like(W), np.zeros_like(O)
+        for w, f, t, l in zip(word, frm, to, label):
+            if w >= 0:
+                T2[w, f, t] = 1
+            elif w == -1:
+                W2[f, t] = 1
+            O2[l, t] = 1
+        assert np.array_equal(T2, T) and np.array_equal(W2, W) and np.array_equal(O2, O)
+        assert np.array_equal(fin2, fin) and np.array_equal(sta2, sta)
