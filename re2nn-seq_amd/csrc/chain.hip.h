@@ -64,8 +64,10 @@ constexpr int CHAIN_MAX_G = 4;
 // FQ > 0: fast path for one-phase steps of exactly FQ chunks per compute wavefront (small S): the
 // next step's block share is read from the ring into registers BEFORE the reduce of the current
 // step, so those LDS reads overlap the reduce instead of following it.  FQ == 0: generic loop.
+// FQ > 3 (one compute wavefront owning up to 24 rows per lane group) needs the register file of a
+// <= 6-wavefront workgroup for the prefetched block share.
 template <int NCH, bool MAXSR, int FQ>
-__global__ void __launch_bounds__(CHAIN_MAX_THREADS)
+__global__ void __launch_bounds__(FQ > 3 ? 384 : CHAIN_MAX_THREADS)
 chain_kernel(const ChainParams p) {
     constexpr int PER = 4 * NCH;                 // DMA pieces (1 KiB each) per 4-row chunk
     extern __shared__ __align__(16) float smem[];

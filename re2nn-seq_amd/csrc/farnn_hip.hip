@@ -180,7 +180,7 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
     m->K = d->C + (m->use_crf ? 2 : 0);
     m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -367,11 +367,15 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 #define FARNN_LAUNCH_CHAIN_MX(NCH, FQ)                                                        \
     do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true, FQ); else FARNN_LAUNCH_CHAIN(NCH, false, FQ); } while (0)
     KernelTimer kt(m, KERN_CHAIN, s);
-    const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= 3 && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
+    const int fq_max = block.x <= 384 ? 6 : 3;
+    const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= fq_max && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
     if (g.NCH == 1) {
         if (fq == 1) FARNN_LAUNCH_CHAIN_MX(1, 1);
         else if (fq == 2) FARNN_LAUNCH_CHAIN_MX(1, 2);
         else if (fq == 3) FARNN_LAUNCH_CHAIN_MX(1, 3);
+        else if (fq == 4) FARNN_LAUNCH_CHAIN_MX(1, 4);
+        else if (fq == 5) FARNN_LAUNCH_CHAIN_MX(1, 5);
+        else if (fq == 6) FARNN_LAUNCH_CHAIN_MX(1, 6);
         else FARNN_LAUNCH_CHAIN_MX(1, 0);
     } else if (g.NCH == 2) FARNN_LAUNCH_CHAIN_MX(2, 0);
     else if (g.NCH <= 4) FARNN_LAUNCH_CHAIN_MX(4, 0);
@@ -716,7 +720,7 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
     m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -757,7 +761,7 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     m->mask_by_output = d->mask_by_output;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 8), env_int("FARNN_NLD", 4));
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
