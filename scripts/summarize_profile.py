@@ -18,9 +18,10 @@ os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, 'bench_*.json')):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
-ks = sorted(glob.glob(os.path.join(src, 'trace', '*', '*_kernel_stats.csv')), key=os.path.getmtime)
-if ks:
-    shutil.copy(ks[-1], os.path.join(dst, tag + '_ifst_kernel_stats.csv'))
+for sub, name in (('trace', 'ifst'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp')):
+    ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
+    if ks:
+        shutil.copy(ks[-1], os.path.join(dst, '{}_{}_kernel_stats.csv'.format(tag, name)))
 
 
 def agg(path):
