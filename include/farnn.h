@@ -75,28 +75,28 @@ typedef struct farnn_onehot_ifst_desc {
 
 int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *desc, int device, farnn_model **out);
 
-/* ---- onehot i-FST built on the device from the automaton's edge list ------------------
- * The reference's loader (wfa/fsa_to_tensor.py:546-615, dfa_to_tensor_slot_single_wildcard) writes
- * a dense float64 [V,S,S] tensor on the host (21 GB at BASELINE configs[4]).  This entry takes the
- * edges it would have written and scatters them straight into HBM:
- *     word[e] >= 0 :  T[word[e], from[e], to[e]] = val[e]          (:594-606)
- *     word[e] == -1:  W[from[e], to[e]]          = val[e]          ('$' edges, :600-601)
- *     word[e] <  -1:  nothing but the label (a class edge none of whose words is in the vocabulary)
- *     label[e] >= 0:  O[label[e], to[e]]         = 1               (destination-state labels, :583-588)
- * Assignment, not accumulation, like the reference (duplicate edges are idempotent).  Class
- * edges ('&' punctuation, '%' numbers, :590-598) are expanded to one edge per word by the caller.
- * The edge arrays are host pointers (they are small); everything else follows
- * farnn_onehot_ifst_desc, whose T/W/O are ignored. */
-typedef struct farnn_ifst_edges_desc {
-    farnn_onehot_ifst_desc base;   /* V,S,C,h0,hT,P,nl,... ; T,W,O unused; weights_on_device covers h0,hT,P,crf_trans */
+/* ---- onehot models built on the device from the automaton's edge list -----------------
+ * The reference's loaders (wfa/fsa_to_tensor.py:398-615) write dense float64 tensors on the host
+ * ([V,S,S]: 21 GB at BASELINE configs[4]; [V,C,S,S]: 2.5 GB at ATIS size).  These entries take the edges
+ * the loader would have written and scatter them straight into HBM.  Per edge e, with w = word[e],
+ * f = from[e], t = to[e], l = label[e] (label column of the edge; destination-state label in the i-FST):
+ *     i-FST   (:546-615)  w >= 0: T[w,f,t] = v     w == -1: W[f,t] = v        l >= 0: O[l,t] = 1
+ *     FST 4-D (:398-474)  w >= 0: T4[w,l,f,t] = v  w == -1: W4[l,f,t] = v
+ *     indep=1 (:477-543)  w >= 0: T[w,f,t] = v     w == -1: W[f,t] = v        l >= 0: Oten[l,f,t] = 1
+ * w < -1 marks an entry that only carries its label (a class edge, '&' / '%', none of whose words is in
+ * the vocabulary).  Assignment, not accumulation, like the reference (duplicates are idempotent); class
+ * edges are expanded to one entry per word by the caller.  The edge arrays are host pointers (they are
+ * small).  The dense tensor fields of `base` are ignored; `base.weights_on_device` covers h0/hT/P/crf_trans. */
+typedef struct farnn_edge_list {
     int64_t n_edges;
     const int32_t *word;           /* [n_edges] word id, -1 wildcard edge, < -1 label only         */
     const int32_t *from, *to;      /* [n_edges] state indices                                      */
-    const int32_t *label;          /* [n_edges] label column of the destination state, or -1       */
+    const int32_t *label;          /* [n_edges] label column, or -1 (NULL: no labels)              */
     const float *val;              /* [n_edges] edge weight, or NULL (= 1)                         */
-} farnn_ifst_edges_desc;
+} farnn_edge_list;
 
-int farnn_onehot_ifst_create_from_edges(const farnn_ifst_edges_desc *desc, int device, farnn_model **out);
+int farnn_onehot_ifst_create_from_edges(const farnn_onehot_ifst_desc *base, const farnn_edge_list *edges,
+                                        int device, farnn_model **out);
 
 /* ---- onehot FST 4-D: FARNN_S_O (reference model_onehot.py:8-129), --independent 0 ---- */
 typedef struct farnn_onehot_fst4_desc {
@@ -129,6 +129,12 @@ typedef struct farnn_onehot_ind1_desc {
 } farnn_onehot_ind1_desc;
 
 int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *desc, int device, farnn_model **out);
+
+/* the same two models from the edge list (see farnn_edge_list above) */
+int farnn_onehot_fst4_create_from_edges(const farnn_onehot_fst4_desc *base, const farnn_edge_list *edges,
+                                        int device, farnn_model **out);
+int farnn_onehot_ind1_create_from_edges(const farnn_onehot_ind1_desc *base, const farnn_edge_list *edges,
+                                        int device, farnn_model **out);
 
 /* ---- decomposed i-FST: FARNN_S_D_W_I_S (reference model_decompose_single.py:12-304) ---- */
 typedef struct farnn_decomp_ifst_desc {

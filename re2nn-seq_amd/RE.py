@@ -73,14 +73,15 @@ def build_onehot_model(args, automata, t2i, s2i, priority_mat):
     if args.local_loss_func != 'CE1':
         raise NotImplementedError('only CE1 is reachable from main.py (:127)')
     o_idx = s2i['o']
+    cls = {1: FARNN_S_O_I, 2: FARNN_S_O_I_S}.get(args.independent, FARNN_S_O)
+    if not args.rand_constant and not os.environ.get('FARNN_DENSE_LOADER'):
+        # no noise to add: skip the dense float64 host tensors and scatter the edges in HBM;
+        # same default dataset kwarg as the dense calls below (the 'MITR-BIO' quirk)
+        return cls.from_automaton(automata, t2i, s2i, priority_mat, args, o_idx=o_idx)
     if args.independent == 1:
         T, _, W, Oten, Ow, fin, sta, _ = f2t.dfa_to_tensor_slot_independent_wildcard(automata, t2i, s2i)
         return FARNN_S_O_I(T, Oten, W, Ow, fin, sta, priority_mat, args, o_idx=o_idx)
     if args.independent == 2:
-        if not args.rand_constant and not os.environ.get('FARNN_DENSE_LOADER'):
-            # no noise to add: skip the dense float64 host tensor, scatter the edges in HBM;
-            # same default dataset kwarg as the dense call below (the 'MITR-BIO' quirk)
-            return FARNN_S_O_I_S.from_automaton(automata, t2i, s2i, priority_mat, args, o_idx=o_idx)
         T, _, W, O, Ow, fin, sta, _ = f2t.dfa_to_tensor_slot_single_wildcard(automata, t2i, s2i)
         return FARNN_S_O_I_S(T, O, W, Ow, fin, sta, priority_mat, args, o_idx=o_idx)
     T4, _, W4, WW, fin, sta, _ = f2t.dfa_to_tensor_slot_new_wildcard(automata, t2i, s2i)

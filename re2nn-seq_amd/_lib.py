@@ -71,8 +71,8 @@ class DecompInd1Desc(C.Structure):
                 ('crf_trans', _f32p), ('weights_on_device', C.c_int32)]
 
 
-class IfstEdgesDesc(C.Structure):
-    _fields_ = [('base', OnehotIfstDesc), ('n_edges', C.c_int64),
+class EdgeList(C.Structure):
+    _fields_ = [('n_edges', C.c_int64),
                 ('word', C.POINTER(C.c_int32)), ('from_', C.POINTER(C.c_int32)), ('to', C.POINTER(C.c_int32)),
                 ('label', C.POINTER(C.c_int32)), ('val', _f32p)]
 
@@ -94,7 +94,12 @@ class DecompFstDesc(C.Structure):
 _vp = C.c_void_p
 SIGNATURES = {
     'farnn_onehot_ifst_create': (C.c_int, [C.POINTER(OnehotIfstDesc), C.c_int, C.POINTER(_vp)]),
-    'farnn_onehot_ifst_create_from_edges': (C.c_int, [C.POINTER(IfstEdgesDesc), C.c_int, C.POINTER(_vp)]),
+    'farnn_onehot_ifst_create_from_edges': (C.c_int, [C.POINTER(OnehotIfstDesc), C.POINTER(EdgeList), C.c_int,
+                                                      C.POINTER(_vp)]),
+    'farnn_onehot_fst4_create_from_edges': (C.c_int, [C.POINTER(OnehotFst4Desc), C.POINTER(EdgeList), C.c_int,
+                                                      C.POINTER(_vp)]),
+    'farnn_onehot_ind1_create_from_edges': (C.c_int, [C.POINTER(OnehotInd1Desc), C.POINTER(EdgeList), C.c_int,
+                                                      C.POINTER(_vp)]),
     'farnn_onehot_fst4_create': (C.c_int, [C.POINTER(OnehotFst4Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_onehot_ind1_create': (C.c_int, [C.POINTER(OnehotInd1Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_ifst_create': (C.c_int, [C.POINTER(DecompIfstDesc), C.c_int, C.POINTER(_vp)]),
@@ -245,27 +250,60 @@ def create_onehot_ifst(T, W, O, h0, hT, P=None, nl='none', semiring='sum', thres
     return _create('farnn_onehot_ifst_create', d, device, (T, W, O, h0, hT, P, crf_trans))
 
 
-def create_onehot_ifst_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, nl='none',
-                                  semiring='sum', threshold=0.5, o_idx=0, use_crf=False, crf_trans=None,
-                                  device=0):
-    """The i-FST built on the device from the automaton's edge list (farnn_ifst_edges_desc): no dense
-    [V,S,S] tensor exists on the host.  `word` = -1 marks a wildcard edge, < -1 an entry that only
-    labels its destination state; `label` < 0: no label."""
+def _edge_list(word, frm, to, label, val):
     i32 = lambda a: np.ascontiguousarray(np.asarray(a), dtype=np.int32)      # noqa: E731
     ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))                     # noqa: E731
     word, frm, to, label = i32(word), i32(frm), i32(to), i32(label)
     n = word.shape[0]
     assert frm.shape == to.shape == label.shape == (n,)
     val = None if val is None else f32(val)
+    return EdgeList(n, ip(word), ip(frm), ip(to), ip(label), ptr(val)), (word, frm, to, label, val)
+
+
+def _create_from_edges(fn_name, base, edges, device, keep):
+    lib = load()
+    out = _vp()
+    check(getattr(lib, fn_name)(C.byref(base), C.byref(edges), int(device), C.byref(out)), fn_name)
+    return Handle(out, keep)
+
+
+def create_onehot_ifst_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, nl='none',
+                                  semiring='sum', threshold=0.5, o_idx=0, use_crf=False, crf_trans=None,
+                                  device=0):
+    """The i-FST built on the device from the automaton's edge list (farnn_edge_list): no dense
+    [V,S,S] tensor exists on the host.  `word` = -1 marks a wildcard edge, < -1 an entry that only
+    labels its destination state; `label` < 0: no label."""
+    edges, keep = _edge_list(word, frm, to, label, val)
     h0, hT = f32(h0), f32(hT)
     P = None if P is None else f32(P)
     crf_trans = None if crf_trans is None else f32(crf_trans)
     base = OnehotIfstDesc(int(V), int(S), int(n_cols), None, None, None, ptr(h0), ptr(hT), ptr(P),
                           NL[nl], SEMIRING[semiring], float(threshold), int(o_idx), int(bool(use_crf)),
                           ptr(crf_trans), 0)
-    d = IfstEdgesDesc(base, n, ip(word), ip(frm), ip(to), ip(label), ptr(val))
-    return _create('farnn_onehot_ifst_create_from_edges', d, device,
-                   (word, frm, to, label, val, h0, hT, P, crf_trans))
+    return _create_from_edges('farnn_onehot_ifst_create_from_edges', base, edges, device,
+                              keep + (h0, hT, P, crf_trans))
+
+
+def create_onehot_fst4_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, semiring='sum',
+                                  threshold=0.5, o_idx=0, device=0):
+    """FARNN_S_O (4-D FST) from the edge list: T4[w,l,f,t] / W4[l,f,t] are scattered on the device."""
+    edges, keep = _edge_list(word, frm, to, label, val)
+    h0, hT = f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    base = OnehotFst4Desc(int(V), int(S), int(n_cols), None, None, ptr(h0), ptr(hT), ptr(P),
+                          SEMIRING[semiring], float(threshold), int(o_idx), 0)
+    return _create_from_edges('farnn_onehot_fst4_create_from_edges', base, edges, device, keep + (h0, hT, P))
+
+
+def create_onehot_ind1_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, semiring='sum',
+                                  mask_by_output=False, threshold=0.5, o_idx=0, device=0):
+    """FARNN_S_O_I (independent=1) from the edge list: T, W and Oten[l,f,t] are scattered on the device."""
+    edges, keep = _edge_list(word, frm, to, label, val)
+    h0, hT = f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    base = OnehotInd1Desc(int(V), int(S), int(n_cols), None, None, None, ptr(h0), ptr(hT), ptr(P),
+                          SEMIRING[semiring], int(bool(mask_by_output)), float(threshold), int(o_idx), 0)
+    return _create_from_edges('farnn_onehot_ind1_create_from_edges', base, edges, device, keep + (h0, hT, P))
 
 
 def create_onehot_fst4(T4, W4, h0, hT, P=None, semiring='sum', threshold=0.5, o_idx=0, device=0):

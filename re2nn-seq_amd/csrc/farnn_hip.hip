@@ -638,72 +638,122 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     }
 }
 
-// ---- create: onehot i-FST from the automaton's edge list ---------------------------------------
-extern "C" int farnn_onehot_ifst_create_from_edges(const farnn_ifst_edges_desc *d, int device, farnn_model **out) {
-    if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
-    *out = nullptr;
-    const farnn_onehot_ifst_desc &b = d->base;
-    if (b.V <= 0 || b.S <= 0 || b.C <= 0) return fail(FARNN_EINVAL, "ifst_from_edges: V, S, C must be positive%s%s");
-    if (d->n_edges < 0 || (d->n_edges > 0 && (!d->word || !d->from || !d->to)))
-        return fail(FARNN_EINVAL, "ifst_from_edges: edge arrays missing%s%s");
-    int rc = select_device(device);
-    if (rc) return rc;
-    struct Tmp {            // device temporaries, freed on every path
-        void *p[16] = {nullptr}; int n = 0;
-        ~Tmp() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
-        int get(void **q, size_t bytes) {
-            FARNN_HIP_TRY(hipMalloc(q, bytes ? bytes : 4));
-            p[n++] = *q;
-            return FARNN_OK;
-        }
-    } tmp;
-    const size_t nT = (size_t)b.V * b.S * b.S, nW = (size_t)b.S * b.S, nO = (size_t)b.C * b.S, ne = (size_t)d->n_edges;
-    float *T = nullptr, *W = nullptr, *O = nullptr, *val = nullptr;
-    int32_t *word = nullptr, *from = nullptr, *to = nullptr, *label = nullptr;
+// ---- create from the automaton's edge list: dense tensors are scattered on the device ------------
+struct EdgeTmp {            // device temporaries, freed on every path
+    void *p[16] = {nullptr}; int n = 0;
+    ~EdgeTmp() { for (int i = 0; i < n; i++) (void)hipFree(p[i]); }
+    int get(void **q, size_t bytes) {
+        FARNN_HIP_TRY(hipMalloc(q, bytes ? bytes : 4));
+        p[n++] = *q;
+        return FARNN_OK;
+    }
+    int zeros(float **q, size_t floats) {
+        int rc = get((void **)q, floats * 4);
+        if (rc) return rc;
+        FARNN_HIP_TRY(hipMemset(*q, 0, floats * 4));
+        return FARNN_OK;
+    }
+    int stage(const float *&ptr, size_t n_) {      // host array -> device copy (NULL stays NULL)
+        if (!ptr) return FARNN_OK;
+        float *dv = nullptr;
+        int rc = get((void **)&dv, n_ * 4);
+        if (rc) return rc;
+        FARNN_HIP_TRY(hipMemcpy(dv, ptr, n_ * 4, hipMemcpyHostToDevice));
+        ptr = dv;
+        return FARNN_OK;
+    }
+};
+
+static int scatter_edges(EdgeTmp &tmp, const farnn_edge_list *e, float *T, float *W, float *O, int V, int S, int C,
+                         int mode) {
+    if (!e || e->n_edges < 0 || (e->n_edges > 0 && (!e->word || !e->from || !e->to)))
+        return fail(FARNN_EINVAL, "from_edges: edge arrays missing%s%s");
+    const size_t ne = (size_t)e->n_edges;
+    if (!ne) return FARNN_OK;
+    int32_t *word = nullptr;
+    float *val = nullptr;
     int *bad = nullptr;
-    if ((rc = tmp.get((void **)&T, nT * 4))) return rc;
-    if ((rc = tmp.get((void **)&W, nW * 4))) return rc;
-    if ((rc = tmp.get((void **)&O, nO * 4))) return rc;
-    if ((rc = tmp.get((void **)&word, ne * 4 * 4 + 4))) return rc;      // word | from | to | label
-    from = word + ne; to = from + ne; label = to + ne;
+    int rc;
+    if ((rc = tmp.get((void **)&word, ne * 4 * 4))) return rc;           // word | from | to | label
+    int32_t *from = word + ne, *to = from + ne, *label = to + ne;
     if ((rc = tmp.get((void **)&val, ne * 4))) return rc;
     if ((rc = tmp.get((void **)&bad, 4))) return rc;
-    FARNN_HIP_TRY(hipMemset(T, 0, nT * 4));
-    FARNN_HIP_TRY(hipMemset(W, 0, nW * 4));
-    FARNN_HIP_TRY(hipMemset(O, 0, nO * 4));
     FARNN_HIP_TRY(hipMemset(bad, 0, 4));
-    if (ne) {
-        FARNN_HIP_TRY(hipMemcpy(word, d->word, ne * 4, hipMemcpyHostToDevice));
-        FARNN_HIP_TRY(hipMemcpy(from, d->from, ne * 4, hipMemcpyHostToDevice));
-        FARNN_HIP_TRY(hipMemcpy(to, d->to, ne * 4, hipMemcpyHostToDevice));
-        if (d->label) FARNN_HIP_TRY(hipMemcpy(label, d->label, ne * 4, hipMemcpyHostToDevice));
-        if (d->val) FARNN_HIP_TRY(hipMemcpy(val, d->val, ne * 4, hipMemcpyHostToDevice));
-        scatter_edges_kernel<<<(unsigned)((ne + 255) / 256), 256>>>(word, from, to, d->label ? label : nullptr,
-                                                                     d->val ? val : nullptr, (long long)ne, T, W, O,
-                                                                     b.V, b.S, b.C, bad);
-        FARNN_HIP_TRY(hipGetLastError());
-    }
+    FARNN_HIP_TRY(hipMemcpy(word, e->word, ne * 4, hipMemcpyHostToDevice));
+    FARNN_HIP_TRY(hipMemcpy(from, e->from, ne * 4, hipMemcpyHostToDevice));
+    FARNN_HIP_TRY(hipMemcpy(to, e->to, ne * 4, hipMemcpyHostToDevice));
+    if (e->label) FARNN_HIP_TRY(hipMemcpy(label, e->label, ne * 4, hipMemcpyHostToDevice));
+    if (e->val) FARNN_HIP_TRY(hipMemcpy(val, e->val, ne * 4, hipMemcpyHostToDevice));
+    scatter_edges_kernel<<<(unsigned)((ne + 255) / 256), 256>>>(word, from, to, e->label ? label : nullptr,
+                                                                 e->val ? val : nullptr, (long long)ne, T, W, O,
+                                                                 V, S, C, mode, bad);
+    FARNN_HIP_TRY(hipGetLastError());
     int hbad = 0;
     FARNN_HIP_TRY(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
-    if (hbad) return fail(FARNN_EINVAL, "ifst_from_edges: an edge has a word, state or label index out of range%s%s");
-    farnn_onehot_ifst_desc full = b;
-    if (!b.weights_on_device) {
-        // h0/hT/P/crf_trans stay host pointers while T/W/O are on the device: stage the small ones too
-        auto stage = [&](const float *&ptr, size_t n) -> int {
-            if (!ptr) return FARNN_OK;
-            float *dv = nullptr;
-            int r = tmp.get((void **)&dv, n * 4);
-            if (r) return r;
-            FARNN_HIP_TRY(hipMemcpy(dv, ptr, n * 4, hipMemcpyHostToDevice));
-            ptr = dv;
-            return FARNN_OK;
-        };
-        const size_t K = (size_t)b.C + (b.use_crf ? 2 : 0);
-        if ((rc = stage(full.h0, b.S)) || (rc = stage(full.hT, b.S)) || (rc = stage(full.P, (size_t)b.C * b.C)) ||
-            (rc = stage(full.crf_trans, K * K))) return rc;
+    if (hbad) return fail(FARNN_EINVAL, "from_edges: an edge has a word, state or label index out of range%s%s");
+    return FARNN_OK;
+}
+
+extern "C" int farnn_onehot_ifst_create_from_edges(const farnn_onehot_ifst_desc *b, const farnn_edge_list *e,
+                                                   int device, farnn_model **out) {
+    if (!b || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (b->V <= 0 || b->S <= 0 || b->C <= 0) return fail(FARNN_EINVAL, "ifst_from_edges: V, S, C must be positive%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    EdgeTmp tmp;
+    float *T = nullptr, *W = nullptr, *O = nullptr;
+    if ((rc = tmp.zeros(&T, (size_t)b->V * b->S * b->S)) || (rc = tmp.zeros(&W, (size_t)b->S * b->S)) ||
+        (rc = tmp.zeros(&O, (size_t)b->C * b->S))) return rc;
+    if ((rc = scatter_edges(tmp, e, T, W, O, b->V, b->S, b->C, 0))) return rc;
+    farnn_onehot_ifst_desc full = *b;
+    if (!b->weights_on_device) {
+        const size_t K = (size_t)b->C + (b->use_crf ? 2 : 0);
+        if ((rc = tmp.stage(full.h0, b->S)) || (rc = tmp.stage(full.hT, b->S)) ||
+            (rc = tmp.stage(full.P, (size_t)b->C * b->C)) || (rc = tmp.stage(full.crf_trans, K * K))) return rc;
     }
     full.T = T; full.W = W; full.O = O; full.weights_on_device = 1;
     return farnn_onehot_ifst_create(&full, device, out);
+}
+
+extern "C" int farnn_onehot_fst4_create_from_edges(const farnn_onehot_fst4_desc *b, const farnn_edge_list *e,
+                                                   int device, farnn_model **out) {
+    if (!b || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (b->V <= 0 || b->S <= 0 || b->C <= 0) return fail(FARNN_EINVAL, "fst4_from_edges: V, S, C must be positive%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    EdgeTmp tmp;
+    float *T4 = nullptr, *W4 = nullptr;
+    if ((rc = tmp.zeros(&T4, (size_t)b->V * b->C * b->S * b->S)) || (rc = tmp.zeros(&W4, (size_t)b->C * b->S * b->S)))
+        return rc;
+    if ((rc = scatter_edges(tmp, e, T4, W4, nullptr, b->V, b->S, b->C, 1))) return rc;
+    farnn_onehot_fst4_desc full = *b;
+    if (!b->weights_on_device)
+        if ((rc = tmp.stage(full.h0, b->S)) || (rc = tmp.stage(full.hT, b->S)) ||
+            (rc = tmp.stage(full.P, (size_t)b->C * b->C))) return rc;
+    full.T4 = T4; full.W4 = W4; full.weights_on_device = 1;
+    return farnn_onehot_fst4_create(&full, device, out);
+}
+
+extern "C" int farnn_onehot_ind1_create_from_edges(const farnn_onehot_ind1_desc *b, const farnn_edge_list *e,
+                                                   int device, farnn_model **out) {
+    if (!b || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (b->V <= 0 || b->S <= 0 || b->C <= 0) return fail(FARNN_EINVAL, "ind1_from_edges: V, S, C must be positive%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    EdgeTmp tmp;
+    float *T = nullptr, *W = nullptr, *Oten = nullptr;
+    if ((rc = tmp.zeros(&T, (size_t)b->V * b->S * b->S)) || (rc = tmp.zeros(&W, (size_t)b->S * b->S)) ||
+        (rc = tmp.zeros(&Oten, (size_t)b->C * b->S * b->S))) return rc;
+    if ((rc = scatter_edges(tmp, e, T, W, Oten, b->V, b->S, b->C, 2))) return rc;
+    farnn_onehot_ind1_desc full = *b;
+    if (!b->weights_on_device)
+        if ((rc = tmp.stage(full.h0, b->S)) || (rc = tmp.stage(full.hT, b->S)) ||
+            (rc = tmp.stage(full.P, (size_t)b->C * b->C))) return rc;
+    full.T = T; full.W = W; full.Oten = Oten; full.weights_on_device = 1;
+    return farnn_onehot_ind1_create(&full, device, out);
 }
 
 // ---- create: onehot FST 4-D -------------------------------------------------------------------

@@ -97,18 +97,31 @@ inline int launch_premix_fst4(const float *T4, const float *W4, float *Mf, float
     return FARNN_OK;
 }
 
-// ---- automaton edge list -> dense device tensors (fsa_to_tensor.py:546-615 without the host tensor) ----
+// ---- automaton edge list -> dense device tensors (fsa_to_tensor.py:398-615 without the host tensors) ----
+// mode 0: i-FST  T[V,S,S] W[S,S] O[C,S];  mode 1: FST 4-D  T = T4[V,C,S,S], W = W4[C,S,S];
+// mode 2: independent=1  T[V,S,S] W[S,S] O = Oten[C,S,S]
 __global__ void scatter_edges_kernel(const int32_t *word, const int32_t *from, const int32_t *to,
                                      const int32_t *label, const float *val, long long n,
-                                     float *T, float *W, float *O, int V, int S, int C, int *bad) {
+                                     float *T, float *W, float *O, int V, int S, int C, int mode, int *bad) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
     const int w = word[e], f = from[e], t = to[e], l = label ? label[e] : -1;
-    if (w >= V || f < 0 || f >= S || t < 0 || t >= S || l >= C) { atomicExch(bad, 1); return; }
+    if (w >= V || f < 0 || f >= S || t < 0 || t >= S || l >= C || (mode == 1 && w >= -1 && l < 0)) {
+        atomicExch(bad, 1);
+        return;
+    }
     const float v = val ? val[e] : 1.0f;
+    if (mode == 1) {
+        if (w >= 0) T[(((long long)w * C + l) * S + f) * S + t] = v;
+        else if (w == -1) W[((long long)l * S + f) * S + t] = v;
+        return;
+    }
     if (w >= 0) T[((long long)w * S + f) * S + t] = v;
     else if (w == -1) W[(long long)f * S + t] = v;          // w < -1: label only
-    if (l >= 0) O[(long long)l * S + t] = 1.0f;
+    if (l >= 0) {
+        if (mode == 0) O[(long long)l * S + t] = 1.0f;
+        else O[((long long)l * S + f) * S + t] = 1.0f;
+    }
 }
 
 }  // namespace farnn

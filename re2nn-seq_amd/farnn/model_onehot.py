@@ -133,10 +133,31 @@ class FARNN_S_O(_OnehotBase):
         self.wildcard_tensor = _noisy(wildcard_tensor, self.amp)
         self.wildcard_wildcard_mat = _lib.f32(wildcard_wildcard_mat)
 
+    @classmethod
+    def from_automaton(cls, automata, word2idx, slot2idx, priority_mat=None, args=None, o_idx=0,
+                       dataset='MITR-BIO'):
+        """Built without the dense [V,C,S,S] host tensor (2.5 GB at ATIS size): see FARNN_S_O_I_S.from_automaton."""
+        from ..wfa.fsa_to_tensor import dfa_to_edges_slot_new_wildcard
+        if args.rand_constant:
+            raise ValueError('from_automaton needs rand_constant == 0')
+        word, frm, to, label, fin, sta, _ = dfa_to_edges_slot_new_wildcard(automata, word2idx, slot2idx, dataset)
+        self = cls.__new__(cls)
+        _OnehotBase.__init__(self, args, o_idx, len(slot2idx) + 1, priority_mat, False)
+        self.S, self.V = len(automata['states']), len(word2idx)
+        self.h0, self.hT = _noisy(sta, 0), _noisy(fin, 0)
+        self.edges = (word, frm, to, label)
+        return self
+
     def _build_handle(self):
         a = self.args
         if a.local_loss_func != 'CE1':
             raise NotImplementedError('only CE1 is reachable from main.py (:127)')
+        if getattr(self, 'edges', None) is not None:
+            word, frm, to, label = self.edges
+            return _lib.create_onehot_fst4_from_edges(
+                self.V, self.S, self.C, word, frm, to, label, self.h0, self.hT, P=self._P(),
+                semiring='max' if a.train_mode == 'max' else 'sum', threshold=a.threshold,
+                o_idx=self.o_idx, device=self.device_index)
         return _lib.create_onehot_fst4(
             self.language_tensor, self.wildcard_tensor, self.h0, self.hT, P=self._P(),
             semiring='max' if a.train_mode == 'max' else 'sum', threshold=a.threshold,
@@ -162,10 +183,32 @@ class FARNN_S_O_I(_OnehotBase):
         self.output_tensor = _lib.f32(output_tensor)
         self.output_wildcard_mat = None if output_wildcard_mat is None else _lib.f32(output_wildcard_mat)
 
+    @classmethod
+    def from_automaton(cls, automata, word2idx, slot2idx, priority_mat=None, args=None, o_idx=0,
+                       dataset='MITR-BIO'):
+        """Built without the dense host tensors: see FARNN_S_O_I_S.from_automaton."""
+        from ..wfa.fsa_to_tensor import dfa_to_edges_slot_independent_wildcard
+        if args.rand_constant:
+            raise ValueError('from_automaton needs rand_constant == 0')
+        word, frm, to, label, fin, sta, _ = dfa_to_edges_slot_independent_wildcard(automata, word2idx, slot2idx,
+                                                                                   dataset)
+        self = cls.__new__(cls)
+        _OnehotBase.__init__(self, args, o_idx, len(slot2idx) + 1, priority_mat, False)
+        self.S, self.V = len(automata['states']), len(word2idx)
+        self.h0, self.hT = _noisy(sta, 0), _noisy(fin, 0)
+        self.edges = (word, frm, to, label)
+        return self
+
     def _build_handle(self):
         a = self.args
         if a.local_loss_func != 'CE1':
             raise NotImplementedError('only CE1 is reachable from main.py (:127)')
+        if getattr(self, 'edges', None) is not None:
+            word, frm, to, label = self.edges
+            return _lib.create_onehot_ind1_from_edges(
+                self.V, self.S, self.C, word, frm, to, label, self.h0, self.hT, P=self._P(),
+                semiring='max' if a.train_mode == 'max' else 'sum', mask_by_output=(a.independent == 2),
+                threshold=a.threshold, o_idx=self.o_idx, device=self.device_index)
         return _lib.create_onehot_ind1(
             self.language_tensor, self.wildcard_mat, self.output_tensor, self.h0, self.hT, P=self._P(),
             semiring='max' if a.train_mode == 'max' else 'sum',

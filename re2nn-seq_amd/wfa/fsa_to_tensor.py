@@ -164,18 +164,35 @@ def dfa_to_tensor_slot_single_wildcard(automata, word2idx, slot2idx, dataset='MI
             output_wildcard_vector, final_vector, start_vector, sorted(language))
 
 
-def dfa_to_edges_slot_single_wildcard(automata, word2idx, slot2idx, dataset='MITR-BIO'):
-    """The edges dfa_to_tensor_slot_single_wildcard (ref :546-615) would write, as flat int32 arrays
-    for the device-side builder (include/farnn.h: farnn_ifst_edges_desc): one entry per (word,
-    from, to) with the class edges '&' / '%' expanded, word = -1 for '$' edges (-2: label only, a class
-    with no member in the vocabulary), and the label column of the destination state.  Returns (word, frm, to, label, final_vector, start_vector, state2idx)."""
-    state2idx, edges = _walk_edges(automata, word2idx, slot2idx, dataset, strict_oo=False)
+def _edge_arrays(automata, word2idx, slot2idx, dataset, strict_oo):
+    state2idx, edges = _walk_edges(automata, word2idx, slot2idx, dataset, strict_oo=strict_oo)
     word, frm, to, label = [], [], [], []
     for wids, col, fi, ti, _ in edges:
         for w in ([-1] if wids is None else wids):
             word.append(w); frm.append(fi); to.append(ti); label.append(col)
-        if wids is not None and not wids:         # an empty class still labels its destination state
+        if wids is not None and not wids:         # an empty class still carries its label
             word.append(-2); frm.append(fi); to.append(ti); label.append(col)
     final_vector, start_vector = _start_final(automata, len(automata['states']))
     as32 = lambda a: np.asarray(a, dtype=np.int32)      # noqa: E731
     return as32(word), as32(frm), as32(to), as32(label), final_vector, start_vector, state2idx
+
+
+def dfa_to_edges_slot_single_wildcard(automata, word2idx, slot2idx, dataset='MITR-BIO'):
+    """The edges dfa_to_tensor_slot_single_wildcard (ref :546-615) would write, as flat int32 arrays
+    for the device-side builder (include/farnn.h: farnn_edge_list): one entry per (word, from, to)
+    with the class edges '&' / '%' expanded, word = -1 for '$' edges (-2: label only, a class with no
+    member in the vocabulary), and the label column of the edge (= of its destination state).
+    Returns (word, frm, to, label, final_vector, start_vector, state2idx)."""
+    return _edge_arrays(automata, word2idx, slot2idx, dataset, strict_oo=False)
+
+
+def dfa_to_edges_slot_independent_wildcard(automata, word2idx, slot2idx, dataset='MITR-BIO'):
+    """Edge arrays of dfa_to_tensor_slot_independent_wildcard (ref :477-543): same entries, the label
+    goes to Oten[label, from, to]."""
+    return _edge_arrays(automata, word2idx, slot2idx, dataset, strict_oo=False)
+
+
+def dfa_to_edges_slot_new_wildcard(automata, word2idx, slot2idx, dataset='MITR-BIO'):
+    """Edge arrays of dfa_to_tensor_slot_new_wildcard (ref :398-474, 4-D FST): T4[word, label, from, to]
+    and W4[label, from, to]; 'oo' must sit on '$' edges (the reference asserts it)."""
+    return _edge_arrays(automata, word2idx, slot2idx, dataset, strict_oo=True)

@@ -217,3 +217,31 @@ def test_ifst_built_on_device_from_edges_matches_dense_upload():
     bad = word.copy(); bad[0] = V + 5
     with pytest.raises(_lib.FarnnError, match='out of range'):
         _lib.create_onehot_ifst_from_edges(V, S, C, bad, frm, to, label, sta2, fin2)
+
+
+@pytest.mark.parametrize('independent', [0, 1])
+def test_fst4_and_ind1_built_on_device_from_edges(independent):
+    """The other two onehot layouts from the edge list: same scores as the dense upload, bit for bit."""
+    from re2nn_seq_amd import synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O, FARNN_S_O_I
+    from re2nn_seq_amd.wfa import fsa_to_tensor as f2t
+    dset, automaton, _ = synth.make_dataset(60, 4, 20, seed=9, max_len=14)
+    t2i = dict(dset['t2i']); t2i['<pad>'] = len(t2i)
+    s2i = dset['s2i']
+    x, lengths = synth.pad_batch(dset['query_test'][:20], 14, t2i['<pad>'])
+    a = ns(independent=independent)
+    if independent == 0:
+        T4, _, W4, WW, fin, sta, _ = f2t.dfa_to_tensor_slot_new_wildcard(automaton, t2i, s2i)
+        dense = FARNN_S_O(T4, W4, WW, fin, sta, None, a, o_idx=s2i['o'])
+        edge = FARNN_S_O.from_automaton(automaton, t2i, s2i, None, a, o_idx=s2i['o'])
+        ref = fo.onehot_fst4_scores(T4, W4, sta, fin, x, lengths)
+    else:
+        T, _, W, Oten, Ow, fin, sta, _ = f2t.dfa_to_tensor_slot_independent_wildcard(automaton, t2i, s2i)
+        dense = FARNN_S_O_I(T, Oten, W, Ow, fin, sta, None, a, o_idx=s2i['o'])
+        edge = FARNN_S_O_I.from_automaton(automaton, t2i, s2i, None, a, o_idx=s2i['o'])
+        ref = fo.onehot_ind1_scores(T, W, Oten, sta, fin, x, lengths)
+    sd, fd, _, _ = _run_all(dense, x, lengths)
+    se, fe, _, _ = _run_all(edge, x, lengths)
+    assert np.array_equal(sd, se) and np.array_equal(fd, fe)
+    assert np.array_equal(se, ref)
+    assert (fe != s2i['o']).sum() > 10

@@ -210,3 +210,24 @@ def test_edge_list_reproduces_the_dense_ifst_tensors():
             O2[l, t] = 1
         assert np.array_equal(T2, T) and np.array_equal(W2, W) and np.array_equal(O2, O)
         assert np.array_equal(fin2, fin) and np.array_equal(sta2, sta)
+
+
+def test_edge_lists_reproduce_the_4d_and_independent1_tensors():
+    dset, automaton, _ = synth.make_dataset(40, 3, 12, seed=5)
+    t2i = dict(dset['t2i']); t2i['<pad>'] = len(t2i)
+    s2i = dset['s2i']
+    T4, _, W4, _, fin, sta, _ = f2t.dfa_to_tensor_slot_new_wildcard(automaton, t2i, s2i)
+    word, frm, to, label, fin2, sta2, _ = f2t.dfa_to_edges_slot_new_wildcard(automaton, t2i, s2i)
+    A, Wd = np.zeros_like(T4), np.zeros_like(W4)
+    lang, wild = word >= 0, word == -1
+    A[word[lang], label[lang], frm[lang], to[lang]] = 1
+    Wd[label[wild], frm[wild], to[wild]] = 1
+    assert np.array_equal(A, T4) and np.array_equal(Wd, W4) and np.array_equal(fin, fin2) and np.array_equal(sta, sta2)
+    T, _, W, Oten, _, _, _, _ = f2t.dfa_to_tensor_slot_independent_wildcard(automaton, t2i, s2i)
+    word, frm, to, label, _, _, _ = f2t.dfa_to_edges_slot_independent_wildcard(automaton, t2i, s2i)
+    T2, W2, O2 = np.zeros_like(T), np.zeros_like(W), np.zeros_like(Oten)
+    lang, wild = word >= 0, word == -1
+    T2[word[lang], frm[lang], to[lang]] = 1
+    W2[frm[wild], to[wild]] = 1
+    O2[label, frm, to] = 1
+    assert np.array_equal(T2, T) and np.array_equal(W2, W) and np.array_equal(O2, Oten)
