@@ -55,6 +55,7 @@ struct farnn_model {
     int wsB = 0, wsL = 0;
     ChainGeom geom;
     int chain_ks = 3;
+    bool prep_in_kernel = false, sort_in_kernel = false;
     bool order_valid = false;
     int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
     long long calls = 0;
@@ -346,6 +347,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
     p.order = m->order_valid ? m->order : nullptr;
+    p.sort = m->sort_in_kernel ? 1 : 0;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
     p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
@@ -524,7 +526,7 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
                                int64_t *flat, float *scores, hipStream_t s) {
     ScoreParams p;
     p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
-    p.offs = flat ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
+    p.offs = (flat && !m->prep_in_kernel) ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
     p.crf_scores = m->crf_scores;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.kch = m->Kc / 64;
@@ -578,8 +580,12 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     // batch preparation: flat-output offsets and the length-sorted launch order (full mode runs
     // every sequence for L steps, so there is nothing to balance)
     const bool want_order = !full && B > 2 && !env_int("FARNN_NOSORT", 0);
-    m->order_valid = want_order;
-    if (flat_tags || want_order) {
+    // the plain i-FST path needs no prep launch up to B = 1024: the chain workgroups select their sequence
+    // by length rank themselves and the score workgroups sum the lengths in front of theirs
+    m->prep_in_kernel = m->kind == KIND_IFST && B <= 1024 && L <= 1023 && !env_int("FARNN_PREP", 0);
+    m->order_valid = want_order && !m->prep_in_kernel;
+    m->sort_in_kernel = want_order && m->prep_in_kernel;
+    if ((flat_tags || want_order) && !m->prep_in_kernel) {
         KernelTimer kt(m, KERN_PREP, s);
         if (B <= 1024) {
             int G = 1;

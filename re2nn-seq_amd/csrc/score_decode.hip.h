@@ -27,7 +27,8 @@ struct ScoreParams {
     const float *P;         // [K][Kc] priority matrix or nullptr
     const float *trT;       // [K][Kp] TRANSPOSED CRF transitions trT[j][i] = tr[i][j], or nullptr
     const int64_t *len;     // [B]
-    const int64_t *offs;    // [B+1] exclusive prefix of lengths (flat output) or nullptr
+    const int64_t *offs;    // [B+1] exclusive prefix of lengths (flat output) or nullptr: with `flat` set the
+                            //        kernel then sums the lengths before its sequence itself (B <= 1024)
     int32_t *tags;          // [B][L] or nullptr
     int64_t *flat;          // [sum len] or nullptr
     float *scores;          // [B][L][K] or nullptr (unclamped, what forward_score returns)
@@ -110,14 +111,33 @@ score_tile_kernel(const ScoreParams p) {
                 st4(ab + tokv[r] * SP + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
                                                              a4[r].z * b4[r].z, a4[r].w * b4[r].w));
     }
+    // no prepared offsets: where this sequence starts in the flat output = sum of the lengths before it
+    // (utils.py:153-164); B <= 1024 here, two loads per thread, hidden behind the DMA
+    __shared__ int foff_w[SCORE_WAVES];
+    int foff_s = 0;
+    if (!p.offs && p.flat) {
+        int part = 0;
+        for (int j = tid; j < b; j += nthreads) {
+            const int v = (int)p.len[j];
+            part += v < 0 ? 0 : (v > p.L ? p.L : v);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+        if (lane == 0) foff_w[w] = part;
+    }
     if (OT_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's DMA pieces landed
     __syncthreads();
+    if (!p.offs && p.flat) {
+#pragma unroll
+        for (int ww = 0; ww < SCORE_WAVES; ww++) foff_s += foff_w[ww];
+    }
 
     // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ----------
     const int tg = w * 4;
     if (tg >= nt && tg >= ntL) return;
     const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
-    const long long foff = p.offs ? p.offs[b] : 0;
+    long long foff = p.offs ? p.offs[b] : 0;
+    if (!p.offs && p.flat) foff = (long long)foff_s;
     float acc[4][KCH];
 #pragma unroll
     for (int j = 0; j < 4; j++)
@@ -223,6 +243,25 @@ inline size_t score_lds_bytes(int S, int SP, int Kc, int has_P, int ot_in_lds) {
 // partition with 16-byte LDS reads, and the quad is combined with (value desc, index asc) --
 // torch.max's first-index rule (lane-local strict `>` keeps the first index inside a block).
 // The sequence's clamped scores and the back-pointers stay in LDS.  IB4 = IB/4 is compile-time.
+// flat-output offset of sequence b without a prepared prefix array: the sum of the (clamped) lengths in
+// front of it (utils.py:153-164).  Called by every thread of the workgroup; B <= 1024.
+__device__ __forceinline__ long long flat_offset_in_kernel(const int64_t *len, int b, int L, int tid, int nthreads) {
+    __shared__ int fo_w[16];
+    int part = 0;
+    for (int j = tid; j < b; j += nthreads) {
+        const int v = (int)len[j];
+        part += v < 0 ? 0 : (v > L ? L : v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+    if ((tid & 63) == 0) fo_w[tid >> 6] = part;
+    __syncthreads();
+    int tot = 0;
+    for (int ww = 0; ww < (nthreads >> 6); ww++) tot += fo_w[ww];
+    __syncthreads();
+    return (long long)tot;
+}
+
 template <int IB4>
 __global__ void __launch_bounds__(1024)
 viterbi_kernel(const ScoreParams p) {
@@ -239,7 +278,7 @@ viterbi_kernel(const ScoreParams p) {
     float *scl = part + 2 * PW;                          // [L][Kp] clamped scores of this sequence
     unsigned short *bp = reinterpret_cast<unsigned short *>(scl + (size_t)p.L * Kp);   // [L][Kp]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
-    const long long foff = p.offs ? p.offs[b] : 0;
+    const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
 
@@ -333,7 +372,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     float *scl = hist + (size_t)p.L * PW;                // [L][Kp] clamped scores of this sequence (whole KiB)
     float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
-    const long long foff = p.offs ? p.offs[b] : 0;
+    const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;

@@ -171,10 +171,12 @@ def test_error_codes_through_the_abi():
         h.num_columns()
 
 
-@pytest.mark.parametrize('B', [3, 257, 1500])
-def test_batch_prep_paths_flat_order(B):
-    """Both batch-prep kernels (B <= 1024: rank kernel; larger: counting sort): the flat output
-    must come out in the reference's batch-major order whatever the internal launch order."""
+@pytest.mark.parametrize('B,prep', [(3, 0), (257, 0), (1024, 0), (257, 1), (1500, 0)])
+def test_batch_prep_paths_flat_order(B, prep, monkeypatch):
+    """Every way the launch order and the flat offsets are produced -- inside the chain / score kernels
+    (B <= 1024), the small rank kernel (FARNN_PREP=1) and the counting-sort kernel (B > 1024): the flat
+    output must come out in the reference's batch-major order whatever the internal launch order."""
+    monkeypatch.setenv('FARNN_PREP', str(prep))
     from re2nn_seq_amd import synth
     from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
     rng = np.random.RandomState(B)
