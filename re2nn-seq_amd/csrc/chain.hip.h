@@ -70,11 +70,14 @@ constexpr int CHAIN_MAX_G = 4;
 // length class and the index inside it, a ballot/popcount pass finds the sequence.  Deterministic
 // (no dependence on atomic order), every workgroup of a launch sees the same permutation.
 // `scratch` needs L + 1 + 16 ints of LDS that nothing else uses yet.
-__device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int slot, int *scratch,
+__device__ __forceinline__ int folded_rank(int slot, int B) {
+    const int half = B / 2;
+    return slot < half ? slot : (B - 1) - (slot - half);
+}
+
+__device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int rank, int *scratch,
                                                      int tid, int nthreads) {
     const int lane = tid & 63, w = tid >> 6, nwaves = nthreads >> 6;
-    const int half = B / 2;
-    const int rank = slot < half ? slot : (B - 1) - (slot - half);
     int *hist = scratch;                 // [L + 1]
     int *misc = scratch + L + 1;         // [0] length class, [1] index inside the class, [2] result, [4..] per-wave counts
     for (int i = tid; i <= L; i += nthreads) hist[i] = 0;
@@ -145,7 +148,7 @@ chain_kernel(const ChainParams p) {
     const int item = blockIdx.x;
     const int dir = item & 1;
     int b = p.order ? p.order[item >> 1] : (item >> 1);
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, item >> 1, reinterpret_cast<int *>(smem), tid, nthreads);
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(item >> 1, p.B), reinterpret_cast<int *>(smem), tid, nthreads);
     const int len = (int)p.len[b];
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ, KS = p.KS;

@@ -40,6 +40,7 @@
 #pragma once
 #include "common.hip.h"
 #include "decomp_chain.hip.h"
+#include "chain.hip.h"      // select_by_length_rank
 
 namespace farnn {
 
@@ -59,6 +60,7 @@ struct DecompRowsParams {
     const float *h0, *hT;
     const int64_t *x, *len;
     const int *order;             // folded launch order (batch_prep) or nullptr
+    int sort;                     // 1: no order array, the workgroup selects its sequences by length rank itself
     float *A, *Bk;
     int B, L, S, SP, R, Rp, farnn, nl, full;
     float sig_k;
@@ -176,6 +178,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             const int half = p.B / 2;
             b = p.order ? p.order[r < half ? r : half + (p.B - 1 - r)] : r;     // undo the fold
         }
+        if (p.sort && have) b = select_by_length_rank(p.len, p.B, p.L, r, reinterpret_cast<int *>(smem), tid, DR_THREADS);
         b = __builtin_amdgcn_readfirstlane(b);                // workgroup-uniform: keep it in SGPRs
         bseq[s] = b;
         slen[s] = have ? __builtin_amdgcn_readfirstlane((int)p.len[b]) : 0;
@@ -452,14 +455,14 @@ inline int launch_rows_n(const DecompRowsParams &p, int groups, size_t lds, hipS
 }
 
 inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, const RowsPlan &pl,
-                              const int64_t *x, const int64_t *len, const int *order, float *A, float *Bk,
-                              int B, int L, int full, hipStream_t s) {
+                              const int64_t *x, const int64_t *len, const int *order, int sort_in_kernel,
+                              float *A, float *Bk, int B, int L, int full, hipStream_t s) {
     DecompRowsParams p;
     p.P1 = k.P1; p.P2[0] = k.P2[0]; p.P2[1] = k.P2[1]; p.P3[0] = k.P3[0]; p.P3[1] = k.P3[1];
     p.n1 = k.n1; p.n2 = k.n2; p.n3 = k.n3; p.ld2 = k.ld2; p.ld3 = k.ld3; p.nch2 = k.nch2; p.nch3 = k.nch3;
     p.res1 = pl.res1; p.res2 = pl.res2; p.res3 = pl.res3;
     p.Vgen = w.Vgen; p.Gz = k.Gz; p.Gr = k.Gr; p.h0 = w.h0; p.hT = w.hT;
-    p.x = x; p.len = len; p.order = order; p.A = A; p.Bk = Bk;
+    p.x = x; p.len = len; p.order = order; p.sort = sort_in_kernel; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;
     p.full = full; p.sig_k = w.sig_k;
     { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }

@@ -436,7 +436,8 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
     const int *order = m->order_valid ? m->order : nullptr;
     RowsPlan pl;
     if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->wsL, pl))
-        return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
+        return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B,
+                                  m->wsL, full, s);
     return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
 }
 
@@ -582,7 +583,8 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     const bool want_order = !full && B > 2 && !env_int("FARNN_NOSORT", 0);
     // the plain i-FST path needs no prep launch up to B = 1024: the chain workgroups select their sequence
     // by length rank themselves and the score workgroups sum the lengths in front of theirs
-    m->prep_in_kernel = m->kind == KIND_IFST && B <= 1024 && L <= 1023 && !env_int("FARNN_PREP", 0);
+    m->prep_in_kernel = (m->kind == KIND_IFST || (m->kind == KIND_DECOMP && m->rows.ok)) && B <= 1024 && L <= 1023 &&
+                        !env_int("FARNN_PREP", 0);
     m->order_valid = want_order && !m->prep_in_kernel;
     m->sort_in_kernel = want_order && m->prep_in_kernel;
     if ((flat_tags || want_order) && !m->prep_in_kernel) {
