@@ -45,6 +45,14 @@ __device__ __forceinline__ float apply_nl(float v, int nl) {
     }
 }
 
+// 16-byte loads through pointers of an EXPLICIT address space: where one code path may read LDS or
+// global memory, two loops over typed pointers keep ds_read / global_load; a select between generic
+// pointers compiles to flat_load with a full vmcnt+lgkmcnt drain.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+typedef __attribute__((address_space(3))) const v4f lds_cv4f;
+typedef __attribute__((address_space(1))) const v4f glb_cv4f;
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

@@ -68,10 +68,6 @@ struct DecompRowsParams {
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) const float lds_cfloat;
-typedef __attribute__((address_space(3))) const v4f lds_cv4f;
-typedef __attribute__((address_space(1))) const v4f glb_cv4f;
 
 // sum over the 4 lanes of a quad, result in all four (two DPP butterflies, no LDS)
 __device__ __forceinline__ float quad_sum(float v) {

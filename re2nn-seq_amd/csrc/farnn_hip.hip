@@ -441,7 +441,14 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
     return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
 }
 
-static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s) {
+// fused: the Viterbi kernel computes the scores itself (no score_tile launch went before it)
+static bool viterbi_can_fuse(const farnn_model *m, const ScoreParams &p) {
+    return m->use_crf && !p.scores && !p.P && p.A && p.OT &&
+           viterbi_hist_lds_bytes(m->K, m->Kp, p.L) <= 158 * 1024 && viterbi_fused_fits(m->K, p.SP, p.L) &&
+           !env_int("FARNN_VITERBI_BP", 0) && !env_int("FARNN_VITERBI_UNFUSED", 0);
+}
+
+static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s, bool fused = false) {
     int rc;
     const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
     int threads = round_up(4 * m->K, 64);
@@ -451,9 +458,12 @@ static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream
     const bool hist = hlds <= 158 * 1024 && !env_int("FARNN_VITERBI_BP", 0);
 #define FARNN_LAUNCH_VIT(N)                                                                   \
     do {                                                                                      \
-        if (hist) {                                                                           \
-            if ((rc = raise_lds_limit(viterbi_hist_kernel<N>, hlds))) return rc;              \
-            viterbi_hist_kernel<N><<<dim3(B), dim3(threads), hlds, s>>>(p);                   \
+        if (hist && fused) {                                                                  \
+            if ((rc = raise_lds_limit(viterbi_hist_kernel<N, true>, hlds))) return rc;        \
+            viterbi_hist_kernel<N, true><<<dim3(B), dim3(threads), hlds, s>>>(p);             \
+        } else if (hist) {                                                                    \
+            if ((rc = raise_lds_limit(viterbi_hist_kernel<N, false>, hlds))) return rc;       \
+            viterbi_hist_kernel<N, false><<<dim3(B), dim3(threads), hlds, s>>>(p);            \
         } else {                                                                              \
             if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                   \
             viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                        \
@@ -533,6 +543,10 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     p.dbg = env_int("FARNN_DBG", 0);
+    if (viterbi_can_fuse(m, p)) {          // stash -> scores -> Viterbi -> tags in one kernel
+        KernelTimer kt(m, KERN_SCORE, s);
+        return launch_viterbi(m, p, B, s, true);
+    }
     const int hasP = m->P ? 1 : 0;
     const int ot = score_lds_bytes(m->S, m->SP, m->Kc, hasP, 1) <= 150 * 1024 ? 1 : 0;
     const size_t lds = score_lds_bytes(m->S, m->SP, m->Kc, hasP, ot);

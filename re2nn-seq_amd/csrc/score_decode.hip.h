@@ -355,7 +355,12 @@ viterbi_kernel(const ScoreParams p) {
 // backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
 // expression on the same values, so the path is bit-identical.  The transposed transition table
 // stays in LDS for that second pass.
-template <int IB4>
+// FUSED: the workgroup also computes the clamped scores of its sequence (what score_tile_kernel would
+// have written to crf_scores) straight into LDS -- one kernel from stash to tags, no score round trip
+// through HBM: alpha*beta products staged transposed in the (not yet used) history area, then a
+// register-blocked [tokens x S].[S x K] product, 4 tokens x 4 tags per lane, against the L2-resident
+// transposed output matrix.  Same fmaf chain in s order as score_tile_kernel: identical bits.
+template <int IB4, bool FUSED>
 __global__ void __launch_bounds__(1024)
 viterbi_hist_kernel(const ScoreParams p) {
     constexpr int IB = IB4 * 4;
@@ -380,11 +385,73 @@ viterbi_hist_kernel(const ScoreParams p) {
     // set-up without a register round trip: the scores and (behind them) the transition table stream
     // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
     // during the forward pass (counted vmcnt: this wavefront's table pieces are its youngest operations)
-    {
+    if (!FUSED) {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)scl);
         const int need = (n * Kp * 4 + 1023) / 1024;
         for (int k = wu; k < need; k += nwaves)
             lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(sc), lds0 + (unsigned)k * 1024u);
+    } else {
+        const int S = p.S, SP = p.SP, SP4 = SP >> 2, Lq = (p.L + 3) & ~3;
+        // the transposed output matrix borrows the transition table's LDS area until the scores are done
+        const int ot_pieces = (S * p.Kc * 4 + 1023) / 1024;
+        const bool ot_lds = ot_pieces <= tr_pieces;
+        if (ot_lds) {
+            const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
+            for (int k = wu; k < ot_pieces; k += nwaves)
+                lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.OT), lds0 + (unsigned)k * 1024u);
+        }
+        float *abT = hist;                               // [SP][Lq] alpha*beta, token-contiguous (aliases hist)
+        const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
+        const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
+        for (int idx = tid; idx < Lq * SP4; idx += nthreads) {
+            const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+            if (tok < n) {       // alpha = state after tok+1 tokens; beta = backward state before token tok+1 (:415-420)
+                a4 = ld4(Ab + (long long)(tok + 1) * SP + s4);
+                b4 = ld4(Bb + (long long)(n - (tok + 1)) * SP + s4);
+            }
+            abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
+            abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
+        }
+        __syncthreads();                                 // (drains vmcnt too: the output matrix has landed)
+        const int ncg = (K + 3) >> 2, ntg = (n + 3) >> 2;
+        const int cg = tid % ncg, tg0 = tid / ncg, tgs = nthreads / ncg;
+        const int clamp_col = K - 3;                     // model_decompose.py:353
+        auto score_tiles = [&](auto op0, int ostride4) {   // op0: this lane's 4 tags in row 0 of the output matrix
+            for (int tg = tg0; tg < ntg && tgs > 0; tg += tgs) {
+                float acc[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) acc[u][c] = 0.0f;
+                lds_cv4f *ap = (lds_cv4f *)((lds_cfloat *)abT + tg * 4);
+#pragma unroll 4
+                for (int s0 = 0; s0 < S; s0++) {
+                    const v4f a4 = ap[s0 * (Lq >> 2)];
+                    const v4f o4 = op0[(long long)s0 * ostride4];
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, ov[4] = {o4.x, o4.y, o4.z, o4.w};
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[u][c] = fmaf(av[u], ov[c], acc[u][c]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int tok = tg * 4 + u;
+                    if (tok >= n) continue;
+                    float v[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        v[c] = acc[u][c] + 0.0f;                      // -0.0 -> +0.0 like score_tile_kernel
+                        if (cg * 4 + c == clamp_col) v[c] = fminf(v[c], p.threshold);
+                    }
+                    st4(scl + (long long)tok * Kp + cg * 4, make_float4(v[0], v[1], v[2], v[3]));
+                }
+            }
+        };
+        if (ot_lds) score_tiles((lds_cv4f *)((lds_cfloat *)trl + cg * 4), p.Kc >> 2);
+        else score_tiles((glb_cv4f *)(p.OT + cg * 4), p.Kc >> 2);
+        __syncthreads();                                 // abT (aliasing hist) is free again
     }
     const int j = tid >> 2, q = tid & 3;
     const bool owner = j < K;
@@ -471,6 +538,10 @@ inline int viterbi_ib4(int K) {
 }
 inline size_t viterbi_lds_bytes(int K, int Kp, int L) {
     return (size_t)2 * 16 * viterbi_ib4(K) * 4 + (size_t)L * Kp * 4 + (size_t)L * Kp * 2;
+}
+// can the fused variant stage [SP][L] products in the history area?
+inline bool viterbi_fused_fits(int K, int SP, int L) {
+    return (size_t)SP * ((L + 3) & ~3) <= (size_t)L * 16 * viterbi_ib4(K);
 }
 inline size_t viterbi_hist_lds_bytes(int K, int Kp, int L) {
     return (size_t)L * 16 * viterbi_ib4(K) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +

@@ -101,11 +101,13 @@ def test_onehot_ifst_with_fused_viterbi(tr_kind):
     assert np.array_equal(pred.numpy(), ref)
 
 
-@pytest.mark.parametrize('variant', ['history', 'backpointers'])
+@pytest.mark.parametrize('variant', ['fused', 'history', 'backpointers'])
 def test_viterbi_atis_scale_vs_oracle(variant, monkeypatch):
-    """K=130 tags, L=64, B=64: both Viterbi kernels (partition history + lazy back-pointers, and the
-    stored-back-pointer fallback for tag sets whose history does not fit the LDS)."""
+    """K=130 tags, L=64, B=64: the Viterbi kernels -- scores computed inside the decode kernel (fused),
+    partition history + lazy back-pointers behind the separate score kernel, and the stored-back-pointer
+    fallback for tag sets whose history does not fit the LDS."""
     monkeypatch.setenv('FARNN_VITERBI_BP', '1' if variant == 'backpointers' else '0')
+    monkeypatch.setenv('FARNN_VITERBI_UNFUSED', '0' if variant == 'fused' else '1')
     from re2nn_seq_amd import synth
     from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
     rng = np.random.RandomState(5)
