@@ -176,12 +176,20 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    # test hook (single-GPU boxes): FARNN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo, to exercise
+    # the N>1 code path where RCCL (one rank per device) cannot be used
+    one_dev = os.environ.get('FARNN_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=dev)       # "nccl" is RCCL on ROCm
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
     from re2nn_seq_amd import _lib
 
     B, L = a.batch, a.seqlen
@@ -195,7 +203,12 @@ def main():
     ld = torch.from_numpy(lengths).to(dev)
     tags_bufs = [torch.empty((B, L), dtype=torch.int32, device=dev) for _ in handles]
     tags = tags_bufs[0]
-    gathered = torch.empty((world * B, L), dtype=torch.int32, device=dev) if world > 1 else None
+    # N > 1: the tag ids of step i are gathered (RCCL all-gather over xGMI, on RCCL's own stream) while
+    # step i+1 computes (re2nn_seq_amd.dist.OverlappedGather: two blocks in rotation)
+    og = None
+    if world > 1:
+        from re2nn_seq_amd.dist import OverlappedGather
+        og = OverlappedGather(B, L, dev)
     for hh in handles:
         hh.reserve(B, L)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in handles[1:]]
@@ -209,14 +222,23 @@ def main():
             k = counter[0] % n_streams
             counter[0] += 1
             st = streams[k]
-            handles[k].tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[k].data_ptr(),
-                           None, None, st.cuda_stream)
-            if world > 1:
-                with torch.cuda.stream(st):
-                    dist.all_gather_into_tensor(gathered, tags_bufs[k])   # RCCL gather of tag ids (xGMI)
+            if world == 1:
+                handles[k].tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[k].data_ptr(),
+                               None, None, st.cuda_stream)
+                return
+            with torch.cuda.stream(st):
+                out = og.next_output()
+                handles[k].tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, out.data_ptr(),
+                               None, None, st.cuda_stream)
+                og.submit()
+
+        def drain():
+            if og is not None:
+                og.drain()
 
         for _ in range(warmup):
             step()
+        drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -226,6 +248,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        drain()                                 # every gather of the K steps is inside the timed region
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()

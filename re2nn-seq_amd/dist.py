@@ -58,3 +58,51 @@ def tag_sharded(tag_fn, x, lengths, group=None):
     on its slice; returns the gathered [B, L] tags on every rank."""
     xs, ls, _ = shard_batch(x, lengths)
     return gather_tags(tag_fn(xs, ls), x.shape[0], group=group)
+
+
+class OverlappedGather:
+    """Weak-scaling serving loop: the tag ids of step i travel (one RCCL all-gather, on RCCL's own
+    stream) while step i+1 computes.  Two output blocks and two gather buffers rotate; a block is
+    handed out again only after the gather that read it has completed.
+
+        og = OverlappedGather(B, L, device)
+        for step in ...:
+            out = og.next_output()          # int32 [B, L] to tag into (waits for its previous gather)
+            tagger(out)                     # enqueue the kernels on the current stream
+            og.submit()                     # async all-gather of `out`
+        og.drain()                          # every gather done; og.last() = [world*B, L] of the last step
+    """
+
+    def __init__(self, B, L, device, group=None, depth=2):
+        _, self.world = world()
+        self.group = group
+        self.out = [torch.empty((B, L), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty((self.world * B, L), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.works = [None] * depth
+        self.i = 0
+        self.cur = 0
+
+    def next_output(self):
+        self.cur = self.i % len(self.out)
+        self.i += 1
+        w = self.works[self.cur]
+        if w is not None:
+            w.wait()
+            self.works[self.cur] = None
+        return self.out[self.cur]
+
+    def submit(self):
+        k = self.cur
+        if self.world == 1:
+            self.gathered[k].copy_(self.out[k])
+            return
+        self.works[k] = dist.all_gather_into_tensor(self.gathered[k], self.out[k], group=self.group, async_op=True)
+
+    def drain(self):
+        for k, w in enumerate(self.works):
+            if w is not None:
+                w.wait()
+                self.works[k] = None
+
+    def last(self):
+        return self.gathered[self.cur]

@@ -69,3 +69,44 @@ def test_shard_bounds_cover_the_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _overlap_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from re2nn_seq_amd.dist import OverlappedGather
+    B, L, steps = 5, 7, 9
+    og = OverlappedGather(B, L, torch.device('cpu'))
+    ok = True
+    seen = []
+    for i in range(steps):
+        out = og.next_output()
+        out.fill_(100 * i + rank)                 # "tagging" step i on this rank
+        og.submit()
+        seen.append(og.last())                    # gather buffers rotate: keep a reference per step
+        if i >= 1:                                # the previous step's gather may still be in flight...
+            pass
+    og.drain()                                    # ...but after drain every one is complete
+    last = og.last()
+    for r in range(world):
+        ok = ok and bool((last[r * B:(r + 1) * B] == 100 * (steps - 1) + r).all())
+    # the buffer of the step before last still holds that step's gather (depth 2)
+    prev = seen[-2]
+    for r in range(world):
+        ok = ok and bool((prev[r * B:(r + 1) * B] == 100 * (steps - 2) + r).all())
+    with open(os.path.join(out_dir, 'ov{}.txt'.format(rank)), 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_two_ranks_gloo(tmp_path):
+    """bench.py's N>1 loop: async all-gather of step i while step i+1 writes the other block."""
+    world = 2
+    mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / 'ov{}.txt'.format(r)).read_text() == 'ok'
