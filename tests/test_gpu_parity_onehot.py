@@ -247,3 +247,39 @@ def test_fst4_and_ind1_built_on_device_from_edges(independent):
     assert np.array_equal(sd, se) and np.array_equal(fd, fe)
     assert np.array_equal(se, ref)
     assert (fe != s2i['o']).sum() > 10
+
+
+def test_tag_call_captures_into_a_hip_graph():
+    """farnn_reserve() + farnn_tag() allocate nothing and call no synchronising API afterwards, so a
+    tagging step can be captured into a HIP graph and replayed on new inputs (same buffers)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(21)
+    V, S, C, B, L = 60, 33, 9, 37, 19
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=1)
+    h.reserve(B, L)
+    dev = torch.device('cuda', 0)
+    xd = torch.zeros((B, L), dtype=torch.int64, device=dev)
+    ld = torch.ones((B,), dtype=torch.int64, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    total = B * L
+    flat = torch.full((total,), -9, dtype=torch.int64, device=dev)
+    side = torch.cuda.Stream(dev)
+    x0, l0 = synth.random_batch(V, B, L, rng, min_len=1)
+    xd.copy_(_t(x0)); ld.copy_(_t(l0))
+    with torch.cuda.stream(side):                       # one eager call first (lazy attribute set-up)
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None,
+              side.cuda_stream)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None,
+              torch.cuda.current_stream(dev).cuda_stream)
+    for seed in (1, 2, 3):
+        x, lengths = synth.random_batch(V, B, L, np.random.RandomState(seed), min_len=1)
+        xd.copy_(_t(x)); ld.copy_(_t(lengths))
+        g.replay()
+        torch.cuda.synchronize()
+        ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+        n = int(lengths.sum())
+        assert np.array_equal(flat.cpu().numpy()[:n], fo.forward_local_tags(ref, lengths, 0.5, 1))
