@@ -62,7 +62,10 @@ def parse():
                     help='in-flight batches for the main timed region: steps alternate over this many '
                          'HIP streams, each with its own model handle and workspace')
     ap.add_argument('--no-pipelined', action='store_true', help='skip the extra 2-streams measurement')
-    ap.add_argument('--event-stride', type=int, default=8,
+    ap.add_argument('--graph', type=int, default=0,
+                    help='N > 0: capture N consecutive steps into one HIP graph and replay it (steps must be a '
+                         'multiple of N); 0 = plain stream launches')
+    ap.add_argument('--event-stride', type=int, default=16,
                     help='time the kernels of every N-th step with HIP events (0 = never)')
     return ap.parse_args()
 
@@ -240,14 +243,30 @@ def main():
             step()
         drain()
         torch.cuda.synchronize(dev)
+        graph = None
+        if a.graph > 0 and world == 1 and n_streams == 1 and event_stride == 0:
+            # the whole step (every kernel farnn_tag enqueues) recorded once, replayed steps/N times
+            side = torch.cuda.Stream(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(a.graph):
+                    handles[0].tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[0].data_ptr(),
+                                   None, None, torch.cuda.current_stream(dev).cuda_stream)
+            graph.replay()
+            torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         for hh in handles[:n_streams]:
             hh.set_profiling(event_stride)     # HIP events around the kernels of every N-th step
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if graph is not None:
+            assert steps % a.graph == 0, '--steps must be a multiple of --graph'
+            for _ in range(steps // a.graph):
+                graph.replay()
+        else:
+            for _ in range(steps):
+                step()
         drain()                                 # every gather of the K steps is inside the timed region
         torch.cuda.synchronize(dev)
         if world > 1:
