@@ -283,3 +283,36 @@ def test_tag_call_captures_into_a_hip_graph():
         ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
         n = int(lengths.sum())
         assert np.array_equal(flat.cpu().numpy()[:n], fo.forward_local_tags(ref, lengths, 0.5, 1))
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_ifst_random_geometries_vs_oracle(seed):
+    """Randomised sweep over (S, C, L, B, non-linearity, semiring, priority): whatever kernel variant the
+    geometry selects (chunks per row, ring shape, register-prefetch depth, prep path), scores and tags
+    equal the oracle's bit for bit (0/1 automata, none/relu) or within 1e-4 (tanh)."""
+    from re2nn_seq_amd import synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(1000 + seed)
+    S = int(rng.choice([2, 3, 7, 12, 20, 33, 48, 71, 96, 127, 160, 200]))
+    C = int(rng.randint(2, 40))
+    L = int(rng.randint(1, 40))
+    B = int(rng.choice([1, 2, 3, 5, 16, 33, 70]))
+    nl = str(rng.choice(['none', 'relu', 'tanh', 'relutanh']))
+    mode = str(rng.choice(['sum', 'max']))
+    V = 31
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=max(2.0, S / 5), n_final=2)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    pri = None
+    if rng.rand() < 0.5:
+        pri = np.eye(C - 1) + (rng.rand(C - 1, C - 1) < 0.1) * -1.0
+    a = ns(update_nonlinear=nl, train_mode=mode, use_priority=int(pri is not None))
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, pri, a, o_idx=1 % C)
+    scores, flat, re_pred, _ = _run_all(m, x, lengths)
+    sem = fo.SEMIRING_MAX if mode == 'max' else fo.SEMIRING_SUM
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths, nl=fo.NL_CODES[nl], semiring=sem)
+    if pri is not None:
+        ref = fo.priority(ref, m.priority_full)
+    assert_scores(scores, ref, exact=(nl in ('none', 'relu') and pri is None))
+    if nl in ('none', 'relu') and pri is None:
+        assert np.array_equal(flat, fo.forward_local_tags(ref, lengths, 0.5, 1 % C))
+        assert np.array_equal(re_pred, fo.decode_argmax(ref, 0.5, 1 % C))
