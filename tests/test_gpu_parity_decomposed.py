@@ -279,3 +279,51 @@ def test_decomposed_independent0_ragged_vs_oracle():
     np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
     assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, 2))
     assert (tags.cpu().numpy()[:, :Lmax][~mask] == -1).all()
+
+
+@pytest.mark.parametrize('S,R,farnn,nl,B,L', [
+    (104, 50, 0, 'tanh', 12, 20),         # BASELINE configs[2] geometry: every packed row LDS-resident
+    (104, 250, 2, 'relutanh', 12, 20),    # the shipped example's geometry: gated, rows streamed from L2
+    (104, 100, 1, 'tanh', 9, 17),
+    (200, 60, 0, 'tanh', 5, 9),           # more than 128 rows: two passes of the row phases
+    (37, 300, 2, 'relu', 7, 11),          # rank >> states
+    (5, 3, 1, 'none', 3, 4),
+])
+def test_decomposed_rows_kernel_geometries_vs_oracle(S, R, farnn, nl, B, L):
+    """The rows kernel at production geometries (residency, streaming, multi-pass rows, gates) against the
+    oracle: scores within 1e-4, tags equal where the margin allows."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(S * 7 + R)
+    V, K = 120, 11
+    p = synth.random_decomposed_params(V, S, K, R, 16, rng)
+    q = {'Vgen': p['V_embed'].astype(np.float32), 'S1': p['S1'].astype(np.float32), 'S2': p['S2'].astype(np.float32),
+         'W': p['wildcard_mat'].astype(np.float32), 'Cout': p['C_output_mat'].astype(np.float32),
+         'h0': p['start_vector'].astype(np.float32), 'hT': p['final_vector'].astype(np.float32),
+         'farnn': farnn, 'nl': fo.NL_CODES[nl], 'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+    gates = None
+    if farnn:
+        gates = {'Wss1': rng.randn(S, S) * 0.1, 'Wrs1': rng.randn(R, S) * 0.1, 'bs1': np.full(S, 0.3)}
+        if farnn == 2:
+            gates.update(Wss2=rng.randn(S, S) * 0.1, Wrs2=rng.randn(R, S) * 0.1, bs2=np.full(S, 0.2))
+        gates = {k: v.astype(np.float32) for k, v in gates.items()}
+        q.update(gates)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn,
+                                gates=gates, sigmoid_exponent=5, nl=nl, o_idx=2)
+    assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), scores.data_ptr())
+    torch.cuda.synchronize()
+    Lmax = int(lengths.max())
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    mask = np.arange(Lmax)[None, :] < lengths[:, None]
+    got = scores.cpu().numpy()[:, :Lmax]
+    np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    # tags: equal wherever the oracle's decision margin exceeds the tolerance
+    rt = fo.forward_local_tags(ref, lengths, 0.5, 2)
+    refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
+    top2 = np.sort(refc[:, :Lmax][mask], axis=1)[:, -2:]
+    safe = (top2[:, 1] - top2[:, 0]) > 1e-3
+    assert np.array_equal(flat.cpu().numpy()[safe], rt[safe])
