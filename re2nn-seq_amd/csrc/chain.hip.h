@@ -149,7 +149,7 @@ chain_kernel(const ChainParams p) {
     const int dir = item & 1;
     int b = p.order ? p.order[item >> 1] : (item >> 1);
     if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(item >> 1, p.B), reinterpret_cast<int *>(smem), tid, nthreads);
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ, KS = p.KS;
     const int NW = p.NW, NLD = p.NLD, NP = NW * p.G;

@@ -53,6 +53,9 @@ typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef __attribute__((address_space(3))) const v4f lds_cv4f;
 typedef __attribute__((address_space(1))) const v4f glb_cv4f;
 
+// a sequence length as the kernels use it: the API says 1..L; anything else is clamped, never trusted
+__device__ __forceinline__ int clamp_len(long long v, int L) { return v < 0 ? 0 : (v > L ? L : (int)v); }
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

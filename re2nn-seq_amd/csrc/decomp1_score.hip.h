@@ -34,7 +34,7 @@ decomp1_score_kernel(const Decomp1ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nt = blockDim.x;
     const int i = blockIdx.x, b = blockIdx.y;
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, RO = p.RO, ROp = p.ROp, K = p.K;
     if (i >= nsteps) {
@@ -162,7 +162,7 @@ decomp0_score_kernel(const Decomp0ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nt = blockDim.x;
     const int i = blockIdx.x, b = blockIdx.y;
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, RW = p.RW, RWp = p.RWp, K = p.K;
     if (i >= nsteps) {

@@ -50,7 +50,7 @@ decomp_chain_kernel(const DecompParams p) {
     const DecompWeights &w = p.w;
     const int tid = threadIdx.x, nt = blockDim.x;
     const int item = blockIdx.x, b = item >> 1, dir = item & 1;
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = w.S, SP = w.SP, R = w.R, Rp = w.Rp;
 

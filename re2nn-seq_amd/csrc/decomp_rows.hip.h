@@ -177,7 +177,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
         if (p.sort && have) b = select_by_length_rank(p.len, p.B, p.L, r, reinterpret_cast<int *>(smem), tid, DR_THREADS);
         b = __builtin_amdgcn_readfirstlane(b);                // workgroup-uniform: keep it in SGPRs
         bseq[s] = b;
-        slen[s] = have ? __builtin_amdgcn_readfirstlane((int)p.len[b]) : 0;
+        slen[s] = have ? __builtin_amdgcn_readfirstlane(clamp_len(p.len[b], p.L)) : 0;
         nst[s] = have ? (p.full ? p.L : slen[s]) : -1;        // -1: no sequence in this slot
         nmax = nst[s] > nmax ? nst[s] : nmax;
     }

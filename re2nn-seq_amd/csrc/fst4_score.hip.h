@@ -33,7 +33,7 @@ fst4_score_kernel(const Fst4Params p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int i = blockIdx.x, b = blockIdx.y;
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, C = p.C;
     if (i >= nsteps) {

@@ -54,7 +54,7 @@ score_tile_kernel(const ScoreParams p) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = SCORE_WAVES * 64;
     const int b = blockIdx.y, t0 = blockIdx.x * SCORE_TT;
-    const int len = (int)p.len[b];
+    const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc;
     const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
@@ -270,7 +270,7 @@ viterbi_kernel(const ScoreParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthreads = blockDim.x;
     const int b = blockIdx.x;
-    const int n = (int)p.len[b];
+    const int n = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : n;
     const int K = p.K, Kp = p.Kp;
     const int PW = 4 * IB;                               // padded partition width (>= K)
@@ -368,7 +368,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nthreads = blockDim.x;
     const int b = blockIdx.x;
-    const int n = (int)p.len[b];
+    const int n = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : n;
     const int K = p.K, Kp = p.Kp;
     const int PW = 4 * IB;                               // padded partition width (>= K)

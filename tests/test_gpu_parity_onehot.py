@@ -316,3 +316,25 @@ def test_ifst_random_geometries_vs_oracle(seed):
     if nl in ('none', 'relu') and pri is None:
         assert np.array_equal(flat, fo.forward_local_tags(ref, lengths, 0.5, 1 % C))
         assert np.array_equal(re_pred, fo.decode_argmax(ref, 0.5, 1 % C))
+
+
+def test_out_of_contract_lengths_are_clamped_not_trusted():
+    """lengths outside 1..L never index out of bounds: they are clamped to [0, L] on the device."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(4)
+    V, S, C, B, L = 40, 11, 6, 6, 9
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    bad = lengths.copy(); bad[0] = L + 50; bad[1] = 0; bad[2] = -3
+    good = np.clip(bad, 0, L)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=2)
+    outs = []
+    for ln in (bad, good):
+        xd, ld = _t(x).cuda(), _t(ln).cuda()
+        tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+        flat = torch.full((int(good.sum()),), -7, dtype=torch.int64, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None)
+        torch.cuda.synchronize()
+        outs.append((tags.cpu().numpy(), flat.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    assert (outs[0][0][1] == -1).all() and (outs[0][0][2] == -1).all()
