@@ -52,6 +52,7 @@ struct ChainParams {
     int sort;               // 1: no order array; every workgroup selects its sequence by length rank itself
     float *A, *Bk;          // stash [B][L+1][SP]: forward / backward states by step count
     int B, L, S, SP, CPR;   // CPR = SP/4 column chunks per row
+    int V;                  // vocabulary (token ids are clamped to it)
     int NW, NLD, G, LPR, RPG, RPGp, NQ, KS;
     int NQP, PPS;           // chunks per phase per compute wave; phases per step (ring/barrier unit)
     int nl, full;
@@ -170,7 +171,7 @@ chain_kernel(const ChainParams p) {
 
     for (int k = tid; k < nsteps; k += nthreads) {
         int idx = (dir == 0) ? k : (k < len ? len - 1 - k : k);
-        tok[k] = (int)p.x[(long long)b * p.L + idx];
+        tok[k] = clamp_tok(p.x[(long long)b * p.L + idx], p.V);
     }
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     const float *hinit = (dir == 0) ? p.h0 : p.hT;
@@ -274,7 +275,7 @@ chain_kernel(const ChainParams p) {
                 int t = f / PPS;
                 t = t < nsteps ? t : nsteps - 1;
                 const int idx = (dir == 0) ? t : (t < len ? len - 1 - t : t);
-                tk[f] = (f < first) ? (int)p.x[(long long)b * p.L + idx] : 0;
+                tk[f] = (f < first) ? clamp_tok(p.x[(long long)b * p.L + idx], p.V) : 0;
             }
 #pragma unroll
             for (int f = 0; f < 8; f++)

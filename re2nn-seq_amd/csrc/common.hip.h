@@ -56,6 +56,10 @@ typedef __attribute__((address_space(1))) const v4f glb_cv4f;
 // a sequence length as the kernels use it: the API says 1..L; anything else is clamped, never trusted
 __device__ __forceinline__ int clamp_len(long long v, int L) { return v < 0 ? 0 : (v > L ? L : (int)v); }
 
+// a token id as the kernels use it: ids outside [0, V) are treated as the pad word V-1 (zero block), never
+// used to index the weights
+__device__ __forceinline__ int clamp_tok(long long v, int V) { return (v < 0 || v >= V) ? V - 1 : (int)v; }
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 

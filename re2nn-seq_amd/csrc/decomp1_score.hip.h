@@ -24,7 +24,7 @@ struct Decomp1ScoreParams {
     const float *P;                 // [K][Kc] or nullptr
     const int64_t *x, *len, *offs;
     int32_t *tags; int64_t *flat; float *scores; float *crf_scores;
-    int B, L, S, SP, R, Rp, RO, ROp, K, Kp, Kc;
+    int B, L, S, SP, R, Rp, RO, ROp, K, Kp, Kc, V;
     int full, use_crf, o_idx;
     float threshold;
 };
@@ -53,7 +53,7 @@ decomp1_score_kernel(const Decomp1ScoreParams p) {
     const float *ar = p.A + ((long long)b * (p.L + 1) + i) * SP;
     const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
     const float *brow = p.Bk + ((long long)b * (p.L + 1) + bidx) * SP;
-    const float *vg = p.Vgen + (long long)p.x[(long long)b * p.L + i] * Rp;
+    const float *vg = p.Vgen + (long long)clamp_tok(p.x[(long long)b * p.L + i], p.V) * Rp;
     for (int s = tid; s < SP; s += nt) { alpha[s] = ar[s]; beta[s] = brow[s]; }
     for (int r = tid; r < Rp; r += nt) v[r] = r < R ? vg[r] : 0.0f;
     __syncthreads();
@@ -152,7 +152,7 @@ struct Decomp0ScoreParams {
     const float *P;                 // [K][Kc] or nullptr
     const int64_t *x, *len, *offs;
     int32_t *tags; int64_t *flat; float *scores; float *crf_scores;
-    int B, L, S, SP, R, Rp, RW, RWp, K, Kp, Kc;
+    int B, L, S, SP, R, Rp, RW, RWp, K, Kp, Kc, V;
     int full, use_crf, o_idx;
     float threshold;
 };
@@ -180,7 +180,7 @@ decomp0_score_kernel(const Decomp0ScoreParams p) {
     const float *ar = p.A + ((long long)b * (p.L + 1) + i) * SP;
     const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
     const float *brow = p.Bk + ((long long)b * (p.L + 1) + bidx) * SP;
-    const float *vg = p.Vgen + (long long)p.x[(long long)b * p.L + i] * Rp;
+    const float *vg = p.Vgen + (long long)clamp_tok(p.x[(long long)b * p.L + i], p.V) * Rp;
     for (int s = tid; s < SP; s += nt) { alpha[s] = ar[s]; beta[s] = brow[s]; }
     __syncthreads();
     for (int r = tid; r < R + RW; r += nt) {

@@ -64,7 +64,7 @@ decomp_chain_kernel(const DecompParams p) {
 
     for (int k = tid; k < nsteps; k += nt) {
         int idx = (dir == 0) ? k : (k < len ? len - 1 - k : k);
-        tok[k] = (int)p.x[(long long)b * p.L + idx];
+        tok[k] = clamp_tok(p.x[(long long)b * p.L + idx], w.V);
     }
     const float *hinit = dir == 0 ? w.h0 : w.hT;
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;

@@ -62,7 +62,7 @@ struct DecompRowsParams {
     const int *order;             // folded launch order (batch_prep) or nullptr
     int sort;                     // 1: no order array, the workgroup selects its sequences by length rank itself
     float *A, *Bk;
-    int B, L, S, SP, R, Rp, farnn, nl, full;
+    int B, L, S, SP, R, Rp, farnn, nl, full, V;
     float sig_k;
     int dbg;                      // diagnostic ablation mask (FARNN_DBG); 0 in production
 };
@@ -194,7 +194,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     for (int s = 0; s < NSEQ; s++)
         for (int k = tid; k < nst[s]; k += DR_THREADS) {
             const int idx = (dir == 0) ? k : (k < slen[s] ? slen[s] - 1 - k : k);
-            tok[s * Lr + k] = (int)p.x[(long long)bseq[s] * p.L + idx];
+            tok[s * Lr + k] = clamp_tok(p.x[(long long)bseq[s] * p.L + idx], p.V);
         }
     {   // resident rows: global -> LDS
         const float *src[3] = {p.P1, p.P2[dir], p.P3[dir]};
@@ -460,7 +460,7 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     p.Vgen = w.Vgen; p.Gz = k.Gz; p.Gr = k.Gr; p.h0 = w.h0; p.hT = w.hT;
     p.x = x; p.len = len; p.order = order; p.sort = sort_in_kernel; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;
-    p.full = full; p.sig_k = w.sig_k;
+    p.full = full; p.V = w.V; p.sig_k = w.sig_k;
     { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int groups = (B + pl.nseq - 1) / pl.nseq;
     if (pl.nseq == 4) return launch_rows_n<4>(p, groups, pl.lds, s);

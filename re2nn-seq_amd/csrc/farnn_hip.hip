@@ -348,7 +348,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
     p.order = m->order_valid ? m->order : nullptr;
     p.sort = m->sort_in_kernel ? 1 : 0;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR;
+    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR; p.V = m->V;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
     p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
     (void)L;
@@ -487,6 +487,7 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
     p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RO = m->RO; p.ROp = m->ROp;
+    p.V = m->V;
     p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
@@ -514,6 +515,7 @@ static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t 
     p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
     p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
     p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RW = m->RW; p.RWp = m->RWp;
+    p.V = m->V;
     p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     const size_t lds = decomp0_score_lds_bytes(m->SP, m->Rp, m->RWp, m->Kc);
@@ -624,7 +626,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->A4, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
                                          tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
-                                         m->o_idx, m->threshold, /*Oten*/ nullptr, s);
+                                         m->o_idx, m->threshold, /*Oten*/ nullptr, m->V, s);
             }
         case KIND_IND1:
             if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
@@ -632,7 +634,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->Ms, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
                                          tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
-                                         m->o_idx, m->threshold, m->Oten, s);
+                                         m->o_idx, m->threshold, m->Oten, m->V, s);
             }
         case KIND_DECOMP: {
             {

@@ -22,7 +22,7 @@ struct Fst4Params {
     const float *P;         // [C][Kp] or nullptr
     const int64_t *x, *len, *offs;
     int32_t *tags; int64_t *flat; float *scores;
-    int B, L, S, SP, C, Kp, full, o_idx;
+    int B, L, S, SP, C, Kp, full, o_idx, V;
     int G, LPR, CPR;
     float threshold;
 };
@@ -60,7 +60,7 @@ fst4_score_kernel(const Fst4Params p) {
         int cc = c4 + 64 * m;
         beta[m] = (active && cc < p.CPR) ? ld4(br + cc * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const long long tok = p.x[(long long)b * p.L + i];
+    const long long tok = clamp_tok(p.x[(long long)b * p.L + i], p.V);
     __syncthreads();
 
     if (p.Oten) {   // Z = (alpha beta^T) .* Tf[x_i]   (model_onehot.py:230-231)
@@ -154,8 +154,9 @@ fst4_score_kernel(const Fst4Params p) {
 inline int launch_fst4_score(const float *blocks, const float *A, const float *Bk, const float *P,
                              const int64_t *x, const int64_t *len, const int64_t *offs, int32_t *tags,
                              int64_t *flat, float *scores, int B, int L, int S, int SP, int C, int Kp,
-                             int full, int o_idx, float threshold, const float *Oten, hipStream_t s) {
+                             int full, int o_idx, float threshold, const float *Oten, int V, hipStream_t s) {
     Fst4Params p;
+    p.V = V;
     p.blocks = blocks; p.Oten = Oten; p.A = A; p.Bk = Bk; p.P = P; p.x = x; p.len = len; p.offs = offs;
     p.tags = tags; p.flat = flat; p.scores = scores;
     p.B = B; p.L = L; p.S = S; p.SP = SP; p.C = C; p.Kp = Kp; p.full = full; p.o_idx = o_idx;

@@ -338,3 +338,24 @@ def test_out_of_contract_lengths_are_clamped_not_trusted():
         outs.append((tags.cpu().numpy(), flat.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
     assert (outs[0][0][1] == -1).all() and (outs[0][0][2] == -1).all()
+
+
+def test_out_of_vocabulary_token_ids_are_treated_as_pad():
+    """Token ids outside [0, V) never index the weight tables: they behave like the pad word V-1."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(8)
+    V, S, C, B, L = 40, 11, 6, 5, 8
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=L)
+    bad = x.copy(); bad[0, 2] = V + 1000; bad[1, 0] = -5; bad[2, 7] = 2 ** 40
+    good = bad.copy(); good[0, 2] = V - 1; good[1, 0] = V - 1; good[2, 7] = V - 1
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=2)
+    outs = []
+    for xx in (bad, good):
+        xd, ld = _t(xx).cuda(), _t(lengths).cuda()
+        scores = torch.empty((B, L, C), dtype=torch.float32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_FULL, None, None, scores.data_ptr())
+        torch.cuda.synchronize()
+        outs.append(scores.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert np.array_equal(outs[1], fo.onehot_ifst_scores(T, W, O, h0, hT, good, lengths))
