@@ -1,6 +1,8 @@
 """GPU parity: the HIP path (through the C-ABI, via the host mirrors of the reference's model
 classes) against (a) the committed golden fixtures captured from the reference and (b) the CPU
 oracle on the same seeded inputs.  Bit-exact for 0/1 automata with none/relu; 1e-4 otherwise."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -359,3 +361,34 @@ def test_out_of_vocabulary_token_ids_are_treated_as_pad():
         outs.append(scores.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert np.array_equal(outs[1], fo.onehot_ifst_scores(T, W, O, h0, hT, good, lengths))
+
+
+def test_soak_random_batches_atis_scale_vs_c_oracle():
+    """Many ragged batches of changing geometry (B, L, lengths) through ONE handle at ATIS scale, each
+    checked tag-for-tag against the C port of the oracle: races in the barrier / ring protocol, workspace
+    reuse across shapes and the in-kernel launch order would show up here."""
+    from oracle import c_port
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(2024)
+    V, S, C = 950, 71, 129
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng)
+    Tf = (T + W).astype(np.float32)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
+    n_iter = int(os.environ.get('FARNN_SOAK_ITERS', '60'))
+    for it in range(n_iter):
+        B = int(rng.choice([1, 2, 7, 64, 200, 256, 300]))
+        L = int(rng.choice([1, 5, 33, 64, 100]))
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        if it % 5 == 0:
+            lengths[:] = L
+        xd, ld = _t(x).cuda(), _t(lengths).cuda()
+        tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+        flat = torch.full((int(lengths.sum()),), -7, dtype=torch.int64, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None)
+        torch.cuda.synchronize()
+        ref, _, _ = c_port.onehot_ifst_tag(Tf, O, h0, hT, x, lengths, threshold=0.5, o_idx=0, nthreads=8)
+        mask = np.arange(L)[None, :] < lengths[:, None]
+        got = tags.cpu().numpy()
+        assert np.array_equal(got[mask], ref[mask]), 'iteration {} B={} L={}'.format(it, B, L)
+        assert (got[~mask] == -1).all()
+        assert np.array_equal(flat.cpu().numpy(), ref[mask].astype(np.int64))
