@@ -315,7 +315,8 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
                               : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel"
-                              : (m->kind == KIND_DECOMP0 ? "decomp0_score_kernel" : "score_decode_kernel")));
+                              : (m->kind == KIND_DECOMP0 ? "decomp0_score_kernel"
+                              : (m->use_crf ? "score_tile_kernel+viterbi_kernel" : "score_tile_kernel"))));
         case KERN_PREP:  return "batch_prep_kernel";
         default: return "";
     }
