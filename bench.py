@@ -55,6 +55,7 @@ def parse():
     ap.add_argument('--seqlen', type=int, default=64)
     ap.add_argument('--rank', type=int, default=50, help='decomp: CP rank')
     ap.add_argument('--farnn', type=int, default=0, help='decomp: gate mode 0/1/2 (reference --farnn)')
+    ap.add_argument('--semiring', default='sum', choices=['sum', 'max'], help='decomp: reference --train_mode')
     ap.add_argument('--full-length', action='store_true', help='all sequences at full length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
@@ -70,7 +71,7 @@ def parse():
     return ap.parse_args()
 
 
-def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0):
+def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring='sum'):
     """Returns (handle, x, lengths, extras).  Weights use one seed on every rank (replicated
     model); the batch is seeded per rank (each rank owns a different shard)."""
     from re2nn_seq_amd import _lib, synth
@@ -125,7 +126,7 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0):
                 gates.update(Wss2=wrng.randn(S, S) * 0.1, Wrs2=wrng.randn(cp_rank, S) * 0.1, bs2=np.full(S, 1.0))
         h = _lib.create_decomp_ifst(Vgen, p['S1'], p['S2'], p['wildcard_mat'], p['C_output_mat'],
                                     p['start_vector'], p['final_vector'], nl='tanh', farnn=farnn, gates=gates,
-                                    sigmoid_exponent=5, device=dev)
+                                    sigmoid_exponent=5, semiring=semiring, device=dev)
     x, lengths = synth.random_batch(V, B, L, brng)
     if full_length:
         lengths[:] = L
@@ -198,9 +199,9 @@ def main():
     B, L = a.batch, a.seqlen
     if a.workload == 'synth512':
         a.no_pipelined = True            # a second 63 GB replica of the weights is pointless here
-    h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn)
+    h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring)
     n_pipe = max(a.streams, 1 if a.no_pipelined else 2)
-    handles = [h] + [build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn)[0]
+    handles = [h] + [build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring)[0]
                      for _ in range(n_pipe - 1)]
     xd = torch.from_numpy(x).to(dev)
     ld = torch.from_numpy(lengths).to(dev)

@@ -56,6 +56,7 @@ struct farnn_model {
     ChainGeom geom;
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
+    bool dense_decomp = false;              // decomposed model served by dense per-word blocks + chain_kernel
     bool order_valid = false;
     int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
     long long calls = 0;
@@ -309,6 +310,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
         case KERN_CHAIN:
+            if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
                 return m->rows.ok ? "decomp_rows_kernel" : "decomp_chain_kernel";
             return "chain_kernel";
@@ -386,6 +388,28 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 #undef FARNN_LAUNCH_CHAIN_MX
 #undef FARNN_LAUNCH_CHAIN
     FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+// ---- decomposed modes whose step matrix is materialised anyway: dense per-word blocks + the chain kernel ----
+static int build_dense_blocks(farnn_model *m) {
+    const DecompWeights &w = m->dw;
+    if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask) || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    m->chain_ks = env_int("FARNN_KS", 3);
+    if (m->geom.NCH > 4 || m->geom.SP != m->SP) return FARNN_OK;
+    const size_t nM = (size_t)m->V * m->geom.SR * m->SP;
+    if (nM * 8 > (size_t)64 << 30) return FARNN_OK;               // keep it under 64 GB; else the generic kernel
+    int rc;
+    if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return rc;
+    if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return rc;
+    FARNN_HIP_TRY(hipMemset(m->Mb, 0, nM * 4));
+    dim3 grid((m->geom.SR * m->SP + 255) / 256, m->V);
+    materialise_blocks_kernel<<<grid, 256>>>(w.Vgen, w.S1, w.S2, w.W, w.mask, m->Mf, m->Mb, m->S, m->SP, m->geom.SR,
+                                             m->R, m->Rp);
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    m->dense_decomp = true;
     return FARNN_OK;
 }
 
@@ -638,7 +662,9 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                                          m->o_idx, m->threshold, m->Oten, m->V, s);
             }
         case KIND_DECOMP: {
-            {
+            if (m->dense_decomp) {
+                if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
+            } else {
                 KernelTimer kt(m, KERN_CHAIN, s);
                 if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
             }
@@ -652,7 +678,9 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
             return launch_decomp0_score(m, x, lengths, B, full, tags, flat_tags, scores, s);
         }
         case KIND_DECOMP1: {
-            {
+            if (m->dense_decomp) {
+                if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
+            } else {
                 KernelTimer kt(m, KERN_CHAIN, s);
                 if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->wsL, full, s))) return rc;
             }
@@ -969,6 +997,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
     if ((rc = build_rows_pack(m))) return bail(rc);
+    if ((rc = build_dense_blocks(m))) return bail(rc);
     *out = m;
     return FARNN_OK;
 }
@@ -1024,6 +1053,7 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    if ((rc = build_dense_blocks(m))) return bail(rc);
     *out = m;
     return FARNN_OK;
 }

@@ -124,4 +124,30 @@ __global__ void scatter_edges_kernel(const int32_t *word, const int32_t *from, c
     }
 }
 
+// ---- decomposed model -> dense per-word transition blocks (max-times semiring / independent=1, farnn==0) ----
+// The step's transition matrix of these modes is materialised from the factors,
+//     Tr[x][i][j] = (sum_r v_x[r] S1[i][r] S2[j][r] + W[i][j]) * mask[i][j]
+// (model_decompose_single.py:159-166, model_decompose_independent.py:165-173), and it depends on the WORD
+// only.  With 288 GB of HBM the whole table (V x S x S fp32, + its transpose: 0.96 GB at V=11k, S=104) is
+// built once at create time, and the recurrence becomes the dense chain kernel: HBM-streamed blocks instead
+// of S*S*R multiply-adds per step and sequence.  Same expression order as the generic kernel (fmaf over r,
+// + W, * mask): identical table entries.   grid = (ceil(SR*SP/256), V)
+__global__ void materialise_blocks_kernel(const float *Vgen, const float *S1, const float *S2, const float *W,
+                                          const float *mask, float *Mf, float *Mb, int S, int SP, int SR,
+                                          int R, int Rp) {
+    const long long v = blockIdx.y;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= SR * SP) return;
+    const int i = idx / SP, j = idx - i * SP;
+    float tr = 0.0f;
+    if (i < S && j < S) {
+        const float *vg = Vgen + v * Rp, *s1 = S1 + (long long)i * Rp, *s2 = S2 + (long long)j * Rp;
+        for (int r = 0; r < R; r++) tr = fmaf(vg[r] * s1[r], s2[r], tr);
+        tr += W[(long long)i * SP + j];
+        if (mask) tr *= mask[(long long)i * SP + j];
+    }
+    Mf[v * SR * SP + idx] = tr;                          // Mf[v][i][j] = Tr[i][j]
+    if (i < SP && j < SR) Mb[v * SR * SP + (long long)j * SP + i] = (i < S && j < S) ? tr : 0.0f;   // Mb[v][j][i]
+}
+
 }  // namespace farnn

@@ -327,3 +327,28 @@ def test_decomposed_rows_kernel_geometries_vs_oracle(S, R, farnn, nl, B, L):
     top2 = np.sort(refc[:, :Lmax][mask], axis=1)[:, -2:]
     safe = (top2[:, 1] - top2[:, 0]) > 1e-3
     assert np.array_equal(flat.cpu().numpy()[safe], rt[safe])
+
+
+def test_materialised_modes_run_on_dense_blocks():
+    """max-times semiring / independent=1 with farnn=0: the per-step matrix depends on the word only, so the
+    handle serves these modes from a dense per-word block table through the chain kernel."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(3)
+    V, S, K, R, B, L = 60, 21, 7, 30, 9, 12
+    p = synth.random_decomposed_params(V, S, K, R, 16, rng)
+    q = {'Vgen': p['V_embed'].astype(np.float32), 'S1': p['S1'].astype(np.float32), 'S2': p['S2'].astype(np.float32),
+         'W': p['wildcard_mat'].astype(np.float32), 'Cout': p['C_output_mat'].astype(np.float32),
+         'h0': p['start_vector'].astype(np.float32), 'hT': p['final_vector'].astype(np.float32),
+         'farnn': 0, 'nl': fo.NL_CODES['relu'], 'semiring': fo.SEMIRING_MAX, 'sig_k': 5}
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], nl='relu',
+                                semiring='max', o_idx=2)
+    assert h.kernel_name(_lib.KERN_CHAIN) == 'chain_kernel'
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, None, scores.data_ptr())
+    torch.cuda.synchronize()
+    Lmax = int(lengths.max())
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    mask = np.arange(Lmax)[None, :] < lengths[:, None]
+    np.testing.assert_allclose(scores.cpu().numpy()[:, :Lmax][mask], ref[mask], rtol=1e-4, atol=1e-4)
