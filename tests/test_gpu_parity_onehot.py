@@ -392,3 +392,30 @@ def test_soak_random_batches_atis_scale_vs_c_oracle():
         assert np.array_equal(got[mask], ref[mask]), 'iteration {} B={} L={}'.format(it, B, L)
         assert (got[~mask] == -1).all()
         assert np.array_equal(flat.cpu().numpy(), ref[mask].astype(np.int64))
+
+
+def test_create_destroy_does_not_leak_device_memory():
+    """farnn_destroy releases everything create / reserve / tag allocated (weights, re-laid-out copies,
+    workspace): 40 create-tag-destroy cycles leave the free HBM where it was."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(5)
+    V, S, C, B, L = 300, 40, 20, 16, 12
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+
+    def cycle(crf):
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=crf)
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        h.close()
+
+    cycle(False); cycle(True)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for k in range(40):
+        cycle(bool(k & 1))
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 8 << 20, 'leaked {} bytes'.format(free0 - free1)
