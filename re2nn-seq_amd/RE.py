@@ -38,11 +38,11 @@ def get_RE_prediction(dataloader, model, args, o_idx=0, i2s=None):
         for batch in dataloader:
             x, label, lengths = batch['x'], batch['s'], batch['l']
             pred_label, all_scores = model.forward_RE(x, label, lengths, train=False)
-            preds.append(pred_label.cpu())
+            pred_cpu = pred_label.cpu()
+            preds.append(pred_cpu)
             scores.append(all_scores.cpu())
-            mask = torch.arange(x.shape[1])[None, :] < lengths[:, None]
-            flat_pred.append(pred_label.cpu()[mask])
-            flat_true.append(label[mask])
+            flat_pred.append(model._flatten(pred_cpu, lengths))      # numpy-backed on host tensors
+            flat_true.append(model._flatten(label, lengths))
     fp, ft = torch.cat(flat_pred), torch.cat(flat_true)
     acc, p, r, f = eval_seq_token(seq_label_pred=fp, seq_label_true=ft, o_idx=o_idx)
     acc_ner, p_ner, r_ner, f_ner, class_res = get_ner_fmeasure(
