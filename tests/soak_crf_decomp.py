@@ -1,5 +1,6 @@
-"""Ad-hoc soak (run on the GPU box): random ragged batches through the fused-Viterbi and the decomposed rows
-paths, each compared with the numpy oracle.  Usage: python scripts/soak_crf_decomp.py [iters]"""
+"""Ad-hoc soak (run on the GPU box; test infrastructure -- it uses the oracle): random ragged batches through
+the fused-Viterbi and the decomposed rows paths, each compared with the numpy oracle.
+Usage: python tests/soak_crf_decomp.py [iters]"""
 import os
 import sys
 
