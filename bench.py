@@ -39,6 +39,8 @@ WORKLOADS = {
     'ifst_crf': ('ATIS-BIO-sized onehot i-FST + fused Viterbi decode (use_crf=1)', 950, 71, 128),
     'fst4': ('ATIS-BIO-sized onehot FST, dense T[V,C,S,S] (--independent 0)', 950, 71, 128),
     'decomp': ('SNIPS-BIO-sized decomposed i-FST (--method decompose --independent 2)', 11000, 104, 73),
+    'decomp1': ('SNIPS-BIO-sized decomposed independent=1 (FARNN_S_D_W_I), output rank 70', 11000, 104, 73),
+    'decomp0': ('SNIPS-BIO-sized decomposed independent=0 (FARNN_S_D_W), wildcard rank 70', 11000, 104, 73),
     # BASELINE configs[4], one GPU's shard: i-FST layout only (the 4-D layout would be 5.5 PB)
     'synth512': ('synthetic onehot i-FST V=20k S=512 C=256 (T = 21 GB fp32 per GPU, + transposed copy)',
                  20000, 512, 256),
@@ -116,6 +118,18 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
         W4 = np.einsum('sj,cj->csj', W, O).astype(np.float32)
         h = _lib.create_onehot_fst4(T4, W4, h0, hT, device=dev)
         del T4
+    elif name in ('decomp1', 'decomp0'):
+        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
+        RO = 70
+        f = lambda *shape, sc=0.2: (wrng.randn(*shape) * sc).astype(np.float32)      # noqa: E731
+        if name == 'decomp1':
+            h = _lib.create_decomp_ind1(p['V_embed'], p['S1'], p['S2'], p['wildcard_mat'], f(C, RO, sc=0.5),
+                                        f(S, RO), f(S, RO), p['start_vector'], p['final_vector'], nl='tanh',
+                                        semiring=semiring, device=dev)
+        else:
+            h = _lib.create_decomp_fst(p['V_embed'], f(C, cp_rank, sc=0.5), p['S1'], p['S2'], f(C, RO, sc=0.5),
+                                       f(S, RO), f(S, RO), p['wildcard_mat'], p['start_vector'],
+                                       p['final_vector'], nl='tanh', semiring=semiring, device=dev)
     else:
         p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
         Vgen = p['V_embed']          # beta = 1: the generalized table is V_embed itself

@@ -118,6 +118,226 @@ decomp1_score_kernel(const Decomp1ScoreParams p) {
     }
 }
 
+// ---- the same scoring on the f32 matrix cores, from a per-word table -----------------------------------
+// bss[x] = sum_r S1 S2 v_x + W depends on the word only: BSS[V][S][SP] is built once at create time (0.48 GB
+// at V=11 k, S=104).  Per token the work is then a real GEMM against weights shared by every token,
+//     U[S x RO] = abw[S x S] . S2o[S x RO],   abw_ij = (a_i b~_j) bss[x]_ij,      br_q = sum_i S1o_iq U_iq
+// 1.5 MFLOP on v_mfma_f32_16x16x4_f32 (exact f32 fma chains): one workgroup of 4 wavefronts per token, a
+// wavefront owns whole 16-row tiles of U across all 16-column tiles (the A fragment is read once per k-step
+// and used for every column tile), abw and S2o live in LDS.  16.5 ms -> see DESIGN.md for the measured time.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int D1M_MAXNT = 8;            // 16-column tiles of U: RO <= 128
+
+struct Decomp1MfmaParams {
+    Decomp1ScoreParams base;
+    const float *BSS;                   // [V][S][SP]
+    int ldA, ldB, MT, NT, KQ;           // LDS strides; row tiles, column tiles, k-steps of 4
+};
+
+template <int NT>
+__global__ void __launch_bounds__(256)
+decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
+    const Decomp1ScoreParams &p = q.base;
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, nt_ = blockDim.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = blockIdx.x, b = blockIdx.y;
+    const int len = clamp_len(p.len[b], p.L);
+    const int nsteps = p.full ? p.L : len;
+    const int S = p.S, SP = p.SP, RO = p.RO, K = p.K;
+    if (i >= nsteps) {
+        if (p.tags && tid == 0) p.tags[(long long)b * p.L + i] = -1;
+        if (p.scores) for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
+        return;
+    }
+    const int ldA = q.ldA, ldB = q.ldB, MT = q.MT, KQ = q.KQ;
+    float *alpha = smem;                 // [SP]
+    float *beta = alpha + SP;            // [SP]
+    float *br = beta + SP;               // [NT*16]
+    float *brp = br + NT * 16;           // [4][NT*16] per-wavefront partial br
+    float *sc = brp + 4 * (NT * 16 > p.Kc ? NT * 16 : p.Kc);     // [Kc]   (brp doubles as the 4 x Kc score partials)
+    float *sc2 = sc + p.Kc;              // [Kc]
+    float *abw = sc2 + p.Kc;             // [MT*16][ldA]
+    float *s2o = abw + MT * 16 * ldA;    // [KQ*4][ldB]
+
+    const float *ar = p.A + ((long long)b * (p.L + 1) + i) * SP;
+    const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
+    const float *brow = p.Bk + ((long long)b * (p.L + 1) + bidx) * SP;
+    const float *bss = q.BSS + (long long)clamp_tok(p.x[(long long)b * p.L + i], p.V) * S * SP;
+    for (int s = tid; s < SP; s += nt_) { alpha[s] = ar[s]; beta[s] = brow[s]; }
+    // Everything below is staged with 16-byte loads issued in batches (8 in flight per lane): the element-
+    // wise version of these loops serialised ~90 dependent L2 round trips per lane (2 ms per batch).
+    for (int idx = tid; idx < (MT * 16 * ldA + KQ * 4 * ldB); idx += nt_) abw[idx] = 0.0f;   // pads (abw | s2o contiguous)
+    __syncthreads();
+    constexpr int UB = 8;
+    const int ro4 = p.ROp >> 2, sp4 = SP >> 2;
+    for (int base = 0; base < S * ro4; base += UB * nt_) {             // S2o -> LDS
+        float4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = base + u * nt_ + tid;
+            v[u] = e < S * ro4 ? ld4(p.S2o + (long long)e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = base + u * nt_ + tid;
+            if (e < S * ro4) {
+                const int k = e / ro4, c = (e - k * ro4) * 4;
+                float *d = s2o + k * ldB + c;
+                if (c + 0 < RO) d[0] = v[u].x;
+                if (c + 1 < RO) d[1] = v[u].y;
+                if (c + 2 < RO) d[2] = v[u].z;
+                if (c + 3 < RO) d[3] = v[u].w;
+            }
+        }
+    }
+    for (int base = 0; base < S * sp4; base += UB * nt_) {             // abw = (a b~^T) . bss[x]   (:202-203)
+        float4 v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = base + u * nt_ + tid;
+            v[u] = e < S * sp4 ? ld4(bss + (long long)e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < UB; u++) {
+            const int e = base + u * nt_ + tid;
+            if (e < S * sp4) {
+                const int r = e / sp4, c = (e - r * sp4) * 4;
+                const float a = alpha[r];
+                float *d = abw + r * ldA + c;              // ldA is odd: scalar stores
+                if (c + 0 < S) d[0] = (a * beta[c + 0]) * v[u].x;
+                if (c + 1 < S) d[1] = (a * beta[c + 1]) * v[u].y;
+                if (c + 2 < S) d[2] = (a * beta[c + 2]) * v[u].z;
+                if (c + 3 < S) d[3] = (a * beta[c + 3]) * v[u].w;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- U = abw . S2o on the matrix cores; br partials straight from the accumulators  (:204) --------
+    const int lr = lane & 15, lk = lane >> 4;
+    float brl[NT];
+#pragma unroll
+    for (int n = 0; n < NT; n++) brl[n] = 0.0f;
+    for (int mt = w; mt < MT; mt += 4) {
+        f32x4_t acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        const float *ap = abw + (mt * 16 + lr) * ldA + lk;
+        const float *bp = s2o + lk * ldB + lr;
+        // the operands of a k-step are read before its MFMAs and the next step's reads are issued before
+        // this step's MFMAs retire (NT is a compile-time constant: no per-tile branches in the loop)
+        float a = ap[0], bv[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) bv[n] = bp[n * 16];
+        for (int kq = 0; kq < KQ; kq++) {
+            const int kn = kq + 1 < KQ ? kq + 1 : kq;
+            const float an = ap[kn * 4];
+            float bn[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) bn[n] = bp[kn * 4 * ldB + n * 16];
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[n], acc[n], 0, 0, 0);
+            a = an;
+#pragma unroll
+            for (int n = 0; n < NT; n++) bv[n] = bn[n];
+        }
+        // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}
+        float s1v[NT][4];
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = mt * 16 + lk * 4 + r, col = n * 16 + lr;
+                s1v[n][r] = (row < S && col < RO) ? p.S1o[(long long)row * p.ROp + col] : 0.0f;
+            }
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) brl[n] = fmaf(s1v[n][r], acc[n][r], brl[n]);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++) {
+        float v = brl[n];
+        v += __shfl_xor(v, 16, WAVE);
+        v += __shfl_xor(v, 32, WAVE);
+        if (lk == 0) brp[w * NT * 16 + n * 16 + lr] = v;
+    }
+    __syncthreads();
+    for (int c = tid; c < NT * 16; c += nt_)
+        br[c] = (brp[c] + brp[NT * 16 + c]) + (brp[2 * NT * 16 + c] + brp[3 * NT * 16 + c]);
+    __syncthreads();
+    // score = br . Cout^T (:205): the output ranks are split over the workgroup's quarter-blocks so that the
+    // 70-odd loads of a column are three batches, not nine; partial sums meet in LDS (fixed order)
+    {
+        const int parts = nt_ / 64 >= 4 ? 4 : 1;                   // K <= 256 columns, 64-lane quarter per part
+        const int part = tid >> 6, per = (RO + parts - 1) / parts;
+        for (int c = lane; c < K; c += WAVE) {
+            float s = 0.0f;
+            const int q0 = part * per, q1 = q0 + per < RO ? q0 + per : RO;
+            for (int qb = q0; qb < q1; qb += UB) {
+                float cv[UB];
+#pragma unroll
+                for (int u = 0; u < UB; u++) cv[u] = qb + u < q1 ? p.CoutT[(long long)(qb + u) * p.Kc + c] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < UB; u++) if (qb + u < q1) s = fmaf(br[qb + u], cv[u], s);
+            }
+            brp[part * p.Kc + c] = s;                               // brp (4 x NT*16 >= ?) -- see lds sizing
+        }
+        __syncthreads();
+        for (int c = tid; c < K; c += nt_) {
+            float s = brp[c];
+            for (int pp = 1; pp < parts; pp++) s += brp[pp * p.Kc + c];
+            sc[c] = s;
+        }
+    }
+    __syncthreads();
+    const float *fin = sc;
+    if (p.P) {
+        for (int d = tid; d < K; d += nt_) {
+            float s = 0.0f;
+            for (int c0 = 0; c0 < K; c0 += UB) {
+                float pv[UB];
+#pragma unroll
+                for (int u = 0; u < UB; u++) pv[u] = c0 + u < K ? p.P[(long long)(c0 + u) * p.Kc + d] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < UB; u++) if (c0 + u < K) s = fmaf(sc[c0 + u], pv[u], s);
+            }
+            sc2[d] = s;
+        }
+        __syncthreads();
+        fin = sc2;
+    }
+    if (p.scores)
+        for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = fin[c];
+    const int clamp_col = p.use_crf ? K - 3 : K - 1;
+    if (p.use_crf) {
+        for (int c = tid; c < K; c += nt_) {
+            float vv = fin[c] + 0.0f;
+            if (c == clamp_col) vv = fminf(vv, p.threshold);
+            p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
+        }
+    } else if (w == 0) {
+        float bv = -INFINITY; int bi = 0x7ffffffe;
+        for (int c = lane; c < K; c += WAVE) {
+            float vv = fin[c] + 0.0f;
+            if (c == clamp_col) vv = fminf(vv, p.threshold);
+            if (vv > bv) { bv = vv; bi = c; }
+        }
+        bi = wave_argmax_dpp(bv, bi);
+        if (lane == 0) {
+            if (bi >= K) bi = 0;
+            const int tag = (bi == K - 1) ? p.o_idx : bi;
+            if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+            if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
+        }
+    }
+}
+
+inline size_t decomp1_mfma_lds_bytes(int SP, int Kc, int ldA, int ldB, int MT, int NT, int KQ) {
+    const size_t brp = 4 * (size_t)(NT * 16 > Kc ? NT * 16 : Kc);
+    return ((size_t)2 * SP + (size_t)NT * 16 + brp + 2 * (size_t)Kc + (size_t)MT * 16 * ldA + (size_t)KQ * 4 * ldB) * 4;
+}
+
 inline size_t decomp1_score_lds_bytes(int S, int SP, int Rp, int ROp, int Kc) {
     return ((size_t)2 * SP + Rp + ROp + 2 * (size_t)Kc + (size_t)S * SP) * sizeof(float);
 }

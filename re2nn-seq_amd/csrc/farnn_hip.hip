@@ -46,6 +46,7 @@ struct farnn_model {
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
     float *d1_S1o = nullptr, *d1_S2o = nullptr, *d1_CoutT = nullptr;
+    float *d1_BSS = nullptr;                // [V][S][SP] per-word bss = sum_r S1 S2 v + W (MFMA scoring)
     int RW = 0, RWp = 0;                    // decomposed independent=0: wildcard factors + label factor
     float *d0_Vgen = nullptr, *d0_CT = nullptr, *d0_S1w = nullptr, *d0_S2w = nullptr, *d0_CwT = nullptr;
     // workspace
@@ -515,11 +516,31 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     p.V = m->V;
     p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
-    const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
     int rc;
-    if ((rc = raise_lds_limit(decomp1_score_kernel, lds))) return rc;
     KernelTimer kt(m, KERN_SCORE, s);
-    decomp1_score_kernel<<<dim3(p.L, B), dim3(256), lds, s>>>(p);
+    Decomp1MfmaParams qm;
+    qm.base = p; qm.BSS = m->d1_BSS;
+    qm.MT = (m->S + 15) / 16; qm.NT = (m->RO + 15) / 16; qm.KQ = (m->S + 3) / 4;
+    qm.ldA = qm.KQ * 4 + 1;
+    qm.ldB = qm.NT * 16; qm.ldB += (qm.ldB % 32 == 16) ? 0 : 16;           // row stride = 16 mod 32 banks
+    const size_t mlds = decomp1_mfma_lds_bytes(m->SP, m->Kc, qm.ldA, qm.ldB, qm.MT, qm.NT, qm.KQ);
+    if (m->d1_BSS && mlds <= 158 * 1024) {
+#define FARNN_LAUNCH_D1M(N)                                                                    \
+        case N:                                                                               \
+            if ((rc = raise_lds_limit(decomp1_score_mfma_kernel<N>, mlds))) return rc;        \
+            decomp1_score_mfma_kernel<N><<<dim3(p.L, B), dim3(256), mlds, s>>>(qm);           \
+            break;
+        switch (qm.NT) {
+            FARNN_LAUNCH_D1M(1) FARNN_LAUNCH_D1M(2) FARNN_LAUNCH_D1M(3) FARNN_LAUNCH_D1M(4)
+            FARNN_LAUNCH_D1M(5) FARNN_LAUNCH_D1M(6) FARNN_LAUNCH_D1M(7) FARNN_LAUNCH_D1M(8)
+            default: return fail(FARNN_ERANGE, "decomp_ind1: output rank above 128%s%s");
+        }
+#undef FARNN_LAUNCH_D1M
+    } else {
+        const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
+        if ((rc = raise_lds_limit(decomp1_score_kernel, lds))) return rc;
+        decomp1_score_kernel<<<dim3(p.L, B), dim3(256), lds, s>>>(p);
+    }
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf) {
         ScoreParams v;
@@ -1053,6 +1074,15 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
+    if (m->RO <= 16 * D1M_MAXNT && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !env_int("FARNN_DECOMP_OLD", 0)) {
+        // per-word bss table for the MFMA scoring kernel (unmasked: the mask only enters the recurrence)
+        if ((rc = dev_alloc(m, (void **)&m->d1_BSS, (size_t)m->V * m->S * m->SP * 4))) return bail(rc);
+        dim3 grid((m->S * m->SP + 255) / 256, m->V);
+        materialise_blocks_kernel<<<grid, 256>>>(m->dw.Vgen, m->dw.S1, m->dw.S2, m->dw.W, nullptr, m->d1_BSS, nullptr,
+                                                 m->S, m->SP, m->S, m->R, m->Rp);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+    }
     if ((rc = build_dense_blocks(m))) return bail(rc);
     *out = m;
     return FARNN_OK;

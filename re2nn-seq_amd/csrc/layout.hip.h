@@ -147,7 +147,7 @@ __global__ void materialise_blocks_kernel(const float *Vgen, const float *S1, co
         if (mask) tr *= mask[(long long)i * SP + j];
     }
     Mf[v * SR * SP + idx] = tr;                          // Mf[v][i][j] = Tr[i][j]
-    if (i < SP && j < SR) Mb[v * SR * SP + (long long)j * SP + i] = (i < S && j < S) ? tr : 0.0f;   // Mb[v][j][i]
+    if (Mb && i < SP && j < SR) Mb[v * SR * SP + (long long)j * SP + i] = (i < S && j < S) ? tr : 0.0f;   // Mb[v][j][i]
 }
 
 }  // namespace farnn
