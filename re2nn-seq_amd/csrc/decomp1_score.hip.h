@@ -119,223 +119,305 @@ decomp1_score_kernel(const Decomp1ScoreParams p) {
 }
 
 // ---- the same scoring on the f32 matrix cores, from a per-word table -----------------------------------
-// bss[x] = sum_r S1 S2 v_x + W depends on the word only: BSS[V][S][SP] is built once at create time (0.48 GB
-// at V=11 k, S=104).  Per token the work is then a real GEMM against weights shared by every token,
+// bss[x] = sum_r S1 S2 v_x + W depends on the word only: it is built once at create time (0.05 MB per word
+// at S=100).  Per token the work is then a real GEMM against weights shared by every token,
 //     U[S x RO] = abw[S x S] . S2o[S x RO],   abw_ij = (a_i b~_j) bss[x]_ij,      br_q = sum_i S1o_iq U_iq
-// 1.5 MFLOP on v_mfma_f32_16x16x4_f32 (exact f32 fma chains): one workgroup of 4 wavefronts per token, a
-// wavefront owns whole 16-row tiles of U across all 16-column tiles (the A fragment is read once per k-step
-// and used for every column tile), abw and S2o live in LDS.  16.5 ms -> see DESIGN.md for the measured time.
+// 1.5 MFLOP on v_mfma_f32_16x16x4_f32 (exact f32 fma chains).  A wavefront scores whole tokens (D1M_TPW of
+// them, one after the other; 4 wavefronts per workgroup):
+//   * B operand: S2o is the same for every token, so the wavefront keeps ALL of it in registers in MFMA
+//     operand order (S2oP[k-group][col tile][lane][4], <= 160 registers) -- the inner loop has no LDS or
+//     memory operand but the A stream.  (Versions with S2o in LDS ran the matrix cores at 40 %: one LDS
+//     read per MFMA, each waited for just before its use.)
+//   * A operand: the table is stored in operand order too (BSSp[x][row tile][k-group][lane][4]): a lane's
+//     four k-steps are ONE coalesced 16-byte load straight from HBM into the registers the MFMA reads,
+//     scaled by a_i b~_j on the way; a row tile's registers are refilled for the next tile as soon as their
+//     group has been issued.  All these loads are unconditional (clamped index): a load under a branch makes
+//     the compiler wait for vmcnt(0) at every later use.
+//   * br: S1o in accumulator order (S1oP[row tile][col tile][lane][4]), one 16-byte load per tile pair.
+//   * score = br . Cout^T and the priority product for the workgroup's tokens together (weights read once,
+//     the reduction index split over the wavefronts, partial sums meet in LDS in a fixed order).
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int D1M_MAXNT = 8;            // 16-column tiles of U: RO <= 128
+constexpr int D1M_MAXNT = 5;            // 16-column tiles of U held in registers: RO <= 80
+constexpr int D1M_MAXKQ4 = 7;           // groups of 4 k-steps per row tile: S <= 112 (register budget)
+constexpr int D1M_TPW = 1;              // tokens per wavefront and work item
+constexpr int D1M_TOK = 4 * D1M_TPW;    // tokens per work item
 
 struct Decomp1MfmaParams {
     Decomp1ScoreParams base;
-    const float *BSS;                   // [V][S][SP]
-    int ldA, ldB, MT, NT, KQ;           // LDS strides; row tiles, column tiles, k-steps of 4
+    const float *BSSp;                  // [V][MT][KQ4][64][4]
+    const float *S1oP;                  // [MT][NT][64][4]
+    const float *S2oP;                  // [KQ4][NT][64][4]
+    int MT, NT, KQ4;                    // row tiles, column tiles, groups of 4 k-steps
+    int *counter;                       // work-item ticket (zeroed on the stream before the launch)
+    int nib;                            // work items per sequence = ceil(L / D1M_TOK)
 };
 
+__global__ void pack_bss_operand_kernel(const float *__restrict__ BSS, float *__restrict__ BSSp, long long total,
+                                        int S, int SP, int MT, int KQ4) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int u = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
+    const long long blk = idx >> 8;
+    const int g = (int)(blk % KQ4), mt = (int)((blk / KQ4) % MT);
+    const long long x = blk / ((long long)KQ4 * MT);
+    const int i = mt * 16 + (lane & 15), j = 4 * (g * 4 + u) + (lane >> 4);
+    BSSp[idx] = (i < S && j < S) ? BSS[(x * S + i) * SP + j] : 0.0f;
+}
+
+__global__ void pack_s1o_operand_kernel(const float *__restrict__ S1o, float *__restrict__ S1oP, int total,
+                                        int S, int RO, int ROp, int NT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int r = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+    const int n = blk % NT, mt = blk / NT;
+    const int row = mt * 16 + (lane >> 4) * 4 + r, col = n * 16 + (lane & 15);
+    S1oP[idx] = (row < S && col < RO) ? S1o[(long long)row * ROp + col] : 0.0f;
+}
+
+__global__ void pack_s2o_operand_kernel(const float *__restrict__ S2o, float *__restrict__ S2oP, int total,
+                                        int S, int RO, int ROp, int NT) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int u = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+    const int n = blk % NT, g = blk / NT;
+    const int j = 4 * (g * 4 + u) + (lane >> 4), col = n * 16 + (lane & 15);
+    S2oP[idx] = (j < S && col < RO) ? S2o[(long long)j * ROp + col] : 0.0f;
+}
+
 template <int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
     const Decomp1ScoreParams &p = q.base;
     extern __shared__ __align__(16) float smem[];
+    constexpr int TOK = D1M_TOK, NC = NT * 16;
     const int tid = threadIdx.x, lane = tid & 63, nt_ = blockDim.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = blockIdx.x, b = blockIdx.y;
+    const int S = p.S, SP = p.SP, RO = p.RO, K = p.K, Kc = p.Kc;
+    const int MT = q.MT, KQ4 = q.KQ4, SPa = MT * 16;
+    float *al = smem;                      // [TOK][SPa]
+    float *be = al + TOK * SPa;            // [TOK][SPa]
+    float *br = be + TOK * SPa;            // [TOK][NC]
+    float *scp = br + TOK * NC;            // [TOK][4][Kc] score partials
+    float *sc = scp + TOK * 4 * Kc;        // [TOK][Kc]
+    float *sc2 = sc + TOK * Kc;            // [TOK][Kc]
+    int *xo = (int *)(sc2 + TOK * Kc);     // [TOK] word ids, [TOK] = the work-item ticket (8 ints)
+    float *s1l = (float *)(xo + 8);        // [MT][NT][64][4] S1o in accumulator order
+    static_assert(D1M_TOK < 8, "ticket slot");
+
+    // ---- persistent workgroup: the token-independent operands are loaded ONCE -----------------------------
+    // S2o into registers (per wavefront) ...
+    const int lr = lane & 15, lk = lane >> 4;
+    f32x4_t Bq[D1M_MAXKQ4][NT];
+#pragma unroll
+    for (int g = 0; g < D1M_MAXKQ4; g++)
+#pragma unroll
+        for (int n = 0; n < NT; n++)
+            Bq[g][n] = *(const f32x4_t *)(q.S2oP + ((long long)((g < KQ4 ? g : KQ4 - 1) * NT + n) * 64 + lane) * 4);
+    // ... and S1oP into LDS: read by the tile epilogues through lgkmcnt, so they never drain the A stream's vmcnt
+    for (int base = 0; base < MT * NT * 64; base += 8 * nt_) {
+        f32x4_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = base + u * nt_ + tid;
+            v[u] = *(const f32x4_t *)(q.S1oP + (long long)(e < MT * NT * 64 ? e : 0) * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int e = base + u * nt_ + tid;
+            if (e < MT * NT * 64) *(f32x4_t *)(s1l + e * 4) = v[u];
+        }
+    }
+    for (int idx = tid; idx < 2 * TOK * SPa; idx += nt_) al[idx] = 0.0f;          // al | be contiguous; pads stay 0
+    const int nitems = q.nib * p.B;
+
+  for (;;) {
+    // work items (D1M_TOK consecutive positions of one sequence) are handed out by ticket: workgroups that
+    // draw short or empty items simply come back sooner, so the matrix cores stay fed to the end
+    __syncthreads();
+    if (tid == 0) xo[TOK] = atomicAdd(q.counter, 1);
+    __syncthreads();
+    const int item = xo[TOK];
+    if (item >= nitems) break;
+    const int b = item / q.nib, i0 = (item - b * q.nib) * TOK;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, RO = p.RO, K = p.K;
-    if (i >= nsteps) {
-        if (p.tags && tid == 0) p.tags[(long long)b * p.L + i] = -1;
-        if (p.scores) for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
-        return;
+    for (int t = 0; t < TOK; t++) {                    // positions past the end of the row
+        const int i = i0 + t;
+        if (i < p.L && i >= nsteps) {
+            if (p.tags && tid == 0) p.tags[(long long)b * p.L + i] = -1;
+            if (p.scores) for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
+        }
     }
-    const int ldA = q.ldA, ldB = q.ldB, MT = q.MT, KQ = q.KQ;
-    float *alpha = smem;                 // [SP]
-    float *beta = alpha + SP;            // [SP]
-    float *br = beta + SP;               // [NT*16]
-    float *brp = br + NT * 16;           // [4][NT*16] per-wavefront partial br
-    float *sc = brp + 4 * (NT * 16 > p.Kc ? NT * 16 : p.Kc);     // [Kc]   (brp doubles as the 4 x Kc score partials)
-    float *sc2 = sc + p.Kc;              // [Kc]
-    float *abw = sc2 + p.Kc;             // [MT*16][ldA]
-    float *s2o = abw + MT * 16 * ldA;    // [KQ*4][ldB]
+    if (i0 >= nsteps) continue;
+    const int ntok = nsteps - i0 < TOK ? nsteps - i0 : TOK;
+    if (tid < TOK) xo[tid] = tid < ntok ? (int)clamp_tok(p.x[(long long)b * p.L + i0 + tid], p.V) : 0;
+    for (int idx = tid; idx < ntok * S; idx += nt_) {
+        const int t = idx / S, s = idx - t * S, i = i0 + t;
+        const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
+        al[t * SPa + s] = p.A[((long long)b * (p.L + 1) + i) * SP + s];
+        be[t * SPa + s] = p.Bk[((long long)b * (p.L + 1) + bidx) * SP + s];
+    }
+    __syncthreads();
 
-    const float *ar = p.A + ((long long)b * (p.L + 1) + i) * SP;
-    const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
-    const float *brow = p.Bk + ((long long)b * (p.L + 1) + bidx) * SP;
-    const float *bss = q.BSS + (long long)clamp_tok(p.x[(long long)b * p.L + i], p.V) * S * SP;
-    for (int s = tid; s < SP; s += nt_) { alpha[s] = ar[s]; beta[s] = brow[s]; }
-    // Everything below is staged with 16-byte loads issued in batches (8 in flight per lane): the element-
-    // wise version of these loops serialised ~90 dependent L2 round trips per lane (2 ms per batch).
-    for (int idx = tid; idx < (MT * 16 * ldA + KQ * 4 * ldB); idx += nt_) abw[idx] = 0.0f;   // pads (abw | s2o contiguous)
+    // ---- U = abw . S2o on the matrix cores; br straight from the accumulators  (:201-204) ----------------
+    for (int tt = 0; tt < D1M_TPW; tt++) {
+        const int t = w * D1M_TPW + tt;
+        if (t >= ntok) {
+            for (int c = lane; c < NC; c += WAVE) br[t * NC + c] = 0.0f;
+            continue;
+        }
+        const float *ap = q.BSSp + (long long)xo[t] * MT * KQ4 * 256 + lane * 4;
+        const float *bet = be + t * SPa + lk;
+        f32x4_t A[D1M_MAXKQ4];
+#pragma unroll
+        for (int g = 0; g < D1M_MAXKQ4; g++) A[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float brl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) brl[n] = 0.0f;
+        // pass mt = -1 only issues the first row tile's loads, in the same program order as every later
+        // refill (a separate prologue gets reordered by the compiler and its wait counts merged into the
+        // loop's: vmcnt(1) instead of vmcnt(7) at the head of every tile)
+        for (int mt = -1; mt < MT; mt++) {
+            const bool act = mt >= 0;
+            f32x4_t acc[NT];
+#pragma unroll
+            for (int n = 0; n < NT; n++) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            const float ai = al[t * SPa + (act ? mt : 0) * 16 + lr];
+            const float *an = ap + (long long)(mt + 1 < MT ? mt + 1 : mt) * KQ4 * 256;
+#pragma unroll
+            for (int g = 0; g < D1M_MAXKQ4; g++) {
+                if (act && g < KQ4) {
+                    float bj[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) bj[u] = bet[g * 16 + u * 4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const float a = (ai * bj[u]) * A[g][u];                          // :202-203
+#pragma unroll
+                        for (int n = 0; n < NT; n++)
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bq[g][n][u], acc[n], 0, 0, 0);
+                    }
+                }
+                A[g] = *(const f32x4_t *)(an + (g < KQ4 ? g : KQ4 - 1) * 256);           // next row tile
+                __builtin_amdgcn_sched_barrier(0);          // keep the refills in program order (vmcnt is in-order)
+            }
+            // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}
+            if (act)
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                const f32x4_t s1 = *(const f32x4_t *)(s1l + ((mt * NT + n) * 64 + lane) * 4);
+#pragma unroll
+                for (int r = 0; r < 4; r++) brl[n] = fmaf(s1[r], acc[n][r], brl[n]);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            float v = brl[n];
+            v += __shfl_xor(v, 16, WAVE);
+            v += __shfl_xor(v, 32, WAVE);
+            if (lk == 0) br[t * NC + n * 16 + lr] = v;
+        }
+    }
     __syncthreads();
+    // score = br . Cout^T (:205): the output ranks are split over the four wavefronts; all of a lane's loads
+    // of a column are in flight together
     constexpr int UB = 8;
-    const int ro4 = p.ROp >> 2, sp4 = SP >> 2;
-    for (int base = 0; base < S * ro4; base += UB * nt_) {             // S2o -> LDS
-        float4 v[UB];
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const int e = base + u * nt_ + tid;
-            v[u] = e < S * ro4 ? ld4(p.S2o + (long long)e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const int e = base + u * nt_ + tid;
-            if (e < S * ro4) {
-                const int k = e / ro4, c = (e - k * ro4) * 4;
-                float *d = s2o + k * ldB + c;
-                if (c + 0 < RO) d[0] = v[u].x;
-                if (c + 1 < RO) d[1] = v[u].y;
-                if (c + 2 < RO) d[2] = v[u].z;
-                if (c + 3 < RO) d[3] = v[u].w;
-            }
-        }
-    }
-    for (int base = 0; base < S * sp4; base += UB * nt_) {             // abw = (a b~^T) . bss[x]   (:202-203)
-        float4 v[UB];
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const int e = base + u * nt_ + tid;
-            v[u] = e < S * sp4 ? ld4(bss + (long long)e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < UB; u++) {
-            const int e = base + u * nt_ + tid;
-            if (e < S * sp4) {
-                const int r = e / sp4, c = (e - r * sp4) * 4;
-                const float a = alpha[r];
-                float *d = abw + r * ldA + c;              // ldA is odd: scalar stores
-                if (c + 0 < S) d[0] = (a * beta[c + 0]) * v[u].x;
-                if (c + 1 < S) d[1] = (a * beta[c + 1]) * v[u].y;
-                if (c + 2 < S) d[2] = (a * beta[c + 2]) * v[u].z;
-                if (c + 3 < S) d[3] = (a * beta[c + 3]) * v[u].w;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- U = abw . S2o on the matrix cores; br partials straight from the accumulators  (:204) --------
-    const int lr = lane & 15, lk = lane >> 4;
-    float brl[NT];
-#pragma unroll
-    for (int n = 0; n < NT; n++) brl[n] = 0.0f;
-    for (int mt = w; mt < MT; mt += 4) {
-        f32x4_t acc[NT];
-#pragma unroll
-        for (int n = 0; n < NT; n++) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        const float *ap = abw + (mt * 16 + lr) * ldA + lk;
-        const float *bp = s2o + lk * ldB + lr;
-        // the operands of a k-step are read before its MFMAs and the next step's reads are issued before
-        // this step's MFMAs retire (NT is a compile-time constant: no per-tile branches in the loop)
-        float a = ap[0], bv[NT];
-#pragma unroll
-        for (int n = 0; n < NT; n++) bv[n] = bp[n * 16];
-        for (int kq = 0; kq < KQ; kq++) {
-            const int kn = kq + 1 < KQ ? kq + 1 : kq;
-            const float an = ap[kn * 4];
-            float bn[NT];
-#pragma unroll
-            for (int n = 0; n < NT; n++) bn[n] = bp[kn * 4 * ldB + n * 16];
-#pragma unroll
-            for (int n = 0; n < NT; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[n], acc[n], 0, 0, 0);
-            a = an;
-#pragma unroll
-            for (int n = 0; n < NT; n++) bv[n] = bn[n];
-        }
-        // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}
-        float s1v[NT][4];
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = mt * 16 + lk * 4 + r, col = n * 16 + lr;
-                s1v[n][r] = (row < S && col < RO) ? p.S1o[(long long)row * p.ROp + col] : 0.0f;
-            }
-#pragma unroll
-        for (int n = 0; n < NT; n++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) brl[n] = fmaf(s1v[n][r], acc[n][r], brl[n]);
-    }
-#pragma unroll
-    for (int n = 0; n < NT; n++) {
-        float v = brl[n];
-        v += __shfl_xor(v, 16, WAVE);
-        v += __shfl_xor(v, 32, WAVE);
-        if (lk == 0) brp[w * NT * 16 + n * 16 + lr] = v;
-    }
-    __syncthreads();
-    for (int c = tid; c < NT * 16; c += nt_)
-        br[c] = (brp[c] + brp[NT * 16 + c]) + (brp[2 * NT * 16 + c] + brp[3 * NT * 16 + c]);
-    __syncthreads();
-    // score = br . Cout^T (:205): the output ranks are split over the workgroup's quarter-blocks so that the
-    // 70-odd loads of a column are three batches, not nine; partial sums meet in LDS (fixed order)
     {
-        const int parts = nt_ / 64 >= 4 ? 4 : 1;                   // K <= 256 columns, 64-lane quarter per part
-        const int part = tid >> 6, per = (RO + parts - 1) / parts;
+        const int per = (RO + 3) / 4;
+        const int q0 = w * per, q1 = q0 + per < RO ? q0 + per : RO;
         for (int c = lane; c < K; c += WAVE) {
-            float s = 0.0f;
-            const int q0 = part * per, q1 = q0 + per < RO ? q0 + per : RO;
+            float s[TOK];
+#pragma unroll
+            for (int t = 0; t < TOK; t++) s[t] = 0.0f;
             for (int qb = q0; qb < q1; qb += UB) {
                 float cv[UB];
 #pragma unroll
-                for (int u = 0; u < UB; u++) cv[u] = qb + u < q1 ? p.CoutT[(long long)(qb + u) * p.Kc + c] : 0.0f;
+                for (int u = 0; u < UB; u++) cv[u] = qb + u < q1 ? p.CoutT[(long long)(qb + u) * Kc + c] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < UB; u++) if (qb + u < q1) s = fmaf(br[qb + u], cv[u], s);
+                for (int u = 0; u < UB; u++)
+                    if (qb + u < q1) {
+#pragma unroll
+                        for (int t = 0; t < TOK; t++) s[t] = fmaf(br[t * NC + qb + u], cv[u], s[t]);
+                    }
             }
-            brp[part * p.Kc + c] = s;                               // brp (4 x NT*16 >= ?) -- see lds sizing
+#pragma unroll
+            for (int t = 0; t < TOK; t++) scp[(t * 4 + w) * Kc + c] = s[t];
         }
         __syncthreads();
-        for (int c = tid; c < K; c += nt_) {
-            float s = brp[c];
-            for (int pp = 1; pp < parts; pp++) s += brp[pp * p.Kc + c];
-            sc[c] = s;
+        for (int idx = tid; idx < ntok * Kc; idx += nt_) {
+            const int t = idx / Kc, c = idx - t * Kc;
+            const float *sq = scp + t * 4 * Kc + c;
+            sc[idx] = c < K ? (sq[0] + sq[Kc]) + (sq[2 * Kc] + sq[3 * Kc]) : 0.0f;
         }
     }
     __syncthreads();
     const float *fin = sc;
     if (p.P) {
-        for (int d = tid; d < K; d += nt_) {
-            float s = 0.0f;
-            for (int c0 = 0; c0 < K; c0 += UB) {
+        // scores . P (:207 priority): same split, over the label index
+        const int per = (K + 3) / 4;
+        const int c0 = w * per, c1 = c0 + per < K ? c0 + per : K;
+        for (int d = lane; d < K; d += WAVE) {
+            float s[TOK];
+#pragma unroll
+            for (int t = 0; t < TOK; t++) s[t] = 0.0f;
+            for (int cb = c0; cb < c1; cb += UB) {
                 float pv[UB];
 #pragma unroll
-                for (int u = 0; u < UB; u++) pv[u] = c0 + u < K ? p.P[(long long)(c0 + u) * p.Kc + d] : 0.0f;
+                for (int u = 0; u < UB; u++) pv[u] = cb + u < c1 ? p.P[(long long)(cb + u) * Kc + d] : 0.0f;
 #pragma unroll
-                for (int u = 0; u < UB; u++) if (c0 + u < K) s = fmaf(sc[c0 + u], pv[u], s);
+                for (int u = 0; u < UB; u++)
+                    if (cb + u < c1) {
+#pragma unroll
+                        for (int t = 0; t < TOK; t++) s[t] = fmaf(sc[t * Kc + cb + u], pv[u], s[t]);
+                    }
             }
-            sc2[d] = s;
+#pragma unroll
+            for (int t = 0; t < TOK; t++) scp[(t * 4 + w) * Kc + d] = s[t];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < ntok * Kc; idx += nt_) {
+            const int t = idx / Kc, d = idx - t * Kc;
+            const float *sq = scp + t * 4 * Kc + d;
+            sc2[idx] = d < K ? (sq[0] + sq[Kc]) + (sq[2 * Kc] + sq[3 * Kc]) : 0.0f;
         }
         __syncthreads();
         fin = sc2;
     }
-    if (p.scores)
-        for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = fin[c];
+    // one wavefront per token: scores, CRF emissions or the argmax
     const int clamp_col = p.use_crf ? K - 3 : K - 1;
-    if (p.use_crf) {
-        for (int c = tid; c < K; c += nt_) {
-            float vv = fin[c] + 0.0f;
-            if (c == clamp_col) vv = fminf(vv, p.threshold);
-            p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
-        }
-    } else if (w == 0) {
-        float bv = -INFINITY; int bi = 0x7ffffffe;
-        for (int c = lane; c < K; c += WAVE) {
-            float vv = fin[c] + 0.0f;
-            if (c == clamp_col) vv = fminf(vv, p.threshold);
-            if (vv > bv) { bv = vv; bi = c; }
-        }
-        bi = wave_argmax_dpp(bv, bi);
-        if (lane == 0) {
-            if (bi >= K) bi = 0;
-            const int tag = (bi == K - 1) ? p.o_idx : bi;
-            if (p.tags) p.tags[(long long)b * p.L + i] = tag;
-            if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
+    for (int t = w; t < ntok; t += 4) {
+        const int i = i0 + t;
+        const float *ft = fin + t * Kc;
+        if (p.scores)
+            for (int c = lane; c < K; c += WAVE) p.scores[((long long)b * p.L + i) * K + c] = ft[c];
+        if (p.use_crf) {
+            for (int c = lane; c < K; c += WAVE) {
+                float vv = ft[c] + 0.0f;
+                if (c == clamp_col) vv = fminf(vv, p.threshold);
+                p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
+            }
+        } else {
+            float bv = -INFINITY; int bi = 0x7ffffffe;
+            for (int c = lane; c < K; c += WAVE) {
+                float vv = ft[c] + 0.0f;
+                if (c == clamp_col) vv = fminf(vv, p.threshold);
+                if (vv > bv) { bv = vv; bi = c; }
+            }
+            bi = wave_argmax_dpp(bv, bi);
+            if (lane == 0) {
+                if (bi >= K) bi = 0;
+                const int tag = (bi == K - 1) ? p.o_idx : bi;
+                if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
+            }
         }
     }
+  }   // work items
 }
 
-inline size_t decomp1_mfma_lds_bytes(int SP, int Kc, int ldA, int ldB, int MT, int NT, int KQ) {
-    const size_t brp = 4 * (size_t)(NT * 16 > Kc ? NT * 16 : Kc);
-    return ((size_t)2 * SP + (size_t)NT * 16 + brp + 2 * (size_t)Kc + (size_t)MT * 16 * ldA + (size_t)KQ * 4 * ldB) * 4;
+inline size_t decomp1_mfma_lds_bytes(int Kc, int MT, int NT) {
+    return ((size_t)2 * D1M_TOK * MT * 16 + D1M_TOK * (size_t)NT * 16 + 6 * (size_t)D1M_TOK * Kc + 8 +
+            (size_t)MT * NT * 256) * 4;
 }
 
 inline size_t decomp1_score_lds_bytes(int S, int SP, int Rp, int ROp, int Kc) {

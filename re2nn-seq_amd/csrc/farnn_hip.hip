@@ -46,7 +46,11 @@ struct farnn_model {
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
     float *d1_S1o = nullptr, *d1_S2o = nullptr, *d1_CoutT = nullptr;
-    float *d1_BSS = nullptr;                // [V][S][SP] per-word bss = sum_r S1 S2 v + W (MFMA scoring)
+    float *d1_BSSp = nullptr;               // [V][MT][KQ4][64][4] per-word bss = sum_r S1 S2 v + W in MFMA operand order
+    float *d1_S1oP = nullptr;               // [MT][NT][64][4] S1o in MFMA accumulator order
+    float *d1_S2oP = nullptr;               // [KQ4][NT][64][4] S2o in MFMA operand order
+    int *d1_ticket = nullptr;               // work-item counter of the persistent scoring kernel
+    int n_cu = 0;                           // compute units of the device (persistent launches)
     int RW = 0, RWp = 0;                    // decomposed independent=0: wildcard factors + label factor
     float *d0_Vgen = nullptr, *d0_CT = nullptr, *d0_S1w = nullptr, *d0_S2w = nullptr, *d0_CwT = nullptr;
     // workspace
@@ -519,21 +523,28 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     int rc;
     KernelTimer kt(m, KERN_SCORE, s);
     Decomp1MfmaParams qm;
-    qm.base = p; qm.BSS = m->d1_BSS;
-    qm.MT = (m->S + 15) / 16; qm.NT = (m->RO + 15) / 16; qm.KQ = (m->S + 3) / 4;
-    qm.ldA = qm.KQ * 4 + 1;
-    qm.ldB = qm.NT * 16; qm.ldB += (qm.ldB % 32 == 16) ? 0 : 16;           // row stride = 16 mod 32 banks
-    const size_t mlds = decomp1_mfma_lds_bytes(m->SP, m->Kc, qm.ldA, qm.ldB, qm.MT, qm.NT, qm.KQ);
-    if (m->d1_BSS && mlds <= 158 * 1024) {
+    qm.base = p; qm.BSSp = m->d1_BSSp; qm.S1oP = m->d1_S1oP; qm.S2oP = m->d1_S2oP;
+    qm.MT = (m->S + 15) / 16; qm.NT = (m->RO + 15) / 16; qm.KQ4 = (m->S + 15) / 16;
+    qm.counter = m->d1_ticket; qm.nib = (p.L + D1M_TOK - 1) / D1M_TOK;
+    const size_t mlds = decomp1_mfma_lds_bytes(m->Kc, qm.MT, qm.NT);
+    if (m->d1_BSSp && mlds <= 80 * 1024) {
+        // persistent: two workgroups per CU draw work items by ticket
+        if (m->n_cu <= 0) {
+            int dev = 0, ncu = 0;
+            FARNN_HIP_TRY(hipGetDevice(&dev));
+            FARNN_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+            m->n_cu = ncu > 0 ? ncu : 256;
+        }
+        const int nwg = std::min(2 * m->n_cu, qm.nib * B);
+        FARNN_HIP_TRY(hipMemsetAsync(m->d1_ticket, 0, sizeof(int), s));
 #define FARNN_LAUNCH_D1M(N)                                                                    \
         case N:                                                                               \
             if ((rc = raise_lds_limit(decomp1_score_mfma_kernel<N>, mlds))) return rc;        \
-            decomp1_score_mfma_kernel<N><<<dim3(p.L, B), dim3(256), mlds, s>>>(qm);           \
+            decomp1_score_mfma_kernel<N><<<dim3(nwg), dim3(256), mlds, s>>>(qm);              \
             break;
         switch (qm.NT) {
-            FARNN_LAUNCH_D1M(1) FARNN_LAUNCH_D1M(2) FARNN_LAUNCH_D1M(3) FARNN_LAUNCH_D1M(4)
-            FARNN_LAUNCH_D1M(5) FARNN_LAUNCH_D1M(6) FARNN_LAUNCH_D1M(7) FARNN_LAUNCH_D1M(8)
-            default: return fail(FARNN_ERANGE, "decomp_ind1: output rank above 128%s%s");
+            FARNN_LAUNCH_D1M(1) FARNN_LAUNCH_D1M(2) FARNN_LAUNCH_D1M(3) FARNN_LAUNCH_D1M(4) FARNN_LAUNCH_D1M(5)
+            default: return fail(FARNN_ERANGE, "decomp_ind1: output rank above 80 on the MFMA path%s%s");
         }
 #undef FARNN_LAUNCH_D1M
     } else {
@@ -1074,14 +1085,32 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
-    if (m->RO <= 16 * D1M_MAXNT && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !env_int("FARNN_DECOMP_OLD", 0)) {
-        // per-word bss table for the MFMA scoring kernel (unmasked: the mask only enters the recurrence)
-        if ((rc = dev_alloc(m, (void **)&m->d1_BSS, (size_t)m->V * m->S * m->SP * 4))) return bail(rc);
+    if (m->RO <= 16 * D1M_MAXNT && m->S <= 16 * D1M_MAXKQ4 && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !env_int("FARNN_DECOMP_OLD", 0)) {
+        // per-word bss table for the MFMA scoring kernel (unmasked: the mask only enters the recurrence),
+        // materialised row-major in a scratch buffer, then re-laid-out in MFMA operand order
+        const int MT = (m->S + 15) / 16, NT = (m->RO + 15) / 16, KQ4 = MT;
+        float *tmp = nullptr;
+        FARNN_HIP_TRY(hipMalloc((void **)&tmp, (size_t)m->V * m->S * m->SP * 4));
         dim3 grid((m->S * m->SP + 255) / 256, m->V);
-        materialise_blocks_kernel<<<grid, 256>>>(m->dw.Vgen, m->dw.S1, m->dw.S2, m->dw.W, nullptr, m->d1_BSS, nullptr,
+        materialise_blocks_kernel<<<grid, 256>>>(m->dw.Vgen, m->dw.S1, m->dw.S2, m->dw.W, nullptr, tmp, nullptr,
                                                  m->S, m->SP, m->S, m->R, m->Rp);
-        FARNN_HIP_TRY(hipGetLastError());
-        FARNN_HIP_TRY(hipDeviceSynchronize());
+        const long long total = (long long)m->V * MT * KQ4 * 256;
+        rc = dev_alloc(m, (void **)&m->d1_BSSp, (size_t)total * 4);
+        if (!rc) rc = dev_alloc(m, (void **)&m->d1_S1oP, (size_t)MT * NT * 256 * 4);
+        if (!rc) rc = dev_alloc(m, (void **)&m->d1_S2oP, (size_t)KQ4 * NT * 256 * 4);
+        if (!rc) rc = dev_alloc(m, (void **)&m->d1_ticket, 256);
+        if (!rc) {
+            pack_s2o_operand_kernel<<<(KQ4 * NT * 256 + 255) / 256, 256>>>(m->d1_S2o, m->d1_S2oP, KQ4 * NT * 256,
+                                                                          m->S, m->RO, m->ROp, NT);
+            pack_bss_operand_kernel<<<(unsigned)((total + 255) / 256), 256>>>(tmp, m->d1_BSSp, total, m->S, m->SP, MT, KQ4);
+            pack_s1o_operand_kernel<<<(MT * NT * 256 + 255) / 256, 256>>>(m->d1_S1o, m->d1_S1oP, MT * NT * 256,
+                                                                         m->S, m->RO, m->ROp, NT);
+        }
+        hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+        (void)hipFree(tmp);
+        if (rc) return bail(rc);
+        FARNN_HIP_TRY(e1);
+        FARNN_HIP_TRY(e2);
     }
     if ((rc = build_dense_blocks(m))) return bail(rc);
     *out = m;
