@@ -122,34 +122,37 @@ decomp1_score_kernel(const Decomp1ScoreParams p) {
 // bss[x] = sum_r S1 S2 v_x + W depends on the word only: it is built once at create time (0.05 MB per word
 // at S=100).  Per token the work is then a real GEMM against weights shared by every token,
 //     U[S x RO] = abw[S x S] . S2o[S x RO],   abw_ij = (a_i b~_j) bss[x]_ij,      br_q = sum_i S1o_iq U_iq
-// 1.5 MFLOP on v_mfma_f32_16x16x4_f32 (exact f32 fma chains).  A wavefront scores whole tokens (D1M_TPW of
-// them, one after the other; 4 wavefronts per workgroup):
+// 1.5 MFLOP on v_mfma_f32_16x16x4_f32 (exact f32 fma chains).  Two kernels:
+//
+// decomp1_br_mfma_kernel -- br for every live position.  Persistent wavefronts (2 per SIMD), each owning a
+// contiguous slice of the batch's live tokens (flat offsets), so there is no workgroup-level synchronisation
+// after start-up.  (Handing tokens out by ticket cost more than the MFMAs: 16 k atomics on one address
+// serialise at ~13 ns each.)
 //   * B operand: S2o is the same for every token, so the wavefront keeps ALL of it in registers in MFMA
-//     operand order (S2oP[k-group][col tile][lane][4], <= 160 registers) -- the inner loop has no LDS or
-//     memory operand but the A stream.  (Versions with S2o in LDS ran the matrix cores at 40 %: one LDS
-//     read per MFMA, each waited for just before its use.)
+//     operand order (S2oP[k-group][col tile][lane][4], <= 140 registers) for its whole life -- the inner
+//     loop has no LDS or memory operand but the A stream.  (Versions with S2o in LDS ran the matrix cores
+//     at 40 %: one LDS read per MFMA, each waited for just before its use.)
 //   * A operand: the table is stored in operand order too (BSSp[x][row tile][k-group][lane][4]): a lane's
 //     four k-steps are ONE coalesced 16-byte load straight from HBM into the registers the MFMA reads,
 //     scaled by a_i b~_j on the way; a row tile's registers are refilled for the next tile as soon as their
-//     group has been issued.  All these loads are unconditional (clamped index): a load under a branch makes
-//     the compiler wait for vmcnt(0) at every later use.
-//   * br: S1o in accumulator order (S1oP[row tile][col tile][lane][4]), one 16-byte load per tile pair.
-//   * score = br . Cout^T and the priority product for the workgroup's tokens together (weights read once,
-//     the reduction index split over the wavefronts, partial sums meet in LDS in a fixed order).
+//     group has been issued.  All these loads are unconditional (clamped index) and pinned in program
+//     order: a load under a branch, or a reordered prologue, makes the compiler wait for vmcnt(0|1) at
+//     every use instead of vmcnt(6).
+//   * br: S1o in accumulator order (S1oP[row tile][col tile][lane][4]) staged once per workgroup in LDS and
+//     read through lgkmcnt, so the tile epilogues never drain the A stream's vmcnt.
+// decomp1_label_kernel -- score = br . Cout^T (:205), the priority product, CRF emissions or the argmax, and
+// the fill values of the dead positions: a few microseconds, weights staged in LDS per workgroup.
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int D1M_MAXNT = 5;            // 16-column tiles of U held in registers: RO <= 80
 constexpr int D1M_MAXKQ4 = 7;           // groups of 4 k-steps per row tile: S <= 112 (register budget)
-constexpr int D1M_TPW = 1;              // tokens per wavefront and work item
-constexpr int D1M_TOK = 4 * D1M_TPW;    // tokens per work item
 
 struct Decomp1MfmaParams {
     Decomp1ScoreParams base;
     const float *BSSp;                  // [V][MT][KQ4][64][4]
     const float *S1oP;                  // [MT][NT][64][4]
     const float *S2oP;                  // [KQ4][NT][64][4]
+    float *br;                          // [B*L][NT*16] out
     int MT, NT, KQ4;                    // row tiles, column tiles, groups of 4 k-steps
-    int *counter;                       // work-item ticket (zeroed on the stream before the launch)
-    int nib;                            // work items per sequence = ceil(L / D1M_TOK)
 };
 
 __global__ void pack_bss_operand_kernel(const float *__restrict__ BSS, float *__restrict__ BSSp, long long total,
@@ -186,26 +189,18 @@ __global__ void pack_s2o_operand_kernel(const float *__restrict__ S2o, float *__
 
 template <int NT>
 __global__ void __launch_bounds__(256, 2)
-decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
+decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
     const Decomp1ScoreParams &p = q.base;
     extern __shared__ __align__(16) float smem[];
-    constexpr int TOK = D1M_TOK, NC = NT * 16;
+    constexpr int NC = NT * 16;
     const int tid = threadIdx.x, lane = tid & 63, nt_ = blockDim.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int S = p.S, SP = p.SP, RO = p.RO, K = p.K, Kc = p.Kc;
+    const int S = p.S, SP = p.SP;
     const int MT = q.MT, KQ4 = q.KQ4, SPa = MT * 16;
-    float *al = smem;                      // [TOK][SPa]
-    float *be = al + TOK * SPa;            // [TOK][SPa]
-    float *br = be + TOK * SPa;            // [TOK][NC]
-    float *scp = br + TOK * NC;            // [TOK][4][Kc] score partials
-    float *sc = scp + TOK * 4 * Kc;        // [TOK][Kc]
-    float *sc2 = sc + TOK * Kc;            // [TOK][Kc]
-    int *xo = (int *)(sc2 + TOK * Kc);     // [TOK] word ids, [TOK] = the work-item ticket (8 ints)
-    float *s1l = (float *)(xo + 8);        // [MT][NT][64][4] S1o in accumulator order
-    static_assert(D1M_TOK < 8, "ticket slot");
+    float *s1l = smem;                               // [MT][NT][64][4] S1o in accumulator order
+    float *al = s1l + MT * NT * 256 + w * 2 * SPa;   // this wavefront's [SPa] a, [SPa] b~
+    float *be = al + SPa;
 
-    // ---- persistent workgroup: the token-independent operands are loaded ONCE -----------------------------
-    // S2o into registers (per wavefront) ...
     const int lr = lane & 15, lk = lane >> 4;
     f32x4_t Bq[D1M_MAXKQ4][NT];
 #pragma unroll
@@ -213,7 +208,6 @@ decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
 #pragma unroll
         for (int n = 0; n < NT; n++)
             Bq[g][n] = *(const f32x4_t *)(q.S2oP + ((long long)((g < KQ4 ? g : KQ4 - 1) * NT + n) * 64 + lane) * 4);
-    // ... and S1oP into LDS: read by the tile epilogues through lgkmcnt, so they never drain the A stream's vmcnt
     for (int base = 0; base < MT * NT * 64; base += 8 * nt_) {
         f32x4_t v[8];
 #pragma unroll
@@ -227,69 +221,68 @@ decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
             if (e < MT * NT * 64) *(f32x4_t *)(s1l + e * 4) = v[u];
         }
     }
-    for (int idx = tid; idx < 2 * TOK * SPa; idx += nt_) al[idx] = 0.0f;          // al | be contiguous; pads stay 0
-    const int nitems = q.nib * p.B;
-
-  for (;;) {
-    // work items (D1M_TOK consecutive positions of one sequence) are handed out by ticket: workgroups that
-    // draw short or empty items simply come back sooner, so the matrix cores stay fed to the end
+    for (int idx = lane; idx < 2 * SPa; idx += WAVE) al[idx] = 0.0f;           // pads stay 0
     __syncthreads();
-    if (tid == 0) xo[TOK] = atomicAdd(q.counter, 1);
-    __syncthreads();
-    const int item = xo[TOK];
-    if (item >= nitems) break;
-    const int b = item / q.nib, i0 = (item - b * q.nib) * TOK;
-    const int len = clamp_len(p.len[b], p.L);
-    const int nsteps = p.full ? p.L : len;
-    for (int t = 0; t < TOK; t++) {                    // positions past the end of the row
-        const int i = i0 + t;
-        if (i < p.L && i >= nsteps) {
-            if (p.tags && tid == 0) p.tags[(long long)b * p.L + i] = -1;
-            if (p.scores) for (int c = tid; c < K; c += nt_) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
+    // live tokens in flat order: [offs[b], offs[b+1]) belongs to sequence b (every position in full mode)
+    const long long total = p.full ? (long long)p.B * p.L : p.offs[p.B];
+    const long long nw = (long long)gridDim.x * 4, wid = (long long)blockIdx.x * 4 + w;
+    const long long f0 = total * wid / nw, f1 = total * (wid + 1) / nw;
+    int b = 0;
+    long long ob = 0, ob1 = 0;
+    if (!p.full && f0 < f1) {
+        int lo = 0, hi = p.B - 1;                      // largest b with offs[b] <= f0
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (p.offs[mid] <= f0) lo = mid; else hi = mid - 1;
         }
+        b = lo; ob = p.offs[b]; ob1 = p.offs[b + 1];
     }
-    if (i0 >= nsteps) continue;
-    const int ntok = nsteps - i0 < TOK ? nsteps - i0 : TOK;
-    if (tid < TOK) xo[tid] = tid < ntok ? (int)clamp_tok(p.x[(long long)b * p.L + i0 + tid], p.V) : 0;
-    for (int idx = tid; idx < ntok * S; idx += nt_) {
-        const int t = idx / S, s = idx - t * S, i = i0 + t;
+    for (long long f = f0; f < f1; f++) {
+        int i;
+        if (p.full) { b = (int)(f / p.L); i = (int)(f - (long long)b * p.L); }
+        else {
+            while (ob1 <= f) { b++; ob = ob1; ob1 = p.offs[b + 1]; }
+            i = (int)(f - ob);
+        }
+        const int item = b * p.L + i;
+        const int len = clamp_len(p.len[b], p.L);
+        const int xw = (int)clamp_tok(p.x[(long long)b * p.L + i], p.V);
         const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
-        al[t * SPa + s] = p.A[((long long)b * (p.L + 1) + i) * SP + s];
-        be[t * SPa + s] = p.Bk[((long long)b * (p.L + 1) + bidx) * SP + s];
-    }
-    __syncthreads();
-
-    // ---- U = abw . S2o on the matrix cores; br straight from the accumulators  (:201-204) ----------------
-    for (int tt = 0; tt < D1M_TPW; tt++) {
-        const int t = w * D1M_TPW + tt;
-        if (t >= ntok) {
-            for (int c = lane; c < NC; c += WAVE) br[t * NC + c] = 0.0f;
-            continue;
+        for (int s = lane; s < S; s += WAVE) {
+            al[s] = p.A[((long long)b * (p.L + 1) + i) * SP + s];
+            be[s] = p.Bk[((long long)b * (p.L + 1) + bidx) * SP + s];
         }
-        const float *ap = q.BSSp + (long long)xo[t] * MT * KQ4 * 256 + lane * 4;
-        const float *bet = be + t * SPa + lk;
+        // ---- U = abw . S2o on the matrix cores; br straight from the accumulators  (:201-204) ------------
+        const float *ap = q.BSSp + (long long)xw * MT * KQ4 * 256 + lane * 4;
+        const float *bet = be + lk;
         f32x4_t A[D1M_MAXKQ4];
 #pragma unroll
         for (int g = 0; g < D1M_MAXKQ4; g++) A[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         float brl[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) brl[n] = 0.0f;
-        // pass mt = -1 only issues the first row tile's loads, in the same program order as every later
-        // refill (a separate prologue gets reordered by the compiler and its wait counts merged into the
-        // loop's: vmcnt(1) instead of vmcnt(7) at the head of every tile)
+        // b~ of a k-group is read from LDS one group ahead of its use (the wrap-around read serves the next
+        // row tile), so the only wait in front of the MFMAs is for data requested 20 MFMAs earlier
+        float bj[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) bj[u] = bet[u * 4];
+        // pass mt = -1 only issues the first row tile's loads, in the same program order as every later refill
         for (int mt = -1; mt < MT; mt++) {
             const bool act = mt >= 0;
             f32x4_t acc[NT];
 #pragma unroll
             for (int n = 0; n < NT; n++) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const float ai = al[t * SPa + (act ? mt : 0) * 16 + lr];
+            const float ai = al[(act ? mt : 0) * 16 + lr];
             const float *an = ap + (long long)(mt + 1 < MT ? mt + 1 : mt) * KQ4 * 256;
 #pragma unroll
             for (int g = 0; g < D1M_MAXKQ4; g++) {
-                if (act && g < KQ4) {
-                    float bj[4];
+                float bjn[4];
+                {
+                    const int gn = (g + 1 < D1M_MAXKQ4 && g + 1 < KQ4) ? g + 1 : 0;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) bj[u] = bet[g * 16 + u * 4];
+                    for (int u = 0; u < 4; u++) bjn[u] = bet[gn * 16 + u * 4];
+                }
+                if (act && g < KQ4) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
                         const float a = (ai * bj[u]) * A[g][u];                          // :202-203
@@ -300,6 +293,8 @@ decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
                 }
                 A[g] = *(const f32x4_t *)(an + (g < KQ4 ? g : KQ4 - 1) * 256);           // next row tile
                 __builtin_amdgcn_sched_barrier(0);          // keep the refills in program order (vmcnt is in-order)
+#pragma unroll
+                for (int u = 0; u < 4; u++) bj[u] = bjn[u];
             }
             // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}
             if (act)
@@ -310,96 +305,156 @@ decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
                 for (int r = 0; r < 4; r++) brl[n] = fmaf(s1[r], acc[n][r], brl[n]);
             }
         }
+        float *bo = q.br + (long long)item * NC;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             float v = brl[n];
             v += __shfl_xor(v, 16, WAVE);
             v += __shfl_xor(v, 32, WAVE);
-            if (lk == 0) br[t * NC + n * 16 + lr] = v;
+            if (lk == 0) bo[n * 16 + lr] = v;
         }
     }
-    __syncthreads();
-    // score = br . Cout^T (:205): the output ranks are split over the four wavefronts; all of a lane's loads
-    // of a column are in flight together
-    constexpr int UB = 8;
-    {
-        const int per = (RO + 3) / 4;
-        const int q0 = w * per, q1 = q0 + per < RO ? q0 + per : RO;
-        for (int c = lane; c < K; c += WAVE) {
-            float s[TOK];
+}
+
+inline size_t decomp1_mfma_lds_bytes(int MT, int NT) {
+    return ((size_t)MT * NT * 256 + 4 * 2 * (size_t)MT * 16) * 4;
+}
+
+// score = br . Cout^T (:205), priority product, emissions / argmax, one position per wavefront at a time; the
+// weights are staged in LDS once per workgroup (STAGED) or read through the caches when they do not fit.
+template <bool STAGED>
+__global__ void __launch_bounds__(1024)
+decomp1_label_kernel(const Decomp1ScoreParams p, const float *__restrict__ brg, int NC,
+                     const int64_t *__restrict__ offs_all) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, nt_ = blockDim.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int RO = p.RO, K = p.K, Kc = p.Kc;
+    float *brl = smem + w * (NC + 2 * Kc);        // [NC] this wavefront's br row
+    float *sc = brl + NC;                         // [Kc]
+    float *sc2 = sc + Kc;                         // [Kc]
+    const int nwv = nt_ >> 6;                     // wavefronts per workgroup (they share the staged weights)
+    float *Ct = smem + nwv * (NC + 2 * Kc);       // [RO][Kc]
+    float *Pl = Ct + RO * Kc;                     // [K][Kc]
+    if (STAGED) {
+        // 16-byte copies, 8 in flight per lane (Kc is a multiple of 64; Ct and Pl are contiguous in LDS)
+        const int n4 = RO * Kc / 4, m4 = p.P ? K * Kc / 4 : 0;
+        for (int base = 0; base < n4 + m4; base += 8 * nt_) {
+            f32x4_t v[8];
 #pragma unroll
-            for (int t = 0; t < TOK; t++) s[t] = 0.0f;
-            for (int qb = q0; qb < q1; qb += UB) {
-                float cv[UB];
-#pragma unroll
-                for (int u = 0; u < UB; u++) cv[u] = qb + u < q1 ? p.CoutT[(long long)(qb + u) * Kc + c] : 0.0f;
-#pragma unroll
-                for (int u = 0; u < UB; u++)
-                    if (qb + u < q1) {
-#pragma unroll
-                        for (int t = 0; t < TOK; t++) s[t] = fmaf(br[t * NC + qb + u], cv[u], s[t]);
-                    }
+            for (int u = 0; u < 8; u++) {
+                const int e = base + u * nt_ + tid;
+                const float *src = e < n4 ? p.CoutT + (long long)e * 4 : p.P + (long long)(e < n4 + m4 ? e - n4 : 0) * 4;
+                v[u] = *(const f32x4_t *)(e < n4 + m4 ? src : p.CoutT);
             }
 #pragma unroll
-            for (int t = 0; t < TOK; t++) scp[(t * 4 + w) * Kc + c] = s[t];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < ntok * Kc; idx += nt_) {
-            const int t = idx / Kc, c = idx - t * Kc;
-            const float *sq = scp + t * 4 * Kc + c;
-            sc[idx] = c < K ? (sq[0] + sq[Kc]) + (sq[2 * Kc] + sq[3 * Kc]) : 0.0f;
-        }
-    }
-    __syncthreads();
-    const float *fin = sc;
-    if (p.P) {
-        // scores . P (:207 priority): same split, over the label index
-        const int per = (K + 3) / 4;
-        const int c0 = w * per, c1 = c0 + per < K ? c0 + per : K;
-        for (int d = lane; d < K; d += WAVE) {
-            float s[TOK];
-#pragma unroll
-            for (int t = 0; t < TOK; t++) s[t] = 0.0f;
-            for (int cb = c0; cb < c1; cb += UB) {
-                float pv[UB];
-#pragma unroll
-                for (int u = 0; u < UB; u++) pv[u] = cb + u < c1 ? p.P[(long long)(cb + u) * Kc + d] : 0.0f;
-#pragma unroll
-                for (int u = 0; u < UB; u++)
-                    if (cb + u < c1) {
-#pragma unroll
-                        for (int t = 0; t < TOK; t++) s[t] = fmaf(sc[t * Kc + cb + u], pv[u], s[t]);
-                    }
+            for (int u = 0; u < 8; u++) {
+                const int e = base + u * nt_ + tid;
+                if (e < n4 + m4) *(f32x4_t *)(Ct + e * 4) = v[u];
             }
-#pragma unroll
-            for (int t = 0; t < TOK; t++) scp[(t * 4 + w) * Kc + d] = s[t];
         }
         __syncthreads();
-        for (int idx = tid; idx < ntok * Kc; idx += nt_) {
-            const int t = idx / Kc, d = idx - t * Kc;
-            const float *sq = scp + t * 4 * Kc + d;
-            sc2[idx] = d < K ? (sq[0] + sq[Kc]) + (sq[2 * Kc] + sq[3 * Kc]) : 0.0f;
-        }
-        __syncthreads();
-        fin = sc2;
     }
-    // one wavefront per token: scores, CRF emissions or the argmax
     const int clamp_col = p.use_crf ? K - 3 : K - 1;
-    for (int t = w; t < ntok; t += 4) {
-        const int i = i0 + t;
-        const float *ft = fin + t * Kc;
+    const long long gw = (long long)gridDim.x * nwv, wid = (long long)blockIdx.x * nwv + w;
+    // positions past the end of their row: fill values, dealt round-robin
+    if (!p.full && (p.tags || p.scores))
+        for (long long pos = wid; pos < (long long)p.B * p.L; pos += gw) {
+            const int b = (int)(pos / p.L), i = (int)(pos - (long long)b * p.L);
+            if (i >= clamp_len(p.len[b], p.L)) {
+                if (p.tags && lane == 0) p.tags[pos] = -1;
+                if (p.scores) for (int c = lane; c < K; c += WAVE) p.scores[pos * K + c] = 0.0f;
+            }
+        }
+    // live tokens: an equal contiguous slice of the flat order per wavefront (offs_all), or every position
+    const long long total = p.full ? (long long)p.B * p.L : offs_all[p.B];
+    const long long f0 = total * wid / gw, f1 = total * (wid + 1) / gw;
+    int b = 0;
+    long long ob = 0, ob1 = 0;
+    if (!p.full && f0 < f1) {
+        int lo = 0, hi = p.B - 1;                      // largest b with offs[b] <= f0
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (offs_all[mid] <= f0) lo = mid; else hi = mid - 1;
+        }
+        b = lo; ob = offs_all[b]; ob1 = offs_all[b + 1];
+    }
+    for (long long f = f0; f < f1; f++) {
+        int i;
+        if (p.full) { b = (int)(f / p.L); i = (int)(f - (long long)b * p.L); }
+        else {
+            while (ob1 <= f) { b++; ob = ob1; ob1 = offs_all[b + 1]; }
+            i = (int)(f - ob);
+        }
+        const long long pos = (long long)b * p.L + i;
+        const int len = clamp_len(p.len[b], p.L);
+        for (int c = lane; c < NC; c += WAVE) brl[c] = brg[pos * NC + c];
+        // two columns per lane (c, c+64; Kc is a multiple of 64 so the second read stays inside the padded
+        // row) and the reduction unrolled by 8: the LDS reads of a batch are in flight together
+        for (int c = lane; c < K; c += 2 * WAVE) {
+            const bool two = c + WAVE < Kc;
+            float s0 = 0.0f, s1 = 0.0f;
+            int qq = 0;
+            for (; qq + 8 <= RO; qq += 8) {
+                float bq[8], c0[8], c1[8];
+                *(f32x4_t *)&bq[0] = *(const f32x4_t *)(brl + qq);         // broadcast reads, 16 B each
+                *(f32x4_t *)&bq[4] = *(const f32x4_t *)(brl + qq + 4);
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    c0[u] = STAGED ? Ct[(qq + u) * Kc + c] : p.CoutT[(long long)(qq + u) * Kc + c];
+                    c1[u] = !two ? 0.0f : STAGED ? Ct[(qq + u) * Kc + c + WAVE] : p.CoutT[(long long)(qq + u) * Kc + c + WAVE];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { s0 = fmaf(bq[u], c0[u], s0); s1 = fmaf(bq[u], c1[u], s1); }
+            }
+            for (; qq < RO; qq++) {
+                const float bq = brl[qq];
+                s0 = fmaf(bq, STAGED ? Ct[qq * Kc + c] : p.CoutT[(long long)qq * Kc + c], s0);
+                if (two) s1 = fmaf(bq, STAGED ? Ct[qq * Kc + c + WAVE] : p.CoutT[(long long)qq * Kc + c + WAVE], s1);
+            }
+            sc[c] = s0;
+            if (two) sc[c + WAVE] = s1;
+        }
+        const float *fin = sc;
+        if (p.P) {
+            for (int d = lane; d < K; d += 2 * WAVE) {
+                const bool two = d + WAVE < Kc;
+                float s0 = 0.0f, s1 = 0.0f;
+                int c = 0;
+                for (; c + 8 <= K; c += 8) {
+                    float sv[8], p0[8], p1[8];
+                    *(f32x4_t *)&sv[0] = *(const f32x4_t *)(sc + c);
+                    *(f32x4_t *)&sv[4] = *(const f32x4_t *)(sc + c + 4);
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        p0[u] = STAGED ? Pl[(c + u) * Kc + d] : p.P[(long long)(c + u) * Kc + d];
+                        p1[u] = !two ? 0.0f : STAGED ? Pl[(c + u) * Kc + d + WAVE] : p.P[(long long)(c + u) * Kc + d + WAVE];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { s0 = fmaf(sv[u], p0[u], s0); s1 = fmaf(sv[u], p1[u], s1); }
+                }
+                for (; c < K; c++) {
+                    const float sv = sc[c];
+                    s0 = fmaf(sv, STAGED ? Pl[c * Kc + d] : p.P[(long long)c * Kc + d], s0);
+                    if (two) s1 = fmaf(sv, STAGED ? Pl[c * Kc + d + WAVE] : p.P[(long long)c * Kc + d + WAVE], s1);
+                }
+                sc2[d] = s0;
+                if (two) sc2[d + WAVE] = s1;
+            }
+            fin = sc2;
+        }
         if (p.scores)
-            for (int c = lane; c < K; c += WAVE) p.scores[((long long)b * p.L + i) * K + c] = ft[c];
+            for (int c = lane; c < K; c += WAVE) p.scores[(long long)pos * K + c] = fin[c];
         if (p.use_crf) {
             for (int c = lane; c < K; c += WAVE) {
-                float vv = ft[c] + 0.0f;
+                float vv = fin[c] + 0.0f;
                 if (c == clamp_col) vv = fminf(vv, p.threshold);
-                p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
+                p.crf_scores[(long long)pos * p.Kp + c] = vv;
             }
         } else {
             float bv = -INFINITY; int bi = 0x7ffffffe;
             for (int c = lane; c < K; c += WAVE) {
-                float vv = ft[c] + 0.0f;
+                float vv = fin[c] + 0.0f;
                 if (c == clamp_col) vv = fminf(vv, p.threshold);
                 if (vv > bv) { bv = vv; bi = c; }
             }
@@ -407,17 +462,15 @@ decomp1_score_mfma_kernel(const Decomp1MfmaParams q) {
             if (lane == 0) {
                 if (bi >= K) bi = 0;
                 const int tag = (bi == K - 1) ? p.o_idx : bi;
-                if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                if (p.tags) p.tags[pos] = tag;
                 if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
             }
         }
     }
-  }   // work items
 }
 
-inline size_t decomp1_mfma_lds_bytes(int Kc, int MT, int NT) {
-    return ((size_t)2 * D1M_TOK * MT * 16 + D1M_TOK * (size_t)NT * 16 + 6 * (size_t)D1M_TOK * Kc + 8 +
-            (size_t)MT * NT * 256) * 4;
+inline size_t decomp1_label_lds_bytes(int NC, int RO, int K, int Kc, bool staged, int nwaves) {
+    return ((size_t)nwaves * (NC + 2 * (size_t)Kc) + (staged ? ((size_t)RO + K) * Kc : 0)) * 4;
 }
 
 inline size_t decomp1_score_lds_bytes(int S, int SP, int Rp, int ROp, int Kc) {

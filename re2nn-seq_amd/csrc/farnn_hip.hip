@@ -49,12 +49,12 @@ struct farnn_model {
     float *d1_BSSp = nullptr;               // [V][MT][KQ4][64][4] per-word bss = sum_r S1 S2 v + W in MFMA operand order
     float *d1_S1oP = nullptr;               // [MT][NT][64][4] S1o in MFMA accumulator order
     float *d1_S2oP = nullptr;               // [KQ4][NT][64][4] S2o in MFMA operand order
-    int *d1_ticket = nullptr;               // work-item counter of the persistent scoring kernel
     int n_cu = 0;                           // compute units of the device (persistent launches)
     int RW = 0, RWp = 0;                    // decomposed independent=0: wildcard factors + label factor
     float *d0_Vgen = nullptr, *d0_CT = nullptr, *d0_S1w = nullptr, *d0_S2w = nullptr, *d0_CwT = nullptr;
     // workspace
     float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
+    float *d1_br = nullptr;                 // [B*L][NT*16] output-rank vector of every position (decomposed independent=1)
     int64_t *offs = nullptr;
     int *order = nullptr;
     int wsB = 0, wsL = 0;
@@ -247,7 +247,9 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
         FARNN_HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); (void)hipFree(m->order);
         if (m->crf_scores) (void)hipFree(m->crf_scores);
+        if (m->d1_br) (void)hipFree(m->d1_br);
     }
+    m->d1_br = nullptr;
     m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->wsB = m->wsL = 0;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
@@ -256,6 +258,8 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
+    if (m->d1_BSSp)
+        FARNN_HIP_TRY(hipMalloc((void **)&m->d1_br, (size_t)nB * nL * ((m->RO + 15) / 16 * 16) * sizeof(float)));
     FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
     FARNN_HIP_TRY(hipMemset(m->Bk, 0, stash));
     FARNN_HIP_TRY(hipDeviceSynchronize());
@@ -321,7 +325,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
             return "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
-                              : (m->kind == KIND_DECOMP1 ? "decomp1_score_kernel"
+                              : (m->kind == KIND_DECOMP1 ? (m->d1_BSSp ? "decomp1_br_mfma_kernel+decomp1_label_kernel" : "decomp1_score_kernel")
                               : (m->kind == KIND_DECOMP0 ? "decomp0_score_kernel"
                               : (m->use_crf ? "score_tile_kernel+viterbi_kernel" : "score_tile_kernel"))));
         case KERN_PREP:  return "batch_prep_kernel";
@@ -523,30 +527,42 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     int rc;
     KernelTimer kt(m, KERN_SCORE, s);
     Decomp1MfmaParams qm;
-    qm.base = p; qm.BSSp = m->d1_BSSp; qm.S1oP = m->d1_S1oP; qm.S2oP = m->d1_S2oP;
+    qm.base = p; qm.BSSp = m->d1_BSSp; qm.S1oP = m->d1_S1oP; qm.S2oP = m->d1_S2oP; qm.br = m->d1_br;
+    if (!full) qm.base.offs = m->offs;       // farnn_tag computes the flat offsets for this path even without flat output
     qm.MT = (m->S + 15) / 16; qm.NT = (m->RO + 15) / 16; qm.KQ4 = (m->S + 15) / 16;
-    qm.counter = m->d1_ticket; qm.nib = (p.L + D1M_TOK - 1) / D1M_TOK;
-    const size_t mlds = decomp1_mfma_lds_bytes(m->Kc, qm.MT, qm.NT);
-    if (m->d1_BSSp && mlds <= 80 * 1024) {
-        // persistent: two workgroups per CU draw work items by ticket
+    const size_t mlds = decomp1_mfma_lds_bytes(qm.MT, qm.NT);
+    if (m->d1_BSSp && m->d1_br && mlds <= 80 * 1024) {
+        // persistent: two workgroups per CU, every wavefront owns a contiguous slice of the live tokens
         if (m->n_cu <= 0) {
             int dev = 0, ncu = 0;
             FARNN_HIP_TRY(hipGetDevice(&dev));
             FARNN_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
             m->n_cu = ncu > 0 ? ncu : 256;
         }
-        const int nwg = std::min(2 * m->n_cu, qm.nib * B);
-        FARNN_HIP_TRY(hipMemsetAsync(m->d1_ticket, 0, sizeof(int), s));
+        const int nwg = std::min(2 * m->n_cu, (B * p.L + 3) / 4);
 #define FARNN_LAUNCH_D1M(N)                                                                    \
         case N:                                                                               \
-            if ((rc = raise_lds_limit(decomp1_score_mfma_kernel<N>, mlds))) return rc;        \
-            decomp1_score_mfma_kernel<N><<<dim3(nwg), dim3(256), mlds, s>>>(qm);              \
+            if ((rc = raise_lds_limit(decomp1_br_mfma_kernel<N>, mlds))) return rc;           \
+            decomp1_br_mfma_kernel<N><<<dim3(nwg), dim3(256), mlds, s>>>(qm);                 \
             break;
         switch (qm.NT) {
             FARNN_LAUNCH_D1M(1) FARNN_LAUNCH_D1M(2) FARNN_LAUNCH_D1M(3) FARNN_LAUNCH_D1M(4) FARNN_LAUNCH_D1M(5)
             default: return fail(FARNN_ERANGE, "decomp_ind1: output rank above 80 on the MFMA path%s%s");
         }
 #undef FARNN_LAUNCH_D1M
+        FARNN_HIP_TRY(hipGetLastError());
+        const int NC = qm.NT * 16;
+        // one 16-wavefront workgroup per CU when the weights fit in LDS beside the per-wavefront rows
+        const bool staged = decomp1_label_lds_bytes(NC, m->RO, m->K, m->Kc, true, 16) <= 150 * 1024;
+        const int lthreads = staged ? 1024 : 256;
+        const size_t llds = decomp1_label_lds_bytes(NC, m->RO, m->K, m->Kc, staged, lthreads / 64);
+        const int lgrid = std::min((staged ? 1 : 4) * m->n_cu, (B * p.L + lthreads / 64 - 1) / (lthreads / 64));
+        if (staged) {
+            if ((rc = raise_lds_limit(decomp1_label_kernel<true>, llds))) return rc;
+            decomp1_label_kernel<true><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, full ? nullptr : m->offs);
+        } else {
+            decomp1_label_kernel<false><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, full ? nullptr : m->offs);
+        }
     } else {
         const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
         if ((rc = raise_lds_limit(decomp1_score_kernel, lds))) return rc;
@@ -660,17 +676,19 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                         !env_int("FARNN_PREP", 0);
     m->order_valid = want_order && !m->prep_in_kernel;
     m->sort_in_kernel = want_order && m->prep_in_kernel;
-    if ((flat_tags || want_order) && !m->prep_in_kernel) {
+    // the decomposed independent=1 scoring kernel slices the batch by flat offsets even when no flat output is asked for
+    const bool want_offs = flat_tags || (m->kind == KIND_DECOMP1 && m->d1_BSSp && !full);
+    if ((want_offs || want_order) && !m->prep_in_kernel) {
         KernelTimer kt(m, KERN_PREP, s);
         if (B <= 1024) {
             int G = 1;
             while (G < 16 && B * G * 2 <= 1024) G *= 2;               // lanes per sequence
             batch_prep_small_kernel<<<1, round_up(B * G, 64), 0, s>>>(
-                lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L, G);
+                lengths, want_offs ? m->offs : nullptr, want_order ? m->order : nullptr, B, L, G);
         }
         else
             batch_prep_kernel<<<1, 1024, (size_t)(L + 2) * sizeof(int), s>>>(
-                lengths, flat_tags ? m->offs : nullptr, want_order ? m->order : nullptr, B, L);
+                lengths, want_offs ? m->offs : nullptr, want_order ? m->order : nullptr, B, L);
         FARNN_HIP_TRY(hipGetLastError());
     }
     switch (m->kind) {
@@ -1098,7 +1116,6 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
         rc = dev_alloc(m, (void **)&m->d1_BSSp, (size_t)total * 4);
         if (!rc) rc = dev_alloc(m, (void **)&m->d1_S1oP, (size_t)MT * NT * 256 * 4);
         if (!rc) rc = dev_alloc(m, (void **)&m->d1_S2oP, (size_t)KQ4 * NT * 256 * 4);
-        if (!rc) rc = dev_alloc(m, (void **)&m->d1_ticket, 256);
         if (!rc) {
             pack_s2o_operand_kernel<<<(KQ4 * NT * 256 + 255) / 256, 256>>>(m->d1_S2o, m->d1_S2oP, KQ4 * NT * 256,
                                                                           m->S, m->RO, m->ROp, NT);
@@ -1192,6 +1209,7 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->offs) (void)hipFree(m->offs);
     if (m->order) (void)hipFree(m->order);
     if (m->crf_scores) (void)hipFree(m->crf_scores);
+    if (m->d1_br) (void)hipFree(m->d1_br);
     delete m;
 }
 
