@@ -1248,7 +1248,8 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     if (!m) return 0.0;
     const double S = m->S, C = m->C, R = m->R, K = m->K, n = (double)valid_tokens;
     if (which == KERN_CHAIN) {
-        if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0) return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
+        if (!m->dense_decomp && (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0))
+            return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
         return (2.0 * S * S * 4 + 8) * n;                 // one block per direction + the token id
     }
     if (which == KERN_SCORE) {

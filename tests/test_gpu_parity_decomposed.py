@@ -202,6 +202,76 @@ def test_decomposed_independent1_ragged_vs_oracle():
     assert (t[:, :Lmax][~mask] == -1).all()
 
 
+@pytest.mark.parametrize('S,RO,K,B,L,prio,crf', [
+    (100, 70, 73, 24, 20, True, False),     # the bench geometry: 7 row tiles, 5 column tiles, 2 label columns per lane
+    (112, 80, 130, 9, 12, False, False),    # largest shape of the MFMA path; 3 label-column passes
+    (16, 16, 5, 5, 9, True, False),         # one tile of everything
+    (17, 15, 7, 3, 6, False, True),         # ragged tiles, CRF emissions
+    (113, 20, 9, 4, 7, True, False),        # S above the register budget: generic kernel
+    (30, 81, 9, 4, 7, False, False),        # output rank above 80: generic kernel
+    (40, 33, 70, 1, 33, True, False),       # one sequence
+])
+def test_decomposed_independent1_scoring_geometries_vs_oracle(S, RO, K, B, L, prio, crf):
+    """The independent=1 scoring kernels (per-word table on the f32 MFMA + label kernel, and the generic
+    fallback) over tile-boundary shapes, with empty sequences, against the oracle; FULL mode too."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(S * 7 + RO)
+    V, R = 60, 12
+    p = {'Vgen': (rng.randn(V, R) * 0.4).astype(np.float32), 'S1': (rng.randn(S, R) * 0.3).astype(np.float32),
+         'S2': (rng.randn(S, R) * 0.3).astype(np.float32), 'W': (rng.rand(S, S) < 0.1).astype(np.float32) * 0.5,
+         'Cout': (rng.randn(K, RO) * 0.5).astype(np.float32), 'S1o': (rng.randn(S, RO) * 0.1).astype(np.float32),
+         'S2o': (rng.randn(S, RO) * 0.1).astype(np.float32), 'Wo': None,
+         'h0': np.eye(S, dtype=np.float32)[0], 'hT': (rng.rand(S) < 0.3).astype(np.float32),
+         'farnn': 0, 'nl': fo.NL_CODES['tanh'], 'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+    P = (np.eye(K) + (rng.rand(K, K) < 0.05) * 0.5).astype(np.float32) if prio else None
+    tr = None
+    if crf:
+        tr = fo.crf_default_transitions(K - 2) + (rng.randn(K, K) * 0.1).astype(np.float32)
+        tr[:, K - 2] = -10000.0
+        tr[K - 1, :] = -10000.0
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    if B > 3:
+        lengths[1] = 0                                   # an empty sequence in the middle of the batch
+        lengths[B - 1] = L
+    h = _lib.create_decomp_ind1(p['Vgen'], p['S1'], p['S2'], p['W'], p['Cout'], p['S1o'], p['S2o'],
+                                p['h0'], p['hT'], P=P, nl='tanh', threshold=0.5, o_idx=2, use_crf=crf,
+                                crf_trans=tr)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+    flat = torch.empty((max(int(lengths.sum()), 1),), dtype=torch.int64, device='cuda')
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(),
+          scores.data_ptr())
+    torch.cuda.synchronize()
+    Lmax = max(int(lengths.max()), 1)
+    ref = fo.decomp_ind1_scores(p, x, lengths, P=P)
+    got = scores.cpu().numpy()[:, :Lmax]
+    mask = np.arange(Lmax)[None, :] < lengths[:, None]
+    np.testing.assert_allclose(got[mask], ref[mask], rtol=2e-4, atol=2e-4)
+    assert (scores.cpu().numpy()[~(np.arange(L)[None, :] < lengths[:, None])] == 0).all()
+    want = fo.forward_local_tags(got, lengths, 0.5, 2, crf_tr=tr)     # decode the kernel's own scores: exact
+    assert np.array_equal(flat.cpu().numpy()[:int(lengths.sum())], want)
+    if not crf:
+        t = tags.cpu().numpy()
+        assert (t[~(np.arange(L)[None, :] < lengths[:, None])] == -1).all()
+        assert np.array_equal(t[np.arange(L)[None, :] < lengths[:, None]], want)
+    # the same call without flat output or scores (the flat offsets are still needed to slice the batch)
+    tags2 = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags2.data_ptr(), None, None)
+    torch.cuda.synchronize()
+    if not crf:
+        assert torch.equal(tags2, tags)
+    # FULL mode: every position is scored; the valid ones must agree with LOCAL mode
+    scores_f = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    tags_f = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_FULL, tags_f.data_ptr(), None, scores_f.data_ptr())
+    torch.cuda.synchronize()
+    gf = scores_f.cpu().numpy()
+    assert np.isfinite(gf).all()
+    valid = np.arange(L)[None, :] < lengths[:, None]
+    np.testing.assert_allclose(gf[valid], scores.cpu().numpy()[valid], rtol=2e-4, atol=2e-4)
+
+
 # ---------------------------------------------------------------- decomposed independent=0 (a15)
 def _fst_configs():
     with open(os.path.join(GOLDEN, 'decomp_fst_small.json')) as f:
