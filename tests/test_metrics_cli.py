@@ -76,3 +76,28 @@ def test_args_path_reload_of_reference_example():
     merged = cli.merge_saved_args(a, path)
     assert merged.run == 'final_222' and merged.method == 'decompose' and merged.independent == 2
     assert merged.data_dir == '../data/'
+
+
+def test_vectorised_entity_metrics_equal_the_string_automaton():
+    """get_ner_fmeasure's array form (bio_spans) against the token-by-token string form that follows the
+    reference (metrics.py:184-229), incl. I- tags of another type, spans left open at the end of the list,
+    two ids with one spelling, and the per-class dict's insertion order."""
+    from re2nn_seq_amd.metrics import metrics as M
+    rng = np.random.RandomState(0)
+    i2s = {0: 'o'}
+    for t in ['city', 'time', 'airline', 'x']:
+        i2s[len(i2s)] = 'B-' + t
+        i2s[len(i2s)] = 'I-' + t
+    i2s[len(i2s)] = 'o'
+    nl = len(i2s)
+    for trial in range(300):
+        n = rng.randint(1, 60)
+        gold = rng.randint(0, nl, n)
+        pred = np.where(rng.rand(n) < rng.rand(), gold, rng.randint(0, nl, n))
+        a = M.get_ner_fmeasure(gold, pred, i2s=i2s, all_class=True)
+        b = M._get_ner_fmeasure_strings(gold, pred, i2s, True)
+        assert a[:4] == b[:4] and a[4] == b[4] and list(a[4]) == list(b[4]), (gold, pred)
+    # a B- label with an empty type takes the string path
+    i2s[nl] = 'B-'
+    gold = rng.randint(0, nl + 1, 50)
+    assert M.get_ner_fmeasure(gold, gold, i2s=i2s, all_class=True) == M._get_ner_fmeasure_strings(gold, gold, i2s, True)
