@@ -151,7 +151,7 @@ struct Decomp1MfmaParams {
     const float *BSSp;                  // [V][MT][KQ4][64][4]
     const float *S1oP;                  // [MT][NT][64][4]
     const float *S2oP;                  // [KQ4][NT][64][4]
-    float *br;                          // [B*L][NT*16] out
+    float *br;                          // [B*L][MT][NT*16] out: per-row-tile partial br
     int MT, NT, KQ4;                    // row tiles, column tiles, groups of 4 k-steps
 };
 
@@ -197,6 +197,7 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int S = p.S, SP = p.SP;
     const int MT = q.MT, KQ4 = q.KQ4, SPa = MT * 16;
+    const int klast = (S + 3) / 4 - (KQ4 - 1) * 4;   // k-steps of 4 in the last group that hold data (1..4)
     float *s1l = smem;                               // [MT][NT][64][4] S1o in accumulator order
     float *al = s1l + MT * NT * 256 + w * 2 * SPa;   // this wavefront's [SPa] a, [SPa] b~
     float *be = al + SPa;
@@ -226,10 +227,14 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
     // live tokens in flat order: [offs[b], offs[b+1]) belongs to sequence b (every position in full mode)
     const long long total = p.full ? (long long)p.B * p.L : p.offs[p.B];
     const long long nw = (long long)gridDim.x * 4, wid = (long long)blockIdx.x * 4 + w;
-    const long long f0 = total * wid / nw, f1 = total * (wid + 1) / nw;
+    // the unit of work is one row tile of one token (total * MT units, an equal contiguous run per wavefront:
+    // whole tokens would quantise 4.3 tokens per wavefront to 5); a token's tiles may end up on two wavefronts,
+    // so every tile writes its own partial br row and the label kernel adds them in tile order
+    const long long u0 = total * MT * wid / nw, u1 = total * MT * (wid + 1) / nw;
+    const long long f0 = u0 / MT;
     int b = 0;
     long long ob = 0, ob1 = 0;
-    if (!p.full && f0 < f1) {
+    if (!p.full && u0 < u1) {
         int lo = 0, hi = p.B - 1;                      // largest b with offs[b] <= f0
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
@@ -237,7 +242,11 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
         }
         b = lo; ob = p.offs[b]; ob1 = p.offs[b + 1];
     }
-    for (long long f = f0; f < f1; f++) {
+    for (long long u = u0; u < u1;) {
+        const long long f = u / MT;
+        const int mt0 = (int)(u - f * MT);
+        const int mt1 = (int)(u1 - u < MT - mt0 ? mt0 + (u1 - u) : MT);      // this token's tiles [mt0, mt1)
+        u += mt1 - mt0;
         int i;
         if (p.full) { b = (int)(f / p.L); i = (int)(f - (long long)b * p.L); }
         else {
@@ -258,22 +267,19 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
         f32x4_t A[D1M_MAXKQ4];
 #pragma unroll
         for (int g = 0; g < D1M_MAXKQ4; g++) A[g] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        float brl[NT];
-#pragma unroll
-        for (int n = 0; n < NT; n++) brl[n] = 0.0f;
         // b~ of a k-group is read from LDS one group ahead of its use (the wrap-around read serves the next
         // row tile), so the only wait in front of the MFMAs is for data requested 20 MFMAs earlier
         float bj[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) bj[u] = bet[u * 4];
-        // pass mt = -1 only issues the first row tile's loads, in the same program order as every later refill
-        for (int mt = -1; mt < MT; mt++) {
-            const bool act = mt >= 0;
+        // pass mt0 - 1 only issues the first row tile's loads, in the same program order as every later refill
+        for (int mt = mt0 - 1; mt < mt1; mt++) {
+            const bool act = mt >= mt0;
             f32x4_t acc[NT];
 #pragma unroll
             for (int n = 0; n < NT; n++) acc[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            const float ai = al[(act ? mt : 0) * 16 + lr];
-            const float *an = ap + (long long)(mt + 1 < MT ? mt + 1 : mt) * KQ4 * 256;
+            const float ai = al[(act ? mt : mt0) * 16 + lr];
+            const float *an = ap + (long long)(mt + 1 < mt1 ? mt + 1 : mt1 - 1) * KQ4 * 256;
 #pragma unroll
             for (int g = 0; g < D1M_MAXKQ4; g++) {
                 float bjn[4];
@@ -283,12 +289,17 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
                     for (int u = 0; u < 4; u++) bjn[u] = bet[gn * 16 + u * 4];
                 }
                 if (act && g < KQ4) {
+                    // all-padding k-steps are skipped in the last register group (compile-time position: guards in
+                    // every group cost 40 spilled registers)
+                    const int nu = g == D1M_MAXKQ4 - 1 ? klast : 4;
 #pragma unroll
                     for (int u = 0; u < 4; u++) {
-                        const float a = (ai * bj[u]) * A[g][u];                          // :202-203
+                        if (g < D1M_MAXKQ4 - 1 || u < nu) {
+                            const float a = (ai * bj[u]) * A[g][u];                      // :202-203
 #pragma unroll
-                        for (int n = 0; n < NT; n++)
-                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bq[g][n][u], acc[n], 0, 0, 0);
+                            for (int n = 0; n < NT; n++)
+                                acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bq[g][n][u], acc[n], 0, 0, 0);
+                        }
                     }
                 }
                 A[g] = *(const f32x4_t *)(an + (g < KQ4 ? g : KQ4 - 1) * 256);           // next row tile
@@ -296,22 +307,20 @@ decomp1_br_mfma_kernel(const Decomp1MfmaParams q) {
 #pragma unroll
                 for (int u = 0; u < 4; u++) bj[u] = bjn[u];
             }
-            // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}
-            if (act)
+            // D: column = n*16 + lr, rows = mt*16 + lk*4 + {0..3}; this tile's share of br_q (:204)
+            if (act) {
+                float *bo = q.br + ((long long)item * MT + mt) * NC;
 #pragma unroll
-            for (int n = 0; n < NT; n++) {
-                const f32x4_t s1 = *(const f32x4_t *)(s1l + ((mt * NT + n) * 64 + lane) * 4);
+                for (int n = 0; n < NT; n++) {
+                    const f32x4_t s1 = *(const f32x4_t *)(s1l + ((mt * NT + n) * 64 + lane) * 4);
+                    float v = 0.0f;
 #pragma unroll
-                for (int r = 0; r < 4; r++) brl[n] = fmaf(s1[r], acc[n][r], brl[n]);
+                    for (int r = 0; r < 4; r++) v = fmaf(s1[r], acc[n][r], v);
+                    v += __shfl_xor(v, 16, WAVE);
+                    v += __shfl_xor(v, 32, WAVE);
+                    if (lk == 0) bo[n * 16 + lr] = v;
+                }
             }
-        }
-        float *bo = q.br + (long long)item * NC;
-#pragma unroll
-        for (int n = 0; n < NT; n++) {
-            float v = brl[n];
-            v += __shfl_xor(v, 16, WAVE);
-            v += __shfl_xor(v, 32, WAVE);
-            if (lk == 0) bo[n * 16 + lr] = v;
         }
     }
 }
@@ -324,7 +333,7 @@ inline size_t decomp1_mfma_lds_bytes(int MT, int NT) {
 // weights are staged in LDS once per workgroup (STAGED) or read through the caches when they do not fit.
 template <bool STAGED>
 __global__ void __launch_bounds__(1024)
-decomp1_label_kernel(const Decomp1ScoreParams p, const float *__restrict__ brg, int NC,
+decomp1_label_kernel(const Decomp1ScoreParams p, const float *__restrict__ brg, int NC, int MT,
                      const int64_t *__restrict__ offs_all) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, nt_ = blockDim.x;
@@ -388,7 +397,11 @@ decomp1_label_kernel(const Decomp1ScoreParams p, const float *__restrict__ brg, 
         }
         const long long pos = (long long)b * p.L + i;
         const int len = clamp_len(p.len[b], p.L);
-        for (int c = lane; c < NC; c += WAVE) brl[c] = brg[pos * NC + c];
+        for (int c = lane; c < NC; c += WAVE) {         // br = sum of the row tiles' partial rows, in tile order
+            float v = 0.0f;
+            for (int mt = 0; mt < MT; mt++) v += brg[(pos * MT + mt) * NC + c];
+            brl[c] = v;
+        }
         // two columns per lane (c, c+64; Kc is a multiple of 64 so the second read stays inside the padded
         // row) and the reduction unrolled by 8: the LDS reads of a batch are in flight together
         for (int c = lane; c < K; c += 2 * WAVE) {

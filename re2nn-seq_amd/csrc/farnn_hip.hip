@@ -54,7 +54,7 @@ struct farnn_model {
     float *d0_Vgen = nullptr, *d0_CT = nullptr, *d0_S1w = nullptr, *d0_S2w = nullptr, *d0_CwT = nullptr;
     // workspace
     float *A = nullptr, *Bk = nullptr, *crf_scores = nullptr;
-    float *d1_br = nullptr;                 // [B*L][NT*16] output-rank vector of every position (decomposed independent=1)
+    float *d1_br = nullptr;                 // [B*L][MT][NT*16] per-row-tile partial output-rank vectors (decomposed independent=1)
     int64_t *offs = nullptr;
     int *order = nullptr;
     int wsB = 0, wsL = 0;
@@ -259,7 +259,7 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     if (m->d1_BSSp)
-        FARNN_HIP_TRY(hipMalloc((void **)&m->d1_br, (size_t)nB * nL * ((m->RO + 15) / 16 * 16) * sizeof(float)));
+        FARNN_HIP_TRY(hipMalloc((void **)&m->d1_br, (size_t)nB * nL * ((m->S + 15) / 16) * ((m->RO + 15) / 16 * 16) * sizeof(float)));
     FARNN_HIP_TRY(hipMemset(m->A, 0, stash));
     FARNN_HIP_TRY(hipMemset(m->Bk, 0, stash));
     FARNN_HIP_TRY(hipDeviceSynchronize());
@@ -559,9 +559,9 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
         const int lgrid = std::min((staged ? 1 : 4) * m->n_cu, (B * p.L + lthreads / 64 - 1) / (lthreads / 64));
         if (staged) {
             if ((rc = raise_lds_limit(decomp1_label_kernel<true>, llds))) return rc;
-            decomp1_label_kernel<true><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, full ? nullptr : m->offs);
+            decomp1_label_kernel<true><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, qm.MT, full ? nullptr : m->offs);
         } else {
-            decomp1_label_kernel<false><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, full ? nullptr : m->offs);
+            decomp1_label_kernel<false><<<dim3(lgrid), dim3(lthreads), llds, s>>>(p, m->d1_br, NC, qm.MT, full ? nullptr : m->offs);
         }
     } else {
         const size_t lds = decomp1_score_lds_bytes(m->S, m->SP, m->Rp, m->ROp, m->Kc);
