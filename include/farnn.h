@@ -238,6 +238,54 @@ int farnn_reserve(farnn_model *m, int32_t B, int32_t L);
 
 void farnn_destroy(farnn_model *m);
 
+/* ---- training step of the decomposed i-FST -----------------------------------
+ * Replaces FARNN_S_D_W_I_S.forward_local(train=True) + loss.backward()
+ * (model_decompose_single.py:207-304, train_decompose.py:186-190) for farnn = 0, the sum semiring and the
+ * CE1 loss without CRF: cross-entropy (mean over the valid tokens) of the scores, and its gradient with
+ * respect to every tensor the recurrence and the scoring read.  The generalized word table Vgen
+ * (model_decompose.py:222-241) is an input; the caller differentiates it from dVgen.
+ * All pointers are DEVICE pointers; matrices are row-major and unpadded. */
+typedef struct farnn_train_ctx farnn_train_ctx;
+
+typedef struct {
+    int32_t V, S, R, K;         /* vocabulary rows of Vgen, states (incl. additional states), rank, score columns */
+    int32_t nl;                 /* FARNN_NL_* (update_nonlinear)                                               */
+    float   threshold;          /* decode clamp of column K-1 (model_decompose.py:365)                         */
+    int32_t o_idx;              /* label written for column K-1 (:367)                                          */
+} farnn_train_dims;
+
+typedef struct {
+    const float *Vgen;          /* [V][R]   */
+    const float *S1, *S2;       /* [S][R]   */
+    const float *W;             /* [S][S] wildcard_mat   */
+    const float *C;             /* [K][S] C_output_mat   */
+    const float *h0, *hT;       /* [S]      */
+    const float *P;             /* [K][K] priority matrix or NULL (args.use_priority = 0) */
+} farnn_train_weights;
+
+typedef struct {
+    float *loss;                /* [1]                                                  */
+    float *dVgen;               /* [V][R]  (rows of words that do not occur stay zero)  */
+    float *dS1, *dS2;           /* [S][R]  */
+    float *dW;                  /* [S][S]  */
+    float *dC;                  /* [K][S]  */
+    float *dh0, *dhT;           /* [S]     */
+    int32_t *tags;              /* [B][L] decoded labels of this forward pass, -1 at pad positions */
+} farnn_train_outputs;
+
+int  farnn_train_create(const farnn_train_dims *dims, int device, farnn_train_ctx **out);
+void farnn_train_destroy(farnn_train_ctx *ctx);
+/* One step on the given stream: zeroes the outputs, runs both chains with the state stash, the loss, the
+ * back-propagation through time and the parameter-gradient reductions.  x, lengths, labels: int64
+ * [B][L], [B], [B][L] (labels outside 0..K-1 are treated as 0; they only matter at valid positions). */
+int  farnn_decomp_ifst_train_step(farnn_train_ctx *ctx, const farnn_train_weights *w, const int64_t *x,
+                                  const int64_t *lengths, const int64_t *labels, int32_t B, int32_t L,
+                                  int64_t valid_tokens, const farnn_train_outputs *out, void *stream);
+/* accumulated HIP-event time of the step's launches since the last call (ms) and the number of steps timed;
+ * profiling is enabled with farnn_train_set_profiling(ctx, 1) */
+int  farnn_train_set_profiling(farnn_train_ctx *ctx, int32_t enable);
+int  farnn_train_time(farnn_train_ctx *ctx, double *total_ms, int64_t *steps);
+
 /* ---- introspection / measurement ----------------------------------------------------- */
 int  farnn_abi_version(void);
 int  farnn_device_count(void);

@@ -92,7 +92,27 @@ class DecompFstDesc(C.Structure):
 
 # every symbol include/farnn.h declares, with its ctypes signature (tests check the exports)
 _vp = C.c_void_p
+class TrainDims(C.Structure):
+    _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('K', C.c_int32), ('nl', C.c_int32),
+                ('threshold', C.c_float), ('o_idx', C.c_int32)]
+
+
+class TrainWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT', 'P')]
+
+
+class TrainOutputs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('loss', 'dVgen', 'dS1', 'dS2', 'dW', 'dC', 'dh0', 'dhT', 'tags')]
+
+
 SIGNATURES = {
+    'farnn_train_create': (C.c_int, [C.POINTER(TrainDims), C.c_int, C.POINTER(C.c_void_p)]),
+    'farnn_train_destroy': (None, [C.c_void_p]),
+    'farnn_decomp_ifst_train_step': (C.c_int, [C.c_void_p, C.POINTER(TrainWeights), C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
+                                               C.POINTER(TrainOutputs), C.c_void_p]),
+    'farnn_train_set_profiling': (C.c_int, [C.c_void_p, C.c_int32]),
+    'farnn_train_time': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     'farnn_onehot_ifst_create': (C.c_int, [C.POINTER(OnehotIfstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_onehot_ifst_create_from_edges': (C.c_int, [C.POINTER(OnehotIfstDesc), C.POINTER(EdgeList), C.c_int,
                                                       C.POINTER(_vp)]),
@@ -382,3 +402,41 @@ def create_decomp_fst(Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P=None, farn
                       int(bool(use_crf)), ptr(crf_trans), 0)
     return _create('farnn_decomp_fst_create', d, device,
                    (Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P, crf_trans, g))
+
+
+class TrainContext:
+    """Owns one farnn_train_ctx* (training step of the decomposed i-FST, include/farnn.h)."""
+
+    def __init__(self, V, S, R, K, nl='none', threshold=0.5, o_idx=0, device=0):
+        d = TrainDims(int(V), int(S), int(R), int(K), NL[nl], float(threshold), int(o_idx))
+        out = C.c_void_p()
+        check(load().farnn_train_create(C.byref(d), int(device), C.byref(out)), 'farnn_train_create')
+        self._raw = out
+        self.dims = (int(V), int(S), int(R), int(K))
+
+    def close(self):
+        if self._raw:
+            load().farnn_train_destroy(self._raw)
+            self._raw = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, weights, x_ptr, len_ptr, labels_ptr, B, L, valid_tokens, outputs, stream=None):
+        """weights / outputs: dicts of device pointers (ints) keyed like the C structs."""
+        w = TrainWeights(**{k: (weights.get(k) or None) for k, _ in TrainWeights._fields_})
+        o = TrainOutputs(**{k: outputs[k] for k, _ in TrainOutputs._fields_})
+        check(load().farnn_decomp_ifst_train_step(self._raw, C.byref(w), x_ptr, len_ptr, labels_ptr, int(B), int(L),
+                                                  int(valid_tokens), C.byref(o), stream),
+              'farnn_decomp_ifst_train_step')
+
+    def set_profiling(self, enable):
+        check(load().farnn_train_set_profiling(self._raw, int(enable)), 'farnn_train_set_profiling')
+
+    def time(self):
+        ms, n = C.c_double(0), C.c_int64(0)
+        check(load().farnn_train_time(self._raw, C.byref(ms), C.byref(n)), 'farnn_train_time')
+        return ms.value, n.value

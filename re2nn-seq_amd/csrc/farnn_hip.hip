@@ -15,6 +15,7 @@
 #include "decomp_chain.hip.h"
 #include "decomp1_score.hip.h"
 #include "decomp_rows.hip.h"
+#include "train.hip.h"
 
 namespace farnn {
 thread_local char g_err[512] = "";
@@ -1211,6 +1212,156 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->crf_scores) (void)hipFree(m->crf_scores);
     if (m->d1_br) (void)hipFree(m->d1_br);
     delete m;
+}
+
+// ---- training step (decomposed i-FST) ------------------------------------------
+struct farnn_train_ctx {
+    farnn_train_dims d;
+    int device = 0;
+    float *ws = nullptr;          // per-batch workspace (zeroed every step)
+    size_t ws_floats = 0;
+    int wsB = 0, wsL = 0;
+    float *S1T = nullptr, *S2T = nullptr, *WT = nullptr, *Osum = nullptr, *dOsum = nullptr;
+    int profiling = 0;
+    double prof_ms = 0.0;
+    int64_t prof_n = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_train_ctx **out) {
+    if (!d || !out) return fail(FARNN_EINVAL, "train_create: null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0) return fail(FARNN_EINVAL, "train_create: bad dimensions%s%s");
+    if (d->nl < FARNN_NL_NONE || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "train_create: bad nonlinearity%s%s");
+    int rc;
+    if ((rc = select_device(device))) return rc;
+    farnn_train_ctx *c = new farnn_train_ctx();
+    c->d = *d; c->device = device;
+    const size_t S = d->S, R = d->R;
+    float *blk = nullptr;
+    if (hipMalloc((void **)&blk, (2 * S * R + S * S + 2 * S) * sizeof(float)) != hipSuccess) {
+        delete c;
+        return fail(FARNN_ENOMEM, "train_create: out of device memory%s%s");
+    }
+    c->S1T = blk; c->S2T = blk + S * R; c->WT = c->S2T + S * R; c->Osum = c->WT + S * S; c->dOsum = c->Osum + S;
+    *out = c;
+    return FARNN_OK;
+}
+
+extern "C" void farnn_train_destroy(farnn_train_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &e : c->pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->S1T) (void)hipFree(c->S1T);
+    delete c;
+}
+
+extern "C" int farnn_train_set_profiling(farnn_train_ctx *c, int32_t enable) {
+    if (!c) return fail(FARNN_EINVAL, "train_set_profiling: null context%s%s");
+    c->profiling = enable;
+    return FARNN_OK;
+}
+
+extern "C" int farnn_train_time(farnn_train_ctx *c, double *total_ms, int64_t *steps) {
+    if (!c || !total_ms || !steps) return fail(FARNN_EINVAL, "train_time: null argument%s%s");
+    FARNN_HIP_TRY(hipSetDevice(c->device));
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    for (auto &e : c->pending) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) { c->prof_ms += ms; c->prof_n++; }
+        (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second);
+    }
+    c->pending.clear();
+    *total_ms = c->prof_ms; *steps = c->prof_n;
+    c->prof_ms = 0.0; c->prof_n = 0;
+    return FARNN_OK;
+}
+
+static void launch_atb(const float *A, const float *Bm, float *out, long long N, int M, int J, hipStream_t s) {
+    if (N <= 0) return;
+    const long long chunk = 512;
+    dim3 grid((M + 31) / 32, (J + 31) / 32, (unsigned)((N + chunk - 1) / chunk));
+    atb_accumulate_kernel<<<grid, 256, 0, s>>>(A, Bm, out, N, M, J, chunk);
+}
+
+extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_train_weights *w, const int64_t *x,
+                                            const int64_t *lengths, const int64_t *labels, int32_t B, int32_t L,
+                                            int64_t valid_tokens, const farnn_train_outputs *o, void *stream) {
+    if (!c || !w || !x || !lengths || !labels || !o) return fail(FARNN_EINVAL, "train_step: null argument%s%s");
+    if (!w->Vgen || !w->S1 || !w->S2 || !w->W || !w->C || !w->h0 || !w->hT)
+        return fail(FARNN_EINVAL, "train_step: null weight%s%s");
+    if (!o->loss || !o->dVgen || !o->dS1 || !o->dS2 || !o->dW || !o->dC || !o->dh0 || !o->dhT || !o->tags)
+        return fail(FARNN_EINVAL, "train_step: null output%s%s");
+    if (B <= 0 || L <= 0 || valid_tokens <= 0) return fail(FARNN_EINVAL, "train_step: B, L and valid_tokens must be positive%s%s");
+    FARNN_HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
+    const size_t N1 = (size_t)B * (L + 1), N0 = (size_t)B * L;
+    const size_t need = N1 * (7 * S + 4 * R) + N0 * (K + S);
+    if (need > c->ws_floats) {
+        if (c->ws) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->ws); c->ws = nullptr; c->ws_floats = 0; }
+        if (hipMalloc((void **)&c->ws, need * sizeof(float)) != hipSuccess)
+            return fail(FARNN_ENOMEM, "train_step: out of device memory for the workspace%s%s");
+        c->ws_floats = need;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (c->profiling && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) (void)hipEventRecord(e0, s);
+
+    TrainParams p;
+    memset(&p, 0, sizeof(p));
+    p.Vgen = w->Vgen; p.S1 = w->S1; p.S2 = w->S2; p.W = w->W; p.C = w->C; p.h0 = w->h0; p.hT = w->hT; p.P = w->P;
+    p.S1T = c->S1T; p.S2T = c->S2T; p.WT = c->WT; p.Osum = c->Osum;
+    p.x = x; p.len = lengths; p.labels = labels;
+    float *q = c->ws;
+    p.A = q; q += N1 * S; p.Bk = q; q += N1 * S; p.GA = q; q += N1 * S; p.GB = q; q += N1 * S;
+    p.Zf = q; q += N1 * S; p.Zb = q; q += N1 * S; p.BBAR = q; q += N1 * S;
+    p.D1f = q; q += N1 * R; p.D1b = q; q += N1 * R; p.Tf = q; q += N1 * R; p.Tb = q; q += N1 * R;
+    p.DS = q; q += N0 * K; p.AB = q; q += N0 * S;
+    p.dVgen = o->dVgen; p.dOsum = c->dOsum; p.dh0 = o->dh0; p.dhT = o->dhT; p.loss = o->loss; p.tags = o->tags;
+    p.B = B; p.L = L; p.V = (int)V; p.S = (int)S; p.R = (int)R; p.K = (int)K; p.nl = c->d.nl; p.o_idx = c->d.o_idx;
+    p.threshold = c->d.threshold; p.inv_tokens = 1.0f / (float)valid_tokens;
+
+    FARNN_HIP_TRY(hipMemsetAsync(c->ws, 0, need * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->loss, 0, sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dVgen, 0, V * R * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dS1, 0, S * R * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dS2, 0, S * R * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dW, 0, S * S * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dC, 0, K * S * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dh0, 0, S * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(o->dhT, 0, S * sizeof(float), s));
+    FARNN_HIP_TRY(hipMemsetAsync(c->dOsum, 0, S * sizeof(float), s));
+
+    transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S1, c->S1T, (int)S, (int)R);
+    transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S2, c->S2T, (int)S, (int)R);
+    transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->W, c->WT, (int)S, (int)S);
+    column_sum_kernel<<<(unsigned)((S + 255) / 256), 256, 0, s>>>(w->C, c->Osum, (int)K, (int)S);
+
+    const size_t SR = S > R ? S : R;
+    const size_t lds_f = (S + R + 4 * SR + 4 * S) * sizeof(float);
+    const size_t lds_l = 4 * (S + 2 * K) * sizeof(float);
+    const size_t lds_b = (5 * S + 4 * R + 16 * SR) * sizeof(float);
+    int rc;
+    if ((rc = raise_lds_limit(train_forward_kernel, lds_f))) return rc;
+    if ((rc = raise_lds_limit(train_loss_kernel, lds_l))) return rc;
+    if ((rc = raise_lds_limit(train_backward_kernel, lds_b))) return rc;
+    train_forward_kernel<<<dim3(B, 2), 256, lds_f, s>>>(p);
+    train_loss_kernel<<<(unsigned)((N0 + 3) / 4), 256, lds_l, s>>>(p);
+    train_backward_kernel<<<dim3(B, 2), 256, lds_b, s>>>(p);
+    // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
+    launch_atb(p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R, s);                 // dS2 += Zf^T (v*rr)
+    launch_atb(p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R, s);         // dS1 += f_{t-1}^T (u*v)
+    launch_atb(p.A, p.Zf + S, o->dW, (long long)N1 - 1, (int)S, (int)S, s);           // dW  += f_{t-1}^T z
+    launch_atb(p.Zb, p.Tb, o->dS1, (long long)N1, (int)S, (int)R, s);                 // backward chain: roles of S1, S2 swap
+    launch_atb(p.BBAR, p.D1b, o->dS2, (long long)N1, (int)S, (int)R, s);
+    launch_atb(p.Zb, p.BBAR, o->dW, (long long)N1, (int)S, (int)S, s);                // pre_j += sum_s bbar_s W[j][s]
+    launch_atb(p.DS, p.AB, o->dC, (long long)N0, (int)K, (int)S, s);                  // dC += ds^T (alpha*beta)
+    add_row_to_all_kernel<<<(unsigned)((K * S + 255) / 256), 256, 0, s>>>(o->dC, c->dOsum, (int)K, (int)S);
+    FARNN_HIP_TRY(hipGetLastError());
+    if (e0 && e1) { (void)hipEventRecord(e1, s); c->pending.emplace_back(e0, e1); }
+    return FARNN_OK;
 }
 
 // ---- introspection ---------------------------------------------------------------------------

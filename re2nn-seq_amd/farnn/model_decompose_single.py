@@ -169,3 +169,95 @@ class FARNN_S_D_W_I_S(NativeTagger):
 
     def forward_RE(self, input, label, lengths, train=False):
         raise NotImplementedError('forward_RE exists only on the onehot models (ref model_onehot.py:148)')
+
+    # ---- training step (reference :207-304 with train=True + train_decompose.py:186-190) ----
+    # which tensors get a gradient: the reference's requires_grad flags (model_decompose.py:53-63,105-132)
+    _TRAIN_FLAGS = {'S1': None, 'S2': None, 'embed_r_generalized': None, 'V_embed': 'train_V_embed',
+                    'C_output_mat': 'train_c_output', 'wildcard_mat': 'train_wildcard', 'h0': 'train_h0',
+                    'hT': 'train_hT', 'beta_vec': 'train_beta', 'embedding.weight': 'train_word_embed'}
+
+    def _check_trainable(self, re_tags):
+        a = self.args
+        if a.farnn != 0 or self.use_crf or a.train_mode != 'sum' or a.local_loss_func != 'CE1' or re_tags is not None \
+                or getattr(a, 'marryup_type', 'none') not in ('none', None):
+            raise NotImplementedError('the HIP training step covers farnn=0, sum semiring, CE1 loss without CRF or '
+                                      'KD/PR teachers (DESIGN.md, row f3)')
+
+    def enable_training(self):
+        """Device-resident leaf tensors for the optimizer (returned by parameters()) and the library context."""
+        if getattr(self, '_tp', None) is not None:
+            return self
+        if not torch.cuda.is_available():
+            raise _lib.FarnnError('no MI355X visible; the training step has no CPU fallback')
+        dev = self._dev()
+        src = dict(self.state_dict())
+        self._tp = {}
+        for k, flag in self._TRAIN_FLAGS.items():
+            t = src[k].detach().to(dev).float().clone()
+            t.requires_grad_(True if flag is None else bool(getattr(self.args, flag, 0)))
+            self._tp[k] = t
+        self._tpP = torch.from_numpy(np.ascontiguousarray(self.priority_full, dtype=np.float32)).to(dev) \
+            if self.args.use_priority else None
+        S, R = self._tp['S1'].shape
+        self._tc = _lib.TrainContext(self._tp['V_embed'].shape[0], S, R, self._tp['C_output_mat'].shape[0],
+                                     nl=self.args.update_nonlinear, threshold=self.args.threshold, o_idx=self.o_idx,
+                                     device=self.device_index)
+        self._dirty = False
+        return self
+
+    def parameters(self):
+        tp = getattr(self, '_tp', None)
+        return iter(()) if tp is None else iter([t for t in tp.values() if t.requires_grad])
+
+    def named_parameters(self):
+        tp = getattr(self, '_tp', None)
+        return iter(()) if tp is None else iter([(k, t) for k, t in tp.items() if t.requires_grad])
+
+    def sync_from_training(self):
+        """Copy the trained tensors back into the host attributes the tagging handle is built from."""
+        tp = getattr(self, '_tp', None)
+        if tp is None or not self._dirty:
+            return
+        for k, t in tp.items():
+            if k == 'embedding.weight':
+                self.embedding = t.detach().cpu()
+            else:
+                setattr(self, k, t.detach().cpu())
+        self._dirty = False
+        self.invalidate()
+
+    def eval(self):
+        self.sync_from_training()
+        return super().eval()
+
+    def _train_vgen(self):
+        tp = self._tp
+        gen = torch.matmul(tp['embedding.weight'], tp['embed_r_generalized'])
+        nl = self.args.additional_nonlinear
+        if nl == 'relu':
+            gen = torch.relu(gen)
+        elif nl == 'tanh':
+            gen = torch.tanh(gen)
+        elif nl == 'sigmoid':
+            gen = torch.sigmoid(gen)
+        elif nl == 'relutanh':
+            gen = torch.tanh(torch.relu(gen))
+        return tp['V_embed'] * tp['beta_vec'] + gen * (1 - tp['beta_vec'])
+
+    def forward_local(self, input, label, lengths, train=True, re_tags=None):
+        if not train:
+            self.sync_from_training()
+            return super().forward_local(input, label, lengths, train=False, re_tags=re_tags)
+        from .train_step import decomp_ifst_train_step
+        self._check_trainable(re_tags)
+        self.enable_training()
+        tp = self._tp
+        Lmax = int(lengths.max().item())
+        x = input[:, :Lmax]
+        lab = label[:, :Lmax]
+        loss, tags = decomp_ifst_train_step(self._tc, self._train_vgen(), tp['S1'], tp['S2'], tp['wildcard_mat'],
+                                            tp['C_output_mat'], tp['h0'], tp['hT'], self._tpP, x, lengths, lab)
+        self._dirty = True
+        pred = self._flatten(tags, lengths.to(tags.device)).to(torch.int64).to(input.device)
+        true = self._flatten(label, lengths).to(input.device)
+        return loss, pred, true

@@ -1,0 +1,58 @@
+"""The training step of the decomposed i-FST on the HIP path, as a torch.autograd.Function around
+farnn_decomp_ifst_train_step (include/farnn.h).
+
+What the reference does in FARNN_S_D_W_I_S.forward_local(train=True) + loss.backward()
+(model_decompose_single.py:207-304, train_decompose.py:186-190) is split like this: the word table
+Vgen = V_embed*beta + act(E G)*(1-beta) (model_decompose.py:222-241) is built for the whole vocabulary
+by ordinary torch ops (one [V,D]x[D,R] product: its gradient flows to the embedding, the bridge matrix,
+V_embed and beta through torch's autograd); everything that depends on the batch -- both chains, the
+scores, the cross-entropy and the back-propagation through time -- is one library call.  The library
+computes loss and all gradients in its forward call (the stash lives in its workspace); backward()
+only hands them out, scaled by the incoming gradient.
+
+Scope: farnn = 0, sum semiring, CE1 loss, no CRF.  Anything else raises.
+"""
+import torch
+
+from .. import _lib
+
+
+class _DecompIfstTrainStep(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels):
+        dev = Vgen.device
+        if dev.type != 'cuda':
+            raise _lib.FarnnError('the training step runs on the HIP device only (no CPU fallback)')
+        ws = [t.detach().contiguous().float() for t in (Vgen, S1, S2, W, Cmat, h0, hT)]
+        Pc = None if P is None else P.detach().contiguous().float()
+        x = x.to(dev).contiguous()
+        lengths = lengths.to(dev).contiguous()
+        labels = labels.to(dev).contiguous()
+        B, L = x.shape
+        ntok = int(lengths.clamp(0, L).sum())
+        if ntok <= 0:
+            raise ValueError('empty batch')
+        grads = [torch.empty_like(t) for t in ws]
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+        names = ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT')
+        weights = {n: t.data_ptr() for n, t in zip(names, ws)}
+        weights['P'] = None if Pc is None else Pc.data_ptr()
+        outputs = {'d' + n: g.data_ptr() for n, g in zip(names, grads)}
+        outputs['loss'] = loss.data_ptr()
+        outputs['tags'] = tags.data_ptr()
+        tc.step(weights, x.data_ptr(), lengths.data_ptr(), labels.data_ptr(), B, L, ntok, outputs,
+                torch.cuda.current_stream(dev).cuda_stream)
+        ctx.save_for_backward(*grads)
+        ctx.mark_non_differentiable(tags)
+        return loss.reshape(()), tags
+
+    @staticmethod
+    def backward(ctx, gloss, _gtags):
+        grads = ctx.saved_tensors
+        return (None,) + tuple(g * gloss for g in grads) + (None, None, None, None)
+
+
+def decomp_ifst_train_step(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels):
+    """Returns (loss scalar tensor with grad, tags int32 [B,L] with -1 at pads)."""
+    return _DecompIfstTrainStep.apply(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels)

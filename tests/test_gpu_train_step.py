@@ -1,0 +1,167 @@
+"""The HIP training step of the decomposed i-FST against loss and gradients captured from the
+reference's forward_local(train=True) + backward(), and against the torch-fp32 oracle on other shapes."""
+import json
+import os
+import sys
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import farnn_train_oracle as to  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PARAMS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_output_mat', 'wildcard_mat', 'h0', 'hT', 'beta_vec',
+          'embedding.weight')
+
+
+def ns(**kw):
+    d = dict(rand_constant=0.0, train_wildcard=0, train_wildcard_wildcard=0, margin=0.3, threshold=0.5,
+             train_mode='sum', local_loss_func='CE1', use_priority=0, independent=2, update_nonlinear='none',
+             additional_states=0, train_word_embed=0, use_crf=0, random=0, train_h0=0, train_hT=0, train_V_embed=0,
+             train_c_output=1, farnn=0, xavier=0, bias_init=5.0, sigmoid_exponent=5, beta=1.0, train_beta=0,
+             additional_nonlinear='none', random_pad_func='uniform', marryup_type='none', c1_kdpr=1.0, c2_kdpr=1.0,
+             c3_pr=1.0)
+    d.update(kw)
+    return Namespace(**d)
+
+
+def load():
+    with open(os.path.join(GOLDEN, 'decomp_train_small.json')) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLDEN, 'decomp_train_small.npz')), np.load(os.path.join(GOLDEN, 'decomp_small.npz'))
+
+
+def close(got, ref, name, rtol=2e-3, atol=2e-6):
+    scale = max(float(np.abs(ref).max()), 1e-6)
+    np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol + 2e-4 * scale, err_msg=name)
+
+
+@pytest.mark.parametrize('k', range(5))
+def test_train_step_matches_reference_loss_and_gradients(k):
+    """Through the model mirror: forward_local(train=True) -> loss.backward() -> .grad of every parameter."""
+    from re2nn_seq_amd.farnn.model_decompose_single import FARNN_S_D_W_I_S
+    meta, g, base = load()
+    cfg = meta['configs'][k]
+    a = ns(**dict(meta['train_flags'], **cfg))
+    torch.manual_seed(0)
+    m = FARNN_S_D_W_I_S(V=base['V_in'], S1=base['S1_in'], S2=base['S2_in'], C_output_mat=base['O_in'],
+                        wildcard_mat=base['W_in'], wildcard_output_vector=base['Ow_in'],
+                        final_vector=base['final_in'], start_vector=base['start_in'],
+                        pretrained_word_embed=base['E_in'], priority_mat=base['priority_in'], args=a,
+                        o_idx=meta['o_idx'])
+    pre = 'c{}.'.format(k)
+    sd = {n: g[pre + 'w.' + n] for n in PARAMS}
+    sd['priority_layer.priority_mat'] = g[pre + 'w.priority_mat']
+    m.load_state_dict(sd)
+    x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
+    m.train()
+    loss, pred, true = m.forward_local(x, labels, lengths, train=True)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g[pre + 'loss'])) < 2e-5
+    assert np.array_equal(pred.cpu().numpy(), g[pre + 'flat_pred'])
+    named = dict(m.named_parameters())
+    assert set(named) == set(PARAMS)
+    for n in PARAMS:
+        close(named[n].grad.cpu().numpy(), g[pre + 'g.' + n], n)
+
+
+@pytest.mark.parametrize('S,R,K,V,B,L,nl,prio', [
+    (104, 50, 73, 300, 12, 20, 'tanh', False),     # SNIPS-sized factors
+    (23, 70, 9, 50, 7, 9, 'relutanh', True),       # rank above the state count
+    (5, 3, 4, 11, 3, 6, 'none', False),
+    (64, 64, 130, 40, 4, 33, 'relu', True),        # more score columns than a wavefront
+])
+def test_train_step_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
+    """The C-ABI entry point directly, with empty and full-length sequences, against the oracle."""
+    from re2nn_seq_amd import _lib
+    rng = np.random.RandomState(S + R)
+    f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
+    D = 6
+    # automaton-like magnitudes: every state feeds one label (Osum near 0/1), about one wildcard edge per state
+    Cm = np.zeros((K, S), np.float32)
+    Cm[rng.randint(0, K, size=S), np.arange(S)] = (rng.rand(S) < 0.8)
+    p = {'S1': f(S, R, sc=1.0 / np.sqrt(S)), 'S2': f(S, R, sc=1.0 / np.sqrt(S)), 'V_embed': f(V, R, sc=0.8),
+         'embed_r_generalized': f(D, R),
+         'C_output_mat': torch.from_numpy(Cm + (rng.rand(K, S) * 0.02).astype(np.float32)),
+         'wildcard_mat': torch.from_numpy(((rng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)),
+         'h0': f(S, sc=0.5), 'hT': f(S, sc=0.5), 'beta_vec': torch.full((R,), 0.7), 'embedding.weight': f(V, D),
+         'priority_mat': torch.from_numpy((np.eye(K) + (rng.rand(K, K) < 0.05) * 0.5).astype(np.float32))}
+    lengths = rng.randint(1, L + 1, size=B).astype(np.int64)
+    lengths[0] = L
+    if B > 2:
+        lengths[1] = 0
+    x = rng.randint(0, V, size=(B, L)).astype(np.int64)
+    labels = rng.randint(0, K, size=(B, L)).astype(np.int64)
+    xt, lt, lab = torch.from_numpy(x), torch.from_numpy(lengths), torch.from_numpy(labels)
+    loss_ref, grads_ref, _ = to.train_step(p, xt, lt, lab, nl=nl, use_priority=prio)
+    # d loss / d Vgen from the oracle, to compare the library's dVgen itself
+    q = {k: v.clone() for k, v in p.items()}
+    Vgen = to.generalized_table(q).detach().requires_grad_(True)
+    leaves = {n: q[n].clone().requires_grad_(True) for n in ('S1', 'S2', 'wildcard_mat', 'C_output_mat', 'h0', 'hT')}
+    s = to.chain_scores(Vgen, leaves['S1'], leaves['S2'], leaves['wildcard_mat'], leaves['C_output_mat'], leaves['h0'],
+                        leaves['hT'], xt, lt, nl, q['priority_mat'] if prio else None)
+    flat_labels = torch.cat([lab[b, :int(lt[b])] for b in range(B)])
+    torch.nn.functional.cross_entropy(s, flat_labels).backward()
+
+    dev = torch.device('cuda')
+    tc = _lib.TrainContext(V, S, R, K, nl=nl, threshold=0.5, o_idx=1)
+    w = {'Vgen': Vgen.detach().to(dev), 'S1': p['S1'].to(dev), 'S2': p['S2'].to(dev), 'W': p['wildcard_mat'].to(dev),
+         'C': p['C_output_mat'].to(dev), 'h0': p['h0'].to(dev), 'hT': p['hT'].to(dev)}
+    P = p['priority_mat'].to(dev) if prio else None
+    out = {'d' + n: torch.full_like(t, 7.0) for n, t in w.items()}           # the library must zero them itself
+    loss = torch.full((1,), 3.0, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    xd, ld, labd = xt.to(dev), lt.to(dev), lab.to(dev)
+    for _ in range(2):                                                        # twice: the workspace is reused
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None if P is None else P.data_ptr()),
+                xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 5e-5 * max(1.0, abs(float(loss_ref)))
+    close(out['dVgen'].cpu().numpy(), Vgen.grad.numpy(), 'dVgen')
+    for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')):
+        close(out['d' + n].cpu().numpy(), leaves[key].grad.numpy(), 'd' + n)
+        close(out['d' + n].cpu().numpy(), grads_ref[key].numpy(), 'd' + n + ' (full graph)')
+    t = tags.cpu().numpy()
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    assert (t[~mask] == -1).all()
+    sc = s.detach().numpy().copy()
+    sc[:, K - 1] = np.minimum(sc[:, K - 1], 0.5)
+    want = sc.argmax(1)
+    want[want == K - 1] = 1
+    assert (t[mask] == want).mean() > 0.99                                   # ties / 1-ulp score differences aside
+
+
+def test_training_loop_reduces_the_loss_and_tagging_sees_the_update():
+    """A few Adam steps through the mirror, then eval: the tagging handle is rebuilt from the trained tensors."""
+    from re2nn_seq_amd.farnn.model_decompose_single import FARNN_S_D_W_I_S
+    meta, g, base = load()
+    a = ns(**dict(meta['train_flags'], update_nonlinear='tanh', beta=0.7))
+    m = FARNN_S_D_W_I_S(V=base['V_in'], S1=base['S1_in'], S2=base['S2_in'], C_output_mat=base['O_in'],
+                        wildcard_mat=base['W_in'], wildcard_output_vector=base['Ow_in'],
+                        final_vector=base['final_in'], start_vector=base['start_in'],
+                        pretrained_word_embed=base['E_in'], priority_mat=base['priority_in'], args=a,
+                        o_idx=meta['o_idx'])
+    x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
+    _, before, _ = m.forward_local(x, labels, lengths, train=False)
+    m.train()
+    m.enable_training()
+    opt = torch.optim.Adam(list(m.parameters()), lr=0.02)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        loss, _, _ = m.forward_local(x, labels, lengths, train=True)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.7 * losses[0], losses
+    m.eval()
+    _, after, true = m.forward_local(x, labels, lengths, train=False)
+    assert (after == true).float().mean() > (before == true).float().mean()

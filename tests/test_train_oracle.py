@@ -1,0 +1,42 @@
+"""The training-step oracle (torch fp32 + autograd on the CPU) against loss and gradients captured from the
+reference's own forward_local(train=True) + backward (tests/golden/make_golden_train.py)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+from oracle import farnn_train_oracle as to  # noqa: E402
+
+PARAMS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_output_mat', 'wildcard_mat', 'h0', 'hT', 'beta_vec',
+          'embedding.weight')
+
+
+def load():
+    with open(os.path.join(GOLDEN, 'decomp_train_small.json')) as f:
+        meta = json.load(f)
+    return meta, np.load(os.path.join(GOLDEN, 'decomp_train_small.npz')), np.load(os.path.join(GOLDEN, 'decomp_small.npz'))
+
+
+@pytest.mark.parametrize('k', range(5))
+def test_train_oracle_matches_reference_loss_and_gradients(k):
+    meta, g, base = load()
+    cfg = meta['configs'][k]
+    pre = 'c{}.'.format(k)
+    p = {n: torch.from_numpy(g[pre + 'w.' + n]) for n in PARAMS}
+    p['priority_mat'] = torch.from_numpy(g[pre + 'w.priority_mat'])
+    x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
+    loss, grads, _ = to.train_step(p, x, lengths, labels, nl=cfg['update_nonlinear'],
+                                   additional_nonlinear=cfg.get('additional_nonlinear', 'none'),
+                                   use_priority=bool(cfg.get('use_priority', 0)))
+    assert abs(float(loss) - float(g[pre + 'loss'])) < 1e-5
+    for n in PARAMS:
+        ref = g[pre + 'g.' + n]
+        got = grads[n].numpy()
+        np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6, err_msg=n)
