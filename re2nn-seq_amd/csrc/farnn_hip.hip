@@ -1281,7 +1281,7 @@ extern "C" int farnn_train_time(farnn_train_ctx *c, double *total_ms, int64_t *s
 
 static void launch_atb(const float *A, const float *Bm, float *out, long long N, int M, int J, hipStream_t s) {
     if (N <= 0) return;
-    const long long chunk = 512;
+    const long long chunk = 128;
     dim3 grid((M + 31) / 32, (J + 31) / 32, (unsigned)((N + chunk - 1) / chunk));
     atb_accumulate_kernel<<<grid, 256, 0, s>>>(A, Bm, out, N, M, J, chunk);
 }
@@ -1299,7 +1299,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
     const size_t N1 = (size_t)B * (L + 1), N0 = (size_t)B * L;
-    const size_t need = N1 * (7 * S + 4 * R) + N0 * (K + S);
+    const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S);
     if (need > c->ws_floats) {
         if (c->ws) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->ws); c->ws = nullptr; c->ws_floats = 0; }
         if (hipMalloc((void **)&c->ws, need * sizeof(float)) != hipSuccess)
@@ -1316,7 +1316,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     p.x = x; p.len = lengths; p.labels = labels;
     float *q = c->ws;
     p.A = q; q += N1 * S; p.Bk = q; q += N1 * S; p.GA = q; q += N1 * S; p.GB = q; q += N1 * S;
-    p.Zf = q; q += N1 * S; p.Zb = q; q += N1 * S; p.BBAR = q; q += N1 * S;
+    p.Zf = q; q += N1 * S; p.Zb = q; q += N1 * S; p.BBAR = q; q += N1 * S; p.PRE = q; q += N1 * S;
     p.D1f = q; q += N1 * R; p.D1b = q; q += N1 * R; p.Tf = q; q += N1 * R; p.Tb = q; q += N1 * R;
     p.DS = q; q += N0 * K; p.AB = q; q += N0 * S;
     p.dVgen = o->dVgen; p.dOsum = c->dOsum; p.dh0 = o->dh0; p.dhT = o->dhT; p.loss = o->loss; p.tags = o->tags;
@@ -1340,16 +1340,31 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     column_sum_kernel<<<(unsigned)((S + 255) / 256), 256, 0, s>>>(w->C, c->Osum, (int)K, (int)S);
 
     const size_t SR = S > R ? S : R;
-    const size_t lds_f = (S + R + 4 * SR + 4 * S) * sizeof(float);
     const size_t lds_l = 4 * (S + 2 * K) * sizeof(float);
-    const size_t lds_b = (5 * S + 4 * R + 16 * SR) * sizeof(float);
+    const size_t vec_f = (2 * S + 2 * R + 8 * SR + 8 * S) * sizeof(float);
+    const size_t vec_b = (10 * S + 2 * R + 16 * SR + 8 * S) * sizeof(float);
+    const size_t mat_f = (2 * S * R + S * S) * sizeof(float), mat_b = (3 * S * R + S * S) * sizeof(float);
+    const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    const size_t lds_f = vec_f + (ldsw_f ? mat_f : 0), lds_b = vec_b + (ldsw_b ? mat_b : 0);
+    const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
-    if ((rc = raise_lds_limit(train_forward_kernel, lds_f))) return rc;
     if ((rc = raise_lds_limit(train_loss_kernel, lds_l))) return rc;
-    if ((rc = raise_lds_limit(train_backward_kernel, lds_b))) return rc;
-    train_forward_kernel<<<dim3(B, 2), 256, lds_f, s>>>(p);
+    if (ldsw_f) {
+        if ((rc = raise_lds_limit(train_forward_kernel<true>, lds_f))) return rc;
+        train_forward_kernel<true><<<cgrid, 256, lds_f, s>>>(p);
+    } else {
+        if ((rc = raise_lds_limit(train_forward_kernel<false>, lds_f))) return rc;
+        train_forward_kernel<false><<<cgrid, 256, lds_f, s>>>(p);
+    }
     train_loss_kernel<<<(unsigned)((N0 + 3) / 4), 256, lds_l, s>>>(p);
-    train_backward_kernel<<<dim3(B, 2), 256, lds_b, s>>>(p);
+    if (ldsw_b) {
+        if ((rc = raise_lds_limit(train_backward_kernel<true>, lds_b))) return rc;
+        train_backward_kernel<true><<<cgrid, 256, lds_b, s>>>(p);
+    } else {
+        if ((rc = raise_lds_limit(train_backward_kernel<false>, lds_b))) return rc;
+        train_backward_kernel<false><<<cgrid, 256, lds_b, s>>>(p);
+    }
     // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
     launch_atb(p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R, s);                 // dS2 += Zf^T (v*rr)
     launch_atb(p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R, s);         // dS1 += f_{t-1}^T (u*v)

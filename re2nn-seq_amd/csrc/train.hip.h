@@ -30,6 +30,7 @@ struct TrainParams {
     float *Zf, *Zb;           // [.][S] pre-activation adjoints
     float *D1f, *D1b, *Tf, *Tb;   // [.][R]  u*v and v*rr
     float *BBAR;              // [.][S]  b_{t-1} * Osum
+    float *PRE;               // [.][S]  forward chain's pre-activation before the output mask
     float *DS, *AB;           // [B][L][K] d loss / d (pre-priority) scores; [B][L][S] alpha*beta
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
     int32_t *tags;
@@ -46,27 +47,38 @@ __device__ __forceinline__ float nl_grad_from_output(float y, int nl) {
     }
 }
 
-// out[j] (+)= sum_k in[k] M[k][j], M row-major [K][J] in global memory, `in` in LDS.  The k range is split over
-// the workgroup's wavefronts; partial sums land in part[wave][J] (LDS) and are added by the caller after a barrier.
-__device__ __forceinline__ void matvec_partial(float *part, const float *in, const float *__restrict__ M, int K, int J,
-                                               int tid, int nthreads) {
+constexpr int TR_NSEQ = 2;      // sequences per workgroup of the chain kernels: every weight element read feeds both
+
+// part[(wave*2+q)*J + j] = sum over this wavefront's share of k of in[q][k] M[k][j]  (M row-major [K][J], in LDS
+// or global memory; `in` = two vectors of stride ldin in LDS).  The caller adds the wavefronts' shares after a barrier.
+__device__ __forceinline__ void matvec2_partial(float *part, const float *in, int ldin, const float *__restrict__ M, int K,
+                                                int J, int tid, int nthreads) {
     const int nw = nthreads >> 6, w = tid >> 6, lane = tid & 63;
     const int k0 = (K * w) / nw, k1 = (K * (w + 1)) / nw;
     for (int j = lane; j < J; j += WAVE) {
-        float a0 = 0.0f, a1 = 0.0f;
+        float a0 = 0.0f, a1 = 0.0f, c0 = 0.0f, c1 = 0.0f;
         int k = k0;
         for (; k + 1 < k1; k += 2) {
-            a0 = fmaf(in[k], M[(long long)k * J + j], a0);
-            a1 = fmaf(in[k + 1], M[(long long)(k + 1) * J + j], a1);
+            const float m0 = M[(long long)k * J + j], m1 = M[(long long)(k + 1) * J + j];
+            a0 = fmaf(in[k], m0, a0); a1 = fmaf(in[k + 1], m1, a1);
+            c0 = fmaf(in[ldin + k], m0, c0); c1 = fmaf(in[ldin + k + 1], m1, c1);
         }
-        if (k < k1) a0 = fmaf(in[k], M[(long long)k * J + j], a0);
-        part[w * J + j] = a0 + a1;
+        if (k < k1) {
+            const float m0 = M[(long long)k * J + j];
+            a0 = fmaf(in[k], m0, a0); c0 = fmaf(in[ldin + k], m0, c0);
+        }
+        part[(w * 2 + 0) * J + j] = a0 + a1;
+        part[(w * 2 + 1) * J + j] = c0 + c1;
     }
 }
-__device__ __forceinline__ float part_sum(const float *part, int J, int j, int nw) {
-    float s = part[j];
-    for (int w = 1; w < nw; w++) s += part[w * J + j];
+__device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int nw) {
+    float s = part[q * J + j];
+    for (int w = 1; w < nw; w++) s += part[(w * 2 + q) * J + j];
     return s;
+}
+// copy a [rows*cols] matrix from global memory into LDS (16-byte pieces when the size allows)
+__device__ __forceinline__ void stage_matrix(float *dst, const float *__restrict__ src, int n, int tid, int nt) {
+    for (int i = tid; i < n; i += nt) dst[i] = src[i];
 }
 
 __global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
@@ -85,39 +97,65 @@ __global__ void column_sum_kernel(const float *__restrict__ C, float *__restrict
 }
 
 // ---- forward chains with the stash ------------------------------------------------------------------------
-// grid (B, 2): blockIdx.y = 0 forward, 1 backward.  LDS: f[S], t[R], part[4][max(S,R)], part2[4][S]
+// grid (ceil(B/2), 2): blockIdx.y = 0 forward, 1 backward chain; TR_NSEQ sequences per workgroup.  LDSW: the three
+// matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
+// LDS: [M1 | M2 | M3] f[2][S] tv[2][R] part[4][2][max(S,R)] part2[4][2][S]
+template <bool LDSW>
 __global__ void __launch_bounds__(256)
 train_forward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
-    const int b = blockIdx.x, dir = blockIdx.y;
+    const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
-    float *f = smem, *tv = f + S, *part = tv + R, *part2 = part + nw * SR;
-    const int len = clamp_len(p.len[b], p.L);
-    float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * S;
-    for (int s = tid; s < S; s += nt) {
+    float *wl = smem;
+    float *f = smem + (LDSW ? 2 * S * R + S * S : 0), *tv = f + 2 * S, *part = tv + 2 * R, *part2 = part + nw * 2 * SR;
+    const float *M1 = dir == 0 ? p.S1 : p.S2, *M2 = dir == 0 ? p.W : p.WT, *M3 = dir == 0 ? p.S2T : p.S1T;
+    if (LDSW) {
+        stage_matrix(wl, M1, S * R, tid, nt);
+        stage_matrix(wl + S * R, M2, S * S, tid, nt);
+        stage_matrix(wl + S * R + S * S, M3, R * S, tid, nt);
+        M1 = wl; M2 = wl + S * R; M3 = wl + S * R + S * S;
+    }
+    int len[TR_NSEQ], maxlen = 0;
+    for (int q = 0; q < TR_NSEQ; q++) {
+        len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
+        maxlen = len[q] > maxlen ? len[q] : maxlen;
+    }
+    for (int e = tid; e < TR_NSEQ * S; e += nt) {
+        const int q = e / S, s = e - q * S;
         const float h = dir == 0 ? p.h0[s] : p.hT[s];
-        stash[s] = h;
-        f[s] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
+        if (b0 + q < p.B) (dir == 0 ? p.A : p.Bk)[(long long)(b0 + q) * (p.L + 1) * S + s] = h;
+        f[e] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
     }
     __syncthreads();
-    for (int t = 1; t <= len; t++) {
-        const int tok = clamp_tok(p.x[(long long)b * p.L + (dir == 0 ? t - 1 : len - t)], p.V);
-        const float *v = p.Vgen + (long long)tok * R;
+    for (int t = 1; t <= maxlen; t++) {
+        const float *v[TR_NSEQ];
+        for (int q = 0; q < TR_NSEQ; q++) {
+            const int bq = b0 + q < p.B ? b0 + q : b0, lq = len[q] > 0 ? len[q] : 1, tq = t <= lq ? t : lq;
+            v[q] = p.Vgen + (long long)clamp_tok(p.x[(long long)bq * p.L + (dir == 0 ? tq - 1 : lq - tq)], p.V) * R;
+        }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
-        matvec_partial(part, f, dir == 0 ? p.S1 : p.S2, S, R, tid, nt);
-        matvec_partial(part2, f, dir == 0 ? p.W : p.WT, S, S, tid, nt);
+        matvec2_partial(part, f, S, M1, S, R, tid, nt);
+        matvec2_partial(part2, f, S, M2, S, S, tid, nt);
         __syncthreads();
-        for (int r = tid; r < R; r += nt) tv[r] = v[r] * part_sum(part, R, r, nw);          // temp = V_vec * _RR
+        for (int e = tid; e < TR_NSEQ * R; e += nt) {
+            const int q = e / R, r = e - q * R;
+            tv[e] = v[q][r] * part2_sum(part, R, q, r, nw);                                  // temp = V_vec * _RR
+        }
         __syncthreads();
-        matvec_partial(part, tv, dir == 0 ? p.S2T : p.S1T, R, S, tid, nt);                   // temp . (S2^T | S1^T)
+        matvec2_partial(part, tv, R, M3, R, S, tid, nt);                                     // temp . (S2^T | S1^T)
         __syncthreads();
-        for (int s = tid; s < S; s += nt) {
-            float pre = part_sum(part, S, s, nw) + part_sum(part2, S, s, nw);
-            if (dir == 0) pre *= p.Osum[s];                                                  // (:181)
-            const float h = apply_nl(pre, p.nl);
-            stash[(long long)t * S + s] = h;
-            f[s] = dir == 0 ? h : h * p.Osum[s];
+        for (int e = tid; e < TR_NSEQ * S; e += nt) {
+            const int q = e / S, s = e - q * S;
+            if (t <= len[q]) {
+                const float pre = part2_sum(part, S, q, s, nw) + part2_sum(part2, S, q, s, nw);
+                const long long row = ((long long)(b0 + q) * (p.L + 1) + t) * S + s;
+                float h;
+                if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * p.Osum[s], p.nl); }   // (:181)
+                else          { h = apply_nl(pre, p.nl); }
+                (dir == 0 ? p.A : p.Bk)[row] = h;
+                f[e] = dir == 0 ? h : h * p.Osum[s];
+            }
         }
         __syncthreads();
     }
@@ -201,76 +239,102 @@ train_loss_kernel(const TrainParams p) {
 }
 
 // ---- back-propagation through time ----------------------------------------------------------------------------
-// grid (B, 2).  LDS: g[S], z[S], y[S], fp[S] (f_{t-1} or bbar), u[R], rr[R], d1[R], tmpv[R], parts 4 x [4][max(S,R)], dO[S]
+// grid (ceil(B/2), 2), TR_NSEQ sequences per workgroup.  LDSW: the four matrices of this direction
+// (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
+// LDS: [Ma | Mb | Mc | Md] g z y fp dO [2][S] each, u rr d1 tmpv [2][R] each, pa pb [4][2][max(S,R)], pc [4][2][S]
+template <bool LDSW>
 __global__ void __launch_bounds__(256)
 train_backward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
-    const int b = blockIdx.x, dir = blockIdx.y;
+    const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
-    float *g = smem, *z = g + S, *y = z + S, *fp = y + S, *dO = fp + S;
-    float *u = dO + S, *rr = u + R, *d1 = rr + R, *tmpv = d1 + R;
-    float *pa = tmpv + R, *pb = pa + nw * SR, *pc = pb + nw * SR, *pd = pc + nw * SR;
-    const int len = clamp_len(p.len[b], p.L);
-    const long long row0 = (long long)b * (p.L + 1);
-    const float *stash = (dir == 0 ? p.A : p.Bk) + row0 * S;
-    const float *G = (dir == 0 ? p.GA : p.GB) + row0 * S;
-    float *Zo = (dir == 0 ? p.Zf : p.Zb) + row0 * S;
-    float *D1o = (dir == 0 ? p.D1f : p.D1b) + row0 * R;
-    float *To = (dir == 0 ? p.Tf : p.Tb) + row0 * R;
-    for (int s = tid; s < S; s += nt) { g[s] = 0.0f; dO[s] = 0.0f; }
+    float *wl = smem;
+    float *g = smem + (LDSW ? 3 * S * R + S * S : 0), *z = g + 2 * S, *y = z + 2 * S, *fp = y + 2 * S, *dO = fp + 2 * S;
+    float *d1 = dO + 2 * S, *pa = d1 + 2 * R, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
+    // rr = fp . Ma, u = z . Mb, d fp = z . Mc + d1 . Md
+    const float *Ma = dir == 0 ? p.S1 : p.S2, *Mb = dir == 0 ? p.S2 : p.S1, *Mc = dir == 0 ? p.WT : p.W,
+                *Md = dir == 0 ? p.S1T : p.S2T;
+    if (LDSW) {
+        stage_matrix(wl, Ma, S * R, tid, nt);
+        stage_matrix(wl + S * R, Mb, S * R, tid, nt);
+        stage_matrix(wl + 2 * S * R, Mc, S * S, tid, nt);
+        stage_matrix(wl + 2 * S * R + S * S, Md, R * S, tid, nt);
+        Ma = wl; Mb = wl + S * R; Mc = wl + 2 * S * R; Md = wl + 2 * S * R + S * S;
+    }
+    int len[TR_NSEQ], maxlen = 0;
+    for (int q = 0; q < TR_NSEQ; q++) {
+        len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
+        maxlen = len[q] > maxlen ? len[q] : maxlen;
+    }
+    for (int e = tid; e < TR_NSEQ * S; e += nt) { g[e] = 0.0f; z[e] = 0.0f; fp[e] = 0.0f; y[e] = 0.0f; }
+    for (int e = tid; e < TR_NSEQ * S; e += nt) dO[e] = 0.0f;       // per sequence: two threads would race on one slot
     __syncthreads();
-    for (int t = len; t >= 1; t--) {
-        const int tok = clamp_tok(p.x[(long long)b * p.L + (dir == 0 ? t - 1 : len - t)], p.V);
-        const float *v = p.Vgen + (long long)tok * R;
-        for (int s = tid; s < S; s += nt) {
-            const float gt = g[s] + G[(long long)t * S + s];
-            const float h = stash[(long long)t * S + s];
-            const float yy = gt * nl_grad_from_output(h, p.nl);
-            const float hp = stash[(long long)(t - 1) * S + s];
-            if (dir == 0) { y[s] = yy; z[s] = yy * p.Osum[s]; fp[s] = hp; }       // mask on the OUTPUT of the step
-            else          { z[s] = yy; fp[s] = hp * p.Osum[s]; y[s] = hp; }       // mask on the INPUT: fp = bbar, y keeps b_{t-1}
-            Zo[(long long)t * S + s] = dir == 0 ? yy * p.Osum[s] : yy;
-            if (dir == 1) p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
-        }
-        __syncthreads();
-        // four products that depend on fp and z only
-        matvec_partial(pa, fp, dir == 0 ? p.S1 : p.S2, S, R, tid, nt);            // rr  = fp . (S1 | S2)
-        matvec_partial(pb, z, dir == 0 ? p.S2 : p.S1, S, R, tid, nt);             // u   = z . (S2 | S1)
-        matvec_partial(pc, z, dir == 0 ? p.WT : p.W, S, S, tid, nt);              // d fp through the wildcard matrix
-        if (dir == 0) matvec_partial(pd, fp, p.W, S, S, tid, nt);                 // wildcard part of pre (for dOsum)
-        __syncthreads();
-        for (int r = tid; r < R; r += nt) {
-            const float rv = part_sum(pa, R, r, nw), uv = part_sum(pb, R, r, nw), vv = v[r];
-            rr[r] = rv; u[r] = uv;
-            const float dd = uv * vv, tt = vv * rv;
-            d1[r] = dd; tmpv[r] = tt;
-            D1o[(long long)t * R + r] = dd;
-            To[(long long)t * R + r] = tt;
-            atomicAdd(p.dVgen + (long long)tok * R + r, uv * rv);                   // d v_t = u * rr
-        }
-        for (int s = tid; s < S; s += nt) g[s] = part_sum(pc, S, s, nw);
-        __syncthreads();
-        matvec_partial(pa, d1, dir == 0 ? p.S1T : p.S2T, R, S, tid, nt);           // d fp through the language factors
-        if (dir == 0) matvec_partial(pb, tmpv, p.S2T, R, S, tid, nt);              // language part of pre (for dOsum)
-        __syncthreads();
-        for (int s = tid; s < S; s += nt) {
-            const float dfp = g[s] + part_sum(pa, S, s, nw);
-            if (dir == 0) {
-                const float pre = part_sum(pb, S, s, nw) + part_sum(pd, S, s, nw);
-                dO[s] = fmaf(y[s], pre, dO[s]);                                     // d Osum += y * pre_t
-                g[s] = dfp;
+    for (int t = maxlen; t >= 1; t--) {
+        int tok[TR_NSEQ];
+        for (int q = 0; q < TR_NSEQ; q++)
+            tok[q] = t <= len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? t - 1 : len[q] - t)], p.V) : 0;
+        for (int e = tid; e < TR_NSEQ * S; e += nt) {
+            const int q = e / S, s = e - q * S;
+            if (t <= len[q]) {
+                const long long row0 = (long long)(b0 + q) * (p.L + 1);
+                const float *stash = (dir == 0 ? p.A : p.Bk) + row0 * S;
+                const float gt = g[e] + (dir == 0 ? p.GA : p.GB)[(row0 + t) * S + s];
+                const float yy = gt * nl_grad_from_output(stash[(long long)t * S + s], p.nl);
+                const float hp = stash[(long long)(t - 1) * S + s];
+                if (dir == 0) {                                   // mask on the OUTPUT of the step
+                    z[e] = yy * p.Osum[s]; fp[e] = hp;
+                    dO[e] = fmaf(yy, p.PRE[(row0 + t) * S + s], dO[e]);               // d Osum += y * pre_t
+                    p.Zf[(row0 + t) * S + s] = yy * p.Osum[s];
+                } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
+                    z[e] = yy; fp[e] = hp * p.Osum[s]; y[e] = hp;
+                    p.Zb[(row0 + t) * S + s] = yy;
+                    p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
+                }
             } else {
-                dO[s] = fmaf(dfp, y[s], dO[s]);                                     // d Osum += d bbar * b_{t-1}
-                g[s] = dfp * p.Osum[s];
+                z[e] = 0.0f; fp[e] = 0.0f;
+            }
+        }
+        __syncthreads();
+        matvec2_partial(pa, fp, S, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
+        matvec2_partial(pb, z, S, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
+        matvec2_partial(pc, z, S, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
+        __syncthreads();
+        for (int e = tid; e < TR_NSEQ * R; e += nt) {
+            const int q = e / R, r = e - q * R;
+            float dd = 0.0f;
+            if (t <= len[q]) {
+                const long long row = (long long)(b0 + q) * (p.L + 1) + t;
+                const float rv = part2_sum(pa, R, q, r, nw), uv = part2_sum(pb, R, q, r, nw);
+                const float vv = p.Vgen[(long long)tok[q] * R + r];
+                dd = uv * vv;
+                (dir == 0 ? p.D1f : p.D1b)[row * R + r] = dd;
+                (dir == 0 ? p.Tf : p.Tb)[row * R + r] = vv * rv;
+                atomicAdd(p.dVgen + (long long)tok[q] * R + r, uv * rv);              // d v_t = u * rr
+            }
+            d1[e] = dd;
+        }
+        __syncthreads();
+        matvec2_partial(pa, d1, R, Md, R, S, tid, nt);            // d fp through the language factors
+        __syncthreads();
+        for (int e = tid; e < TR_NSEQ * S; e += nt) {
+            const int q = e / S, s = e - q * S;
+            if (t <= len[q]) {
+                const float dfp = part2_sum(pc, S, q, s, nw) + part2_sum(pa, S, q, s, nw);
+                if (dir == 0) g[e] = dfp;
+                else { dO[e] = fmaf(dfp, y[e], dO[e]); g[e] = dfp * p.Osum[s]; }       // d Osum += d bbar * b_{t-1}
             }
         }
         __syncthreads();
     }
-    for (int s = tid; s < S; s += nt) {
-        atomicAdd((dir == 0 ? p.dh0 : p.dhT) + s, g[s] + G[s]);
-        atomicAdd(p.dOsum + s, dO[s]);
+    for (int e = tid; e < TR_NSEQ * S; e += nt) {
+        const int q = e / S, s = e - q * S;
+        if (b0 + q < p.B) {
+            const float g0 = g[e] + (dir == 0 ? p.GA : p.GB)[(long long)(b0 + q) * (p.L + 1) * S + s];
+            if (g0 != 0.0f) atomicAdd((dir == 0 ? p.dh0 : p.dhT) + s, g0);
+        }
     }
+    for (int s = tid; s < S; s += nt) atomicAdd(p.dOsum + s, dO[s] + dO[S + s]);
 }
 
 // out[M][J] += sum_n A[n][M] B[n][J]   (A, B row-major with the reduction index as the row; rows that do not
