@@ -1295,6 +1295,8 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     if (!o->loss || !o->dVgen || !o->dS1 || !o->dS2 || !o->dW || !o->dC || !o->dh0 || !o->dhT || !o->tags)
         return fail(FARNN_EINVAL, "train_step: null output%s%s");
     if (B <= 0 || L <= 0 || valid_tokens <= 0) return fail(FARNN_EINVAL, "train_step: B, L and valid_tokens must be positive%s%s");
+    if (c->d.S > TR_VPT * TR_THREADS / TR_NSEQ || c->d.R > TR_VPT * TR_THREADS / TR_NSEQ)
+        return fail(FARNN_ERANGE, "train_step: more than 512 states or rank above 512%s%s");
     FARNN_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
@@ -1341,8 +1343,9 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
 
     const size_t SR = S > R ? S : R;
     const size_t lds_l = 4 * (S + 2 * K) * sizeof(float);
-    const size_t vec_f = (2 * S + 2 * R + 8 * SR + 8 * S) * sizeof(float);
-    const size_t vec_b = (10 * S + 2 * R + 16 * SR + 8 * S) * sizeof(float);
+    const size_t nwv = TR_THREADS / 64;
+    const size_t vec_f = (2 * S + 2 * R + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
+    const size_t vec_b = (10 * S + 2 * R + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
     const size_t mat_f = (2 * S * R + S * S) * sizeof(float), mat_b = (3 * S * R + S * S) * sizeof(float);
     const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
     const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
@@ -1352,18 +1355,18 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     if ((rc = raise_lds_limit(train_loss_kernel, lds_l))) return rc;
     if (ldsw_f) {
         if ((rc = raise_lds_limit(train_forward_kernel<true>, lds_f))) return rc;
-        train_forward_kernel<true><<<cgrid, 256, lds_f, s>>>(p);
+        train_forward_kernel<true><<<cgrid, TR_THREADS, lds_f, s>>>(p);
     } else {
         if ((rc = raise_lds_limit(train_forward_kernel<false>, lds_f))) return rc;
-        train_forward_kernel<false><<<cgrid, 256, lds_f, s>>>(p);
+        train_forward_kernel<false><<<cgrid, TR_THREADS, lds_f, s>>>(p);
     }
     train_loss_kernel<<<(unsigned)((N0 + 3) / 4), 256, lds_l, s>>>(p);
     if (ldsw_b) {
         if ((rc = raise_lds_limit(train_backward_kernel<true>, lds_b))) return rc;
-        train_backward_kernel<true><<<cgrid, 256, lds_b, s>>>(p);
+        train_backward_kernel<true><<<cgrid, TR_THREADS, lds_b, s>>>(p);
     } else {
         if ((rc = raise_lds_limit(train_backward_kernel<false>, lds_b))) return rc;
-        train_backward_kernel<false><<<cgrid, 256, lds_b, s>>>(p);
+        train_backward_kernel<false><<<cgrid, TR_THREADS, lds_b, s>>>(p);
     }
     // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
     launch_atb(p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R, s);                 // dS2 += Zf^T (v*rr)

@@ -10,8 +10,10 @@
 // What is computed here is exactly what autograd computes for those expressions; the table v = Vgen[x]
 // (model_decompose.py:222-241) is differentiated by the caller from dVgen.
 //
-// First version: one workgroup per (sequence, direction), weights read through L2, every matrix-vector product
-// of a step split over the workgroup's four wavefronts.  Parameter gradients that are sums of outer products
+// One workgroup per pair of sequences and direction; the direction's matrices live in LDS when they fit, every
+// matrix-vector product of a step is split over the workgroup's wavefronts, everything a step reads from global
+// memory is fetched one step ahead, and the step barriers wait for LDS only (a __syncthreads would drain the
+// prefetches and the stash stores: one L2 round trip per barrier).  Parameter gradients that are sums of outer products
 // over tokens (dS1, dS2, dW, dC) are NOT accumulated with per-token atomics: the chain kernels store the
 // per-token adjoint rows and atb_accumulate_kernel reduces them as tall-skinny A^T B products.
 #pragma once
@@ -47,38 +49,58 @@ __device__ __forceinline__ float nl_grad_from_output(float y, int nl) {
     }
 }
 
+constexpr int TR_THREADS = 512;  // chain kernels: 8 wavefronts split every matrix-vector product's reduction index
+constexpr int TR_VPT = 2;        // per-thread slots covering 2 R (R <= 512) and 2 S (S <= 512) values
 constexpr int TR_NSEQ = 2;      // sequences per workgroup of the chain kernels: every weight element read feeds both
 
 // part[(wave*2+q)*J + j] = sum over this wavefront's share of k of in[q][k] M[k][j]  (M row-major [K][J], in LDS
 // or global memory; `in` = two vectors of stride ldin in LDS).  The caller adds the wavefronts' shares after a barrier.
 __device__ __forceinline__ void matvec2_partial(float *part, const float *in, int ldin, const float *__restrict__ M, int K,
                                                 int J, int tid, int nthreads) {
-    const int nw = nthreads >> 6, w = tid >> 6, lane = tid & 63;
+    constexpr int nw = TR_THREADS / 64;
+    const int w = tid >> 6, lane = tid & 63;
     const int k0 = (K * w) / nw, k1 = (K * (w + 1)) / nw;
     for (int j = lane; j < J; j += WAVE) {
-        float a0 = 0.0f, a1 = 0.0f, c0 = 0.0f, c1 = 0.0f;
-        int k = k0;
-        for (; k + 1 < k1; k += 2) {
-            const float m0 = M[(long long)k * J + j], m1 = M[(long long)(k + 1) * J + j];
-            a0 = fmaf(in[k], m0, a0); a1 = fmaf(in[k + 1], m1, a1);
-            c0 = fmaf(in[ldin + k], m0, c0); c1 = fmaf(in[ldin + k + 1], m1, c1);
+        // rounds of eight reduction indices, every read of a round issued before its use (the loop is bound by
+        // LDS latency, not issue); the last round is predicated instead of falling into a scalar tail loop
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; k += 8) {
+            float m[8], x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const bool ok = k + u < k1;
+                const int kk = ok ? k + u : k1 - 1;
+                m[u] = ok ? M[(long long)kk * J + j] : 0.0f;
+                x0[u] = in[kk]; x1[u] = in[ldin + kk];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { a[u & 3] = fmaf(x0[u], m[u], a[u & 3]); c[u & 3] = fmaf(x1[u], m[u], c[u & 3]); }
         }
-        if (k < k1) {
-            const float m0 = M[(long long)k * J + j];
-            a0 = fmaf(in[k], m0, a0); c0 = fmaf(in[ldin + k], m0, c0);
-        }
-        part[(w * 2 + 0) * J + j] = a0 + a1;
-        part[(w * 2 + 1) * J + j] = c0 + c1;
+        part[(w * 2 + 0) * J + j] = (a[0] + a[1]) + (a[2] + a[3]);
+        part[(w * 2 + 1) * J + j] = (c[0] + c[1]) + (c[2] + c[3]);
     }
 }
-__device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int nw) {
-    float s = part[q * J + j];
-    for (int w = 1; w < nw; w++) s += part[(w * 2 + q) * J + j];
+__device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int /*nw*/) {
+    constexpr int nw = TR_THREADS / 64;
+    float v[nw];
+#pragma unroll
+    for (int w = 0; w < nw; w++) v[w] = part[(w * 2 + q) * J + j];
+    float s = v[0];
+#pragma unroll
+    for (int w = 1; w < nw; w++) s += v[w];
     return s;
 }
 // copy a [rows*cols] matrix from global memory into LDS (16-byte pieces when the size allows)
 __device__ __forceinline__ void stage_matrix(float *dst, const float *__restrict__ src, int n, int tid, int nt) {
-    for (int i = tid; i < n; i += nt) dst[i] = src[i];
+    int i = tid;
+    for (; i + 7 * nt < n; i += 8 * nt) {              // eight loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[i + u * nt];
+#pragma unroll
+        for (int u = 0; u < 8; u++) dst[i + u * nt] = v[u];
+    }
+    for (; i < n; i += nt) dst[i] = src[i];
 }
 
 __global__ void transpose_kernel(const float *__restrict__ in, float *__restrict__ out, int rows, int cols) {
@@ -101,7 +123,7 @@ __global__ void column_sum_kernel(const float *__restrict__ C, float *__restrict
 // matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
 // LDS: [M1 | M2 | M3] f[2][S] tv[2][R] part[4][2][max(S,R)] part2[4][2][S]
 template <bool LDSW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TR_THREADS)
 train_forward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
@@ -121,6 +143,12 @@ train_forward_kernel(const TrainParams p) {
         len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
         maxlen = len[q] > maxlen ? len[q] : maxlen;
     }
+    // the token of every step, in step order, so that no step waits for an index load
+    int *toks = (int *)(part2 + nw * 2 * S);                  // [TR_NSEQ][L]
+    for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
+        const int q = e / p.L, i = e - q * p.L;
+        toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
+    }
     for (int e = tid; e < TR_NSEQ * S; e += nt) {
         const int q = e / S, s = e - q * S;
         const float h = dir == 0 ? p.h0[s] : p.hT[s];
@@ -128,23 +156,31 @@ train_forward_kernel(const TrainParams p) {
         f[e] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
     }
     __syncthreads();
+    // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
+    float vcur[TR_VPT], vnext[TR_VPT];
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        const int e = tid + k * nt, q = e / R, r = e - q * R;
+        vcur[k] = (e < TR_NSEQ * R && maxlen >= 1) ? p.Vgen[(long long)toks[q * p.L] * R + r] : 0.0f;
+    }
     for (int t = 1; t <= maxlen; t++) {
-        const float *v[TR_NSEQ];
-        for (int q = 0; q < TR_NSEQ; q++) {
-            const int bq = b0 + q < p.B ? b0 + q : b0, lq = len[q] > 0 ? len[q] : 1, tq = t <= lq ? t : lq;
-            v[q] = p.Vgen + (long long)clamp_tok(p.x[(long long)bq * p.L + (dir == 0 ? tq - 1 : lq - tq)], p.V) * R;
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
+            const int e = tid + k * nt, q = e / R, r = e - q * R;
+            vnext[k] = (e < TR_NSEQ * R && t < maxlen) ? p.Vgen[(long long)toks[q * p.L + t] * R + r] : 0.0f;
         }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
         matvec2_partial(part, f, S, M1, S, R, tid, nt);
         matvec2_partial(part2, f, S, M2, S, S, tid, nt);
-        __syncthreads();
-        for (int e = tid; e < TR_NSEQ * R; e += nt) {
-            const int q = e / R, r = e - q * R;
-            tv[e] = v[q][r] * part2_sum(part, R, q, r, nw);                                  // temp = V_vec * _RR
+        wg_barrier_lds();
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
+            const int e = tid + k * nt, q = e / R, r = e - q * R;
+            if (e < TR_NSEQ * R) tv[e] = vcur[k] * part2_sum(part, R, q, r, nw);             // temp = V_vec * _RR
         }
-        __syncthreads();
+        wg_barrier_lds();
         matvec2_partial(part, tv, R, M3, R, S, tid, nt);                                     // temp . (S2^T | S1^T)
-        __syncthreads();
+        wg_barrier_lds();
         for (int e = tid; e < TR_NSEQ * S; e += nt) {
             const int q = e / S, s = e - q * S;
             if (t <= len[q]) {
@@ -157,7 +193,9 @@ train_forward_kernel(const TrainParams p) {
                 f[e] = dir == 0 ? h : h * p.Osum[s];
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) vcur[k] = vnext[k];
+        wg_barrier_lds();
     }
 }
 
@@ -243,7 +281,7 @@ train_loss_kernel(const TrainParams p) {
 // (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
 // LDS: [Ma | Mb | Mc | Md] g z y fp dO [2][S] each, u rr d1 tmpv [2][R] each, pa pb [4][2][max(S,R)], pc [4][2][S]
 template <bool LDSW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(TR_THREADS)
 train_backward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
@@ -267,56 +305,90 @@ train_backward_kernel(const TrainParams p) {
         len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
         maxlen = len[q] > maxlen ? len[q] : maxlen;
     }
+    int *toks = (int *)(pc + nw * 2 * S);                     // [TR_NSEQ][L] tokens in step order
+    for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
+        const int q = e / p.L, i = e - q * p.L;
+        toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
+    }
     for (int e = tid; e < TR_NSEQ * S; e += nt) { g[e] = 0.0f; z[e] = 0.0f; fp[e] = 0.0f; y[e] = 0.0f; }
     for (int e = tid; e < TR_NSEQ * S; e += nt) dO[e] = 0.0f;       // per sequence: two threads would race on one slot
     __syncthreads();
+    // everything a step reads from the stash is fetched one step ahead into registers (the rows of a sequence
+    // beyond its length are zero, so the reads need no guard): h_t, h_{t-1}, dL/dh_t from the scoring, pre_t, v_t
+    const float *stash_base = dir == 0 ? p.A : p.Bk, *G_base = dir == 0 ? p.GA : p.GB;
+    float hcur[TR_VPT], hprev[TR_VPT], hpp[TR_VPT], gs[TR_VPT], gsn[TR_VPT], pr[TR_VPT], prn[TR_VPT], vcur[TR_VPT], vnext[TR_VPT];
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        const int e = tid + k * nt, q = e / S, sx = e - q * S;
+        const bool ok = e < TR_NSEQ * S && b0 + q < p.B && maxlen >= 1;
+        const long long row = ((long long)(b0 + (ok ? q : 0)) * (p.L + 1) + maxlen) * S + sx;
+        hcur[k] = ok ? stash_base[row] : 0.0f;
+        hprev[k] = ok ? stash_base[row - S] : 0.0f;
+        gs[k] = ok ? G_base[row] : 0.0f;
+        pr[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
+        const int e2 = tid + k * nt, q2 = e2 / R, r2 = e2 - q2 * R;
+        vcur[k] = (e2 < TR_NSEQ * R && maxlen >= 1) ? p.Vgen[(long long)toks[q2 * p.L + (maxlen - 1 < len[q2] ? maxlen - 1 : 0)] * R + r2] : 0.0f;
+    }
     for (int t = maxlen; t >= 1; t--) {
-        int tok[TR_NSEQ];
-        for (int q = 0; q < TR_NSEQ; q++)
-            tok[q] = t <= len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? t - 1 : len[q] - t)], p.V) : 0;
-        for (int e = tid; e < TR_NSEQ * S; e += nt) {
-            const int q = e / S, s = e - q * S;
-            if (t <= len[q]) {
-                const long long row0 = (long long)(b0 + q) * (p.L + 1);
-                const float *stash = (dir == 0 ? p.A : p.Bk) + row0 * S;
-                const float gt = g[e] + (dir == 0 ? p.GA : p.GB)[(row0 + t) * S + s];
-                const float yy = gt * nl_grad_from_output(stash[(long long)t * S + s], p.nl);
-                const float hp = stash[(long long)(t - 1) * S + s];
-                if (dir == 0) {                                   // mask on the OUTPUT of the step
-                    z[e] = yy * p.Osum[s]; fp[e] = hp;
-                    dO[e] = fmaf(yy, p.PRE[(row0 + t) * S + s], dO[e]);               // d Osum += y * pre_t
-                    p.Zf[(row0 + t) * S + s] = yy * p.Osum[s];
-                } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
-                    z[e] = yy; fp[e] = hp * p.Osum[s]; y[e] = hp;
-                    p.Zb[(row0 + t) * S + s] = yy;
-                    p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {                        // prefetch for step t-1
+            const int e = tid + k * nt, q = e / S, sx = e - q * S;
+            const bool ok = e < TR_NSEQ * S && b0 + q < p.B && t >= 2;
+            const long long row = ((long long)(b0 + (ok ? q : 0)) * (p.L + 1) + (t - 1)) * S + sx;
+            hpp[k] = ok ? stash_base[row - S] : 0.0f;
+            gsn[k] = ok ? G_base[row] : 0.0f;
+            prn[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
+            const int e2 = tid + k * nt, q2 = e2 / R, r2 = e2 - q2 * R;
+            vnext[k] = (e2 < TR_NSEQ * R && t >= 2) ? p.Vgen[(long long)toks[q2 * p.L + (t - 2 < len[q2] ? t - 2 : 0)] * R + r2] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
+            const int e = tid + k * nt, q = e / S, s = e - q * S;
+            if (e < TR_NSEQ * S) {
+                if (t <= len[q]) {
+                    const long long row0 = (long long)(b0 + q) * (p.L + 1);
+                    const float gt = g[e] + gs[k];
+                    const float yy = gt * nl_grad_from_output(hcur[k], p.nl);
+                    const float hp = hprev[k];
+                    if (dir == 0) {                                   // mask on the OUTPUT of the step
+                        z[e] = yy * p.Osum[s]; fp[e] = hp;
+                        dO[e] = fmaf(yy, pr[k], dO[e]);                               // d Osum += y * pre_t
+                        p.Zf[(row0 + t) * S + s] = yy * p.Osum[s];
+                    } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
+                        z[e] = yy; fp[e] = hp * p.Osum[s]; y[e] = hp;
+                        p.Zb[(row0 + t) * S + s] = yy;
+                        p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
+                    }
+                } else {
+                    z[e] = 0.0f; fp[e] = 0.0f;
                 }
-            } else {
-                z[e] = 0.0f; fp[e] = 0.0f;
             }
         }
-        __syncthreads();
+        wg_barrier_lds();
         matvec2_partial(pa, fp, S, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
         matvec2_partial(pb, z, S, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
         matvec2_partial(pc, z, S, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
-        __syncthreads();
-        for (int e = tid; e < TR_NSEQ * R; e += nt) {
-            const int q = e / R, r = e - q * R;
-            float dd = 0.0f;
-            if (t <= len[q]) {
-                const long long row = (long long)(b0 + q) * (p.L + 1) + t;
-                const float rv = part2_sum(pa, R, q, r, nw), uv = part2_sum(pb, R, q, r, nw);
-                const float vv = p.Vgen[(long long)tok[q] * R + r];
-                dd = uv * vv;
-                (dir == 0 ? p.D1f : p.D1b)[row * R + r] = dd;
-                (dir == 0 ? p.Tf : p.Tb)[row * R + r] = vv * rv;
-                atomicAdd(p.dVgen + (long long)tok[q] * R + r, uv * rv);              // d v_t = u * rr
+        wg_barrier_lds();
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
+            const int e = tid + k * nt, q = e / R, r = e - q * R;
+            if (e < TR_NSEQ * R) {
+                float dd = 0.0f;
+                if (t <= len[q]) {
+                    const long long row = (long long)(b0 + q) * (p.L + 1) + t;
+                    const float rv = part2_sum(pa, R, q, r, nw), uv = part2_sum(pb, R, q, r, nw);
+                    const float vv = vcur[k];
+                    dd = uv * vv;
+                    (dir == 0 ? p.D1f : p.D1b)[row * R + r] = dd;
+                    (dir == 0 ? p.Tf : p.Tb)[row * R + r] = vv * rv;
+                    atomicAdd(p.dVgen + (long long)toks[q * p.L + t - 1] * R + r, uv * rv);   // d v_t = u * rr
+                }
+                d1[e] = dd;
             }
-            d1[e] = dd;
         }
-        __syncthreads();
+        wg_barrier_lds();
         matvec2_partial(pa, d1, R, Md, R, S, tid, nt);            // d fp through the language factors
-        __syncthreads();
+        wg_barrier_lds();
         for (int e = tid; e < TR_NSEQ * S; e += nt) {
             const int q = e / S, s = e - q * S;
             if (t <= len[q]) {
@@ -325,7 +397,11 @@ train_backward_kernel(const TrainParams p) {
                 else { dO[e] = fmaf(dfp, y[e], dO[e]); g[e] = dfp * p.Osum[s]; }       // d Osum += d bbar * b_{t-1}
             }
         }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
+            hcur[k] = hprev[k]; hprev[k] = hpp[k]; gs[k] = gsn[k]; pr[k] = prn[k]; vcur[k] = vnext[k];
+        }
+        wg_barrier_lds();
     }
     for (int e = tid; e < TR_NSEQ * S; e += nt) {
         const int q = e / S, s = e - q * S;
