@@ -55,39 +55,56 @@ constexpr int TR_NSEQ = 2;      // sequences per workgroup of the chain kernels:
 
 // part[(wave*2+q)*J + j] = sum over this wavefront's share of k of in[q][k] M[k][j]  (M row-major [K][J], in LDS
 // or global memory; `in` = two vectors of stride ldin in LDS).  The caller adds the wavefronts' shares after a barrier.
+// Wavefront w works on column block jb = w % njb (64 columns) and reduction share ks = w / njb of nks = 8 / njb.
+__device__ __forceinline__ int mv_nks(int J) {
+    const int njb = (J + 63) >> 6, n = (TR_THREADS / 64) / njb;
+    return n < 1 ? 1 : n;
+}
+__device__ __forceinline__ int mv_pad(int n) { return ((n + 3) & ~3) + 8; }     // stride of a matvec input vector in LDS
+
+// part[(ks*2+q)*J + j] = sum over share ks of k of in[q][k] M[k][j]   (M row-major [K][J] in LDS or global memory; `in` =
+// two vectors of stride ldin = mv_pad(K) in LDS, 16-byte aligned, zero beyond K).  Measured on the first version (one
+// LDS read per operand): 5.8 k cycles for the two products of a step, 2/3 of the LDS instructions being broadcast reads
+// of `in` -- those are 16-byte reads here, and the shares start at multiples of 4.
 __device__ __forceinline__ void matvec2_partial(float *part, const float *in, int ldin, const float *__restrict__ M, int K,
-                                                int J, int tid, int nthreads) {
-    constexpr int nw = TR_THREADS / 64;
+                                                int J, int tid, int /*nthreads*/) {
+    const int njb = (J + 63) >> 6, nks = mv_nks(J);
     const int w = tid >> 6, lane = tid & 63;
-    const int k0 = (K * w) / nw, k1 = (K * (w + 1)) / nw;
-    for (int j = lane; j < J; j += WAVE) {
-        // rounds of eight reduction indices, every read of a round issued before its use (the loop is bound by
-        // LDS latency, not issue); the last round is predicated instead of falling into a scalar tail loop
-        float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int k = k0; k < k1; k += 8) {
-            float m[8], x0[8], x1[8];
+    const int jb = w % njb, ks = w / njb;
+    if (ks >= nks) return;
+    const int j = jb * 64 + lane;
+    const int K4 = (K + 3) >> 2;
+    const int k0 = 4 * ((K4 * ks) / nks), k1r = 4 * ((K4 * (ks + 1)) / nks), k1 = k1r < K ? k1r : K;
+    const bool jok = j < J;
+    const int jc = jok ? j : J - 1;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = k0; k < k1; k += 8) {
+        float m[8];
+        const v4f x0a = *(const v4f *)(in + k), x0b = *(const v4f *)(in + k + 4);
+        const v4f x1a = *(const v4f *)(in + ldin + k), x1b = *(const v4f *)(in + ldin + k + 4);
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const bool ok = k + u < k1;
-                const int kk = ok ? k + u : k1 - 1;
-                m[u] = ok ? M[(long long)kk * J + j] : 0.0f;
-                x0[u] = in[kk]; x1[u] = in[ldin + kk];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { a[u & 3] = fmaf(x0[u], m[u], a[u & 3]); c[u & 3] = fmaf(x1[u], m[u], c[u & 3]); }
+        for (int u = 0; u < 8; u++) {
+            const bool ok = k + u < k1;
+            m[u] = ok ? M[(long long)(ok ? k + u : k1 - 1) * J + jc] : 0.0f;
         }
-        part[(w * 2 + 0) * J + j] = (a[0] + a[1]) + (a[2] + a[3]);
-        part[(w * 2 + 1) * J + j] = (c[0] + c[1]) + (c[2] + c[3]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = fmaf(x0a[u], m[u], a[u]); c[u] = fmaf(x1a[u], m[u], c[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = fmaf(x0b[u], m[4 + u], a[u]); c[u] = fmaf(x1b[u], m[4 + u], c[u]);
+        }
+    }
+    if (jok) {
+        part[(ks * 2 + 0) * J + j] = (a[0] + a[1]) + (a[2] + a[3]);
+        part[(ks * 2 + 1) * J + j] = (c[0] + c[1]) + (c[2] + c[3]);
     }
 }
 __device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int /*nw*/) {
-    constexpr int nw = TR_THREADS / 64;
-    float v[nw];
-#pragma unroll
-    for (int w = 0; w < nw; w++) v[w] = part[(w * 2 + q) * J + j];
-    float s = v[0];
-#pragma unroll
-    for (int w = 1; w < nw; w++) s += v[w];
+    const int nks = mv_nks(J);
+    float s = part[q * J + j];
+    for (int w = 1; w < nks; w++) s += part[(w * 2 + q) * J + j];
     return s;
 }
 // copy a [rows*cols] matrix from global memory into LDS (16-byte pieces when the size allows)
@@ -130,7 +147,8 @@ train_forward_kernel(const TrainParams p) {
     const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
     float *wl = smem;
-    float *f = smem + (LDSW ? 2 * S * R + S * S : 0), *tv = f + 2 * S, *part = tv + 2 * R, *part2 = part + nw * 2 * SR;
+    const int SP = mv_pad(S), RP = mv_pad(R);                  // strides of the two sequences' vectors (zero pads)
+    float *f = smem + (LDSW ? ((2 * S * R + S * S + 3) & ~3) : 0), *tv = f + 2 * SP, *part = tv + 2 * RP, *part2 = part + nw * 2 * SR;
     const float *M1 = dir == 0 ? p.S1 : p.S2, *M2 = dir == 0 ? p.W : p.WT, *M3 = dir == 0 ? p.S2T : p.S1T;
     if (LDSW) {
         stage_matrix(wl, M1, S * R, tid, nt);
@@ -149,11 +167,13 @@ train_forward_kernel(const TrainParams p) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
+    for (int e = tid; e < 2 * SP + 2 * RP; e += nt) f[e] = 0.0f;          // f | tv contiguous: pads stay zero
+    __syncthreads();
     for (int e = tid; e < TR_NSEQ * S; e += nt) {
         const int q = e / S, s = e - q * S;
         const float h = dir == 0 ? p.h0[s] : p.hT[s];
         if (b0 + q < p.B) (dir == 0 ? p.A : p.Bk)[(long long)(b0 + q) * (p.L + 1) * S + s] = h;
-        f[e] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
+        f[q * SP + s] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
     }
     __syncthreads();
     // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
@@ -170,16 +190,16 @@ train_forward_kernel(const TrainParams p) {
             vnext[k] = (e < TR_NSEQ * R && t < maxlen) ? p.Vgen[(long long)toks[q * p.L + t] * R + r] : 0.0f;
         }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
-        matvec2_partial(part, f, S, M1, S, R, tid, nt);
-        matvec2_partial(part2, f, S, M2, S, S, tid, nt);
+        matvec2_partial(part, f, SP, M1, S, R, tid, nt);
+        matvec2_partial(part2, f, SP, M2, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
             const int e = tid + k * nt, q = e / R, r = e - q * R;
-            if (e < TR_NSEQ * R) tv[e] = vcur[k] * part2_sum(part, R, q, r, nw);             // temp = V_vec * _RR
+            if (e < TR_NSEQ * R) tv[q * RP + r] = vcur[k] * part2_sum(part, R, q, r, nw);             // temp = V_vec * _RR
         }
         wg_barrier_lds();
-        matvec2_partial(part, tv, R, M3, R, S, tid, nt);                                     // temp . (S2^T | S1^T)
+        matvec2_partial(part, tv, RP, M3, R, S, tid, nt);                                     // temp . (S2^T | S1^T)
         wg_barrier_lds();
         for (int e = tid; e < TR_NSEQ * S; e += nt) {
             const int q = e / S, s = e - q * S;
@@ -190,7 +210,7 @@ train_forward_kernel(const TrainParams p) {
                 if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * p.Osum[s], p.nl); }   // (:181)
                 else          { h = apply_nl(pre, p.nl); }
                 (dir == 0 ? p.A : p.Bk)[row] = h;
-                f[e] = dir == 0 ? h : h * p.Osum[s];
+                f[q * SP + s] = dir == 0 ? h : h * p.Osum[s];
             }
         }
 #pragma unroll
@@ -288,8 +308,9 @@ train_backward_kernel(const TrainParams p) {
     const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
     float *wl = smem;
-    float *g = smem + (LDSW ? 3 * S * R + S * S : 0), *z = g + 2 * S, *y = z + 2 * S, *fp = y + 2 * S, *dO = fp + 2 * S;
-    float *d1 = dO + 2 * S, *pa = d1 + 2 * R, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
+    const int SP = mv_pad(S), RP = mv_pad(R);                  // strides of the matvec inputs z, fp, d1 (zero pads)
+    float *z = smem + (LDSW ? ((3 * S * R + S * S + 3) & ~3) : 0), *fp = z + 2 * SP, *d1 = fp + 2 * SP;
+    float *g = d1 + 2 * RP, *y = g + 2 * S, *dO = y + 2 * S, *pa = dO + 2 * S, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
     // rr = fp . Ma, u = z . Mb, d fp = z . Mc + d1 . Md
     const float *Ma = dir == 0 ? p.S1 : p.S2, *Mb = dir == 0 ? p.S2 : p.S1, *Mc = dir == 0 ? p.WT : p.W,
                 *Md = dir == 0 ? p.S1T : p.S2T;
@@ -310,8 +331,7 @@ train_backward_kernel(const TrainParams p) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
-    for (int e = tid; e < TR_NSEQ * S; e += nt) { g[e] = 0.0f; z[e] = 0.0f; fp[e] = 0.0f; y[e] = 0.0f; }
-    for (int e = tid; e < TR_NSEQ * S; e += nt) dO[e] = 0.0f;       // per sequence: two threads would race on one slot
+    for (int e = tid; e < 4 * SP + 2 * RP + 6 * S; e += nt) z[e] = 0.0f;   // z fp d1 g y dO contiguous; dO per sequence (two threads would race on one slot)
     __syncthreads();
     // everything a step reads from the stash is fetched one step ahead into registers (the rows of a sequence
     // beyond its length are zero, so the reads need no guard): h_t, h_{t-1}, dL/dh_t from the scoring, pre_t, v_t
@@ -351,23 +371,23 @@ train_backward_kernel(const TrainParams p) {
                     const float yy = gt * nl_grad_from_output(hcur[k], p.nl);
                     const float hp = hprev[k];
                     if (dir == 0) {                                   // mask on the OUTPUT of the step
-                        z[e] = yy * p.Osum[s]; fp[e] = hp;
+                        z[q * SP + s] = yy * p.Osum[s]; fp[q * SP + s] = hp;
                         dO[e] = fmaf(yy, pr[k], dO[e]);                               // d Osum += y * pre_t
                         p.Zf[(row0 + t) * S + s] = yy * p.Osum[s];
                     } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
-                        z[e] = yy; fp[e] = hp * p.Osum[s]; y[e] = hp;
+                        z[q * SP + s] = yy; fp[q * SP + s] = hp * p.Osum[s]; y[e] = hp;
                         p.Zb[(row0 + t) * S + s] = yy;
                         p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
                     }
                 } else {
-                    z[e] = 0.0f; fp[e] = 0.0f;
+                    z[q * SP + s] = 0.0f; fp[q * SP + s] = 0.0f;
                 }
             }
         }
         wg_barrier_lds();
-        matvec2_partial(pa, fp, S, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
-        matvec2_partial(pb, z, S, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
-        matvec2_partial(pc, z, S, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
+        matvec2_partial(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
+        matvec2_partial(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
+        matvec2_partial(pc, z, SP, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
@@ -383,11 +403,11 @@ train_backward_kernel(const TrainParams p) {
                     (dir == 0 ? p.Tf : p.Tb)[row * R + r] = vv * rv;
                     atomicAdd(p.dVgen + (long long)toks[q * p.L + t - 1] * R + r, uv * rv);   // d v_t = u * rr
                 }
-                d1[e] = dd;
+                d1[q * RP + r] = dd;
             }
         }
         wg_barrier_lds();
-        matvec2_partial(pa, d1, R, Md, R, S, tid, nt);            // d fp through the language factors
+        matvec2_partial(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
         wg_barrier_lds();
         for (int e = tid; e < TR_NSEQ * S; e += nt) {
             const int q = e / S, s = e - q * S;
