@@ -66,6 +66,7 @@ __device__ __forceinline__ int mv_pad(int n) { return ((n + 3) & ~3) + 8; }     
 // two vectors of stride ldin = mv_pad(K) in LDS, 16-byte aligned, zero beyond K).  Measured on the first version (one
 // LDS read per operand): 5.8 k cycles for the two products of a step, 2/3 of the LDS instructions being broadcast reads
 // of `in` -- those are 16-byte reads here, and the shares start at multiples of 4.
+template <bool INLDS>
 __device__ __forceinline__ void matvec2_partial(float *part, const float *in, int ldin, const float *__restrict__ M, int K,
                                                 int J, int tid, int /*nthreads*/) {
     const int njb = (J + 63) >> 6, nks = mv_nks(J);
@@ -78,14 +79,27 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
     const bool jok = j < J;
     const int jc = jok ? j : J - 1;
     float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = k0; k < k1; k += 8) {
+    // 32-bit offsets stepped by J (64-bit index arithmetic per operand cost more than the reads).  A round past the
+    // end of the share is masked on the INPUT side; the matrix rows it touches are read unguarded when the matrix is
+    // in LDS (they stay inside the allocation) and clamped to the last row otherwise.
+    int off = k0 * J + jc;
+    const int last = (K - 1) * J + jc;
+    for (int k = k0; k < k1; k += 8, off += 8 * J) {
         float m[8];
-        const v4f x0a = *(const v4f *)(in + k), x0b = *(const v4f *)(in + k + 4);
-        const v4f x1a = *(const v4f *)(in + ldin + k), x1b = *(const v4f *)(in + ldin + k + 4);
+        v4f x0a = *(const v4f *)(in + k), x0b = *(const v4f *)(in + k + 4);
+        v4f x1a = *(const v4f *)(in + ldin + k), x1b = *(const v4f *)(in + ldin + k + 4);
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const bool ok = k + u < k1;
-            m[u] = ok ? M[(long long)(ok ? k + u : k1 - 1) * J + jc] : 0.0f;
+            const int o = off + u * J;
+            m[u] = M[INLDS ? o : (o < last ? o : last)];
+        }
+        const int left = k1 - k;                          // wave-uniform
+        if (left < 8) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (u >= left) { x0a[u] = 0.0f; x1a[u] = 0.0f; }
+                if (4 + u >= left) { x0b[u] = 0.0f; x1b[u] = 0.0f; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -176,41 +190,50 @@ train_forward_kernel(const TrainParams p) {
         f[q * SP + s] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
     }
     __syncthreads();
-    // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
-    float vcur[TR_VPT], vnext[TR_VPT];
+    // per-thread slots: which (sequence, state) and (sequence, rank) element this thread owns -- fixed for the whole
+    // kernel, so the time loop has no divisions and steps its stash rows by S
+    int sq[TR_VPT], ss[TR_VPT], rq[TR_VPT], rr_[TR_VPT];
+    bool sv[TR_VPT], rv[TR_VPT];
+    long long srow[TR_VPT];
 #pragma unroll
     for (int k = 0; k < TR_VPT; k++) {
-        const int e = tid + k * nt, q = e / R, r = e - q * R;
-        vcur[k] = (e < TR_NSEQ * R && maxlen >= 1) ? p.Vgen[(long long)toks[q * p.L] * R + r] : 0.0f;
+        const int e = tid + k * nt;
+        sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        srow[k] = (long long)(b0 + sq[k]) * (p.L + 1) * S + ss[k];
+    }
+    float *stash_out = dir == 0 ? p.A : p.Bk;
+    // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
+    float vcur[TR_VPT], vnext[TR_VPT], osum[TR_VPT];
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L] * R + rr_[k]] : 0.0f;
+        osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
     }
     for (int t = 1; t <= maxlen; t++) {
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
-            const int e = tid + k * nt, q = e / R, r = e - q * R;
-            vnext[k] = (e < TR_NSEQ * R && t < maxlen) ? p.Vgen[(long long)toks[q * p.L + t] * R + r] : 0.0f;
-        }
+        for (int k = 0; k < TR_VPT; k++)
+            vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(long long)toks[rq[k] * p.L + t] * R + rr_[k]] : 0.0f;
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
-        matvec2_partial(part, f, SP, M1, S, R, tid, nt);
-        matvec2_partial(part2, f, SP, M2, S, S, tid, nt);
+        matvec2_partial<LDSW>(part, f, SP, M1, S, R, tid, nt);
+        matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
+        wg_barrier_lds();
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++)
+            if (rv[k]) tv[rq[k] * RP + rr_[k]] = vcur[k] * part2_sum(part, R, rq[k], rr_[k], nw);     // temp = V_vec * _RR
+        wg_barrier_lds();
+        matvec2_partial<LDSW>(part, tv, RP, M3, R, S, tid, nt);                              // temp . (S2^T | S1^T)
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
-            const int e = tid + k * nt, q = e / R, r = e - q * R;
-            if (e < TR_NSEQ * R) tv[q * RP + r] = vcur[k] * part2_sum(part, R, q, r, nw);             // temp = V_vec * _RR
-        }
-        wg_barrier_lds();
-        matvec2_partial(part, tv, RP, M3, R, S, tid, nt);                                     // temp . (S2^T | S1^T)
-        wg_barrier_lds();
-        for (int e = tid; e < TR_NSEQ * S; e += nt) {
-            const int q = e / S, s = e - q * S;
-            if (t <= len[q]) {
-                const float pre = part2_sum(part, S, q, s, nw) + part2_sum(part2, S, q, s, nw);
-                const long long row = ((long long)(b0 + q) * (p.L + 1) + t) * S + s;
+            if (sv[k] && t <= len[sq[k]]) {
+                const float pre = part2_sum(part, S, sq[k], ss[k], nw) + part2_sum(part2, S, sq[k], ss[k], nw);
+                const long long row = srow[k] + (long long)t * S;
                 float h;
-                if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * p.Osum[s], p.nl); }   // (:181)
+                if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * osum[k], p.nl); }      // (:181)
                 else          { h = apply_nl(pre, p.nl); }
-                (dir == 0 ? p.A : p.Bk)[row] = h;
-                f[q * SP + s] = dir == 0 ? h : h * p.Osum[s];
+                stash_out[row] = h;
+                f[sq[k] * SP + ss[k]] = dir == 0 ? h : h * osum[k];
             }
         }
 #pragma unroll
@@ -385,9 +408,9 @@ train_backward_kernel(const TrainParams p) {
             }
         }
         wg_barrier_lds();
-        matvec2_partial(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
-        matvec2_partial(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
-        matvec2_partial(pc, z, SP, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
+        matvec2_partial<LDSW>(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
+        matvec2_partial<LDSW>(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
+        matvec2_partial<LDSW>(pc, z, SP, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
@@ -407,7 +430,7 @@ train_backward_kernel(const TrainParams p) {
             }
         }
         wg_barrier_lds();
-        matvec2_partial(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
+        matvec2_partial<LDSW>(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
         wg_barrier_lds();
         for (int e = tid; e < TR_NSEQ * S; e += nt) {
             const int q = e / S, s = e - q * S;
