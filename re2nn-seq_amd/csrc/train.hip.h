@@ -356,54 +356,70 @@ train_backward_kernel(const TrainParams p) {
     }
     for (int e = tid; e < 4 * SP + 2 * RP + 6 * S; e += nt) z[e] = 0.0f;   // z fp d1 g y dO contiguous; dO per sequence (two threads would race on one slot)
     __syncthreads();
+    // per-thread slots, fixed for the whole kernel (no divisions in the time loop); g, y and dOsum of a slot are only
+    // ever touched by its owner, so they live in registers
+    int sq[TR_VPT], ss[TR_VPT], rq[TR_VPT], rr_[TR_VPT];
+    bool sv[TR_VPT], rv[TR_VPT];
+    long long srow[TR_VPT], rrow[TR_VPT];
+    float osum[TR_VPT], gacc[TR_VPT], dOacc[TR_VPT], yk[TR_VPT];
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        const int e = tid + k * nt;
+        sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        sv[k] = sv[k] && b0 + sq[k] < p.B;
+        rv[k] = rv[k] && b0 + rq[k] < p.B;
+        srow[k] = (long long)(b0 + (sv[k] ? sq[k] : 0)) * (p.L + 1) * S + ss[k];
+        rrow[k] = (long long)(b0 + (rv[k] ? rq[k] : 0)) * (p.L + 1) * R + rr_[k];
+        osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
+        gacc[k] = 0.0f; dOacc[k] = 0.0f; yk[k] = 0.0f;
+    }
     // everything a step reads from the stash is fetched one step ahead into registers (the rows of a sequence
     // beyond its length are zero, so the reads need no guard): h_t, h_{t-1}, dL/dh_t from the scoring, pre_t, v_t
     const float *stash_base = dir == 0 ? p.A : p.Bk, *G_base = dir == 0 ? p.GA : p.GB;
+    float *Zo = dir == 0 ? p.Zf : p.Zb, *D1o = dir == 0 ? p.D1f : p.D1b, *To = dir == 0 ? p.Tf : p.Tb;
     float hcur[TR_VPT], hprev[TR_VPT], hpp[TR_VPT], gs[TR_VPT], gsn[TR_VPT], pr[TR_VPT], prn[TR_VPT], vcur[TR_VPT], vnext[TR_VPT];
 #pragma unroll
     for (int k = 0; k < TR_VPT; k++) {
-        const int e = tid + k * nt, q = e / S, sx = e - q * S;
-        const bool ok = e < TR_NSEQ * S && b0 + q < p.B && maxlen >= 1;
-        const long long row = ((long long)(b0 + (ok ? q : 0)) * (p.L + 1) + maxlen) * S + sx;
+        const bool ok = sv[k] && maxlen >= 1;
+        const long long row = srow[k] + (long long)maxlen * S;
         hcur[k] = ok ? stash_base[row] : 0.0f;
         hprev[k] = ok ? stash_base[row - S] : 0.0f;
         gs[k] = ok ? G_base[row] : 0.0f;
         pr[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
-        const int e2 = tid + k * nt, q2 = e2 / R, r2 = e2 - q2 * R;
-        vcur[k] = (e2 < TR_NSEQ * R && maxlen >= 1) ? p.Vgen[(long long)toks[q2 * p.L + (maxlen - 1 < len[q2] ? maxlen - 1 : 0)] * R + r2] : 0.0f;
+        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L + (maxlen - 1 < len[rq[k]] ? maxlen - 1 : 0)] * R + rr_[k]] : 0.0f;
     }
     for (int t = maxlen; t >= 1; t--) {
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {                        // prefetch for step t-1
-            const int e = tid + k * nt, q = e / S, sx = e - q * S;
-            const bool ok = e < TR_NSEQ * S && b0 + q < p.B && t >= 2;
-            const long long row = ((long long)(b0 + (ok ? q : 0)) * (p.L + 1) + (t - 1)) * S + sx;
+            const bool ok = sv[k] && t >= 2;
+            const long long row = srow[k] + (long long)(t - 1) * S;
             hpp[k] = ok ? stash_base[row - S] : 0.0f;
             gsn[k] = ok ? G_base[row] : 0.0f;
             prn[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
-            const int e2 = tid + k * nt, q2 = e2 / R, r2 = e2 - q2 * R;
-            vnext[k] = (e2 < TR_NSEQ * R && t >= 2) ? p.Vgen[(long long)toks[q2 * p.L + (t - 2 < len[q2] ? t - 2 : 0)] * R + r2] : 0.0f;
+            vnext[k] = (rv[k] && t >= 2) ? p.Vgen[(long long)toks[rq[k] * p.L + (t - 2 < len[rq[k]] ? t - 2 : 0)] * R + rr_[k]] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
-            const int e = tid + k * nt, q = e / S, s = e - q * S;
-            if (e < TR_NSEQ * S) {
-                if (t <= len[q]) {
-                    const long long row0 = (long long)(b0 + q) * (p.L + 1);
-                    const float gt = g[e] + gs[k];
-                    const float yy = gt * nl_grad_from_output(hcur[k], p.nl);
+            if (sv[k]) {
+                const int li = sq[k] * SP + ss[k];
+                if (t <= len[sq[k]]) {
+                    const long long row = srow[k] + (long long)t * S;
+                    const float yy = (gacc[k] + gs[k]) * nl_grad_from_output(hcur[k], p.nl);
                     const float hp = hprev[k];
                     if (dir == 0) {                                   // mask on the OUTPUT of the step
-                        z[q * SP + s] = yy * p.Osum[s]; fp[q * SP + s] = hp;
-                        dO[e] = fmaf(yy, pr[k], dO[e]);                               // d Osum += y * pre_t
-                        p.Zf[(row0 + t) * S + s] = yy * p.Osum[s];
+                        const float zz = yy * osum[k];
+                        z[li] = zz; fp[li] = hp;
+                        dOacc[k] = fmaf(yy, pr[k], dOacc[k]);                         // d Osum += y * pre_t
+                        Zo[row] = zz;
                     } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
-                        z[q * SP + s] = yy; fp[q * SP + s] = hp * p.Osum[s]; y[e] = hp;
-                        p.Zb[(row0 + t) * S + s] = yy;
-                        p.BBAR[(row0 + t) * S + s] = hp * p.Osum[s];
+                        const float bb = hp * osum[k];
+                        z[li] = yy; fp[li] = bb; yk[k] = hp;
+                        Zo[row] = yy;
+                        p.BBAR[row] = bb;
                     }
                 } else {
-                    z[q * SP + s] = 0.0f; fp[q * SP + s] = 0.0f;
+                    z[li] = 0.0f; fp[li] = 0.0f;
                 }
             }
         }
@@ -414,46 +430,42 @@ train_backward_kernel(const TrainParams p) {
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
-            const int e = tid + k * nt, q = e / R, r = e - q * R;
-            if (e < TR_NSEQ * R) {
+            if (rv[k]) {
                 float dd = 0.0f;
-                if (t <= len[q]) {
-                    const long long row = (long long)(b0 + q) * (p.L + 1) + t;
-                    const float rv = part2_sum(pa, R, q, r, nw), uv = part2_sum(pb, R, q, r, nw);
+                if (t <= len[rq[k]]) {
+                    const long long row = rrow[k] + (long long)t * R;
+                    const float rvv = part2_sum(pa, R, rq[k], rr_[k], nw), uv = part2_sum(pb, R, rq[k], rr_[k], nw);
                     const float vv = vcur[k];
                     dd = uv * vv;
-                    (dir == 0 ? p.D1f : p.D1b)[row * R + r] = dd;
-                    (dir == 0 ? p.Tf : p.Tb)[row * R + r] = vv * rv;
-                    atomicAdd(p.dVgen + (long long)toks[q * p.L + t - 1] * R + r, uv * rv);   // d v_t = u * rr
+                    D1o[row] = dd;
+                    To[row] = vv * rvv;
+                    atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], uv * rvv);   // d v_t = u * rr
                 }
-                d1[q * RP + r] = dd;
+                d1[rq[k] * RP + rr_[k]] = dd;
             }
         }
         wg_barrier_lds();
         matvec2_partial<LDSW>(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
         wg_barrier_lds();
-        for (int e = tid; e < TR_NSEQ * S; e += nt) {
-            const int q = e / S, s = e - q * S;
-            if (t <= len[q]) {
-                const float dfp = part2_sum(pc, S, q, s, nw) + part2_sum(pa, S, q, s, nw);
-                if (dir == 0) g[e] = dfp;
-                else { dO[e] = fmaf(dfp, y[e], dO[e]); g[e] = dfp * p.Osum[s]; }       // d Osum += d bbar * b_{t-1}
-            }
-        }
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++) {
+            if (sv[k] && t <= len[sq[k]]) {
+                const float dfp = part2_sum(pc, S, sq[k], ss[k], nw) + part2_sum(pa, S, sq[k], ss[k], nw);
+                if (dir == 0) gacc[k] = dfp;
+                else { dOacc[k] = fmaf(dfp, yk[k], dOacc[k]); gacc[k] = dfp * osum[k]; }   // d Osum += d bbar * b_{t-1}
+            }
             hcur[k] = hprev[k]; hprev[k] = hpp[k]; gs[k] = gsn[k]; pr[k] = prn[k]; vcur[k] = vnext[k];
         }
         wg_barrier_lds();
     }
-    for (int e = tid; e < TR_NSEQ * S; e += nt) {
-        const int q = e / S, s = e - q * S;
-        if (b0 + q < p.B) {
-            const float g0 = g[e] + (dir == 0 ? p.GA : p.GB)[(long long)(b0 + q) * (p.L + 1) * S + s];
-            if (g0 != 0.0f) atomicAdd((dir == 0 ? p.dh0 : p.dhT) + s, g0);
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        if (sv[k]) {
+            const float g0 = gacc[k] + G_base[srow[k]];
+            if (g0 != 0.0f) atomicAdd((dir == 0 ? p.dh0 : p.dhT) + ss[k], g0);
+            if (dOacc[k] != 0.0f) atomicAdd(p.dOsum + ss[k], dOacc[k]);
         }
     }
-    for (int s = tid; s < S; s += nt) atomicAdd(p.dOsum + s, dO[s] + dO[S + s]);
 }
 
 // out[M][J] += sum_n A[n][M] B[n][J]   (A, B row-major with the reduction index as the row; rows that do not
