@@ -1219,6 +1219,8 @@ struct farnn_train_ctx {
     farnn_train_dims d;
     int device = 0;
     float *ws = nullptr;          // per-batch workspace (zeroed every step)
+    float *part = nullptr;        // partial products of the parameter-gradient reductions
+    size_t part_floats = 0;
     size_t ws_floats = 0;
     int wsB = 0, wsL = 0;
     float *S1T = nullptr, *S2T = nullptr, *WT = nullptr, *Osum = nullptr, *dOsum = nullptr;
@@ -1254,6 +1256,7 @@ extern "C" void farnn_train_destroy(farnn_train_ctx *c) {
     (void)hipDeviceSynchronize();
     for (auto &e : c->pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ws) (void)hipFree(c->ws);
+    if (c->part) (void)hipFree(c->part);
     if (c->S1T) (void)hipFree(c->S1T);
     delete c;
 }
@@ -1279,11 +1282,22 @@ extern "C" int farnn_train_time(farnn_train_ctx *c, double *total_ms, int64_t *s
     return FARNN_OK;
 }
 
-static void launch_atb(const float *A, const float *Bm, float *out, long long N, int M, int J, hipStream_t s) {
-    if (N <= 0) return;
-    const long long chunk = 128;
-    dim3 grid((M + 31) / 32, (J + 31) / 32, (unsigned)((N + chunk - 1) / chunk));
-    atb_accumulate_kernel<<<grid, 256, 0, s>>>(A, Bm, out, N, M, J, chunk);
+static void atb_add(AtbJobs &jobs, const float *A, const float *Bm, float *out, long long N, int M, int J) {
+    if (N <= 0 || jobs.n >= ATB_MAX_JOBS) return;
+    AtbJob &j = jobs.j[jobs.n];
+    j.A = A; j.B = Bm; j.out = out; j.N = N; j.M = M; j.J = J;
+    j.tiles_m = (M + 31) / 32; j.tiles_j = (J + 31) / 32;
+    j.nsplit = (int)((N + jobs.chunk - 1) / jobs.chunk);
+    j.wg0 = jobs.total_wgs; j.out0 = jobs.total_out;
+    j.part_off = jobs.n ? jobs.j[jobs.n - 1].part_off + (long long)jobs.j[jobs.n - 1].nsplit * jobs.j[jobs.n - 1].M * jobs.j[jobs.n - 1].J : 0;
+    jobs.total_wgs += j.tiles_m * j.tiles_j * j.nsplit;
+    jobs.total_out += M * J;
+    jobs.n++;
+}
+static size_t atb_partial_floats(const AtbJobs &jobs) {
+    if (!jobs.n) return 0;
+    const AtbJob &l = jobs.j[jobs.n - 1];
+    return (size_t)(l.part_off + (long long)l.nsplit * l.M * l.J);
 }
 
 extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_train_weights *w, const int64_t *x,
@@ -1370,13 +1384,26 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         train_backward_kernel<false><<<cgrid, TR_THREADS, lds_b, s>>>(p);
     }
     // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
-    launch_atb(p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R, s);                 // dS2 += Zf^T (v*rr)
-    launch_atb(p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R, s);         // dS1 += f_{t-1}^T (u*v)
-    launch_atb(p.A, p.Zf + S, o->dW, (long long)N1 - 1, (int)S, (int)S, s);           // dW  += f_{t-1}^T z
-    launch_atb(p.Zb, p.Tb, o->dS1, (long long)N1, (int)S, (int)R, s);                 // backward chain: roles of S1, S2 swap
-    launch_atb(p.BBAR, p.D1b, o->dS2, (long long)N1, (int)S, (int)R, s);
-    launch_atb(p.Zb, p.BBAR, o->dW, (long long)N1, (int)S, (int)S, s);                // pre_j += sum_s bbar_s W[j][s]
-    launch_atb(p.DS, p.AB, o->dC, (long long)N0, (int)K, (int)S, s);                  // dC += ds^T (alpha*beta)
+    AtbJobs jobs;
+    memset(&jobs, 0, sizeof(jobs));
+    jobs.chunk = 128;
+    atb_add(jobs, p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R);                 // dS2 += Zf^T (v*rr)
+    atb_add(jobs, p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R);         // dS1 += f_{t-1}^T (u*v)
+    atb_add(jobs, p.A, p.Zf + S, o->dW, (long long)N1 - 1, (int)S, (int)S);           // dW  += f_{t-1}^T z
+    atb_add(jobs, p.Zb, p.Tb, o->dS1, (long long)N1, (int)S, (int)R);                 // backward chain: roles of S1, S2 swap
+    atb_add(jobs, p.BBAR, p.D1b, o->dS2, (long long)N1, (int)S, (int)R);
+    atb_add(jobs, p.Zb, p.BBAR, o->dW, (long long)N1, (int)S, (int)S);                // pre_j += sum_s bbar_s W[j][s]
+    atb_add(jobs, p.DS, p.AB, o->dC, (long long)N0, (int)K, (int)S);                  // dC += ds^T (alpha*beta)
+    const size_t pf = atb_partial_floats(jobs);
+    if (pf > c->part_floats) {
+        if (c->part) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->part); c->part = nullptr; c->part_floats = 0; }
+        if (hipMalloc((void **)&c->part, pf * sizeof(float)) != hipSuccess)
+            return fail(FARNN_ENOMEM, "train_step: out of device memory for the gradient partials%s%s");
+        c->part_floats = pf;
+    }
+    jobs.partial = c->part;
+    atb_partial_kernel<<<jobs.total_wgs, 256, 0, s>>>(jobs);
+    atb_reduce_kernel<<<(jobs.total_out + 255) / 256, 256, 0, s>>>(jobs);
     add_row_to_all_kernel<<<(unsigned)((K * S + 255) / 256), 256, 0, s>>>(o->dC, c->dOsum, (int)K, (int)S);
     FARNN_HIP_TRY(hipGetLastError());
     if (e0 && e1) { (void)hipEventRecord(e1, s); c->pending.emplace_back(e0, e1); }

@@ -468,22 +468,44 @@ train_backward_kernel(const TrainParams p) {
     }
 }
 
-// out[M][J] += sum_n A[n][M] B[n][J]   (A, B row-major with the reduction index as the row; rows that do not
-// belong to a valid token are zero).  grid (ceil(M/32), ceil(J/32), splits); 256 threads, 2x2 outputs each.
+// ---- parameter gradients: out[M][J] += sum_n A[n][M] B[n][J] for several (A, B, out) at once -------------------
+// (A, B row-major with the reduction index as the row; rows that do not belong to a valid token are zero.)  Two
+// launches for all products of a step: atb_partial_kernel computes 32x32 output tiles over row chunks and writes them
+// to a partial buffer without atomics (130 chunks adding into the same 10 k addresses ran at the contended atomic
+// rate: 33 us per product); atb_reduce_kernel adds the chunks of every output element.
+constexpr int ATB_MAX_JOBS = 8;
+struct AtbJob {
+    const float *A, *B;
+    float *out;
+    long long N, part_off;
+    int M, J, tiles_m, tiles_j, nsplit, wg0, out0;
+};
+struct AtbJobs {
+    AtbJob j[ATB_MAX_JOBS];
+    int n, total_wgs, total_out;
+    long long chunk;
+    float *partial;
+};
+
 __global__ void __launch_bounds__(256)
-atb_accumulate_kernel(const float *__restrict__ A, const float *__restrict__ Bm, float *out, long long N, int M, int J,
-                      long long chunk) {
+atb_partial_kernel(const AtbJobs jobs) {
     __shared__ float sa[32][33], sb[32][33];
+    int ji = 0;
+    while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ji++;
+    const AtbJob &jb = jobs.j[ji];
+    const int local = blockIdx.x - jb.wg0;
+    const int tiles = jb.tiles_m * jb.tiles_j, split = local / tiles, tile = local - split * tiles;
+    const int m0 = (tile / jb.tiles_j) * 32, j0 = (tile % jb.tiles_j) * 32;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int m0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
-    const long long n0 = (long long)blockIdx.z * chunk, n1 = n0 + chunk < N ? n0 + chunk : N;
+    const int M = jb.M, J = jb.J;
+    const long long n0 = (long long)split * jobs.chunk, n1 = n0 + jobs.chunk < jb.N ? n0 + jobs.chunk : jb.N;
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
     for (long long nb = n0; nb < n1; nb += 32) {
         for (int e = tid; e < 32 * 32; e += 256) {
             const int rn = e >> 5, c = e & 31;
             const long long n = nb + rn;
-            sa[rn][c] = (n < n1 && m0 + c < M) ? A[n * M + m0 + c] : 0.0f;
-            sb[rn][c] = (n < n1 && j0 + c < J) ? Bm[n * J + j0 + c] : 0.0f;
+            sa[rn][c] = (n < n1 && m0 + c < M) ? jb.A[n * M + m0 + c] : 0.0f;
+            sb[rn][c] = (n < n1 && j0 + c < J) ? jb.B[n * J + j0 + c] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -494,11 +516,29 @@ atb_accumulate_kernel(const float *__restrict__ A, const float *__restrict__ Bm,
         }
         __syncthreads();
     }
+    float *po = jobs.partial + jb.part_off + (long long)split * M * J;
     for (int a = 0; a < 2; a++)
         for (int c = 0; c < 2; c++) {
             const int m = m0 + ty * 2 + a, j = j0 + tx * 2 + c;
-            if (m < M && j < J && acc[a][c] != 0.0f) atomicAdd(out + (long long)m * J + j, acc[a][c]);
+            if (m < M && j < J) po[(long long)m * J + j] = acc[a][c];
         }
+}
+
+__global__ void __launch_bounds__(256)
+atb_reduce_kernel(const AtbJobs jobs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= jobs.total_out) return;
+    int ji = 0;
+    while (ji + 1 < jobs.n && idx >= jobs.j[ji + 1].out0) ji++;
+    const AtbJob &jb = jobs.j[ji];
+    const int e = idx - jb.out0;
+    const long long mj = (long long)jb.M * jb.J;
+    const float *po = jobs.partial + jb.part_off + e;
+    float s0 = 0.0f, s1 = 0.0f;
+    int sp = 0;
+    for (; sp + 1 < jb.nsplit; sp += 2) { s0 += po[sp * mj]; s1 += po[(sp + 1) * mj]; }
+    if (sp < jb.nsplit) s0 += po[sp * mj];
+    atomicAdd(jb.out + e, s0 + s1);                      // two products may share an output (both chains add into dS1, dS2, dW)
 }
 
 // dC[c][s] += dOsum[s] for every label row (Osum = C.sum(0))
