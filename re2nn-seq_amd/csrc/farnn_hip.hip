@@ -1356,7 +1356,10 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     column_sum_kernel<<<(unsigned)((S + 255) / 256), 256, 0, s>>>(w->C, c->Osum, (int)K, (int)S);
 
     const size_t SR = S > R ? S : R;
-    const size_t lds_l = 4 * (S + 2 * K) * sizeof(float);
+    const size_t SPd0 = ((S + 3) & ~(size_t)3) + 8;
+    const size_t lds_lw = 8 * (SPd0 + 2 * K) * sizeof(float), lds_lc = ((K * (S + 1) + 3) & ~(size_t)3) * sizeof(float);
+    const bool clds = lds_lw + lds_lc <= 150 * 1024;
+    const size_t lds_l = lds_lw + (clds ? lds_lc : 0);
     const size_t nwv = TR_THREADS / 64;
     const size_t SPd = ((S + 3) & ~(size_t)3) + 8, RPd = ((R + 3) & ~(size_t)3) + 8;
     const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
@@ -1367,7 +1370,6 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t lds_f = vec_f + (ldsw_f ? mat_f : 0), lds_b = vec_b + (ldsw_b ? mat_b : 0);
     const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
-    if ((rc = raise_lds_limit(train_loss_kernel, lds_l))) return rc;
     if (ldsw_f) {
         if ((rc = raise_lds_limit(train_forward_kernel<true>, lds_f))) return rc;
         train_forward_kernel<true><<<cgrid, TR_THREADS, lds_f, s>>>(p);
@@ -1375,7 +1377,19 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         if ((rc = raise_lds_limit(train_forward_kernel<false>, lds_f))) return rc;
         train_forward_kernel<false><<<cgrid, TR_THREADS, lds_f, s>>>(p);
     }
-    train_loss_kernel<<<(unsigned)((N0 + 3) / 4), 256, lds_l, s>>>(p);
+    {
+        int dev = 0, ncu = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const unsigned lgrid = (unsigned)std::min<size_t>(ncu > 0 ? ncu : 256, (N0 + 7) / 8);
+        if (clds) {
+            if ((rc = raise_lds_limit(train_loss_kernel<true>, lds_l))) return rc;
+            train_loss_kernel<true><<<lgrid, 512, lds_l, s>>>(p);
+        } else {
+            if ((rc = raise_lds_limit(train_loss_kernel<false>, lds_l))) return rc;
+            train_loss_kernel<false><<<lgrid, 512, lds_l, s>>>(p);
+        }
+    }
     if (ldsw_b) {
         if ((rc = raise_lds_limit(train_backward_kernel<true>, lds_b))) return rc;
         train_backward_kernel<true><<<cgrid, TR_THREADS, lds_b, s>>>(p);

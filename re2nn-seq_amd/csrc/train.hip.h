@@ -243,80 +243,109 @@ train_forward_kernel(const TrainParams p) {
 }
 
 // ---- scores, cross-entropy, and the adjoints of alpha / beta ------------------------------------------------
-// one wavefront per valid position.  LDS per wavefront: ab[S], sc[K], ds[K]
-__global__ void __launch_bounds__(256)
+// Persistent workgroups of 8 wavefronts; a wavefront takes positions round-robin and does one position at a time.
+// CLDS: C_output_mat staged once per workgroup in LDS with row stride S+1 (lanes = labels read it conflict-free).
+// LDS: [Cs[K][S+1]] then per wavefront ab[mv_pad(S)], sc[K], ds[K]
+template <bool CLDS>
+__global__ void __launch_bounds__(512)
 train_loss_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = blockDim.x >> 6;
-    const int S = p.S, K = p.K;
-    float *ab = smem + w * (S + 2 * K), *sc = ab + S, *ds = sc + K;
-    const long long pos = (long long)blockIdx.x * nw + w;
-    if (pos >= (long long)p.B * p.L) return;
-    const int b = (int)(pos / p.L), i = (int)(pos - (long long)b * p.L);
-    const int len = clamp_len(p.len[b], p.L);
-    if (i >= len) {
-        if (lane == 0) p.tags[pos] = -1;
-        return;
+    const int S = p.S, K = p.K, SP = mv_pad(S), ldc = CLDS ? S + 1 : S;
+    float *Cs = smem;
+    float *ab = smem + (CLDS ? ((K * (S + 1) + 3) & ~3) : 0) + w * (SP + 2 * K), *sc = ab + SP, *ds = sc + K;
+    if (CLDS) {
+        for (int e = tid; e < K * S; e += blockDim.x) { const int c = e / S, s_ = e - c * S; Cs[c * (S + 1) + s_] = p.C[e]; }
+        __syncthreads();
     }
-    const float *al = p.A + ((long long)b * (p.L + 1) + i + 1) * S;                  // h0_forward_score[:, i+1]
-    const float *be = p.Bk + ((long long)b * (p.L + 1) + (len - 1 - i)) * S;         // reverse(.., lengths+1)[:, i+1]
-    for (int s = lane; s < S; s += WAVE) {
-        const float v = al[s] * be[s];
-        ab[s] = v;
-        p.AB[pos * S + s] = v;
-    }
-    for (int c = lane; c < K; c += WAVE) {                                            // get_final_score (:200-203)
-        const float *cr = p.C + (long long)c * S;
-        float a = 0.0f;
-        for (int s = 0; s < S; s++) a = fmaf(ab[s], cr[s], a);
-        sc[c] = a;
-    }
-    if (p.P) {                                                                         // priority layer
-        for (int d = lane; d < K; d += WAVE) {
-            float a = 0.0f;
-            for (int c = 0; c < K; c++) a = fmaf(sc[c], p.P[(long long)c * K + d], a);
-            ds[d] = a;
+    const float *Cm = CLDS ? Cs : p.C;
+    float loss_acc = 0.0f;
+    for (long long pos = (long long)blockIdx.x * nw + w; pos < (long long)p.B * p.L; pos += (long long)gridDim.x * nw) {
+        const int b = (int)(pos / p.L), i = (int)(pos - (long long)b * p.L);
+        const int len = clamp_len(p.len[b], p.L);
+        if (i >= len) {
+            if (lane == 0) p.tags[pos] = -1;
+            continue;
         }
-        for (int d = lane; d < K; d += WAVE) sc[d] = ds[d];
-    }
-    // softmax cross-entropy (mean over the batch's valid tokens) and the prediction (decode, argmax branch)
-    float mx = -INFINITY;
-    for (int c = lane; c < K; c += WAVE) mx = fmaxf(mx, sc[c]);
-    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-    float se = 0.0f;
-    for (int c = lane; c < K; c += WAVE) se += expf(sc[c] - mx);
-    for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, WAVE);
-    const int lab = (int)p.labels[pos];
-    const float lse = mx + logf(se);
-    if (lane == 0) atomicAdd(p.loss, (lse - sc[lab < 0 || lab >= K ? 0 : lab]) * p.inv_tokens);
-    {
-        float bv = -INFINITY; int bi = 0x7ffffffe;
-        for (int c = lane; c < K; c += WAVE) {
-            float vv = sc[c] + 0.0f;
-            if (c == K - 1) vv = fminf(vv, p.threshold);
-            if (vv > bv) { bv = vv; bi = c; }
+        const float *al = p.A + ((long long)b * (p.L + 1) + i + 1) * S;                  // h0_forward_score[:, i+1]
+        const float *be = p.Bk + ((long long)b * (p.L + 1) + (len - 1 - i)) * S;         // reverse(.., lengths+1)[:, i+1]
+        for (int s = lane; s < S; s += WAVE) {
+            const float v = al[s] * be[s];
+            ab[s] = v;
+            p.AB[pos * S + s] = v;
         }
-        bi = wave_argmax_dpp(bv, bi);
-        if (lane == 0) p.tags[pos] = (bi >= K) ? 0 : (bi == K - 1 ? p.o_idx : bi);
-    }
-    for (int c = lane; c < K; c += WAVE) ds[c] = (expf(sc[c] - lse) - (c == lab ? 1.0f : 0.0f)) * p.inv_tokens;
-    if (p.P) {                                                                         // back through scores . P
-        for (int c = lane; c < K; c += WAVE) {
-            float a = 0.0f;
-            for (int d = 0; d < K; d++) a = fmaf(ds[d], p.P[(long long)c * K + d], a);
-            sc[c] = a;
+        for (int c = lane; c < K; c += WAVE) {                                            // get_final_score (:200-203)
+            const float *cr = Cm + (long long)c * ldc;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            int s = 0;
+            for (; s + 8 <= S; s += 8) {
+                float cv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) cv[u] = cr[s + u];
+                const v4f x0 = *(const v4f *)(ab + s), x1 = *(const v4f *)(ab + s + 4);
+                a0 = fmaf(x0[0], cv[0], a0); a1 = fmaf(x0[1], cv[1], a1); a2 = fmaf(x0[2], cv[2], a2); a3 = fmaf(x0[3], cv[3], a3);
+                a0 = fmaf(x1[0], cv[4], a0); a1 = fmaf(x1[1], cv[5], a1); a2 = fmaf(x1[2], cv[6], a2); a3 = fmaf(x1[3], cv[7], a3);
+            }
+            for (; s < S; s++) a0 = fmaf(ab[s], cr[s], a0);
+            sc[c] = (a0 + a1) + (a2 + a3);
         }
-        for (int c = lane; c < K; c += WAVE) ds[c] = sc[c];
+        if (p.P) {                                                                         // priority layer
+            for (int d = lane; d < K; d += WAVE) {
+                float a = 0.0f;
+                for (int c = 0; c < K; c++) a = fmaf(sc[c], p.P[(long long)c * K + d], a);
+                ds[d] = a;
+            }
+            for (int d = lane; d < K; d += WAVE) sc[d] = ds[d];
+        }
+        // softmax cross-entropy (mean over the batch's valid tokens) and the prediction (decode, argmax branch)
+        float mx = -INFINITY;
+        for (int c = lane; c < K; c += WAVE) mx = fmaxf(mx, sc[c]);
+        for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
+        float se = 0.0f;
+        for (int c = lane; c < K; c += WAVE) se += expf(sc[c] - mx);
+        for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, WAVE);
+        const int lab = (int)p.labels[pos];
+        const float lse = mx + logf(se);
+        loss_acc += lse - sc[lab < 0 || lab >= K ? 0 : lab];
+        {
+            float bv = -INFINITY; int bi = 0x7ffffffe;
+            for (int c = lane; c < K; c += WAVE) {
+                float vv = sc[c] + 0.0f;
+                if (c == K - 1) vv = fminf(vv, p.threshold);
+                if (vv > bv) { bv = vv; bi = c; }
+            }
+            bi = wave_argmax_dpp(bv, bi);
+            if (lane == 0) p.tags[pos] = (bi >= K) ? 0 : (bi == K - 1 ? p.o_idx : bi);
+        }
+        for (int c = lane; c < K; c += WAVE) ds[c] = (expf(sc[c] - lse) - (c == lab ? 1.0f : 0.0f)) * p.inv_tokens;
+        if (p.P) {                                                                         // back through scores . P
+            for (int c = lane; c < K; c += WAVE) {
+                float a = 0.0f;
+                for (int d = 0; d < K; d++) a = fmaf(ds[d], p.P[(long long)c * K + d], a);
+                sc[c] = a;
+            }
+            for (int c = lane; c < K; c += WAVE) ds[c] = sc[c];
+        }
+        for (int c = lane; c < K; c += WAVE) p.DS[pos * K + c] = ds[c];
+        float *ga = p.GA + ((long long)b * (p.L + 1) + i + 1) * S;
+        float *gb = p.GB + ((long long)b * (p.L + 1) + (len - 1 - i)) * S;
+        for (int s = lane; s < S; s += WAVE) {
+            float d0 = 0.0f, d1 = 0.0f;
+            int c = 0;
+            for (; c + 8 <= K; c += 8) {
+                float cv[8], dv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { cv[u] = Cm[(long long)(c + u) * ldc + s]; dv[u] = ds[c + u]; }
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { d0 = fmaf(dv[u], cv[u], d0); d1 = fmaf(dv[u + 1], cv[u + 1], d1); }
+            }
+            for (; c < K; c++) d0 = fmaf(ds[c], Cm[(long long)c * ldc + s], d0);           // d(alpha*beta)
+            const float d = d0 + d1;
+            ga[s] = d * be[s];
+            gb[s] = d * al[s];
+        }
     }
-    for (int c = lane; c < K; c += WAVE) p.DS[pos * K + c] = ds[c];
-    float *ga = p.GA + ((long long)b * (p.L + 1) + i + 1) * S;
-    float *gb = p.GB + ((long long)b * (p.L + 1) + (len - 1 - i)) * S;
-    for (int s = lane; s < S; s += WAVE) {
-        float d = 0.0f;
-        for (int c = 0; c < K; c++) d = fmaf(ds[c], p.C[(long long)c * S + s], d);     // d(alpha*beta)
-        ga[s] = d * be[s];
-        gb[s] = d * al[s];
-    }
+    if (lane == 0 && loss_acc != 0.0f) atomicAdd(p.loss, loss_acc * p.inv_tokens);
 }
 
 // ---- back-propagation through time ----------------------------------------------------------------------------
@@ -489,7 +518,8 @@ struct AtbJobs {
 
 __global__ void __launch_bounds__(256)
 atb_partial_kernel(const AtbJobs jobs) {
-    __shared__ float sa[32][33], sb[32][33];
+    constexpr int CH = 128;                          // rows per chunk = jobs.chunk: the whole chunk is staged at once,
+    __shared__ float sa[CH][33], sb[CH][33];         // 32 loads per thread in flight, one barrier
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ji++;
     const AtbJob &jb = jobs.j[ji];
@@ -498,23 +528,26 @@ atb_partial_kernel(const AtbJobs jobs) {
     const int m0 = (tile / jb.tiles_j) * 32, j0 = (tile % jb.tiles_j) * 32;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int M = jb.M, J = jb.J;
-    const long long n0 = (long long)split * jobs.chunk, n1 = n0 + jobs.chunk < jb.N ? n0 + jobs.chunk : jb.N;
+    const long long n0 = (long long)split * CH, n1 = n0 + CH < jb.N ? n0 + CH : jb.N;
+    {
+        const int c = tid & 31, r0 = tid >> 5;       // 8 rows per pass, 16 passes
+        float va[16], vb[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const long long n = n0 + r0 + u * 8;
+            va[u] = (n < n1 && m0 + c < M) ? jb.A[n * M + m0 + c] : 0.0f;
+            vb[u] = (n < n1 && j0 + c < J) ? jb.B[n * J + j0 + c] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) { sa[r0 + u * 8][c] = va[u]; sb[r0 + u * 8][c] = vb[u]; }
+    }
+    __syncthreads();
     float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-    for (long long nb = n0; nb < n1; nb += 32) {
-        for (int e = tid; e < 32 * 32; e += 256) {
-            const int rn = e >> 5, c = e & 31;
-            const long long n = nb + rn;
-            sa[rn][c] = (n < n1 && m0 + c < M) ? jb.A[n * M + m0 + c] : 0.0f;
-            sb[rn][c] = (n < n1 && j0 + c < J) ? jb.B[n * J + j0 + c] : 0.0f;
-        }
-        __syncthreads();
 #pragma unroll 8
-        for (int k = 0; k < 32; k++) {
-            const float a0 = sa[k][ty * 2], a1 = sa[k][ty * 2 + 1], b0 = sb[k][tx * 2], b1 = sb[k][tx * 2 + 1];
-            acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
-            acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
-        }
-        __syncthreads();
+    for (int k = 0; k < CH; k++) {
+        const float a0 = sa[k][ty * 2], a1 = sa[k][ty * 2 + 1], b0 = sb[k][tx * 2], b1 = sb[k][tx * 2 + 1];
+        acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
+        acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
     }
     float *po = jobs.partial + jb.part_off + (long long)split * M * J;
     for (int a = 0; a < 2; a++)
