@@ -47,11 +47,62 @@ def init_evaluation(model, splits, args, s2i, i2s, logger, model_dir='../model_s
                                    init_results_test=results['test'],
                                    save_model=bool(getattr(args, 'save_model', 0)))
     if args.epoch > 0:
-        raise NotImplementedError(
-            'training epochs (backward pass, optimizer) are outside the forward tagging path this '
-            'package accelerates; run with --epoch 0 (see DESIGN.md, out of scope)')
+        if not hasattr(model, 'enable_training'):
+            raise NotImplementedError(
+                'training epochs are implemented for the decomposed i-FST (--method decompose --independent 2, '
+                'farnn 0, no CRF: DESIGN.md row f3); run the other models with --epoch 0')
+        train_epochs(model, splits, args, s2i, i2s, logger, recorder, stats)
     path = save_model_and_log(logger, recorder, args, model_dir=model_dir)
     return results, stats, path
+
+
+def train_epochs(model, splits, args, s2i, i2s, logger, recorder, stats):
+    """The epoch loop of the reference (train_decompose.py:161-221): forward_local(train=True), loss.backward(),
+    optimizer.step() per batch, then the three evaluations and the best-model record."""
+    import time
+
+    import torch
+    from .metrics.metrics import eval_seq_token, get_ner_fmeasure
+
+    model.enable_training()                       # raises for the configurations the HIP training step does not cover
+    params = list(model.parameters())
+    if args.optimizer == 'SGD':
+        optimizer = torch.optim.SGD(params, lr=args.lr, weight_decay=0)
+    else:
+        optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=0)
+    print('ALL TRAINABLE PARAMETERS: {}'.format(sum(p.numel() for p in params)))
+    for epoch in range(1, args.epoch + 1):
+        model.train()
+        preds, trues, avg_loss, n_tok = [], [], 0.0, 0
+        t0 = time.perf_counter()
+        for batch in iter_batches(splits['train'], args.bz):
+            optimizer.zero_grad()
+            loss, pred, true = model.forward_local(batch['x'], batch['s'], batch['l'], train=True)
+            loss.backward()
+            optimizer.step()
+            avg_loss += float(loss.detach())
+            preds.append(pred.cpu())
+            trues.append(true.cpu())
+            n_tok += int(batch['l'].sum())
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        avg_loss /= max(len(splits['train']), 1)
+        info = '{} Epoch: {} | LOSS: {}'.format('TRAIN', epoch, avg_loss)
+        print(info)
+        logger.add(info)
+        info = 'THROUGHPUT | TRAIN-STEP | {} tokens in {:.4f} s = {:.1f} tokens/s'.format(n_tok, el, n_tok / el)
+        print(info)
+        logger.add(info)
+        stats.setdefault('train_step', []).append({'tokens': n_tok, 'seconds': el, 'tokens_per_s': n_tok / el})
+        all_pred, all_true = torch.cat(preds), torch.cat(trues)
+        res_train = {'token-level': list(eval_seq_token(seq_label_pred=all_pred, seq_label_true=all_true, o_idx=s2i['o'])),
+                     'entity-level': list(get_ner_fmeasure(golden_lists=all_true, predict_lists=all_pred, i2s=i2s))}
+        print_and_log_results(logger, res_train, epoch, 'TRAIN')
+        res_dev = val_onehot(iter_batches(splits['dev'], args.bz), model, args, s2i['o'], i2s)
+        print_and_log_results(logger, res_dev, epoch, 'DEV')
+        res_test = val_onehot(iter_batches(splits['test'], args.bz), model, args, s2i['o'], i2s)
+        print_and_log_results(logger, res_test, epoch, 'TEST')
+        recorder.update_and_record(res_train, res_dev, res_test, model.state_dict())
 
 
 def train_slot_onehot(args, data_dir='../data/', model_dir='../model_seq/'):

@@ -139,3 +139,22 @@ def test_predict_by_RE_scores_and_cache(tree, tmp_path):
         assert np.array_equal(out[3 + k].numpy(), ref)
     again = predict_by_RE(args, data_dir=tree['paths']['data_dir'])                       # cache hit
     assert torch.equal(again[0], out[0])
+
+
+def test_decompose_cli_trains_for_two_epochs(tree, tmp_path):
+    """--epoch 2 with a training portion: the epoch loop (reference train_decompose.py:161-221) runs on the HIP
+    training step, the loss goes down and the evaluations after each epoch use the updated weights."""
+    L = 12
+    argv = ['--dataset', 'ATIS-BIO', '--method', 'decompose', '--independent', '2',
+            '--automata_path', tree['paths']['IIID'], '--rank', '100', '--seed', '1', '--beta', '0.9',
+            '--embed_dim', '16', '--normalize_automata', 'none', '--rand_constant', '0',
+            '--update_nonlinear', 'tanh', '--bz', '9', '--seq_max_len', str(L), '--epoch', '2', '--lr', '0.01',
+            '--train_portion', '1.0', '--data_dir', tree['paths']['data_dir'], '--model_dir', str(tmp_path)]
+    results, stats, res_path = cli.main(argv)
+    steps = stats['train_step']
+    assert len(steps) == 2 and all(s['tokens'] > 0 and s['tokens_per_s'] > 0 for s in steps)
+    saved = cli.load_res(res_path)
+    assert saved['args'].epoch == 2
+    losses = [float(line.split('LOSS:')[1]) for line in saved['logger'].record if 'LOSS:' in line]
+    assert len(losses) == 2 and losses[1] < losses[0]
+    assert sum('| 2 |' in line or 'Epoch: 2' in line for line in saved['logger'].record) >= 1
