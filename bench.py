@@ -42,6 +42,8 @@ WORKLOADS = {
     'decomp': ('SNIPS-BIO-sized decomposed i-FST (--method decompose --independent 2)', 11000, 104, 73),
     'decomp1': ('SNIPS-BIO-sized decomposed independent=1 (FARNN_S_D_W_I), output rank 70', 11000, 104, 73),
     'decomp0': ('SNIPS-BIO-sized decomposed independent=0 (FARNN_S_D_W), wildcard rank 70', 11000, 104, 73),
+    # one training step (forward with stash, cross-entropy, BPTT, gradient reductions, Adam)
+    'train': ('SNIPS-BIO-sized decomposed i-FST, TRAINING step (farnn 0, tanh, CE1 loss, Adam)', 11000, 104, 73),
     # BASELINE configs[4], one GPU's shard: i-FST layout only (the 4-D layout would be 5.5 PB)
     'synth512': ('synthetic onehot i-FST V=20k S=512 C=256 (T = 21 GB fp32 per GPU, + transposed copy)',
                  20000, 512, 256),
@@ -190,6 +192,131 @@ def cpu_baseline(extras, x, lengths, gpu_tags, seconds):
                       '{}-thread host'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu)}, parity
 
 
+def run_train(a, world, rank, dev, dist):
+    """--workload train: K training steps of the decomposed i-FST (reference train_decompose.py:171-193) on
+    synthetic SNIPS-sized factors: word table from the embedding bridge (torch GEMM), the library's step
+    (farnn_decomp_ifst_train_step), backward through the table, Adam.  N > 1: data parallel, gradients
+    all-reduced over RCCL (one flat bucket)."""
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.farnn.train_step import decomp_ifst_train_step
+    desc, V, S, K = WORKLOADS['train']
+    R, D, B, L = a.rank, 100, a.batch, a.seqlen
+    wrng = np.random.RandomState(1234)
+    brng = np.random.RandomState(4321 + rank)
+
+    def f(*shape, sc=0.3):
+        return torch.from_numpy((wrng.randn(*shape) * sc).astype(np.float32)).to(dev).requires_grad_(True)
+    Cm = np.zeros((K, S), np.float32)
+    Cm[wrng.randint(0, K, size=S), np.arange(S)] = 1
+    p = dict(S1=f(S, R, sc=0.1), S2=f(S, R, sc=0.1), V_embed=f(V, R, sc=0.8), G=f(D, R), E=f(V, D),
+             C=torch.from_numpy(Cm).to(dev).requires_grad_(True),
+             W=torch.from_numpy(((wrng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)).to(dev).requires_grad_(True),
+             h0=f(S, sc=0.5), hT=f(S, sc=0.5))
+    beta = torch.full((R,), 0.7, device=dev)
+    x, lengths = synth.random_batch(V, B, L, brng)
+    if a.full_length:
+        lengths[:] = L
+    labels = brng.randint(0, K, size=(B, L)).astype(np.int64)
+    xd, ld, lab = torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), torch.from_numpy(labels).to(dev)
+    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0)
+    params = list(p.values())
+    opt = torch.optim.Adam(params, lr=1e-4)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        Vgen = p['V_embed'] * beta + torch.tanh(p['E'] @ p['G']) * (1 - beta)
+        loss, _ = decomp_ifst_train_step(tc, Vgen, p['S1'], p['S2'], p['W'], p['C'], p['h0'], p['hT'], None, xd, ld, lab)
+        loss.backward()
+        if world > 1:
+            flat = torch.cat([q.grad.reshape(-1) for q in params])
+            dist.all_reduce(flat)
+            flat /= world
+            o = 0
+            for q in params:
+                q.grad.copy_(flat[o:o + q.numel()].view_as(q))
+                o += q.numel()
+        opt.step()
+        return loss
+
+    for _ in range(max(a.warmup, 1)):
+        step()
+    tc.set_profiling(1 if a.event_stride else 0)
+    tc.time()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        n = torch.tensor([int(lengths.sum())], dtype=torch.int64, device=dev)
+        dist.all_reduce(n)
+        tok_total = int(n.item())
+    else:
+        tok_total = int(lengths.sum())
+    lib_ms, lib_n = tc.time()
+    if rank == 0:
+        tok_local = int(lengths.sum())
+        # algorithmic bytes of the library part per valid token: the state stash, the per-token adjoint rows and
+        # the score-side rows, each written once and read once (DESIGN.md K14)
+        alg = (2.0 * (16 * S + 6 * R + 2 * K) * 4) * tok_local
+        lib_s = (lib_ms / max(lib_n, 1)) * 1e-3
+        achieved = alg / lib_s / 1e9 if lib_s > 0 else 0.0
+        out = {
+            'metric': 'trained tokens/sec @ batch=256, seqlen=64 (decomposed i-FST, one optimizer step per batch)',
+            'value': tok_total * a.steps / el, 'unit': 'tokens/s', 'n_gpus': world, 'steps': a.steps,
+            'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '{}: V={} S={} R={} K={}, batch {} x seqlen {} per GPU'.format(desc, V, S, R, K, B, L),
+                       'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
+                       'parallelism': 'data parallel x{}{}'.format(world, ', one RCCL all-reduce of the gradients' if world > 1 else ''),
+                       'final_loss': float(loss.detach())},
+            'roofline': {'bound': 'hbm', 'kernel': 'train_backward_kernel (+train_forward_kernel, train_loss_kernel, atb_*)',
+                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+                         'traffic': None, 'algorithmic_bytes_per_launch': alg,
+                         'kernel_avg_us': lib_s * 1e6, 'launches_timed': lib_n,
+                         'note': 'the library part of the step is bound by the latency of 64 sequential recurrence '
+                                 'steps per direction, not by bandwidth'},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = train_cpu_baseline(p, beta, x, lengths, labels, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_cpu_baseline(p, beta, x, lengths, labels, budget_s):
+    """The torch-fp32 training oracle (oracle/farnn_train_oracle.py) on the host cores, on a bounded sample
+    of the same batch: the first sequences that fit the time budget."""
+    from oracle import farnn_train_oracle as to
+    q = {'S1': p['S1'], 'S2': p['S2'], 'V_embed': p['V_embed'], 'embed_r_generalized': p['G'],
+         'embedding.weight': p['E'], 'C_output_mat': p['C'], 'wildcard_mat': p['W'], 'h0': p['h0'], 'hT': p['hT'],
+         'beta_vec': beta}
+    q = {k: v.detach().cpu() for k, v in q.items()}
+    q['priority_mat'] = torch.eye(q['C_output_mat'].shape[0])
+    nseq, best = 2, None
+    t_all0 = time.perf_counter()
+    while True:
+        xs, ls, lb = torch.from_numpy(x[:nseq]), torch.from_numpy(lengths[:nseq]), torch.from_numpy(labels[:nseq])
+        t0 = time.perf_counter()
+        to.train_step(q, xs, ls, lb, nl='tanh', additional_nonlinear='tanh')
+        dt = time.perf_counter() - t0
+        best = (int(lengths[:nseq].sum()) / dt, nseq, dt)
+        if time.perf_counter() - t_all0 + 2.5 * dt > budget_s or nseq * 2 > len(lengths):
+            break
+        nseq *= 2
+    return {'value': best[0], 'unit': 'tokens/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': 'torch-fp32 autograd oracle, one step on the first {} sequences of the batch ({:.1f} s)'.format(best[1], best[2])}
+
+
 def main():
     a = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -214,6 +341,8 @@ def main():
     from re2nn_seq_amd import _lib
 
     B, L = a.batch, a.seqlen
+    if a.workload == 'train':
+        return run_train(a, world, rank, dev, dist)
     if a.workload == 'synth512':
         a.no_pipelined = True            # a second 63 GB replica of the weights is pointless here
     h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring)
