@@ -241,8 +241,8 @@ void farnn_destroy(farnn_model *m);
 /* ---- training step of the decomposed i-FST -----------------------------------
  * Replaces FARNN_S_D_W_I_S.forward_local(train=True) + loss.backward()
  * (model_decompose_single.py:207-304, train_decompose.py:186-190) for farnn = 0, the sum semiring and the
- * CE1 loss without CRF: cross-entropy (mean over the valid tokens) of the scores, and its gradient with
- * respect to every tensor the recurrence and the scoring read.  The generalized word table Vgen
+ * CE1 loss: cross-entropy (mean over the valid tokens) of the scores, or with use_crf the CRF negative
+ * log-likelihood, and the gradient with respect to every tensor the recurrence and the scoring read.  The generalized word table Vgen
  * (model_decompose.py:222-241) is an input; the caller differentiates it from dVgen.
  * All pointers are DEVICE pointers; matrices are row-major and unpadded. */
 typedef struct farnn_train_ctx farnn_train_ctx;
@@ -251,7 +251,9 @@ typedef struct {
     int32_t V, S, R, K;         /* vocabulary rows of Vgen, states (incl. additional states), rank, score columns */
     int32_t nl;                 /* FARNN_NL_* (update_nonlinear)                                               */
     float   threshold;          /* decode clamp of column K-1 (model_decompose.py:365)                         */
-    int32_t o_idx;              /* label written for column K-1 (:367)                                          */
+    int32_t o_idx;              /* label written for column K-1 (:367) / K-3 with the CRF (:356)                 */
+    int32_t use_crf;            /* 1: loss = CRF.neg_log_likelihood_loss (baselines/crf.py:250-260, a sum over the
+                                   batch) on the scores, K = labels + 2 (START, STOP); decode = Viterbi (:351-356) */
 } farnn_train_dims;
 
 typedef struct {
@@ -261,6 +263,7 @@ typedef struct {
     const float *C;             /* [K][S] C_output_mat   */
     const float *h0, *hT;       /* [S]      */
     const float *P;             /* [K][K] priority matrix or NULL (args.use_priority = 0) */
+    const float *crf_trans;     /* [K][K] crf.transitions (use_crf = 1), else NULL        */
 } farnn_train_weights;
 
 typedef struct {
@@ -271,6 +274,7 @@ typedef struct {
     float *dC;                  /* [K][S]  */
     float *dh0, *dhT;           /* [S]     */
     int32_t *tags;              /* [B][L] decoded labels of this forward pass, -1 at pad positions */
+    float *dtrans;              /* [K][K] gradient of crf.transitions (use_crf = 1), else NULL     */
 } farnn_train_outputs;
 
 int  farnn_train_create(const farnn_train_dims *dims, int device, farnn_train_ctx **out);

@@ -94,15 +94,15 @@ class DecompFstDesc(C.Structure):
 _vp = C.c_void_p
 class TrainDims(C.Structure):
     _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('K', C.c_int32), ('nl', C.c_int32),
-                ('threshold', C.c_float), ('o_idx', C.c_int32)]
+                ('threshold', C.c_float), ('o_idx', C.c_int32), ('use_crf', C.c_int32)]
 
 
 class TrainWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT', 'P')]
+    _fields_ = [(n, C.c_void_p) for n in ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT', 'P', 'crf_trans')]
 
 
 class TrainOutputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('loss', 'dVgen', 'dS1', 'dS2', 'dW', 'dC', 'dh0', 'dhT', 'tags')]
+    _fields_ = [(n, C.c_void_p) for n in ('loss', 'dVgen', 'dS1', 'dS2', 'dW', 'dC', 'dh0', 'dhT', 'tags', 'dtrans')]
 
 
 SIGNATURES = {
@@ -407,8 +407,8 @@ def create_decomp_fst(Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P=None, farn
 class TrainContext:
     """Owns one farnn_train_ctx* (training step of the decomposed i-FST, include/farnn.h)."""
 
-    def __init__(self, V, S, R, K, nl='none', threshold=0.5, o_idx=0, device=0):
-        d = TrainDims(int(V), int(S), int(R), int(K), NL[nl], float(threshold), int(o_idx))
+    def __init__(self, V, S, R, K, nl='none', threshold=0.5, o_idx=0, device=0, use_crf=False):
+        d = TrainDims(int(V), int(S), int(R), int(K), NL[nl], float(threshold), int(o_idx), int(bool(use_crf)))
         out = C.c_void_p()
         check(load().farnn_train_create(C.byref(d), int(device), C.byref(out)), 'farnn_train_create')
         self._raw = out
@@ -428,7 +428,7 @@ class TrainContext:
     def step(self, weights, x_ptr, len_ptr, labels_ptr, B, L, valid_tokens, outputs, stream=None):
         """weights / outputs: dicts of device pointers (ints) keyed like the C structs."""
         w = TrainWeights(**{k: (weights.get(k) or None) for k, _ in TrainWeights._fields_})
-        o = TrainOutputs(**{k: outputs[k] for k, _ in TrainOutputs._fields_})
+        o = TrainOutputs(**{k: outputs.get(k) for k, _ in TrainOutputs._fields_})
         check(load().farnn_decomp_ifst_train_step(self._raw, C.byref(w), x_ptr, len_ptr, labels_ptr, int(B), int(L),
                                                   int(valid_tokens), C.byref(o), stream),
               'farnn_decomp_ifst_train_step')

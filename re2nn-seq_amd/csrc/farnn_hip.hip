@@ -1235,6 +1235,7 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
     *out = nullptr;
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0) return fail(FARNN_EINVAL, "train_create: bad dimensions%s%s");
     if (d->nl < FARNN_NL_NONE || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "train_create: bad nonlinearity%s%s");
+    if (d->use_crf && (d->K < 4 || d->K > 256)) return fail(FARNN_ERANGE, "train_create: CRF needs 4..256 score columns%s%s");
     int rc;
     if ((rc = select_device(device))) return rc;
     farnn_train_ctx *c = new farnn_train_ctx();
@@ -1308,6 +1309,8 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         return fail(FARNN_EINVAL, "train_step: null weight%s%s");
     if (!o->loss || !o->dVgen || !o->dS1 || !o->dS2 || !o->dW || !o->dC || !o->dh0 || !o->dhT || !o->tags)
         return fail(FARNN_EINVAL, "train_step: null output%s%s");
+    const bool crf = c->d.use_crf != 0;
+    if (crf && (!w->crf_trans || !o->dtrans)) return fail(FARNN_EINVAL, "train_step: CRF transitions / their gradient missing%s%s");
     if (B <= 0 || L <= 0 || valid_tokens <= 0) return fail(FARNN_EINVAL, "train_step: B, L and valid_tokens must be positive%s%s");
     if (c->d.S > TR_VPT * TR_THREADS / TR_NSEQ || c->d.R > TR_VPT * TR_THREADS / TR_NSEQ)
         return fail(FARNN_ERANGE, "train_step: more than 512 states or rank above 512%s%s");
@@ -1315,7 +1318,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
     const size_t N1 = (size_t)B * (L + 1), N0 = (size_t)B * L;
-    const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S);
+    const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S) + (crf ? N0 * K + (size_t)B * K * K : 0);
     if (need > c->ws_floats) {
         if (c->ws) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->ws); c->ws = nullptr; c->ws_floats = 0; }
         if (hipMalloc((void **)&c->ws, need * sizeof(float)) != hipSuccess)
@@ -1335,6 +1338,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     p.Zf = q; q += N1 * S; p.Zb = q; q += N1 * S; p.BBAR = q; q += N1 * S; p.PRE = q; q += N1 * S;
     p.D1f = q; q += N1 * R; p.D1b = q; q += N1 * R; p.Tf = q; q += N1 * R; p.Tb = q; q += N1 * R;
     p.DS = q; q += N0 * K; p.AB = q; q += N0 * S;
+    if (crf) { p.SC = q; q += N0 * K; p.dtrans_part = q; q += (size_t)B * K * K; p.trans = w->crf_trans; }
     p.dVgen = o->dVgen; p.dOsum = c->dOsum; p.dh0 = o->dh0; p.dhT = o->dhT; p.loss = o->loss; p.tags = o->tags;
     p.B = B; p.L = L; p.V = (int)V; p.S = (int)S; p.R = (int)R; p.K = (int)K; p.nl = c->d.nl; p.o_idx = c->d.o_idx;
     p.threshold = c->d.threshold; p.inv_tokens = 1.0f / (float)valid_tokens;
@@ -1382,13 +1386,27 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         const unsigned lgrid = (unsigned)std::min<size_t>(ncu > 0 ? ncu : 256, (N0 + 7) / 8);
-        if (clds) {
-            if ((rc = raise_lds_limit(train_loss_kernel<true>, lds_l))) return rc;
-            train_loss_kernel<true><<<lgrid, 512, lds_l, s>>>(p);
-        } else {
-            if ((rc = raise_lds_limit(train_loss_kernel<false>, lds_l))) return rc;
-            train_loss_kernel<false><<<lgrid, 512, lds_l, s>>>(p);
+#define FARNN_LAUNCH_LOSS(PH)                                                                          \
+        if (clds) {                                                                                   \
+            if ((rc = raise_lds_limit(train_loss_kernel<true, PH>, lds_l))) return rc;                \
+            train_loss_kernel<true, PH><<<lgrid, 512, lds_l, s>>>(p);                                 \
+        } else {                                                                                      \
+            if ((rc = raise_lds_limit(train_loss_kernel<false, PH>, lds_l))) return rc;               \
+            train_loss_kernel<false, PH><<<lgrid, 512, lds_l, s>>>(p);                                \
         }
+        if (!crf) {
+            FARNN_LAUNCH_LOSS(0)
+        } else {
+            // emissions -> CRF forward-backward (loss, d loss / d emissions, transition counts, Viterbi tags) -> adjoints
+            FARNN_LAUNCH_LOSS(1)
+            const size_t K1 = K + 1;
+            const size_t lds_c = (2 * K * K1 + (size_t)L * K + 4 * K + 4) * sizeof(float) + (((size_t)L * K + 3) & ~(size_t)3);
+            if ((rc = raise_lds_limit(train_crf_kernel, lds_c))) return rc;
+            train_crf_kernel<<<B, 256, lds_c, s>>>(p);
+            crf_reduce_kernel<<<(unsigned)((K * K + 255) / 256), 256, 0, s>>>(p.dtrans_part, o->dtrans, B, (int)(K * K));
+            FARNN_LAUNCH_LOSS(2)
+        }
+#undef FARNN_LAUNCH_LOSS
     }
     if (ldsw_b) {
         if ((rc = raise_lds_limit(train_backward_kernel<true>, lds_b))) return rc;

@@ -34,6 +34,9 @@ struct TrainParams {
     float *BBAR;              // [.][S]  b_{t-1} * Osum
     float *PRE;               // [.][S]  forward chain's pre-activation before the output mask
     float *DS, *AB;           // [B][L][K] d loss / d (pre-priority) scores; [B][L][S] alpha*beta
+    float *SC;                // [B][L][K] scores after the priority layer (CRF mode: the emissions)
+    const float *trans;       // [K][K] CRF transitions (CRF mode) and the per-sequence partials of their gradient
+    float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
     int32_t *tags;
     int B, L, V, S, R, K, nl, o_idx;
@@ -246,7 +249,9 @@ train_forward_kernel(const TrainParams p) {
 // Persistent workgroups of 8 wavefronts; a wavefront takes positions round-robin and does one position at a time.
 // CLDS: C_output_mat staged once per workgroup in LDS with row stride S+1 (lanes = labels read it conflict-free).
 // LDS: [Cs[K][S+1]] then per wavefront ab[mv_pad(S)], sc[K], ds[K]
-template <bool CLDS>
+// PHASE 0: fused cross-entropy (scores, loss, adjoints).  CRF mode splits it around train_crf_kernel: PHASE 1 writes the
+// emissions SC (and alpha*beta), PHASE 2 reads d loss / d emissions from DS and produces the adjoints.
+template <bool CLDS, int PHASE>
 __global__ void __launch_bounds__(512)
 train_loss_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -269,55 +274,65 @@ train_loss_kernel(const TrainParams p) {
         }
         const float *al = p.A + ((long long)b * (p.L + 1) + i + 1) * S;                  // h0_forward_score[:, i+1]
         const float *be = p.Bk + ((long long)b * (p.L + 1) + (len - 1 - i)) * S;         // reverse(.., lengths+1)[:, i+1]
-        for (int s = lane; s < S; s += WAVE) {
-            const float v = al[s] * be[s];
-            ab[s] = v;
-            p.AB[pos * S + s] = v;
-        }
-        for (int c = lane; c < K; c += WAVE) {                                            // get_final_score (:200-203)
-            const float *cr = Cm + (long long)c * ldc;
-            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-            int s = 0;
-            for (; s + 8 <= S; s += 8) {
-                float cv[8];
+        if (PHASE != 2) {
+            for (int s = lane; s < S; s += WAVE) {
+                const float v = al[s] * be[s];
+                ab[s] = v;
+                p.AB[pos * S + s] = v;
+            }
+            for (int c = lane; c < K; c += WAVE) {                                        // get_final_score (:200-203)
+                const float *cr = Cm + (long long)c * ldc;
+                float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+                int s = 0;
+                for (; s + 8 <= S; s += 8) {
+                    float cv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) cv[u] = cr[s + u];
-                const v4f x0 = *(const v4f *)(ab + s), x1 = *(const v4f *)(ab + s + 4);
-                a0 = fmaf(x0[0], cv[0], a0); a1 = fmaf(x0[1], cv[1], a1); a2 = fmaf(x0[2], cv[2], a2); a3 = fmaf(x0[3], cv[3], a3);
-                a0 = fmaf(x1[0], cv[4], a0); a1 = fmaf(x1[1], cv[5], a1); a2 = fmaf(x1[2], cv[6], a2); a3 = fmaf(x1[3], cv[7], a3);
+                    for (int u = 0; u < 8; u++) cv[u] = cr[s + u];
+                    const v4f x0 = *(const v4f *)(ab + s), x1 = *(const v4f *)(ab + s + 4);
+                    a0 = fmaf(x0[0], cv[0], a0); a1 = fmaf(x0[1], cv[1], a1); a2 = fmaf(x0[2], cv[2], a2); a3 = fmaf(x0[3], cv[3], a3);
+                    a0 = fmaf(x1[0], cv[4], a0); a1 = fmaf(x1[1], cv[5], a1); a2 = fmaf(x1[2], cv[6], a2); a3 = fmaf(x1[3], cv[7], a3);
+                }
+                for (; s < S; s++) a0 = fmaf(ab[s], cr[s], a0);
+                sc[c] = (a0 + a1) + (a2 + a3);
             }
-            for (; s < S; s++) a0 = fmaf(ab[s], cr[s], a0);
-            sc[c] = (a0 + a1) + (a2 + a3);
-        }
-        if (p.P) {                                                                         // priority layer
-            for (int d = lane; d < K; d += WAVE) {
-                float a = 0.0f;
-                for (int c = 0; c < K; c++) a = fmaf(sc[c], p.P[(long long)c * K + d], a);
-                ds[d] = a;
+            if (p.P) {                                                                     // priority layer
+                for (int d = lane; d < K; d += WAVE) {
+                    float a = 0.0f;
+                    for (int c = 0; c < K; c++) a = fmaf(sc[c], p.P[(long long)c * K + d], a);
+                    ds[d] = a;
+                }
+                for (int d = lane; d < K; d += WAVE) sc[d] = ds[d];
             }
-            for (int d = lane; d < K; d += WAVE) sc[d] = ds[d];
         }
-        // softmax cross-entropy (mean over the batch's valid tokens) and the prediction (decode, argmax branch)
-        float mx = -INFINITY;
-        for (int c = lane; c < K; c += WAVE) mx = fmaxf(mx, sc[c]);
-        for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
-        float se = 0.0f;
-        for (int c = lane; c < K; c += WAVE) se += expf(sc[c] - mx);
-        for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, WAVE);
-        const int lab = (int)p.labels[pos];
-        const float lse = mx + logf(se);
-        loss_acc += lse - sc[lab < 0 || lab >= K ? 0 : lab];
-        {
-            float bv = -INFINITY; int bi = 0x7ffffffe;
-            for (int c = lane; c < K; c += WAVE) {
-                float vv = sc[c] + 0.0f;
-                if (c == K - 1) vv = fminf(vv, p.threshold);
-                if (vv > bv) { bv = vv; bi = c; }
+        if (PHASE == 1) {
+            for (int c = lane; c < K; c += WAVE) p.SC[pos * K + c] = sc[c];
+            continue;
+        }
+        if (PHASE == 0) {
+            // softmax cross-entropy (mean over the batch's valid tokens) and the prediction (decode, argmax branch)
+            float mx = -INFINITY;
+            for (int c = lane; c < K; c += WAVE) mx = fmaxf(mx, sc[c]);
+            for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, WAVE));
+            float se = 0.0f;
+            for (int c = lane; c < K; c += WAVE) se += expf(sc[c] - mx);
+            for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, WAVE);
+            const int lab = (int)p.labels[pos];
+            const float lse = mx + logf(se);
+            loss_acc += lse - sc[lab < 0 || lab >= K ? 0 : lab];
+            {
+                float bv = -INFINITY; int bi = 0x7ffffffe;
+                for (int c = lane; c < K; c += WAVE) {
+                    float vv = sc[c] + 0.0f;
+                    if (c == K - 1) vv = fminf(vv, p.threshold);
+                    if (vv > bv) { bv = vv; bi = c; }
+                }
+                bi = wave_argmax_dpp(bv, bi);
+                if (lane == 0) p.tags[pos] = (bi >= K) ? 0 : (bi == K - 1 ? p.o_idx : bi);
             }
-            bi = wave_argmax_dpp(bv, bi);
-            if (lane == 0) p.tags[pos] = (bi >= K) ? 0 : (bi == K - 1 ? p.o_idx : bi);
+            for (int c = lane; c < K; c += WAVE) ds[c] = (expf(sc[c] - lse) - (c == lab ? 1.0f : 0.0f)) * p.inv_tokens;
+        } else {
+            for (int c = lane; c < K; c += WAVE) ds[c] = p.DS[pos * K + c];                 // d loss / d emissions (CRF)
         }
-        for (int c = lane; c < K; c += WAVE) ds[c] = (expf(sc[c] - lse) - (c == lab ? 1.0f : 0.0f)) * p.inv_tokens;
         if (p.P) {                                                                         // back through scores . P
             for (int c = lane; c < K; c += WAVE) {
                 float a = 0.0f;
@@ -346,6 +361,133 @@ train_loss_kernel(const TrainParams p) {
         }
     }
     if (lane == 0 && loss_acc != 0.0f) atomicAdd(p.loss, loss_acc * p.inv_tokens);
+}
+
+// ---- CRF negative log-likelihood on the emissions (reference baselines/crf.py:48-99, 202-260) -------------------
+// One workgroup per sequence.  loss += log Z - score(gold path) (a SUM over the batch, :250-260); d loss / d emissions
+// = posterior marginals - gold one-hot (into DS); d loss / d transitions = expected - gold transition counts (per
+// sequence into dtrans_part, reduced afterwards); the decoded tags are the Viterbi path of the emissions with
+// column K-3 clamped (model_decompose.py:351-356).  Tags K-2 / K-1 are START / STOP.
+// LDS: tr[K][K+1], al[L][K] (forward log-messages), bt[2][K], ex[K][K+1] (expected counts), bp[L][K] bytes
+__global__ void __launch_bounds__(256)
+train_crf_kernel(const TrainParams p) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
+    const int K = p.K, K1 = K + 1, START = K - 2, STOP = K - 1;
+    const int n = clamp_len(p.len[b], p.L);
+    float *tr = smem, *al = tr + K * K1, *bt = al + (long long)p.L * K, *ex = bt + 2 * K, *red = ex + K * K1;
+    unsigned char *bp = (unsigned char *)(red + 4);
+    float *vit = (float *)(bp + (((long long)p.L * K + 3) & ~3LL));           // [2][K]
+    float *dpart = p.dtrans_part + (long long)b * K * K;
+    for (int e = tid; e < K * K; e += nt) { tr[(e / K) * K1 + e % K] = p.trans[e]; ex[(e / K) * K1 + e % K] = 0.0f; }
+    __syncthreads();
+    if (n == 0) {
+        for (int e = tid; e < K * K; e += nt) dpart[e] = 0.0f;
+        return;
+    }
+    const float *F = p.SC + (long long)b * p.L * K;
+    const int64_t *y = p.labels + (long long)b * p.L;
+    // forward messages and the Viterbi recursion on the clamped emissions (association as in :123,:145)
+    for (int j = tid; j < K; j += nt) {
+        const float f0 = F[j];
+        al[j] = f0 + tr[START * K1 + j];
+        vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * K1 + j];
+    }
+    __syncthreads();
+    for (int t = 1; t < n; t++) {
+        const float *ap = al + (long long)(t - 1) * K, *vp = vit + ((t - 1) & 1) * K;
+        for (int j = tid; j < K; j += nt) {
+            const float ft = F[(long long)t * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
+            float mx = -INFINITY;
+            for (int i = 0; i < K; i++) mx = fmaxf(mx, ap[i] + tr[i * K1 + j]);
+            float se = 0.0f, bv = -INFINITY;
+            int bi = 0;
+            for (int i = 0; i < K; i++) {
+                se += expf(ap[i] + tr[i * K1 + j] - mx);
+                const float cand = (fc + tr[i * K1 + j]) + vp[i];
+                if (cand > bv) { bv = cand; bi = i; }
+            }
+            al[(long long)t * K + j] = mx + logf(se) + ft;
+            vit[(t & 1) * K + j] = bv;
+            bp[(long long)t * K + j] = (unsigned char)bi;
+        }
+        __syncthreads();
+    }
+    // log Z, the gold score and the Viterbi backtrace (one thread: n steps)
+    if (tid == 0) {
+        const float *ap = al + (long long)(n - 1) * K, *vp = vit + ((n - 1) & 1) * K;
+        float mx = -INFINITY;
+        for (int i = 0; i < K; i++) mx = fmaxf(mx, ap[i] + tr[i * K1 + STOP]);
+        float se = 0.0f;
+        for (int i = 0; i < K; i++) se += expf(ap[i] + tr[i * K1 + STOP] - mx);
+        const float logZ = mx + logf(se);
+        int prev = START;
+        float gold = 0.0f;
+        for (int t = 0; t < n; t++) {
+            int yt = (int)y[t];
+            yt = yt < 0 || yt >= K ? 0 : yt;
+            gold += F[(long long)t * K + yt] + tr[prev * K1 + yt];
+            ex[prev * K1 + yt] -= 1.0f;                                         // gold transition counts
+            prev = yt;
+        }
+        gold += tr[prev * K1 + STOP];
+        ex[prev * K1 + STOP] -= 1.0f;
+        red[0] = logZ;
+        atomicAdd(p.loss, logZ - gold);
+        float bv = -INFINITY; int ptr = 0;
+        for (int i = 0; i < K; i++) { const float c = vp[i] + tr[i * K1 + STOP]; if (c > bv) { bv = c; ptr = i; } }
+        for (int t = n - 1; t >= 0; t--) {
+            p.tags[(long long)b * p.L + t] = ptr == K - 3 ? p.o_idx : ptr;
+            if (t > 0) ptr = bp[(long long)t * K + ptr];
+        }
+    }
+    for (int t = n + tid; t < p.L; t += nt) p.tags[(long long)b * p.L + t] = -1;
+    for (int i = tid; i < K; i += nt) bt[((n - 1) & 1) * K + i] = tr[i * K1 + STOP];      // backward message at the last token
+    __syncthreads();
+    const float logZ = red[0];
+    // backward messages, marginals and expected transition counts
+    for (int t = n - 1; t >= 0; t--) {
+        const float *bc = bt + (t & 1) * K;
+        float *bn = bt + ((t + 1) & 1) * K;                                     // becomes beta_{t-1}
+        const float *at = al + (long long)t * K;
+        for (int j = tid; j < K; j += nt) {
+            const float m = expf(at[j] + bc[j] - logZ);
+            int yt = (int)y[t];
+            yt = yt < 0 || yt >= K ? 0 : yt;
+            p.DS[((long long)b * p.L + t) * K + j] = m - (j == yt ? 1.0f : 0.0f);
+            if (t == 0) ex[START * K1 + j] += m;
+            if (t == n - 1) ex[j * K1 + STOP] += m;
+        }
+        __syncthreads();                                                        // the START row / STOP column are also xi targets
+        if (t > 0) {
+            const float *ap = al + (long long)(t - 1) * K;
+            for (int e = tid; e < K * K; e += nt) {                             // xi_{t-1}(i, j)
+                const int i = e / K, j = e - i * K;
+                ex[i * K1 + j] += expf(ap[i] + tr[i * K1 + j] + F[(long long)t * K + j] + bc[j] - logZ);
+            }
+            __syncthreads();
+            for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = lse_j(tr[i][j] + f_t[j] + beta_t[j])
+                float mx = -INFINITY;
+                for (int j = 0; j < K; j++) mx = fmaxf(mx, tr[i * K1 + j] + F[(long long)t * K + j] + bc[j]);
+                float se = 0.0f;
+                for (int j = 0; j < K; j++) se += expf(tr[i * K1 + j] + F[(long long)t * K + j] + bc[j] - mx);
+                bn[i] = mx + logf(se);
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < K * K; e += nt) dpart[e] = ex[(e / K) * K1 + e % K];
+}
+
+// dtrans[e] = sum_b dtrans_part[b][e]
+__global__ void crf_reduce_kernel(const float *__restrict__ part, float *dtrans, int B, int KK) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= KK) return;
+    float s0 = 0.0f, s1 = 0.0f;
+    int b = 0;
+    for (; b + 1 < B; b += 2) { s0 += part[(long long)b * KK + e]; s1 += part[(long long)(b + 1) * KK + e]; }
+    if (b < B) s0 += part[(long long)b * KK + e];
+    dtrans[e] = s0 + s1;
 }
 
 // ---- back-propagation through time ----------------------------------------------------------------------------

@@ -10,7 +10,7 @@ scores, the cross-entropy and the back-propagation through time -- is one librar
 computes loss and all gradients in its forward call (the stash lives in its workspace); backward()
 only hands them out, scaled by the incoming gradient.
 
-Scope: farnn = 0, sum semiring, CE1 loss, no CRF.  Anything else raises.
+Scope: farnn = 0, sum semiring, CE1 loss or (use_crf) the CRF negative log-likelihood.
 """
 import torch
 
@@ -19,12 +19,13 @@ from .. import _lib
 
 class _DecompIfstTrainStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels):
+    def forward(ctx, tc, Vgen, S1, S2, W, Cmat, h0, hT, P, trans, x, lengths, labels):
         dev = Vgen.device
         if dev.type != 'cuda':
             raise _lib.FarnnError('the training step runs on the HIP device only (no CPU fallback)')
         ws = [t.detach().contiguous().float() for t in (Vgen, S1, S2, W, Cmat, h0, hT)]
         Pc = None if P is None else P.detach().contiguous().float()
+        tr = None if trans is None else trans.detach().contiguous().float()
         x = x.to(dev).contiguous()
         lengths = lengths.to(dev).contiguous()
         labels = labels.to(dev).contiguous()
@@ -33,26 +34,32 @@ class _DecompIfstTrainStep(torch.autograd.Function):
         if ntok <= 0:
             raise ValueError('empty batch')
         grads = [torch.empty_like(t) for t in ws]
+        gtr = None if tr is None else torch.empty_like(tr)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         tags = torch.empty((B, L), dtype=torch.int32, device=dev)
         names = ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT')
         weights = {n: t.data_ptr() for n, t in zip(names, ws)}
         weights['P'] = None if Pc is None else Pc.data_ptr()
+        weights['crf_trans'] = None if tr is None else tr.data_ptr()
         outputs = {'d' + n: g.data_ptr() for n, g in zip(names, grads)}
         outputs['loss'] = loss.data_ptr()
         outputs['tags'] = tags.data_ptr()
+        outputs['dtrans'] = None if gtr is None else gtr.data_ptr()
         tc.step(weights, x.data_ptr(), lengths.data_ptr(), labels.data_ptr(), B, L, ntok, outputs,
                 torch.cuda.current_stream(dev).cuda_stream)
-        ctx.save_for_backward(*grads)
+        ctx.has_tr = gtr is not None
+        ctx.save_for_backward(*(grads + ([gtr] if gtr is not None else [])))
         ctx.mark_non_differentiable(tags)
         return loss.reshape(()), tags
 
     @staticmethod
     def backward(ctx, gloss, _gtags):
-        grads = ctx.saved_tensors
-        return (None,) + tuple(g * gloss for g in grads) + (None, None, None, None)
+        saved = ctx.saved_tensors
+        grads = saved[:7]
+        gtr = saved[7] * gloss if ctx.has_tr else None
+        return (None,) + tuple(g * gloss for g in grads) + (None, gtr, None, None, None)
 
 
-def decomp_ifst_train_step(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels):
+def decomp_ifst_train_step(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels, crf_trans=None):
     """Returns (loss scalar tensor with grad, tags int32 [B,L] with -1 at pads)."""
-    return _DecompIfstTrainStep.apply(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels)
+    return _DecompIfstTrainStep.apply(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, crf_trans, x, lengths, labels)
