@@ -83,7 +83,7 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
     const int jc = jok ? j : J - 1;
     float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
     // 32-bit offsets stepped by J (64-bit index arithmetic per operand cost more than the reads).  A round past the
-    // end of the share is masked on the INPUT side; the matrix rows it touches are read unguarded when the matrix is
+    // end of the share is masked after the reads; the matrix rows it touches are read unguarded when the matrix is
     // in LDS (they stay inside the allocation) and clamped to the last row otherwise.
     int off = k0 * J + jc;
     const int last = (K - 1) * J + jc;
@@ -97,11 +97,11 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
             m[u] = M[INLDS ? o : (o < last ? o : last)];
         }
         const int left = k1 - k;                          // wave-uniform
-        if (left < 8) {
-#pragma unroll
+        if (left < 8) {                                   // both operands: whatever sits past the share (another share's
+#pragma unroll                                            // inputs, LDS beyond the matrix -- possibly NaN) must not count
             for (int u = 0; u < 4; u++) {
-                if (u >= left) { x0a[u] = 0.0f; x1a[u] = 0.0f; }
-                if (4 + u >= left) { x0b[u] = 0.0f; x1b[u] = 0.0f; }
+                if (u >= left) { x0a[u] = 0.0f; x1a[u] = 0.0f; m[u] = 0.0f; }
+                if (4 + u >= left) { x0b[u] = 0.0f; x1b[u] = 0.0f; m[4 + u] = 0.0f; }
             }
         }
 #pragma unroll

@@ -158,3 +158,18 @@ def test_decompose_cli_trains_for_two_epochs(tree, tmp_path):
     losses = [float(line.split('LOSS:')[1]) for line in saved['logger'].record if 'LOSS:' in line]
     assert len(losses) == 2 and losses[1] < losses[0]
     assert sum('| 2 |' in line or 'Epoch: 2' in line for line in saved['logger'].record) >= 1
+
+
+def test_decompose_cli_trains_with_the_crf(tree, tmp_path):
+    """--use_crf 1 --epoch 1: the CRF negative log-likelihood path of the HIP training step through the CLI."""
+    L = 12
+    argv = ['--dataset', 'ATIS-BIO', '--method', 'decompose', '--independent', '2',
+            '--automata_path', tree['paths']['IIID'], '--rank', '100', '--seed', '1', '--beta', '0.9',
+            '--embed_dim', '16', '--normalize_automata', 'none', '--rand_constant', '0', '--use_crf', '1',
+            '--update_nonlinear', 'tanh', '--bz', '9', '--seq_max_len', str(L), '--epoch', '1', '--lr', '0.01',
+            '--train_portion', '1.0', '--data_dir', tree['paths']['data_dir'], '--model_dir', str(tmp_path)]
+    results, stats, res_path = cli.main(argv)
+    assert len(stats['train_step']) == 1 and stats['train_step'][0]['tokens'] > 0
+    saved = cli.load_res(res_path)
+    losses = [float(line.split('LOSS:')[1]) for line in saved['logger'].record if 'LOSS:' in line]
+    assert len(losses) == 1 and np.isfinite(losses[0]) and losses[0] > 0

@@ -134,6 +134,17 @@ def test_train_step_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
     for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')):
         close(out['d' + n].cpu().numpy(), leaves[key].grad.numpy(), 'd' + n)
         close(out['d' + n].cpu().numpy(), grads_ref[key].numpy(), 'd' + n + ' (full graph)')
+    # repeated steps give the same gradients up to the summation order of the atomics (and never a NaN: partial
+    # reduction rounds once multiplied a masked input by whatever LDS held past the matrix)
+    first = {n: t.clone() for n, t in out.items()}
+    for _ in range(10):
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None if P is None else P.data_ptr()),
+                xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr()))
+        torch.cuda.synchronize()
+        for n, t in out.items():
+            assert torch.isfinite(t).all(), n
+            assert float((t - first[n]).abs().max()) <= 1e-5 * max(1.0, float(first[n].abs().max())), n
     t = tags.cpu().numpy()
     mask = np.arange(L)[None, :] < lengths[:, None]
     assert (t[~mask] == -1).all()
@@ -170,3 +181,69 @@ def test_training_loop_reduces_the_loss_and_tagging_sees_the_update():
     m.eval()
     _, after, true = m.forward_local(x, labels, lengths, train=False)
     assert (after == true).float().mean() > (before == true).float().mean()
+
+
+@pytest.mark.parametrize('S,R,K,V,B,L,nl,prio', [
+    (104, 50, 75, 200, 9, 40, 'tanh', False),      # SNIPS-sized label set + START/STOP
+    (20, 8, 6, 30, 5, 7, 'relu', True),
+])
+def test_train_step_crf_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
+    """CRF mode of the C-ABI entry point (loss = sum of log Z - gold score) against the oracle, with an empty and a
+    full-length sequence; the decoded tags are the Viterbi path of the clamped emissions."""
+    from re2nn_seq_amd import _lib
+    from oracle import farnn_oracle as fo
+    rng = np.random.RandomState(S + K)
+    f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
+    D = 6
+    Cm = np.zeros((K, S), np.float32)
+    Cm[rng.randint(0, K - 2, size=S), np.arange(S)] = (rng.rand(S) < 0.8)
+    tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    p = {'S1': f(S, R, sc=1.0 / np.sqrt(S)), 'S2': f(S, R, sc=1.0 / np.sqrt(S)), 'V_embed': f(V, R, sc=0.8),
+         'embed_r_generalized': f(D, R), 'C_output_mat': torch.from_numpy(Cm + (rng.rand(K, S) * 0.02).astype(np.float32)),
+         'wildcard_mat': torch.from_numpy(((rng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)),
+         'h0': f(S, sc=0.5), 'hT': f(S, sc=0.5), 'beta_vec': torch.full((R,), 0.7), 'embedding.weight': f(V, D),
+         'priority_mat': torch.from_numpy((np.eye(K) + (rng.rand(K, K) < 0.05) * 0.5).astype(np.float32)),
+         'crf.transitions': torch.from_numpy(tr)}
+    lengths = rng.randint(1, L + 1, size=B).astype(np.int64)
+    lengths[0] = L
+    lengths[1] = 0
+    x = rng.randint(0, V, size=(B, L)).astype(np.int64)
+    labels = rng.randint(0, K - 2, size=(B, L)).astype(np.int64)
+    xt, lt, lab = torch.from_numpy(x), torch.from_numpy(lengths), torch.from_numpy(labels)
+    loss_ref, grads_ref, flat_scores = to.train_step(p, xt, lt, lab, nl=nl, use_priority=prio)
+    dev = torch.device('cuda')
+    Vgen = to.generalized_table(p)
+    w = {'Vgen': Vgen.to(dev), 'S1': p['S1'].to(dev), 'S2': p['S2'].to(dev), 'W': p['wildcard_mat'].to(dev),
+         'C': p['C_output_mat'].to(dev), 'h0': p['h0'].to(dev), 'hT': p['hT'].to(dev)}
+    P = p['priority_mat'].to(dev) if prio else None
+    trd = p['crf.transitions'].to(dev)
+    tc = _lib.TrainContext(V, S, R, K, nl=nl, threshold=0.5, o_idx=1, use_crf=True)
+    out = {'d' + n: torch.full_like(t, 7.0) for n, t in w.items()}
+    dtr = torch.full_like(trd, 7.0)
+    loss = torch.full((1,), 3.0, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    xd, ld, labd = xt.to(dev), lt.to(dev), lab.to(dev)
+    for _ in range(2):
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None if P is None else P.data_ptr(), crf_trans=trd.data_ptr()),
+                xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr(),
+                     dtrans=dtr.data_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 5e-5 * max(1.0, abs(float(loss_ref)))
+    for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')):
+        close(out['d' + n].cpu().numpy(), grads_ref[key].numpy(), 'd' + n)
+    close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), 'dtrans')
+    # Viterbi tags of the oracle's scores
+    sc = np.zeros((B, L, K), np.float32)
+    o = 0
+    for b in range(B):
+        n = int(lengths[b])
+        sc[b, :n] = flat_scores[o:o + n].numpy()
+        o += n
+    want = fo.decode_crf(sc, lengths, tr, 0.5, 1)
+    t = tags.cpu().numpy()
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    assert (t[~mask] == -1).all()
+    assert (t[mask] == want[mask]).mean() > 0.98
