@@ -64,6 +64,7 @@ def parse():
     ap.add_argument('--full-length', action='store_true', help='all sequences at full length')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=10.0)
+    ap.add_argument('--crf', action='store_true', help='train: CRF negative log-likelihood instead of the cross-entropy')
     ap.add_argument('--streams', type=int, default=1,
                     help='in-flight batches for the main timed region: steps alternate over this many '
                          'HIP streams, each with its own model handle and workspace')
@@ -200,6 +201,8 @@ def run_train(a, world, rank, dev, dist):
     from re2nn_seq_amd import _lib, synth
     from re2nn_seq_amd.farnn.train_step import decomp_ifst_train_step
     desc, V, S, K = WORKLOADS['train']
+    if a.crf:
+        K += 2                      # START / STOP tags (baselines/crf.py:31-46)
     R, D, B, L = a.rank, 100, a.batch, a.seqlen
     wrng = np.random.RandomState(1234)
     brng = np.random.RandomState(4321 + rank)
@@ -207,25 +210,31 @@ def run_train(a, world, rank, dev, dist):
     def f(*shape, sc=0.3):
         return torch.from_numpy((wrng.randn(*shape) * sc).astype(np.float32)).to(dev).requires_grad_(True)
     Cm = np.zeros((K, S), np.float32)
-    Cm[wrng.randint(0, K, size=S), np.arange(S)] = 1
+    Cm[wrng.randint(0, K - (2 if a.crf else 0), size=S), np.arange(S)] = 1
     p = dict(S1=f(S, R, sc=0.1), S2=f(S, R, sc=0.1), V_embed=f(V, R, sc=0.8), G=f(D, R), E=f(V, D),
              C=torch.from_numpy(Cm).to(dev).requires_grad_(True),
              W=torch.from_numpy(((wrng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)).to(dev).requires_grad_(True),
              h0=f(S, sc=0.5), hT=f(S, sc=0.5))
+    if a.crf:
+        tr = np.zeros((K, K), np.float32)
+        tr[:, K - 2] = -10000.0
+        tr[K - 1, :] = -10000.0
+        p['trans'] = torch.from_numpy(tr).to(dev).requires_grad_(True)
     beta = torch.full((R,), 0.7, device=dev)
     x, lengths = synth.random_batch(V, B, L, brng)
     if a.full_length:
         lengths[:] = L
-    labels = brng.randint(0, K, size=(B, L)).astype(np.int64)
+    labels = brng.randint(0, K - (2 if a.crf else 0), size=(B, L)).astype(np.int64)
     xd, ld, lab = torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), torch.from_numpy(labels).to(dev)
-    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0)
+    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0, use_crf=a.crf)
     params = list(p.values())
     opt = torch.optim.Adam(params, lr=1e-4)
 
     def step():
         opt.zero_grad(set_to_none=True)
         Vgen = p['V_embed'] * beta + torch.tanh(p['E'] @ p['G']) * (1 - beta)
-        loss, _ = decomp_ifst_train_step(tc, Vgen, p['S1'], p['S2'], p['W'], p['C'], p['h0'], p['hT'], None, xd, ld, lab)
+        loss, _ = decomp_ifst_train_step(tc, Vgen, p['S1'], p['S2'], p['W'], p['C'], p['h0'], p['hT'], None, xd, ld, lab,
+                                         crf_trans=p.get('trans'))
         loss.backward()
         if world > 1:
             flat = torch.cat([q.grad.reshape(-1) for q in params])
@@ -274,7 +283,8 @@ def run_train(a, world, rank, dev, dist):
             'value': tok_total * a.steps / el, 'unit': 'tokens/s', 'n_gpus': world, 'steps': a.steps,
             'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '{}: V={} S={} R={} K={}, batch {} x seqlen {} per GPU'.format(desc, V, S, R, K, B, L),
+            'config': {'workload': '{}{}: V={} S={} R={} K={}, batch {} x seqlen {} per GPU'.format(
+                           desc, ' with the CRF loss' if a.crf else '', V, S, R, K, B, L),
                        'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
                        'parallelism': 'data parallel x{}{}'.format(world, ', one RCCL all-reduce of the gradients' if world > 1 else ''),
                        'final_loss': float(loss.detach())},
@@ -285,7 +295,7 @@ def run_train(a, world, rank, dev, dist):
                          'note': 'the library part of the step is bound by the latency of 64 sequential recurrence '
                                  'steps per direction, not by bandwidth'},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if world == 1 and not a.no_cpu_baseline and not a.crf:
             out['cpu_baseline'] = train_cpu_baseline(p, beta, x, lengths, labels, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:

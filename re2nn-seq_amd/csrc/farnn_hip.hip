@@ -1400,7 +1400,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
             // emissions -> CRF forward-backward (loss, d loss / d emissions, transition counts, Viterbi tags) -> adjoints
             FARNN_LAUNCH_LOSS(1)
             const size_t K1 = K + 1;
-            const size_t lds_c = (2 * K * K1 + (size_t)L * K + 4 * K + 4) * sizeof(float) + (((size_t)L * K + 3) & ~(size_t)3);
+            const size_t lds_c = (3 * K * K1 + 3 * (size_t)L * K + (size_t)L + 5 * K + 8) * sizeof(float) + (((size_t)L * K + 3) & ~(size_t)3);
             if ((rc = raise_lds_limit(train_crf_kernel, lds_c))) return rc;
             train_crf_kernel<<<B, 256, lds_c, s>>>(p);
             crf_reduce_kernel<<<(unsigned)((K * K + 255) / 256), 256, 0, s>>>(p.dtrans_part, o->dtrans, B, (int)(K * K));

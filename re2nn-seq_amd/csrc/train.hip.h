@@ -368,24 +368,39 @@ train_loss_kernel(const TrainParams p) {
 // = posterior marginals - gold one-hot (into DS); d loss / d transitions = expected - gold transition counts (per
 // sequence into dtrans_part, reduced afterwards); the decoded tags are the Viterbi path of the emissions with
 // column K-3 clamped (model_decompose.py:351-356).  Tags K-2 / K-1 are START / STOP.
-// LDS: tr[K][K+1], al[L][K] (forward log-messages), bt[2][K], ex[K][K+1] (expected counts), bp[L][K] bytes
+// Scaled (exp-domain) messages: with etr = exp(tr) kept in LDS, a step of either recursion is a plain dot product,
+//   alpha_t[j] = amax + log(sum_i exp(alpha_{t-1}[i] - amax) etr[i][j]) + f_t[j],   amax = max_i alpha_{t-1}[i],
+// and the expected transition counts are products of the stored factors -- no exp in any K x K loop (the first
+// version evaluated expf K^2 times per step: 1.85 ms for 256 sequences).
+// LDS: tr, etr, ex [K][K+1]; al[L][K] log-messages; ea[L][K] = exp(al - amax_t); am[L]; bt[2][K]; eb[K]; red[8];
+//      vit[2][K]; fl[L][K] emissions; bp[L][K] bytes
 __global__ void __launch_bounds__(256)
 train_crf_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     const int K = p.K, K1 = K + 1, START = K - 2, STOP = K - 1;
     const int n = clamp_len(p.len[b], p.L);
-    float *tr = smem, *al = tr + K * K1, *bt = al + (long long)p.L * K, *ex = bt + 2 * K, *red = ex + K * K1;
-    unsigned char *bp = (unsigned char *)(red + 4);
-    float *vit = (float *)(bp + (((long long)p.L * K + 3) & ~3LL));           // [2][K]
+    float *tr = smem, *etr = tr + K * K1, *ex = etr + K * K1, *al = ex + K * K1, *ea = al + (long long)p.L * K;
+    float *am = ea + (long long)p.L * K, *bt = am + p.L, *eb = bt + 2 * K, *red = eb + K, *vit = red + 8;
+    float *fl = vit + 2 * K;                                                   // [L][K] this sequence's emissions
+    unsigned char *bp = (unsigned char *)(fl + (long long)p.L * K);
     float *dpart = p.dtrans_part + (long long)b * K * K;
-    for (int e = tid; e < K * K; e += nt) { tr[(e / K) * K1 + e % K] = p.trans[e]; ex[(e / K) * K1 + e % K] = 0.0f; }
+    for (int e = tid; e < K * K; e += nt) {
+        const int o = (e / K) * K1 + e % K;
+        const float t = p.trans[e];
+        tr[o] = t; etr[o] = __expf(t); ex[o] = 0.0f;
+    }
     __syncthreads();
     if (n == 0) {
         for (int e = tid; e < K * K; e += nt) dpart[e] = 0.0f;
         return;
     }
-    const float *F = p.SC + (long long)b * p.L * K;
+    {
+        const float *Fg = p.SC + (long long)b * p.L * K;
+        for (int e = tid; e < n * K; e += nt) fl[e] = Fg[e];
+    }
+    __syncthreads();
+    const float *F = fl;
     const int64_t *y = p.labels + (long long)b * p.L;
     // forward messages and the Viterbi recursion on the clamped emissions (association as in :123,:145)
     for (int j = tid; j < K; j += nt) {
@@ -394,33 +409,38 @@ train_crf_kernel(const TrainParams p) {
         vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * K1 + j];
     }
     __syncthreads();
-    for (int t = 1; t < n; t++) {
-        const float *ap = al + (long long)(t - 1) * K, *vp = vit + ((t - 1) & 1) * K;
-        for (int j = tid; j < K; j += nt) {
-            const float ft = F[(long long)t * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
-            float mx = -INFINITY;
-            for (int i = 0; i < K; i++) mx = fmaxf(mx, ap[i] + tr[i * K1 + j]);
-            float se = 0.0f, bv = -INFINITY;
-            int bi = 0;
-            for (int i = 0; i < K; i++) {
-                se += expf(ap[i] + tr[i * K1 + j] - mx);
-                const float cand = (fc + tr[i * K1 + j]) + vp[i];
-                if (cand > bv) { bv = cand; bi = i; }
-            }
-            al[(long long)t * K + j] = mx + logf(se) + ft;
-            vit[(t & 1) * K + j] = bv;
-            bp[(long long)t * K + j] = (unsigned char)bi;
-        }
+    for (int t = 0; t < n; t++) {
+        // scale of step t: amax_t and ea_t = exp(al_t - amax_t)
+        const float *at = al + (long long)t * K;
+        float mx = -INFINITY;
+        for (int i = 0; i < K; i++) mx = fmaxf(mx, at[i]);                     // every thread: K broadcast reads
+        for (int j = tid; j < K; j += nt) ea[(long long)t * K + j] = __expf(at[j] - mx);
+        if (tid == 0) am[t] = mx;
         __syncthreads();
+        if (t + 1 < n) {
+            const float *et = ea + (long long)t * K, *vp = vit + (t & 1) * K;
+            for (int j = tid; j < K; j += nt) {
+                const float ft = F[(long long)(t + 1) * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
+                float se = 0.0f, bv = -INFINITY;
+                int bi = 0;
+                for (int i = 0; i < K; i++) {
+                    se = fmaf(et[i], etr[i * K1 + j], se);
+                    const float cand = (fc + tr[i * K1 + j]) + vp[i];
+                    if (cand > bv) { bv = cand; bi = i; }
+                }
+                al[(long long)(t + 1) * K + j] = mx + __logf(se) + ft;
+                vit[((t + 1) & 1) * K + j] = bv;
+                bp[(long long)(t + 1) * K + j] = (unsigned char)bi;
+            }
+            __syncthreads();
+        }
     }
     // log Z, the gold score and the Viterbi backtrace (one thread: n steps)
     if (tid == 0) {
-        const float *ap = al + (long long)(n - 1) * K, *vp = vit + ((n - 1) & 1) * K;
-        float mx = -INFINITY;
-        for (int i = 0; i < K; i++) mx = fmaxf(mx, ap[i] + tr[i * K1 + STOP]);
+        const float *et = ea + (long long)(n - 1) * K, *vp = vit + ((n - 1) & 1) * K;
         float se = 0.0f;
-        for (int i = 0; i < K; i++) se += expf(ap[i] + tr[i * K1 + STOP] - mx);
-        const float logZ = mx + logf(se);
+        for (int i = 0; i < K; i++) se = fmaf(et[i], etr[i * K1 + STOP], se);
+        const float logZ = am[n - 1] + logf(se);
         int prev = START;
         float gold = 0.0f;
         for (int t = 0; t < n; t++) {
@@ -450,28 +470,30 @@ train_crf_kernel(const TrainParams p) {
         const float *bc = bt + (t & 1) * K;
         float *bn = bt + ((t + 1) & 1) * K;                                     // becomes beta_{t-1}
         const float *at = al + (long long)t * K;
+        // scale of the backward side at step t: bmax over f_t + beta_t, eb = exp(f_t + beta_t - bmax)
+        float bmx = -INFINITY;
+        for (int j = 0; j < K; j++) bmx = fmaxf(bmx, F[(long long)t * K + j] + bc[j]);
         for (int j = tid; j < K; j += nt) {
-            const float m = expf(at[j] + bc[j] - logZ);
+            eb[j] = __expf(F[(long long)t * K + j] + bc[j] - bmx);
+            const float m = __expf(at[j] + bc[j] - logZ);
             int yt = (int)y[t];
             yt = yt < 0 || yt >= K ? 0 : yt;
             p.DS[((long long)b * p.L + t) * K + j] = m - (j == yt ? 1.0f : 0.0f);
             if (t == 0) ex[START * K1 + j] += m;
             if (t == n - 1) ex[j * K1 + STOP] += m;
         }
-        __syncthreads();                                                        // the START row / STOP column are also xi targets
+        __syncthreads();                                                        // eb ready; START row / STOP column settled
         if (t > 0) {
-            const float *ap = al + (long long)(t - 1) * K;
-            for (int e = tid; e < K * K; e += nt) {                             // xi_{t-1}(i, j)
+            const float *ep = ea + (long long)(t - 1) * K;
+            const float scale = __expf(am[t - 1] + bmx - logZ);                 // xi_{t-1}(i,j) = ea[i] etr[i][j] eb[j] scale
+            for (int e = tid; e < K * K; e += nt) {
                 const int i = e / K, j = e - i * K;
-                ex[i * K1 + j] += expf(ap[i] + tr[i * K1 + j] + F[(long long)t * K + j] + bc[j] - logZ);
+                ex[i * K1 + j] = fmaf(ep[i] * scale, etr[i * K1 + j] * eb[j], ex[i * K1 + j]);
             }
-            __syncthreads();
-            for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = lse_j(tr[i][j] + f_t[j] + beta_t[j])
-                float mx = -INFINITY;
-                for (int j = 0; j < K; j++) mx = fmaxf(mx, tr[i * K1 + j] + F[(long long)t * K + j] + bc[j]);
+            for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = bmax + log sum_j etr[i][j] eb[j]
                 float se = 0.0f;
-                for (int j = 0; j < K; j++) se += expf(tr[i * K1 + j] + F[(long long)t * K + j] + bc[j] - mx);
-                bn[i] = mx + logf(se);
+                for (int j = 0; j < K; j++) se = fmaf(etr[i * K1 + j], eb[j], se);
+                bn[i] = bmx + __logf(se);
             }
         }
         __syncthreads();
