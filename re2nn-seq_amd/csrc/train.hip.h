@@ -413,7 +413,9 @@ train_crf_kernel(const TrainParams p) {
         // scale of step t: amax_t and ea_t = exp(al_t - amax_t)
         const float *at = al + (long long)t * K;
         float mx = -INFINITY;
-        for (int i = 0; i < K; i++) mx = fmaxf(mx, at[i]);                     // every thread: K broadcast reads
+#pragma unroll 8
+        for (int i = 0; i < K; i++) mx = fmaxf(mx, at[i]);                     // every thread: K broadcast reads (unrolled: a
+                                                                                // rolled loop pays the LDS latency per element)
         for (int j = tid; j < K; j += nt) ea[(long long)t * K + j] = __expf(at[j] - mx);
         if (tid == 0) am[t] = mx;
         __syncthreads();
@@ -423,6 +425,7 @@ train_crf_kernel(const TrainParams p) {
                 const float ft = F[(long long)(t + 1) * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
                 float se = 0.0f, bv = -INFINITY;
                 int bi = 0;
+#pragma unroll 8
                 for (int i = 0; i < K; i++) {
                     se = fmaf(et[i], etr[i * K1 + j], se);
                     const float cand = (fc + tr[i * K1 + j]) + vp[i];
@@ -472,6 +475,7 @@ train_crf_kernel(const TrainParams p) {
         const float *at = al + (long long)t * K;
         // scale of the backward side at step t: bmax over f_t + beta_t, eb = exp(f_t + beta_t - bmax)
         float bmx = -INFINITY;
+#pragma unroll 8
         for (int j = 0; j < K; j++) bmx = fmaxf(bmx, F[(long long)t * K + j] + bc[j]);
         for (int j = tid; j < K; j += nt) {
             eb[j] = __expf(F[(long long)t * K + j] + bc[j] - bmx);
@@ -486,12 +490,19 @@ train_crf_kernel(const TrainParams p) {
         if (t > 0) {
             const float *ep = ea + (long long)(t - 1) * K;
             const float scale = __expf(am[t - 1] + bmx - logZ);                 // xi_{t-1}(i,j) = ea[i] etr[i][j] eb[j] scale
-            for (int e = tid; e < K * K; e += nt) {
-                const int i = e / K, j = e - i * K;
-                ex[i * K1 + j] = fmaf(ep[i] * scale, etr[i * K1 + j] * eb[j], ex[i * K1 + j]);
+            // thread (row group r0, column j): rows r0, r0 + rstep, ... -- no divisions, all reads of a round independent
+            {
+                const int cj = tid % K1, r0 = tid / K1, rstep = nt / K1;        // K1 columns per row in LDS (the pad column is skipped)
+                if (cj < K && r0 < rstep) {
+                    const float ebj = eb[cj];
+#pragma unroll 4
+                    for (int i = r0; i < K; i += rstep)
+                        ex[i * K1 + cj] = fmaf(ep[i] * scale, etr[i * K1 + cj] * ebj, ex[i * K1 + cj]);
+                }
             }
             for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = bmax + log sum_j etr[i][j] eb[j]
                 float se = 0.0f;
+#pragma unroll 8
                 for (int j = 0; j < K; j++) se = fmaf(etr[i * K1 + j], eb[j], se);
                 bn[i] = bmx + __logf(se);
             }
