@@ -1367,7 +1367,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t nwv = TR_THREADS / 64;
     const size_t SPd = ((S + 3) & ~(size_t)3) + 8, RPd = ((R + 3) & ~(size_t)3) + 8;
     const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
-    const size_t vec_b = (4 * SPd + 2 * RPd + 6 * S + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
+    const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
     const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
     const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);

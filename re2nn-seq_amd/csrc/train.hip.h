@@ -526,7 +526,7 @@ __global__ void crf_reduce_kernel(const float *__restrict__ part, float *dtrans,
 // ---- back-propagation through time ----------------------------------------------------------------------------
 // grid (ceil(B/2), 2), TR_NSEQ sequences per workgroup.  LDSW: the four matrices of this direction
 // (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
-// LDS: [Ma | Mb | Mc | Md] g z y fp dO [2][S] each, u rr d1 tmpv [2][R] each, pa pb [4][2][max(S,R)], pc [4][2][S]
+// LDS: [Ma | Mb | Mc | Md] z fp [2][mv_pad(S)], d1 [2][mv_pad(R)], pa pb [8][2][max(S,R)], pc [8][2][S], toks [2][L]
 template <bool LDSW>
 __global__ void __launch_bounds__(TR_THREADS)
 train_backward_kernel(const TrainParams p) {
@@ -537,7 +537,7 @@ train_backward_kernel(const TrainParams p) {
     float *wl = smem;
     const int SP = mv_pad(S), RP = mv_pad(R);                  // strides of the matvec inputs z, fp, d1 (zero pads)
     float *z = smem + (LDSW ? ((3 * S * R + S * S + 3) & ~3) : 0), *fp = z + 2 * SP, *d1 = fp + 2 * SP;
-    float *g = d1 + 2 * RP, *y = g + 2 * S, *dO = y + 2 * S, *pa = dO + 2 * S, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
+    float *pa = d1 + 2 * RP, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
     // rr = fp . Ma, u = z . Mb, d fp = z . Mc + d1 . Md
     const float *Ma = dir == 0 ? p.S1 : p.S2, *Mb = dir == 0 ? p.S2 : p.S1, *Mc = dir == 0 ? p.WT : p.W,
                 *Md = dir == 0 ? p.S1T : p.S2T;
@@ -558,7 +558,7 @@ train_backward_kernel(const TrainParams p) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
-    for (int e = tid; e < 4 * SP + 2 * RP + 6 * S; e += nt) z[e] = 0.0f;   // z fp d1 g y dO contiguous; dO per sequence (two threads would race on one slot)
+    for (int e = tid; e < 4 * SP + 2 * RP; e += nt) z[e] = 0.0f;          // z fp d1 contiguous: pads stay zero
     __syncthreads();
     // per-thread slots, fixed for the whole kernel (no divisions in the time loop); g, y and dOsum of a slot are only
     // ever touched by its owner, so they live in registers
