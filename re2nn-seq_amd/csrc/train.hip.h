@@ -412,10 +412,17 @@ train_crf_kernel(const TrainParams p) {
     for (int t = 0; t < n; t++) {
         // scale of step t: amax_t and ea_t = exp(al_t - amax_t)
         const float *at = al + (long long)t * K;
-        float mx = -INFINITY;
-#pragma unroll 8
-        for (int i = 0; i < K; i++) mx = fmaxf(mx, at[i]);                     // every thread: K broadcast reads (unrolled: a
-                                                                                // rolled loop pays the LDS latency per element)
+        // four independent chains: a single dependent max/fma chain over LDS reads runs at ~105 cycles per element, four
+        // chains unrolled by 16 at ~12 (scripts/probe/lds_rate.hip)
+        float mx;
+        {
+            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            int i = 0;
+#pragma unroll 4
+            for (; i + 4 <= K; i += 4) { m0 = fmaxf(m0, at[i]); m1 = fmaxf(m1, at[i + 1]); m2 = fmaxf(m2, at[i + 2]); m3 = fmaxf(m3, at[i + 3]); }
+            for (; i < K; i++) m0 = fmaxf(m0, at[i]);
+            mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        }
         for (int j = tid; j < K; j += nt) ea[(long long)t * K + j] = __expf(at[j] - mx);
         if (tid == 0) am[t] = mx;
         __syncthreads();
@@ -423,14 +430,29 @@ train_crf_kernel(const TrainParams p) {
             const float *et = ea + (long long)t * K, *vp = vit + (t & 1) * K;
             for (int j = tid; j < K; j += nt) {
                 const float ft = F[(long long)(t + 1) * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
-                float se = 0.0f, bv = -INFINITY;
-                int bi = 0;
-#pragma unroll 8
-                for (int i = 0; i < K; i++) {
-                    se = fmaf(et[i], etr[i * K1 + j], se);
-                    const float cand = (fc + tr[i * K1 + j]) + vp[i];
-                    if (cand > bv) { bv = cand; bi = i; }
+                float s4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                int i4[4] = {0, 0, 0, 0};
+                int i = 0;
+#pragma unroll 4
+                for (; i + 4 <= K; i += 4) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        s4[u] = fmaf(et[i + u], etr[(i + u) * K1 + j], s4[u]);
+                        const float cand = (fc + tr[(i + u) * K1 + j]) + vp[i + u];
+                        if (cand > b4[u]) { b4[u] = cand; i4[u] = i + u; }
+                    }
                 }
+                for (; i < K; i++) {
+                    s4[0] = fmaf(et[i], etr[i * K1 + j], s4[0]);
+                    const float cand = (fc + tr[i * K1 + j]) + vp[i];
+                    if (cand > b4[0]) { b4[0] = cand; i4[0] = i; }
+                }
+                const float se = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                float bv = b4[0];
+                int bi = i4[0];
+#pragma unroll
+                for (int u = 1; u < 4; u++)                                  // first maximum over i, like torch.max (:149)
+                    if (b4[u] > bv || (b4[u] == bv && i4[u] < bi)) { bv = b4[u]; bi = i4[u]; }
                 al[(long long)(t + 1) * K + j] = mx + __logf(se) + ft;
                 vit[((t + 1) & 1) * K + j] = bv;
                 bp[(long long)(t + 1) * K + j] = (unsigned char)bi;
@@ -474,9 +496,19 @@ train_crf_kernel(const TrainParams p) {
         float *bn = bt + ((t + 1) & 1) * K;                                     // becomes beta_{t-1}
         const float *at = al + (long long)t * K;
         // scale of the backward side at step t: bmax over f_t + beta_t, eb = exp(f_t + beta_t - bmax)
-        float bmx = -INFINITY;
-#pragma unroll 8
-        for (int j = 0; j < K; j++) bmx = fmaxf(bmx, F[(long long)t * K + j] + bc[j]);
+        float bmx;
+        {
+            const float *ft = F + (long long)t * K;
+            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+            int j = 0;
+#pragma unroll 4
+            for (; j + 4 <= K; j += 4) {
+                m0 = fmaxf(m0, ft[j] + bc[j]); m1 = fmaxf(m1, ft[j + 1] + bc[j + 1]);
+                m2 = fmaxf(m2, ft[j + 2] + bc[j + 2]); m3 = fmaxf(m3, ft[j + 3] + bc[j + 3]);
+            }
+            for (; j < K; j++) m0 = fmaxf(m0, ft[j] + bc[j]);
+            bmx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+        }
         for (int j = tid; j < K; j += nt) {
             eb[j] = __expf(F[(long long)t * K + j] + bc[j] - bmx);
             const float m = __expf(at[j] + bc[j] - logZ);
@@ -501,9 +533,15 @@ train_crf_kernel(const TrainParams p) {
                 }
             }
             for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = bmax + log sum_j etr[i][j] eb[j]
-                float se = 0.0f;
-#pragma unroll 8
-                for (int j = 0; j < K; j++) se = fmaf(etr[i * K1 + j], eb[j], se);
+                float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+                int j = 0;
+#pragma unroll 4
+                for (; j + 4 <= K; j += 4) {
+                    s0 = fmaf(etr[i * K1 + j], eb[j], s0); s1 = fmaf(etr[i * K1 + j + 1], eb[j + 1], s1);
+                    s2 = fmaf(etr[i * K1 + j + 2], eb[j + 2], s2); s3 = fmaf(etr[i * K1 + j + 3], eb[j + 3], s3);
+                }
+                for (; j < K; j++) s0 = fmaf(etr[i * K1 + j], eb[j], s0);
+                const float se = (s0 + s1) + (s2 + s3);
                 bn[i] = bmx + __logf(se);
             }
         }
