@@ -119,9 +119,16 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
     }
 }
 __device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int /*nw*/) {
+    // all shares are read before any is added (at most 8): a read-add chain over LDS costs ~105 cycles per element
+    // (scripts/probe/lds_rate.hip), independent reads ~12
+    constexpr int NW = TR_THREADS / 64;
     const int nks = mv_nks(J);
-    float s = part[q * J + j];
-    for (int w = 1; w < nks; w++) s += part[(w * 2 + q) * J + j];
+    float v[NW];
+#pragma unroll
+    for (int w = 0; w < NW; w++) v[w] = w < nks ? part[((w < nks ? w : 0) * 2 + q) * J + j] : 0.0f;
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NW; w++) s += v[w];
     return s;
 }
 // copy a [rows*cols] matrix from global memory into LDS (16-byte pieces when the size allows)
