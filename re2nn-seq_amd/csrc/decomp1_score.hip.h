@@ -555,20 +555,50 @@ decomp0_score_kernel(const Decomp0ScoreParams p) {
         const bool lang = r < R;
         const int col = lang ? r : r - R, ld = lang ? Rp : RWp;
         const float *f1 = (lang ? p.S1 : p.S1w) + col, *f2 = (lang ? p.S2 : p.S2w) + col;
-        float a = 0.0f, bb = 0.0f;
-        for (int s = 0; s < S; s++) {
-            a = fmaf(alpha[s], f1[(long long)s * ld], a);                             // :314 / :318
-            bb = fmaf(beta[s], f2[(long long)s * ld], bb);                            // :315 / :319
+        // two independent chains per product and the loads of eight steps in flight: a rolled single chain pays a
+        // memory round trip per element (scripts/probe/lds_rate.hip)
+        float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+        int s = 0;
+        for (; s + 8 <= S; s += 8) {
+            float u1[8], u2[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { u1[u] = f1[(long long)(s + u) * ld]; u2[u] = f2[(long long)(s + u) * ld]; }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                a0 = fmaf(alpha[s + u], u1[u], a0); a1 = fmaf(alpha[s + u + 1], u1[u + 1], a1);       // :314 / :318
+                b0 = fmaf(beta[s + u], u2[u], b0); b1 = fmaf(beta[s + u + 1], u2[u + 1], b1);         // :315 / :319
+            }
         }
+        for (; s < S; s++) {
+            a0 = fmaf(alpha[s], f1[(long long)s * ld], a0);
+            b0 = fmaf(beta[s], f2[(long long)s * ld], b0);
+        }
+        const float a = a0 + a1, bb = b0 + b1;
         if (lang) ab[col] = vg[col] * (a * bb);                                       // :313,:316
         else abw[col] = a * bb;                                                       // :320
     }
     __syncthreads();
     for (int c = tid; c < K; c += nt) {
-        float s = 0.0f, sw = 0.0f;
-        for (int r = 0; r < R; r++) s = fmaf(ab[r], p.CT[(long long)r * p.Kc + c], s);       // :317
-        for (int q = 0; q < RW; q++) sw = fmaf(abw[q], p.CwT[(long long)q * p.Kc + c], sw);  // :321
-        sc[c] = s + sw;                                                                      // :322
+        float s0 = 0.0f, s1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {
+            float cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = p.CT[(long long)(r + u) * p.Kc + c];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { s0 = fmaf(ab[r + u], cv[u], s0); s1 = fmaf(ab[r + u + 1], cv[u + 1], s1); }   // :317
+        }
+        for (; r < R; r++) s0 = fmaf(ab[r], p.CT[(long long)r * p.Kc + c], s0);
+        int q = 0;
+        for (; q + 8 <= RW; q += 8) {
+            float cv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) cv[u] = p.CwT[(long long)(q + u) * p.Kc + c];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { w0 = fmaf(abw[q + u], cv[u], w0); w1 = fmaf(abw[q + u + 1], cv[u + 1], w1); } // :321
+        }
+        for (; q < RW; q++) w0 = fmaf(abw[q], p.CwT[(long long)q * p.Kc + c], w0);
+        sc[c] = (s0 + s1) + (w0 + w1);                                                       // :322
     }
     __syncthreads();
     const float *fin = sc;

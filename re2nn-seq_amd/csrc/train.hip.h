@@ -151,12 +151,18 @@ __global__ void transpose_kernel(const float *__restrict__ in, float *__restrict
     out[(long long)c * rows + r] = in[idx];
 }
 
+// Osum[s] = sum_c C[c][s] (C_output_mat.sum(0), :232): one thread per state, rows read coalesced across the block
 __global__ void column_sum_kernel(const float *__restrict__ C, float *__restrict__ Osum, int K, int S) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S) return;
-    float a = 0.0f;
-    for (int c = 0; c < K; c++) a += C[(long long)c * S + s];          // C_output_mat.sum(0)  (:232)
-    Osum[s] = a;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    int c = 0;
+    for (; c + 4 <= K; c += 4) {
+        a0 += C[(long long)c * S + s]; a1 += C[(long long)(c + 1) * S + s];
+        a2 += C[(long long)(c + 2) * S + s]; a3 += C[(long long)(c + 3) * S + s];
+    }
+    for (; c < K; c++) a0 += C[(long long)c * S + s];
+    Osum[s] = (a0 + a1) + (a2 + a3);
 }
 
 // ---- forward chains with the stash ------------------------------------------------------------------------
