@@ -14,6 +14,7 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 from oracle import farnn_train_oracle as to  # noqa: E402
 
+GATES = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
 PARAMS = ('S1', 'S2', 'V_embed', 'embed_r_generalized', 'C_output_mat', 'wildcard_mat', 'h0', 'hT', 'beta_vec',
           'embedding.weight')
 
@@ -24,7 +25,7 @@ def load():
     return meta, np.load(os.path.join(GOLDEN, 'decomp_train_small.npz')), np.load(os.path.join(GOLDEN, 'decomp_small.npz'))
 
 
-@pytest.mark.parametrize('k', range(7))
+@pytest.mark.parametrize('k', range(10))
 def test_train_oracle_matches_reference_loss_and_gradients(k):
     meta, g, base = load()
     cfg = meta['configs'][k]
@@ -34,11 +35,15 @@ def test_train_oracle_matches_reference_loss_and_gradients(k):
     if cfg.get('use_crf'):
         p['crf.transitions'] = torch.from_numpy(g[pre + 'w.crf.transitions'])
     x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
+    gate_names = tuple(n for n in GATES if pre + 'w.' + n in g.files)
+    for n in gate_names:
+        p[n] = torch.from_numpy(g[pre + 'w.' + n])
     loss, grads, _ = to.train_step(p, x, lengths, labels, nl=cfg['update_nonlinear'],
                                    additional_nonlinear=cfg.get('additional_nonlinear', 'none'),
-                                   use_priority=bool(cfg.get('use_priority', 0)))
+                                   use_priority=bool(cfg.get('use_priority', 0)), farnn=cfg.get('farnn', 0),
+                                   sig_k=float(cfg.get('sigmoid_exponent', 5)))
     assert abs(float(loss) - float(g[pre + 'loss'])) < 1e-5 * max(1.0, abs(float(g[pre + 'loss'])))
-    for n in PARAMS + (('crf.transitions',) if cfg.get('use_crf') else ()):
+    for n in PARAMS + (('crf.transitions',) if cfg.get('use_crf') else ()) + gate_names:
         ref = g[pre + 'g.' + n]
         got = grads[n].numpy()
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=n)
