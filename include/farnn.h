@@ -240,7 +240,7 @@ void farnn_destroy(farnn_model *m);
 
 /* ---- training step of the decomposed i-FST -----------------------------------
  * Replaces FARNN_S_D_W_I_S.forward_local(train=True) + loss.backward()
- * (model_decompose_single.py:207-304, train_decompose.py:186-190) for farnn = 0, the sum semiring and the
+ * (model_decompose_single.py:207-304, train_decompose.py:186-190) for farnn = 0/1/2, the sum semiring and the
  * CE1 loss: cross-entropy (mean over the valid tokens) of the scores, or with use_crf the CRF negative
  * log-likelihood, and the gradient with respect to every tensor the recurrence and the scoring read.  The generalized word table Vgen
  * (model_decompose.py:222-241) is an input; the caller differentiates it from dVgen.
@@ -252,6 +252,8 @@ typedef struct {
     int32_t nl;                 /* FARNN_NL_* (update_nonlinear)                                               */
     float   threshold;          /* decode clamp of column K-1 (model_decompose.py:365)                         */
     int32_t o_idx;              /* label written for column K-1 (:367) / K-3 with the CRF (:356)                 */
+    int32_t farnn;              /* 0 plain recurrence, 1 update gate, 2 update + reset gate (:143-154,:193-198) */
+    float   sigmoid_exponent;   /* k of the gate activation sigmoid(k x) (model_decompose.py:97-103)              */
     int32_t use_crf;            /* 1: loss = CRF.neg_log_likelihood_loss (baselines/crf.py:250-260, a sum over the
                                    batch) on the scores, K = labels + 2 (START, STOP); decode = Viterbi (:351-356) */
 } farnn_train_dims;
@@ -264,6 +266,8 @@ typedef struct {
     const float *h0, *hT;       /* [S]      */
     const float *P;             /* [K][K] priority matrix or NULL (args.use_priority = 0) */
     const float *crf_trans;     /* [K][K] crf.transitions (use_crf = 1), else NULL        */
+    const float *Wss1, *Wrs1, *bs1;   /* [S][S], [R][S], [S] update gate (farnn >= 1), else NULL */
+    const float *Wss2, *Wrs2, *bs2;   /* reset gate (farnn = 2), else NULL                       */
 } farnn_train_weights;
 
 typedef struct {
@@ -275,6 +279,8 @@ typedef struct {
     float *dh0, *dhT;           /* [S]     */
     int32_t *tags;              /* [B][L] decoded labels of this forward pass, -1 at pad positions */
     float *dtrans;              /* [K][K] gradient of crf.transitions (use_crf = 1), else NULL     */
+    float *dWss1, *dWrs1, *dbs1;      /* gate gradients (farnn >= 1), else NULL */
+    float *dWss2, *dWrs2, *dbs2;      /* (farnn = 2), else NULL                 */
 } farnn_train_outputs;
 
 int  farnn_train_create(const farnn_train_dims *dims, int device, farnn_train_ctx **out);

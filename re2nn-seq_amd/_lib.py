@@ -94,15 +94,18 @@ class DecompFstDesc(C.Structure):
 _vp = C.c_void_p
 class TrainDims(C.Structure):
     _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('K', C.c_int32), ('nl', C.c_int32),
-                ('threshold', C.c_float), ('o_idx', C.c_int32), ('use_crf', C.c_int32)]
+                ('threshold', C.c_float), ('o_idx', C.c_int32), ('farnn', C.c_int32), ('sigmoid_exponent', C.c_float),
+                ('use_crf', C.c_int32)]
 
 
 class TrainWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT', 'P', 'crf_trans')]
+    _fields_ = [(n, C.c_void_p) for n in ('Vgen', 'S1', 'S2', 'W', 'C', 'h0', 'hT', 'P', 'crf_trans',
+                                          'Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')]
 
 
 class TrainOutputs(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ('loss', 'dVgen', 'dS1', 'dS2', 'dW', 'dC', 'dh0', 'dhT', 'tags', 'dtrans')]
+    _fields_ = [(n, C.c_void_p) for n in ('loss', 'dVgen', 'dS1', 'dS2', 'dW', 'dC', 'dh0', 'dhT', 'tags', 'dtrans',
+                                          'dWss1', 'dWrs1', 'dbs1', 'dWss2', 'dWrs2', 'dbs2')]
 
 
 SIGNATURES = {
@@ -407,8 +410,10 @@ def create_decomp_fst(Vgen, Cemb, S1, S2, Cw, S1w, S2w, WW, h0, hT, P=None, farn
 class TrainContext:
     """Owns one farnn_train_ctx* (training step of the decomposed i-FST, include/farnn.h)."""
 
-    def __init__(self, V, S, R, K, nl='none', threshold=0.5, o_idx=0, device=0, use_crf=False):
-        d = TrainDims(int(V), int(S), int(R), int(K), NL[nl], float(threshold), int(o_idx), int(bool(use_crf)))
+    def __init__(self, V, S, R, K, nl='none', threshold=0.5, o_idx=0, device=0, use_crf=False, farnn=0,
+                 sigmoid_exponent=5.0):
+        d = TrainDims(int(V), int(S), int(R), int(K), NL[nl], float(threshold), int(o_idx), int(farnn),
+                      float(sigmoid_exponent), int(bool(use_crf)))
         out = C.c_void_p()
         check(load().farnn_train_create(C.byref(d), int(device), C.byref(out)), 'farnn_train_create')
         self._raw = out

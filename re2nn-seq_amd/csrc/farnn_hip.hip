@@ -1224,6 +1224,9 @@ struct farnn_train_ctx {
     size_t ws_floats = 0;
     int wsB = 0, wsL = 0;
     float *S1T = nullptr, *S2T = nullptr, *WT = nullptr, *Osum = nullptr, *dOsum = nullptr;
+    float *Wss1T = nullptr, *Wss2T = nullptr, *Wrs1T = nullptr, *Wrs2T = nullptr;   // gate transposes (farnn > 0)
+    float *ones = nullptr;        // [ones_n] of 1.0f: bias gradients as a product with a column of ones
+    size_t ones_n = 0;
     int profiling = 0;
     double prof_ms = 0.0;
     int64_t prof_n = 0;
@@ -1236,17 +1239,19 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0) return fail(FARNN_EINVAL, "train_create: bad dimensions%s%s");
     if (d->nl < FARNN_NL_NONE || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "train_create: bad nonlinearity%s%s");
     if (d->use_crf && (d->K < 4 || d->K > 256)) return fail(FARNN_ERANGE, "train_create: CRF needs 4..256 score columns%s%s");
+    if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "train_create: farnn must be 0, 1 or 2%s%s");
     int rc;
     if ((rc = select_device(device))) return rc;
     farnn_train_ctx *c = new farnn_train_ctx();
     c->d = *d; c->device = device;
     const size_t S = d->S, R = d->R;
     float *blk = nullptr;
-    if (hipMalloc((void **)&blk, (2 * S * R + S * S + 2 * S) * sizeof(float)) != hipSuccess) {
+    if (hipMalloc((void **)&blk, (2 * S * R + S * S + 2 * S + (d->farnn ? 2 * S * S + 2 * S * R : 0)) * sizeof(float)) != hipSuccess) {
         delete c;
         return fail(FARNN_ENOMEM, "train_create: out of device memory%s%s");
     }
     c->S1T = blk; c->S2T = blk + S * R; c->WT = c->S2T + S * R; c->Osum = c->WT + S * S; c->dOsum = c->Osum + S;
+    if (d->farnn) { c->Wss1T = c->dOsum + S; c->Wss2T = c->Wss1T + S * S; c->Wrs1T = c->Wss2T + S * S; c->Wrs2T = c->Wrs1T + S * R; }
     *out = c;
     return FARNN_OK;
 }
@@ -1258,6 +1263,7 @@ extern "C" void farnn_train_destroy(farnn_train_ctx *c) {
     for (auto &e : c->pending) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ws) (void)hipFree(c->ws);
     if (c->part) (void)hipFree(c->part);
+    if (c->ones) (void)hipFree(c->ones);
     if (c->S1T) (void)hipFree(c->S1T);
     delete c;
 }
@@ -1311,6 +1317,11 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         return fail(FARNN_EINVAL, "train_step: null output%s%s");
     const bool crf = c->d.use_crf != 0;
     if (crf && (!w->crf_trans || !o->dtrans)) return fail(FARNN_EINVAL, "train_step: CRF transitions / their gradient missing%s%s");
+    const int farnn = c->d.farnn;
+    if (farnn >= 1 && (!w->Wss1 || !w->Wrs1 || !w->bs1 || !o->dWss1 || !o->dWrs1 || !o->dbs1))
+        return fail(FARNN_EINVAL, "train_step: update-gate weights / gradients missing%s%s");
+    if (farnn == 2 && (!w->Wss2 || !w->Wrs2 || !w->bs2 || !o->dWss2 || !o->dWrs2 || !o->dbs2))
+        return fail(FARNN_EINVAL, "train_step: reset-gate weights / gradients missing%s%s");
     if (B <= 0 || L <= 0 || valid_tokens <= 0) return fail(FARNN_EINVAL, "train_step: B, L and valid_tokens must be positive%s%s");
     if (c->d.S > TR_VPT * TR_THREADS / TR_NSEQ || c->d.R > TR_VPT * TR_THREADS / TR_NSEQ)
         return fail(FARNN_ERANGE, "train_step: more than 512 states or rank above 512%s%s");
@@ -1318,7 +1329,8 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
     const size_t N1 = (size_t)B * (L + 1), N0 = (size_t)B * L;
-    const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S) + (crf ? N0 * K + (size_t)B * K * K : 0);
+    const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S) + (crf ? N0 * K + (size_t)B * K * K : 0) +
+                        (farnn ? N1 * (11 * S + 2 * R) : 0);
     if (need > c->ws_floats) {
         if (c->ws) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->ws); c->ws = nullptr; c->ws_floats = 0; }
         if (hipMalloc((void **)&c->ws, need * sizeof(float)) != hipSuccess)
@@ -1339,6 +1351,24 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     p.D1f = q; q += N1 * R; p.D1b = q; q += N1 * R; p.Tf = q; q += N1 * R; p.Tb = q; q += N1 * R;
     p.DS = q; q += N0 * K; p.AB = q; q += N0 * S;
     if (crf) { p.SC = q; q += N0 * K; p.dtrans_part = q; q += (size_t)B * K * K; p.trans = w->crf_trans; }
+    p.farnn = farnn; p.sig_k = c->d.sigmoid_exponent;
+    if (farnn) {
+        p.ZGf = q; q += N1 * S; p.ZGb = q; q += N1 * S; p.RGf = q; q += N1 * S; p.RGb = q; q += N1 * S;
+        p.CDf = q; q += N1 * S; p.CDb = q; q += N1 * S;
+        p.DAZf = q; q += N1 * S; p.DAZb = q; q += N1 * S; p.DARf = q; q += N1 * S; p.DARb = q; q += N1 * S;
+        p.HBARf = q; q += N1 * S;
+        p.VRf = q; q += N1 * R; p.VRb = q; q += N1 * R;
+        p.Wss1 = w->Wss1; p.Wrs1 = w->Wrs1; p.bs1 = w->bs1; p.Wss2 = w->Wss2; p.Wrs2 = w->Wrs2; p.bs2 = w->bs2;
+        p.Wss1T = c->Wss1T; p.Wss2T = c->Wss2T; p.Wrs1T = c->Wrs1T; p.Wrs2T = c->Wrs2T;
+        if (c->ones_n < N1) {
+            if (c->ones) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->ones); c->ones = nullptr; c->ones_n = 0; }
+            if (hipMalloc((void **)&c->ones, N1 * sizeof(float)) != hipSuccess)
+                return fail(FARNN_ENOMEM, "train_step: out of device memory%s%s");
+            c->ones_n = N1;
+            std::vector<float> hones(N1, 1.0f);
+            FARNN_HIP_TRY(hipMemcpy(c->ones, hones.data(), N1 * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
     p.dVgen = o->dVgen; p.dOsum = c->dOsum; p.dh0 = o->dh0; p.dhT = o->dhT; p.loss = o->loss; p.tags = o->tags;
     p.B = B; p.L = L; p.V = (int)V; p.S = (int)S; p.R = (int)R; p.K = (int)K; p.nl = c->d.nl; p.o_idx = c->d.o_idx;
     p.threshold = c->d.threshold; p.inv_tokens = 1.0f / (float)valid_tokens;
@@ -1353,6 +1383,20 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     FARNN_HIP_TRY(hipMemsetAsync(o->dh0, 0, S * sizeof(float), s));
     FARNN_HIP_TRY(hipMemsetAsync(o->dhT, 0, S * sizeof(float), s));
     FARNN_HIP_TRY(hipMemsetAsync(c->dOsum, 0, S * sizeof(float), s));
+    if (farnn) {
+        FARNN_HIP_TRY(hipMemsetAsync(o->dWss1, 0, S * S * sizeof(float), s));
+        FARNN_HIP_TRY(hipMemsetAsync(o->dWrs1, 0, R * S * sizeof(float), s));
+        FARNN_HIP_TRY(hipMemsetAsync(o->dbs1, 0, S * sizeof(float), s));
+        transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->Wss1, c->Wss1T, (int)S, (int)S);
+        transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->Wrs1, c->Wrs1T, (int)R, (int)S);
+        if (farnn == 2) {
+            FARNN_HIP_TRY(hipMemsetAsync(o->dWss2, 0, S * S * sizeof(float), s));
+            FARNN_HIP_TRY(hipMemsetAsync(o->dWrs2, 0, R * S * sizeof(float), s));
+            FARNN_HIP_TRY(hipMemsetAsync(o->dbs2, 0, S * sizeof(float), s));
+            transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->Wss2, c->Wss2T, (int)S, (int)S);
+            transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->Wrs2, c->Wrs2T, (int)R, (int)S);
+        }
+    }
 
     transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S1, c->S1T, (int)S, (int)R);
     transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S2, c->S2T, (int)S, (int)R);
@@ -1366,8 +1410,10 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t lds_l = lds_lw + (clds ? lds_lc : 0);
     const size_t nwv = TR_THREADS / 64;
     const size_t SPd = ((S + 3) & ~(size_t)3) + 8, RPd = ((R + 3) & ~(size_t)3) + 8;
-    const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
-    const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L) * sizeof(float);
+    const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
+                          (farnn ? 2 * SPd + 2 * RPd + 4 * 2 * nwv * S : 0)) * sizeof(float);
+    const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
+                          (farnn ? 4 * SPd + 2 * nwv * SR : 0)) * sizeof(float);
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
     const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
     const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
@@ -1420,12 +1466,34 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     memset(&jobs, 0, sizeof(jobs));
     jobs.chunk = 128;
     atb_add(jobs, p.Zf, p.Tf, o->dS2, (long long)N1, (int)S, (int)R);                 // dS2 += Zf^T (v*rr)
-    atb_add(jobs, p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R);         // dS1 += f_{t-1}^T (u*v)
-    atb_add(jobs, p.A, p.Zf + S, o->dW, (long long)N1 - 1, (int)S, (int)S);           // dW  += f_{t-1}^T z
+    if (!farnn) {
+        atb_add(jobs, p.A, p.D1f + R, o->dS1, (long long)N1 - 1, (int)S, (int)R);     // dS1 += f_{t-1}^T (u*v)
+        atb_add(jobs, p.A, p.Zf + S, o->dW, (long long)N1 - 1, (int)S, (int)S);       // dW  += f_{t-1}^T z
+    } else {                                                                            // the chain input is hbar_t, stored per row
+        atb_add(jobs, p.HBARf, p.D1f, o->dS1, (long long)N1, (int)S, (int)R);
+        atb_add(jobs, p.HBARf, p.Zf, o->dW, (long long)N1, (int)S, (int)S);
+    }
     atb_add(jobs, p.Zb, p.Tb, o->dS1, (long long)N1, (int)S, (int)R);                 // backward chain: roles of S1, S2 swap
     atb_add(jobs, p.BBAR, p.D1b, o->dS2, (long long)N1, (int)S, (int)R);
     atb_add(jobs, p.Zb, p.BBAR, o->dW, (long long)N1, (int)S, (int)S);                // pre_j += sum_s bbar_s W[j][s]
     atb_add(jobs, p.DS, p.AB, o->dC, (long long)N0, (int)K, (int)S);                  // dC += ds^T (alpha*beta)
+    if (farnn) {
+        // gates read the raw previous state (stash shifted by one row) and v_t: dWss = h_{t-1}^T da, dWrs = v^T da, dbs = 1^T da
+        atb_add(jobs, p.A, p.DAZf + S, o->dWss1, (long long)N1 - 1, (int)S, (int)S);
+        atb_add(jobs, p.Bk, p.DAZb + S, o->dWss1, (long long)N1 - 1, (int)S, (int)S);
+        atb_add(jobs, p.VRf, p.DAZf, o->dWrs1, (long long)N1, (int)R, (int)S);
+        atb_add(jobs, p.VRb, p.DAZb, o->dWrs1, (long long)N1, (int)R, (int)S);
+        atb_add(jobs, c->ones, p.DAZf, o->dbs1, (long long)N1, 1, (int)S);
+        atb_add(jobs, c->ones, p.DAZb, o->dbs1, (long long)N1, 1, (int)S);
+        if (farnn == 2) {
+            atb_add(jobs, p.A, p.DARf + S, o->dWss2, (long long)N1 - 1, (int)S, (int)S);
+            atb_add(jobs, p.Bk, p.DARb + S, o->dWss2, (long long)N1 - 1, (int)S, (int)S);
+            atb_add(jobs, p.VRf, p.DARf, o->dWrs2, (long long)N1, (int)R, (int)S);
+            atb_add(jobs, p.VRb, p.DARb, o->dWrs2, (long long)N1, (int)R, (int)S);
+            atb_add(jobs, c->ones, p.DARf, o->dbs2, (long long)N1, 1, (int)S);
+            atb_add(jobs, c->ones, p.DARb, o->dbs2, (long long)N1, 1, (int)S);
+        }
+    }
     const size_t pf = atb_partial_floats(jobs);
     if (pf > c->part_floats) {
         if (c->part) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->part); c->part = nullptr; c->part_floats = 0; }

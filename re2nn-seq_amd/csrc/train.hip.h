@@ -35,6 +35,15 @@ struct TrainParams {
     float *PRE;               // [.][S]  forward chain's pre-activation before the output mask
     float *DS, *AB;           // [B][L][K] d loss / d (pre-priority) scores; [B][L][S] alpha*beta
     float *SC;                // [B][L][K] scores after the priority layer (CRF mode: the emissions)
+    // GRU-style gates (farnn 1/2, model_decompose_single.py:143-154,193-198)
+    int farnn;
+    float sig_k;
+    const float *Wss1, *Wrs1, *bs1, *Wss2, *Wrs2, *bs2;     // [S][S], [R][S], [S]
+    const float *Wss1T, *Wss2T, *Wrs1T, *Wrs2T;             // [S][S], [S][R]
+    float *ZGf, *ZGb, *RGf, *RGb, *CDf, *CDb;               // [.][S] gates z, r and the candidate state of every step
+    float *DAZf, *DAZb, *DARf, *DARb;                       // [.][S] adjoints of the gate pre-activations
+    float *VRf, *VRb;                                       // [.][R] v_t rows (for d Wrs)
+    float *HBARf;                                           // [.][S] forward chain input hbar_t (= f_{t-1} without gates)
     const float *trans;       // [K][K] CRF transitions (CRF mode) and the per-sequence partials of their gradient
     float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
@@ -193,17 +202,22 @@ train_forward_kernel(const TrainParams p) {
     }
     // the token of every step, in step order, so that no step waits for an index load
     int *toks = (int *)(part2 + nw * 2 * S);                  // [TR_NSEQ][L]
+    // gated steps: raw state and v_t as matvec inputs, four more partial buffers
+    float *hv = (float *)(toks + TR_NSEQ * p.L), *vv = hv + 2 * SP, *pg = vv + 2 * RP;
+    const int farnn = p.farnn;
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
     for (int e = tid; e < 2 * SP + 2 * RP; e += nt) f[e] = 0.0f;          // f | tv contiguous: pads stay zero
+    if (farnn) for (int e = tid; e < 2 * SP + 2 * RP; e += nt) hv[e] = 0.0f;   // hv | vv contiguous
     __syncthreads();
     for (int e = tid; e < TR_NSEQ * S; e += nt) {
         const int q = e / S, s = e - q * S;
         const float h = dir == 0 ? p.h0[s] : p.hT[s];
         if (b0 + q < p.B) (dir == 0 ? p.A : p.Bk)[(long long)(b0 + q) * (p.L + 1) * S + s] = h;
         f[q * SP + s] = dir == 0 ? h : h * p.Osum[s];                  // the backward chain masks its INPUT (:157-158)
+        if (farnn) hv[q * SP + s] = h;
     }
     __syncthreads();
     // per-thread slots: which (sequence, state) and (sequence, rank) element this thread owns -- fixed for the whole
@@ -220,16 +234,48 @@ train_forward_kernel(const TrainParams p) {
     }
     float *stash_out = dir == 0 ? p.A : p.Bk;
     // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
-    float vcur[TR_VPT], vnext[TR_VPT], osum[TR_VPT];
+    float vcur[TR_VPT], vnext[TR_VPT], osum[TR_VPT], hk[TR_VPT], hin[TR_VPT], zk[TR_VPT], rk[TR_VPT];
 #pragma unroll
     for (int k = 0; k < TR_VPT; k++) {
         vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L] * R + rr_[k]] : 0.0f;
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
+        hin[k] = sv[k] ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
+        hk[k] = hin[k]; zk[k] = 1.0f; rk[k] = 1.0f;
     }
+    float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
     for (int t = 1; t <= maxlen; t++) {
 #pragma unroll
         for (int k = 0; k < TR_VPT; k++)
             vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(long long)toks[rq[k] * p.L + t] * R + rr_[k]] : 0.0f;
+        if (farnn) {
+            // z = sigma(k (h Wss1 + v Wrs1 + bs1)), r likewise (:146-149); hbar = (1-r) h_init + r h (:150-151)
+#pragma unroll
+            for (int k = 0; k < TR_VPT; k++) if (rv[k]) vv[rq[k] * RP + rr_[k]] = vcur[k];
+            wg_barrier_lds();
+            matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
+            matvec2_partial<false>(pg + nw * 2 * S, vv, RP, p.Wrs1, R, S, tid, nt);
+            if (farnn == 2) {
+                matvec2_partial<false>(pg + 2 * nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
+                matvec2_partial<false>(pg + 3 * nw * 2 * S, vv, RP, p.Wrs2, R, S, tid, nt);
+            }
+            wg_barrier_lds();
+#pragma unroll
+            for (int k = 0; k < TR_VPT; k++) {
+                if (sv[k]) {
+                    const float az = part2_sum(pg, S, sq[k], ss[k], nw) + part2_sum(pg + nw * 2 * S, S, sq[k], ss[k], nw) + p.bs1[ss[k]];
+                    zk[k] = 1.0f / (1.0f + expf(-p.sig_k * az));
+                    float hbar = hk[k];
+                    if (farnn == 2) {
+                        const float ar = part2_sum(pg + 2 * nw * 2 * S, S, sq[k], ss[k], nw) +
+                                         part2_sum(pg + 3 * nw * 2 * S, S, sq[k], ss[k], nw) + p.bs2[ss[k]];
+                        rk[k] = 1.0f / (1.0f + expf(-p.sig_k * ar));
+                        hbar = (1.0f - rk[k]) * hin[k] + rk[k] * hk[k];
+                    }
+                    f[sq[k] * SP + ss[k]] = dir == 0 ? hbar : hbar * osum[k];
+                }
+            }
+            wg_barrier_lds();
+        }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
         matvec2_partial<LDSW>(part, f, SP, M1, S, R, tid, nt);
         matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
@@ -248,8 +294,15 @@ train_forward_kernel(const TrainParams p) {
                 float h;
                 if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * osum[k], p.nl); }      // (:181)
                 else          { h = apply_nl(pre, p.nl); }
+                if (farnn) {                                                                 // (:193-196)
+                    CD[row] = h; ZG[row] = zk[k]; RG[row] = rk[k];
+                    h = (1.0f - zk[k]) * hk[k] + zk[k] * h;
+                    hk[k] = h;
+                    hv[sq[k] * SP + ss[k]] = h;
+                } else {
+                    f[sq[k] * SP + ss[k]] = dir == 0 ? h : h * osum[k];
+                }
                 stash_out[row] = h;
-                f[sq[k] * SP + ss[k]] = dir == 0 ? h : h * osum[k];
             }
         }
 #pragma unroll
@@ -605,11 +658,15 @@ train_backward_kernel(const TrainParams p) {
         maxlen = len[q] > maxlen ? len[q] : maxlen;
     }
     int *toks = (int *)(pc + nw * 2 * S);                     // [TR_NSEQ][L] tokens in step order
+    // gated steps: the gate pre-activation adjoints as matvec inputs and a fourth partial buffer
+    float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP, *pd = darv + 2 * SP;
+    const int farnn = p.farnn;
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
     for (int e = tid; e < 4 * SP + 2 * RP; e += nt) z[e] = 0.0f;          // z fp d1 contiguous: pads stay zero
+    if (farnn) for (int e = tid; e < 4 * SP; e += nt) dazv[e] = 0.0f;       // dazv | darv contiguous
     __syncthreads();
     // per-thread slots, fixed for the whole kernel (no divisions in the time loop); g, y and dOsum of a slot are only
     // ever touched by its owner, so they live in registers
@@ -629,6 +686,14 @@ train_backward_kernel(const TrainParams p) {
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
         gacc[k] = 0.0f; dOacc[k] = 0.0f; yk[k] = 0.0f;
     }
+    float hin[TR_VPT], dhin[TR_VPT], zc[TR_VPT], zn[TR_VPT], rc[TR_VPT], rn[TR_VPT], cc[TR_VPT], cn[TR_VPT], dhk[TR_VPT];
+    const float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
+    float *DAZ = dir == 0 ? p.DAZf : p.DAZb, *DAR = dir == 0 ? p.DARf : p.DARb, *VR = dir == 0 ? p.VRf : p.VRb;
+#pragma unroll
+    for (int k = 0; k < TR_VPT; k++) {
+        hin[k] = (farnn && sv[k]) ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
+        dhin[k] = 0.0f; zc[k] = zn[k] = rc[k] = rn[k] = 1.0f; cc[k] = cn[k] = 0.0f; dhk[k] = 0.0f;
+    }
     // everything a step reads from the stash is fetched one step ahead into registers (the rows of a sequence
     // beyond its length are zero, so the reads need no guard): h_t, h_{t-1}, dL/dh_t from the scoring, pre_t, v_t
     const float *stash_base = dir == 0 ? p.A : p.Bk, *G_base = dir == 0 ? p.GA : p.GB;
@@ -642,6 +707,7 @@ train_backward_kernel(const TrainParams p) {
         hprev[k] = ok ? stash_base[row - S] : 0.0f;
         gs[k] = ok ? G_base[row] : 0.0f;
         pr[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
+        if (farnn) { zc[k] = ok ? ZG[row] : 1.0f; rc[k] = ok ? RG[row] : 1.0f; cc[k] = ok ? CD[row] : 0.0f; }
         vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L + (maxlen - 1 < len[rq[k]] ? maxlen - 1 : 0)] * R + rr_[k]] : 0.0f;
     }
     for (int t = maxlen; t >= 1; t--) {
@@ -652,6 +718,7 @@ train_backward_kernel(const TrainParams p) {
             hpp[k] = ok ? stash_base[row - S] : 0.0f;
             gsn[k] = ok ? G_base[row] : 0.0f;
             prn[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
+            if (farnn) { zn[k] = ok ? ZG[row] : 1.0f; rn[k] = ok ? RG[row] : 1.0f; cn[k] = ok ? CD[row] : 0.0f; }
             vnext[k] = (rv[k] && t >= 2) ? p.Vgen[(long long)toks[rq[k] * p.L + (t - 2 < len[rq[k]] ? t - 2 : 0)] * R + rr_[k]] : 0.0f;
         }
 #pragma unroll
@@ -660,13 +727,25 @@ train_backward_kernel(const TrainParams p) {
                 const int li = sq[k] * SP + ss[k];
                 if (t <= len[sq[k]]) {
                     const long long row = srow[k] + (long long)t * S;
-                    const float yy = (gacc[k] + gs[k]) * nl_grad_from_output(hcur[k], p.nl);
-                    const float hp = hprev[k];
+                    const float gt = gacc[k] + gs[k];
+                    float yy, hp = hprev[k];
+                    if (farnn) {                                      // h_t = (1-z) h_{t-1} + z cand (:193-196)
+                        dhk[k] = gt * (1.0f - zc[k]);                  // direct path to h_{t-1}
+                        yy = (gt * zc[k]) * nl_grad_from_output(cc[k], p.nl);
+                        // d z pre-activation: dz = gt (cand - h_{t-1}); sigma'(k a) = k z (1-z)
+                        const float daz = gt * (cc[k] - hp) * p.sig_k * zc[k] * (1.0f - zc[k]);
+                        dazv[li] = daz;
+                        DAZ[row] = daz;
+                        if (farnn == 2) hp = (1.0f - rc[k]) * hin[k] + rc[k] * hp;          // hbar (:150-151)
+                    } else {
+                        yy = gt * nl_grad_from_output(hcur[k], p.nl);
+                    }
                     if (dir == 0) {                                   // mask on the OUTPUT of the step
                         const float zz = yy * osum[k];
                         z[li] = zz; fp[li] = hp;
                         dOacc[k] = fmaf(yy, pr[k], dOacc[k]);                         // d Osum += y * pre_t
                         Zo[row] = zz;
+                        if (farnn) p.HBARf[row] = hp;
                     } else {                                          // mask on the INPUT: fp = bbar, y keeps b_{t-1}
                         const float bb = hp * osum[k];
                         z[li] = yy; fp[li] = bb; yk[k] = hp;
@@ -675,6 +754,7 @@ train_backward_kernel(const TrainParams p) {
                     }
                 } else {
                     z[li] = 0.0f; fp[li] = 0.0f;
+                    if (farnn) { dazv[li] = 0.0f; darv[li] = 0.0f; }
                 }
             }
         }
@@ -694,6 +774,7 @@ train_backward_kernel(const TrainParams p) {
                     dd = uv * vv;
                     D1o[row] = dd;
                     To[row] = vv * rvv;
+                    if (farnn) VR[row] = vv;
                     atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], uv * rvv);   // d v_t = u * rr
                 }
                 d1[rq[k] * RP + rr_[k]] = dd;
@@ -706,17 +787,59 @@ train_backward_kernel(const TrainParams p) {
         for (int k = 0; k < TR_VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
                 const float dfp = part2_sum(pc, S, sq[k], ss[k], nw) + part2_sum(pa, S, sq[k], ss[k], nw);
-                if (dir == 0) gacc[k] = dfp;
-                else { dOacc[k] = fmaf(dfp, yk[k], dOacc[k]); gacc[k] = dfp * osum[k]; }   // d Osum += d bbar * b_{t-1}
+                float dhb;                                             // adjoint of the (unmasked) chain input
+                if (dir == 0) dhb = dfp;
+                else { dOacc[k] = fmaf(dfp, yk[k], dOacc[k]); dhb = dfp * osum[k]; }       // d Osum += d bbar * (unmasked input)
+                if (!farnn) gacc[k] = dhb;
+                else {
+                    float dar = 0.0f;
+                    if (farnn == 2) {                                  // hbar = (1-r) h_init + r h_{t-1}
+                        dar = dhb * (hprev[k] - hin[k]) * p.sig_k * rc[k] * (1.0f - rc[k]);
+                        dhin[k] = fmaf(dhb, 1.0f - rc[k], dhin[k]);
+                        dhk[k] = fmaf(dhb, rc[k], dhk[k]);
+                        DAR[srow[k] + (long long)t * S] = dar;
+                    } else {
+                        dhk[k] += dhb;
+                    }
+                    darv[sq[k] * SP + ss[k]] = dar;
+                }
             }
+        }
+        if (farnn) {
+            // the gates read the raw h_{t-1} and v_t: d h_{t-1} += daz Wss1^T + dar Wss2^T, d v_t += daz Wrs1^T + dar Wrs2^T
+            wg_barrier_lds();
+            matvec2_partial<false>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
+            matvec2_partial<false>(pb, dazv, SP, p.Wrs1T, S, R, tid, nt);
+            if (farnn == 2) {
+                matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
+                matvec2_partial<false>(pd, darv, SP, p.Wrs2T, S, R, tid, nt);
+            }
+            wg_barrier_lds();
+#pragma unroll
+            for (int k = 0; k < TR_VPT; k++) {
+                if (sv[k] && t <= len[sq[k]]) {
+                    float dh = dhk[k] + part2_sum(pa, S, sq[k], ss[k], nw);
+                    if (farnn == 2) dh += part2_sum(pc, S, sq[k], ss[k], nw);
+                    gacc[k] = dh;
+                }
+                if (rv[k] && t <= len[rq[k]]) {
+                    float dv = part2_sum(pb, R, rq[k], rr_[k], nw);
+                    if (farnn == 2) dv += part2_sum(pd, R, rq[k], rr_[k], nw);
+                    atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], dv);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TR_VPT; k++) {
             hcur[k] = hprev[k]; hprev[k] = hpp[k]; gs[k] = gsn[k]; pr[k] = prn[k]; vcur[k] = vnext[k];
+            zc[k] = zn[k]; rc[k] = rn[k]; cc[k] = cn[k];
         }
         wg_barrier_lds();
     }
 #pragma unroll
     for (int k = 0; k < TR_VPT; k++) {
         if (sv[k]) {
-            const float g0 = gacc[k] + G_base[srow[k]];
+            const float g0 = gacc[k] + G_base[srow[k]] + dhin[k];
             if (g0 != 0.0f) atomicAdd((dir == 0 ? p.dh0 : p.dhT) + ss[k], g0);
             if (dOacc[k] != 0.0f) atomicAdd(p.dOsum + ss[k], dOacc[k]);
         }
@@ -728,7 +851,7 @@ train_backward_kernel(const TrainParams p) {
 // launches for all products of a step: atb_partial_kernel computes 32x32 output tiles over row chunks and writes them
 // to a partial buffer without atomics (130 chunks adding into the same 10 k addresses ran at the contended atomic
 // rate: 33 us per product); atb_reduce_kernel adds the chunks of every output element.
-constexpr int ATB_MAX_JOBS = 8;
+constexpr int ATB_MAX_JOBS = 20;
 struct AtbJob {
     const float *A, *B;
     float *out;

@@ -178,10 +178,10 @@ class FARNN_S_D_W_I_S(NativeTagger):
 
     def _check_trainable(self, re_tags):
         a = self.args
-        if a.farnn != 0 or a.train_mode != 'sum' or a.local_loss_func != 'CE1' or re_tags is not None \
+        if a.farnn not in (0, 1, 2) or a.train_mode != 'sum' or a.local_loss_func != 'CE1' or re_tags is not None \
                 or getattr(a, 'marryup_type', 'none') not in ('none', None):
-            raise NotImplementedError('the HIP training step covers farnn=0, sum semiring, CE1 loss (with or without '
-                                      'the CRF) and no KD/PR teachers (DESIGN.md, row f3)')
+            raise NotImplementedError('the HIP training step covers the sum semiring and the CE1 loss (with or without '
+                                      'the CRF), no KD/PR teachers (DESIGN.md, row f3)')
 
     def enable_training(self):
         """Device-resident leaf tensors for the optimizer (returned by parameters()) and the library context."""
@@ -196,6 +196,8 @@ class FARNN_S_D_W_I_S(NativeTagger):
             t = src[k].detach().to(dev).float().clone()
             t.requires_grad_(True if flag is None else bool(getattr(self.args, flag, 0)))
             self._tp[k] = t
+        for k in _GATE_KEYS[:3 * int(self.args.farnn)]:
+            self._tp[k] = src[k].detach().to(dev).float().clone().requires_grad_(True)
         if self.use_crf:
             self._tp['crf.transitions'] = self.crf_transitions.detach().to(dev).float().clone().requires_grad_(True)
         self._tpP = torch.from_numpy(np.ascontiguousarray(self.priority_full, dtype=np.float32)).to(dev) \
@@ -203,7 +205,8 @@ class FARNN_S_D_W_I_S(NativeTagger):
         S, R = self._tp['S1'].shape
         self._tc = _lib.TrainContext(self._tp['V_embed'].shape[0], S, R, self._tp['C_output_mat'].shape[0],
                                      nl=self.args.update_nonlinear, threshold=self.args.threshold, o_idx=self.o_idx,
-                                     device=self.device_index, use_crf=self.use_crf)
+                                     device=self.device_index, use_crf=self.use_crf, farnn=int(self.args.farnn),
+                                     sigmoid_exponent=float(self.args.sigmoid_exponent))
         self._dirty = False
         return self
 
@@ -261,7 +264,8 @@ class FARNN_S_D_W_I_S(NativeTagger):
         lab = label[:, :Lmax]
         loss, tags = decomp_ifst_train_step(self._tc, self._train_vgen(), tp['S1'], tp['S2'], tp['wildcard_mat'],
                                             tp['C_output_mat'], tp['h0'], tp['hT'], self._tpP, x, lengths, lab,
-                                            crf_trans=tp.get('crf.transitions'))
+                                            crf_trans=tp.get('crf.transitions'),
+                                            gates=tuple(tp[k] for k in _GATE_KEYS[:3 * int(self.args.farnn)]))
         self._dirty = True
         pred = self._flatten(tags, lengths.to(tags.device)).to(torch.int64).to(input.device)
         true = self._flatten(label, lengths).to(input.device)

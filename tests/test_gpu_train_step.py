@@ -43,7 +43,7 @@ def close(got, ref, name, rtol=2e-3, atol=2e-6):
     np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol + 2e-4 * scale, err_msg=name)
 
 
-@pytest.mark.parametrize('k', range(7))
+@pytest.mark.parametrize('k', range(10))
 def test_train_step_matches_reference_loss_and_gradients(k):
     """Through the model mirror: forward_local(train=True) -> loss.backward() -> .grad of every parameter."""
     from re2nn_seq_amd.farnn.model_decompose_single import FARNN_S_D_W_I_S
@@ -63,6 +63,10 @@ def test_train_step_matches_reference_loss_and_gradients(k):
     if cfg.get('use_crf'):
         sd['crf.transitions'] = g[pre + 'w.crf.transitions']
         names = PARAMS + ('crf.transitions',)
+    for n in ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2'):
+        if pre + 'w.' + n in g.files:
+            sd[n] = g[pre + 'w.' + n]
+            names = names + (n,)
     m.load_state_dict(sd)
     x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
     m.train()
