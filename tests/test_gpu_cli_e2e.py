@@ -173,3 +173,19 @@ def test_decompose_cli_trains_with_the_crf(tree, tmp_path):
     saved = cli.load_res(res_path)
     losses = [float(line.split('LOSS:')[1]) for line in saved['logger'].record if 'LOSS:' in line]
     assert len(losses) == 1 and np.isfinite(losses[0]) and losses[0] > 0
+
+
+def test_decompose_cli_trains_the_shipped_configuration_shape(tree, tmp_path):
+    """--farnn 2 --use_crf 1 (what the reference's example configurations use) for one epoch through the CLI."""
+    L = 12
+    argv = ['--dataset', 'ATIS-BIO', '--method', 'decompose', '--independent', '2',
+            '--automata_path', tree['paths']['IIID'], '--rank', '100', '--seed', '1', '--beta', '0.9',
+            '--embed_dim', '16', '--normalize_automata', 'none', '--rand_constant', '0', '--use_crf', '1',
+            '--farnn', '2', '--update_nonlinear', 'tanh', '--bz', '9', '--seq_max_len', str(L), '--epoch', '2',
+            '--lr', '0.005', '--train_portion', '1.0', '--data_dir', tree['paths']['data_dir'],
+            '--model_dir', str(tmp_path)]
+    results, stats, res_path = cli.main(argv)
+    assert len(stats['train_step']) == 2
+    saved = cli.load_res(res_path)
+    losses = [float(line.split('LOSS:')[1]) for line in saved['logger'].record if 'LOSS:' in line]
+    assert len(losses) == 2 and np.isfinite(losses).all() and losses[1] < losses[0]

@@ -251,3 +251,65 @@ def test_train_step_crf_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
     mask = np.arange(L)[None, :] < lengths[:, None]
     assert (t[~mask] == -1).all()
     assert (t[mask] == want[mask]).mean() > 0.98
+
+
+@pytest.mark.parametrize('farnn,S,R,K,V,B,L,nl,crf', [
+    (2, 104, 50, 75, 200, 9, 30, 'tanh', True),       # the shipped example configurations' shape: gates + CRF
+    (1, 23, 40, 9, 50, 7, 9, 'relu', False),
+    (2, 5, 3, 4, 11, 3, 6, 'none', False),
+])
+def test_train_step_gated_c_abi_vs_oracle(farnn, S, R, K, V, B, L, nl, crf):
+    """GRU-gated recurrence (farnn 1/2) through the C-ABI entry point against the oracle, with an empty sequence."""
+    from re2nn_seq_amd import _lib
+    rng = np.random.RandomState(S + R + farnn)
+    f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
+    D = 6
+    Cm = np.zeros((K, S), np.float32)
+    Cm[rng.randint(0, K - (2 if crf else 0), size=S), np.arange(S)] = (rng.rand(S) < 0.8)
+    p = {'S1': f(S, R, sc=1.0 / np.sqrt(S)), 'S2': f(S, R, sc=1.0 / np.sqrt(S)), 'V_embed': f(V, R, sc=0.8),
+         'embed_r_generalized': f(D, R), 'C_output_mat': torch.from_numpy(Cm + (rng.rand(K, S) * 0.02).astype(np.float32)),
+         'wildcard_mat': torch.from_numpy(((rng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)),
+         'h0': f(S, sc=0.5), 'hT': f(S, sc=0.5), 'beta_vec': torch.full((R,), 0.7), 'embedding.weight': f(V, D),
+         'priority_mat': torch.eye(K),
+         'Wss1': f(S, S, sc=0.5 / np.sqrt(S)), 'Wrs1': f(R, S, sc=0.5 / np.sqrt(R)), 'bs1': f(1, S, sc=0.5)}
+    if farnn == 2:
+        p.update(Wss2=f(S, S, sc=0.5 / np.sqrt(S)), Wrs2=f(R, S, sc=0.5 / np.sqrt(R)), bs2=f(1, S, sc=0.5))
+    if crf:
+        tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+        tr[:, K - 2] = -10000.0
+        tr[K - 1, :] = -10000.0
+        p['crf.transitions'] = torch.from_numpy(tr)
+    lengths = rng.randint(1, L + 1, size=B).astype(np.int64)
+    lengths[0] = L
+    if B > 2:
+        lengths[1] = 0
+    x = rng.randint(0, V, size=(B, L)).astype(np.int64)
+    labels = rng.randint(0, K - (2 if crf else 0), size=(B, L)).astype(np.int64)
+    xt, lt, lab = torch.from_numpy(x), torch.from_numpy(lengths), torch.from_numpy(labels)
+    loss_ref, grads_ref, _ = to.train_step(p, xt, lt, lab, nl=nl, farnn=farnn, sig_k=2.0)
+    dev = torch.device('cuda')
+    gate_names = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')[:3 * farnn]
+    w = {'Vgen': to.generalized_table(p).to(dev), 'S1': p['S1'].to(dev), 'S2': p['S2'].to(dev), 'W': p['wildcard_mat'].to(dev),
+         'C': p['C_output_mat'].to(dev), 'h0': p['h0'].to(dev), 'hT': p['hT'].to(dev)}
+    w.update({n: p[n].to(dev).contiguous() for n in gate_names})
+    trd = p['crf.transitions'].to(dev) if crf else None
+    tc = _lib.TrainContext(V, S, R, K, nl=nl, threshold=0.5, o_idx=1, use_crf=crf, farnn=farnn, sigmoid_exponent=2.0)
+    out = {'d' + n: torch.full_like(t, 7.0) for n, t in w.items()}
+    dtr = torch.full_like(trd, 7.0) if crf else None
+    loss = torch.full((1,), 3.0, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    xd, ld, labd = xt.to(dev), lt.to(dev), lab.to(dev)
+    for _ in range(2):
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None, crf_trans=None if trd is None else trd.data_ptr()),
+                xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr(),
+                     dtrans=None if dtr is None else dtr.data_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 5e-5 * max(1.0, abs(float(loss_ref)))
+    for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')) + \
+            tuple((n, n) for n in gate_names):
+        close(out['d' + n].cpu().numpy(), grads_ref[key].numpy().reshape(out['d' + n].shape), 'd' + n)
+    if crf:
+        close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), 'dtrans')
+    for n, t in out.items():
+        assert torch.isfinite(t).all(), n
