@@ -215,6 +215,9 @@ def run_train(a, world, rank, dev, dist):
              C=torch.from_numpy(Cm).to(dev).requires_grad_(True),
              W=torch.from_numpy(((wrng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)).to(dev).requires_grad_(True),
              h0=f(S, sc=0.5), hT=f(S, sc=0.5))
+    gate_names = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')[:3 * a.farnn]
+    for n in gate_names:                      # xavier-sized gates, bias as --bias_init would set it
+        p[n] = f(1, S, sc=0.5) if n.startswith('bs') else (f(S, S, sc=1.0 / np.sqrt(S)) if n.startswith('Wss') else f(R, S, sc=1.0 / np.sqrt(R)))
     if a.crf:
         tr = np.zeros((K, K), np.float32)
         tr[:, K - 2] = -10000.0
@@ -226,7 +229,8 @@ def run_train(a, world, rank, dev, dist):
         lengths[:] = L
     labels = brng.randint(0, K - (2 if a.crf else 0), size=(B, L)).astype(np.int64)
     xd, ld, lab = torch.from_numpy(x).to(dev), torch.from_numpy(lengths).to(dev), torch.from_numpy(labels).to(dev)
-    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0, use_crf=a.crf)
+    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0, use_crf=a.crf,
+                           farnn=a.farnn, sigmoid_exponent=5.0)
     params = list(p.values())
     opt = torch.optim.Adam(params, lr=1e-4)
 
@@ -234,7 +238,7 @@ def run_train(a, world, rank, dev, dist):
         opt.zero_grad(set_to_none=True)
         Vgen = p['V_embed'] * beta + torch.tanh(p['E'] @ p['G']) * (1 - beta)
         loss, _ = decomp_ifst_train_step(tc, Vgen, p['S1'], p['S2'], p['W'], p['C'], p['h0'], p['hT'], None, xd, ld, lab,
-                                         crf_trans=p.get('trans'))
+                                         crf_trans=p.get('trans'), gates=tuple(p[n] for n in gate_names))
         loss.backward()
         if world > 1:
             flat = torch.cat([q.grad.reshape(-1) for q in params])
@@ -284,7 +288,7 @@ def run_train(a, world, rank, dev, dist):
             'warmup': a.warmup, 'ms_per_step': el / a.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '{}{}: V={} S={} R={} K={}, batch {} x seqlen {} per GPU'.format(
-                           desc, ' with the CRF loss' if a.crf else '', V, S, R, K, B, L),
+                           desc.replace('farnn 0', 'farnn {}'.format(a.farnn)), ' with the CRF loss' if a.crf else '', V, S, R, K, B, L),
                        'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
                        'parallelism': 'data parallel x{}{}'.format(world, ', one RCCL all-reduce of the gradients' if world > 1 else ''),
                        'final_loss': float(loss.detach())},
@@ -295,7 +299,7 @@ def run_train(a, world, rank, dev, dist):
                          'note': 'the library part of the step is bound by the latency of 64 sequential recurrence '
                                  'steps per direction, not by bandwidth'},
         }
-        if world == 1 and not a.no_cpu_baseline and not a.crf:
+        if world == 1 and not a.no_cpu_baseline and not a.crf and not a.farnn:
             out['cpu_baseline'] = train_cpu_baseline(p, beta, x, lengths, labels, a.cpu_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
