@@ -1293,7 +1293,7 @@ static void atb_add(AtbJobs &jobs, const float *A, const float *Bm, float *out, 
     if (N <= 0 || jobs.n >= ATB_MAX_JOBS) return;
     AtbJob &j = jobs.j[jobs.n];
     j.A = A; j.B = Bm; j.out = out; j.N = N; j.M = M; j.J = J;
-    j.tiles_m = (M + 31) / 32; j.tiles_j = (J + 31) / 32;
+    j.tiles_m = (M + 63) / 64; j.tiles_j = (J + 63) / 64;
     j.nsplit = (int)((N + jobs.chunk - 1) / jobs.chunk);
     j.wg0 = jobs.total_wgs; j.out0 = jobs.total_out;
     j.part_off = jobs.n ? jobs.j[jobs.n - 1].part_off + (long long)jobs.j[jobs.n - 1].nsplit * jobs.j[jobs.n - 1].M * jobs.j[jobs.n - 1].J : 0;

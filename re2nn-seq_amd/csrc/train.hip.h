@@ -848,7 +848,7 @@ train_backward_kernel(const TrainParams p) {
 
 // ---- parameter gradients: out[M][J] += sum_n A[n][M] B[n][J] for several (A, B, out) at once -------------------
 // (A, B row-major with the reduction index as the row; rows that do not belong to a valid token are zero.)  Two
-// launches for all products of a step: atb_partial_kernel computes 32x32 output tiles over row chunks and writes them
+// launches for all products of a step: atb_partial_kernel computes 64x64 output tiles over row chunks and writes them
 // to a partial buffer without atomics (130 chunks adding into the same 10 k addresses ran at the contended atomic
 // rate: 33 us per product); atb_reduce_kernel adds the chunks of every output element.
 constexpr int ATB_MAX_JOBS = 20;
@@ -865,45 +865,62 @@ struct AtbJobs {
     float *partial;
 };
 
+// 64x64 output tile per workgroup (four wavefronts, 32x32 each as 2x2 v_mfma_f32_16x16x4_f32 tiles) over one 128-row
+// chunk.  Both operands are read straight from global memory in MFMA operand order: lane (l & 15, l >> 4) needs
+// A[n + (l >> 4)][m0 + (l & 15)] and B[n + (l >> 4)][j0 + (l & 15)] -- 64 contiguous bytes per 16 lanes, no LDS, no
+// transposition.  (The first version staged 32x32 tiles in LDS and did 2x2 outputs per thread on the VALU: 18 TFLOP/s.)
 __global__ void __launch_bounds__(256)
 atb_partial_kernel(const AtbJobs jobs) {
-    constexpr int CH = 128;                          // rows per chunk = jobs.chunk: the whole chunk is staged at once,
-    __shared__ float sa[CH][33], sb[CH][33];         // 32 loads per thread in flight, one barrier
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    constexpr int CH = 128;                          // rows per chunk = jobs.chunk
     int ji = 0;
     while (ji + 1 < jobs.n && (int)blockIdx.x >= jobs.j[ji + 1].wg0) ji++;
     const AtbJob &jb = jobs.j[ji];
     const int local = blockIdx.x - jb.wg0;
     const int tiles = jb.tiles_m * jb.tiles_j, split = local / tiles, tile = local - split * tiles;
-    const int m0 = (tile / jb.tiles_j) * 32, j0 = (tile % jb.tiles_j) * 32;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    const int M = jb.M, J = jb.J;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int m0 = (tile / jb.tiles_j) * 64 + (wv >> 1) * 32, j0 = (tile % jb.tiles_j) * 64 + (wv & 1) * 32;
+    const int M = jb.M, J = jb.J, lr = lane & 15, lk = lane >> 4;
     const long long n0 = (long long)split * CH, n1 = n0 + CH < jb.N ? n0 + CH : jb.N;
-    {
-        const int c = tid & 31, r0 = tid >> 5;       // 8 rows per pass, 16 passes
-        float va[16], vb[16];
+    f32x4_t acc[2][2];
 #pragma unroll
-        for (int u = 0; u < 16; u++) {
-            const long long n = n0 + r0 + u * 8;
-            va[u] = (n < n1 && m0 + c < M) ? jb.A[n * M + m0 + c] : 0.0f;
-            vb[u] = (n < n1 && j0 + c < J) ? jb.B[n * J + j0 + c] : 0.0f;
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++) acc[x][y] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (m0 < M && j0 < J) {
+        const bool ma0 = m0 + lr < M, ma1 = m0 + 16 + lr < M, jb0 = j0 + lr < J, jb1 = j0 + 16 + lr < J;
+        const float *Ap = jb.A + m0 + lr, *Bp = jb.B + j0 + lr;
+        for (long long nb = n0; nb < n1; nb += 16) {                 // four k-steps of 4 rows, their loads in flight together
+            float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long long n = nb + u * 4 + lk;
+                const bool ok = n < n1;
+                a0[u] = ok && ma0 ? Ap[n * M] : 0.0f;
+                a1[u] = ok && ma1 ? Ap[n * M + 16] : 0.0f;
+                b0[u] = ok && jb0 ? Bp[n * J] : 0.0f;
+                b1[u] = ok && jb1 ? Bp[n * J + 16] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 16; u++) { sa[r0 + u * 8][c] = va[u]; sb[r0 + u * 8][c] = vb[u]; }
     }
-    __syncthreads();
-    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll 8
-    for (int k = 0; k < CH; k++) {
-        const float a0 = sa[k][ty * 2], a1 = sa[k][ty * 2 + 1], b0 = sb[k][tx * 2], b1 = sb[k][tx * 2 + 1];
-        acc[0][0] = fmaf(a0, b0, acc[0][0]); acc[0][1] = fmaf(a0, b1, acc[0][1]);
-        acc[1][0] = fmaf(a1, b0, acc[1][0]); acc[1][1] = fmaf(a1, b1, acc[1][1]);
-    }
+    // D: column = lr, rows = lk*4 + {0..3} of each 16x16 tile
     float *po = jobs.partial + jb.part_off + (long long)split * M * J;
-    for (int a = 0; a < 2; a++)
-        for (int c = 0; c < 2; c++) {
-            const int m = m0 + ty * 2 + a, j = j0 + tx * 2 + c;
-            if (m < M && j < J) po[(long long)m * J + j] = acc[a][c];
-        }
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int m = m0 + x * 16 + lk * 4 + r, j = j0 + y * 16 + lr;
+                if (m < M && j < J) po[(long long)m * J + j] = acc[x][y][r];
+            }
 }
 
 __global__ void __launch_bounds__(256)
