@@ -1420,13 +1420,20 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t lds_f = vec_f + (ldsw_f ? mat_f : 0), lds_b = vec_b + (ldsw_b ? mat_b : 0);
     const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
-    if (ldsw_f) {
-        if ((rc = raise_lds_limit(train_forward_kernel<true>, lds_f))) return rc;
-        train_forward_kernel<true><<<cgrid, TR_THREADS, lds_f, s>>>(p);
-    } else {
-        if ((rc = raise_lds_limit(train_forward_kernel<false>, lds_f))) return rc;
-        train_forward_kernel<false><<<cgrid, TR_THREADS, lds_f, s>>>(p);
-    }
+    // instantiation: weights in LDS or through L2, with or without the gate state, one or two slots per thread
+    const bool two = 2 * SR > (size_t)TR_THREADS;
+#define FARNN_TRAIN_CHAIN(KERN, LDSWV, LDSB)                                                              \
+    do {                                                                                                  \
+        if (farnn) {                                                                                      \
+            if (two) { if ((rc = raise_lds_limit(KERN<LDSWV, true, 2>, LDSB))) return rc; KERN<LDSWV, true, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); }   \
+            else     { if ((rc = raise_lds_limit(KERN<LDSWV, true, 1>, LDSB))) return rc; KERN<LDSWV, true, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); }   \
+        } else {                                                                                          \
+            if (two) { if ((rc = raise_lds_limit(KERN<LDSWV, false, 2>, LDSB))) return rc; KERN<LDSWV, false, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+            else     { if ((rc = raise_lds_limit(KERN<LDSWV, false, 1>, LDSB))) return rc; KERN<LDSWV, false, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        }                                                                                                 \
+    } while (0)
+    if (ldsw_f) FARNN_TRAIN_CHAIN(train_forward_kernel, true, lds_f);
+    else        FARNN_TRAIN_CHAIN(train_forward_kernel, false, lds_f);
     {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
@@ -1454,13 +1461,9 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         }
 #undef FARNN_LAUNCH_LOSS
     }
-    if (ldsw_b) {
-        if ((rc = raise_lds_limit(train_backward_kernel<true>, lds_b))) return rc;
-        train_backward_kernel<true><<<cgrid, TR_THREADS, lds_b, s>>>(p);
-    } else {
-        if ((rc = raise_lds_limit(train_backward_kernel<false>, lds_b))) return rc;
-        train_backward_kernel<false><<<cgrid, TR_THREADS, lds_b, s>>>(p);
-    }
+    if (ldsw_b) FARNN_TRAIN_CHAIN(train_backward_kernel, true, lds_b);
+    else        FARNN_TRAIN_CHAIN(train_backward_kernel, false, lds_b);
+#undef FARNN_TRAIN_CHAIN
     // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
     AtbJobs jobs;
     memset(&jobs, 0, sizeof(jobs));

@@ -178,7 +178,7 @@ __global__ void column_sum_kernel(const float *__restrict__ C, float *__restrict
 // grid (ceil(B/2), 2): blockIdx.y = 0 forward, 1 backward chain; TR_NSEQ sequences per workgroup.  LDSW: the three
 // matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
 // LDS: [M1 | M2 | M3] f[2][S] tv[2][R] part[4][2][max(S,R)] part2[4][2][S]
-template <bool LDSW>
+template <bool LDSW, bool GATED, int VPT>
 __global__ void __launch_bounds__(TR_THREADS)
 train_forward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -204,7 +204,7 @@ train_forward_kernel(const TrainParams p) {
     int *toks = (int *)(part2 + nw * 2 * S);                  // [TR_NSEQ][L]
     // gated steps: raw state and v_t as matvec inputs, four more partial buffers
     float *hv = (float *)(toks + TR_NSEQ * p.L), *vv = hv + 2 * SP, *pg = vv + 2 * RP;
-    const int farnn = p.farnn;
+    const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
@@ -222,21 +222,21 @@ train_forward_kernel(const TrainParams p) {
     __syncthreads();
     // per-thread slots: which (sequence, state) and (sequence, rank) element this thread owns -- fixed for the whole
     // kernel, so the time loop has no divisions and steps its stash rows by S
-    int sq[TR_VPT], ss[TR_VPT], rq[TR_VPT], rr_[TR_VPT];
-    bool sv[TR_VPT], rv[TR_VPT];
-    long long srow[TR_VPT];
+    int sq[VPT], ss[VPT], rq[VPT], rr_[VPT];
+    bool sv[VPT], rv[VPT];
+    long long srow[VPT];
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
         sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
         rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         srow[k] = (long long)(b0 + sq[k]) * (p.L + 1) * S + ss[k];
     }
     float *stash_out = dir == 0 ? p.A : p.Bk;
-    // v_t = Vgen[token] is fetched one step ahead into registers (TR_VPT values per thread cover 2 R)
-    float vcur[TR_VPT], vnext[TR_VPT], osum[TR_VPT], hk[TR_VPT], hin[TR_VPT], zk[TR_VPT], rk[TR_VPT];
+    // v_t = Vgen[token] is fetched one step ahead into registers (VPT values per thread cover 2 R)
+    float vcur[VPT], vnext[VPT], osum[VPT], hk[VPT], hin[VPT], zk[VPT], rk[VPT];
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L] * R + rr_[k]] : 0.0f;
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
         hin[k] = sv[k] ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
@@ -245,12 +245,12 @@ train_forward_kernel(const TrainParams p) {
     float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
     for (int t = 1; t <= maxlen; t++) {
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++)
+        for (int k = 0; k < VPT; k++)
             vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(long long)toks[rq[k] * p.L + t] * R + rr_[k]] : 0.0f;
         if (farnn) {
             // z = sigma(k (h Wss1 + v Wrs1 + bs1)), r likewise (:146-149); hbar = (1-r) h_init + r h (:150-151)
 #pragma unroll
-            for (int k = 0; k < TR_VPT; k++) if (rv[k]) vv[rq[k] * RP + rr_[k]] = vcur[k];
+            for (int k = 0; k < VPT; k++) if (rv[k]) vv[rq[k] * RP + rr_[k]] = vcur[k];
             wg_barrier_lds();
             matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
             matvec2_partial<false>(pg + nw * 2 * S, vv, RP, p.Wrs1, R, S, tid, nt);
@@ -260,7 +260,7 @@ train_forward_kernel(const TrainParams p) {
             }
             wg_barrier_lds();
 #pragma unroll
-            for (int k = 0; k < TR_VPT; k++) {
+            for (int k = 0; k < VPT; k++) {
                 if (sv[k]) {
                     const float az = part2_sum(pg, S, sq[k], ss[k], nw) + part2_sum(pg + nw * 2 * S, S, sq[k], ss[k], nw) + p.bs1[ss[k]];
                     zk[k] = 1.0f / (1.0f + expf(-p.sig_k * az));
@@ -281,13 +281,13 @@ train_forward_kernel(const TrainParams p) {
         matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++)
+        for (int k = 0; k < VPT; k++)
             if (rv[k]) tv[rq[k] * RP + rr_[k]] = vcur[k] * part2_sum(part, R, rq[k], rr_[k], nw);     // temp = V_vec * _RR
         wg_barrier_lds();
         matvec2_partial<LDSW>(part, tv, RP, M3, R, S, tid, nt);                              // temp . (S2^T | S1^T)
         wg_barrier_lds();
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
                 const float pre = part2_sum(part, S, sq[k], ss[k], nw) + part2_sum(part2, S, sq[k], ss[k], nw);
                 const long long row = srow[k] + (long long)t * S;
@@ -306,7 +306,7 @@ train_forward_kernel(const TrainParams p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) vcur[k] = vnext[k];
+        for (int k = 0; k < VPT; k++) vcur[k] = vnext[k];
         wg_barrier_lds();
     }
 }
@@ -631,7 +631,7 @@ __global__ void crf_reduce_kernel(const float *__restrict__ part, float *dtrans,
 // grid (ceil(B/2), 2), TR_NSEQ sequences per workgroup.  LDSW: the four matrices of this direction
 // (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
 // LDS: [Ma | Mb | Mc | Md] z fp [2][mv_pad(S)], d1 [2][mv_pad(R)], pa pb [8][2][max(S,R)], pc [8][2][S], toks [2][L]
-template <bool LDSW>
+template <bool LDSW, bool GATED, int VPT>
 __global__ void __launch_bounds__(TR_THREADS)
 train_backward_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -660,7 +660,7 @@ train_backward_kernel(const TrainParams p) {
     int *toks = (int *)(pc + nw * 2 * S);                     // [TR_NSEQ][L] tokens in step order
     // gated steps: the gate pre-activation adjoints as matvec inputs and a fourth partial buffer
     float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP, *pd = darv + 2 * SP;
-    const int farnn = p.farnn;
+    const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
@@ -670,12 +670,12 @@ train_backward_kernel(const TrainParams p) {
     __syncthreads();
     // per-thread slots, fixed for the whole kernel (no divisions in the time loop); g, y and dOsum of a slot are only
     // ever touched by its owner, so they live in registers
-    int sq[TR_VPT], ss[TR_VPT], rq[TR_VPT], rr_[TR_VPT];
-    bool sv[TR_VPT], rv[TR_VPT];
-    long long srow[TR_VPT], rrow[TR_VPT];
-    float osum[TR_VPT], gacc[TR_VPT], dOacc[TR_VPT], yk[TR_VPT];
+    int sq[VPT], ss[VPT], rq[VPT], rr_[VPT];
+    bool sv[VPT], rv[VPT];
+    long long srow[VPT], rrow[VPT];
+    float osum[VPT], gacc[VPT], dOacc[VPT], yk[VPT];
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
         sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
         rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
@@ -686,11 +686,11 @@ train_backward_kernel(const TrainParams p) {
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
         gacc[k] = 0.0f; dOacc[k] = 0.0f; yk[k] = 0.0f;
     }
-    float hin[TR_VPT], dhin[TR_VPT], zc[TR_VPT], zn[TR_VPT], rc[TR_VPT], rn[TR_VPT], cc[TR_VPT], cn[TR_VPT], dhk[TR_VPT];
+    float hin[VPT], dhin[VPT], zc[VPT], zn[VPT], rc[VPT], rn[VPT], cc[VPT], cn[VPT], dhk[VPT];
     const float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
     float *DAZ = dir == 0 ? p.DAZf : p.DAZb, *DAR = dir == 0 ? p.DARf : p.DARb, *VR = dir == 0 ? p.VRf : p.VRb;
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         hin[k] = (farnn && sv[k]) ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
         dhin[k] = 0.0f; zc[k] = zn[k] = rc[k] = rn[k] = 1.0f; cc[k] = cn[k] = 0.0f; dhk[k] = 0.0f;
     }
@@ -698,9 +698,9 @@ train_backward_kernel(const TrainParams p) {
     // beyond its length are zero, so the reads need no guard): h_t, h_{t-1}, dL/dh_t from the scoring, pre_t, v_t
     const float *stash_base = dir == 0 ? p.A : p.Bk, *G_base = dir == 0 ? p.GA : p.GB;
     float *Zo = dir == 0 ? p.Zf : p.Zb, *D1o = dir == 0 ? p.D1f : p.D1b, *To = dir == 0 ? p.Tf : p.Tb;
-    float hcur[TR_VPT], hprev[TR_VPT], hpp[TR_VPT], gs[TR_VPT], gsn[TR_VPT], pr[TR_VPT], prn[TR_VPT], vcur[TR_VPT], vnext[TR_VPT];
+    float hcur[VPT], hprev[VPT], hpp[VPT], gs[VPT], gsn[VPT], pr[VPT], prn[VPT], vcur[VPT], vnext[VPT];
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         const bool ok = sv[k] && maxlen >= 1;
         const long long row = srow[k] + (long long)maxlen * S;
         hcur[k] = ok ? stash_base[row] : 0.0f;
@@ -712,7 +712,7 @@ train_backward_kernel(const TrainParams p) {
     }
     for (int t = maxlen; t >= 1; t--) {
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {                        // prefetch for step t-1
+        for (int k = 0; k < VPT; k++) {                        // prefetch for step t-1
             const bool ok = sv[k] && t >= 2;
             const long long row = srow[k] + (long long)(t - 1) * S;
             hpp[k] = ok ? stash_base[row - S] : 0.0f;
@@ -722,7 +722,7 @@ train_backward_kernel(const TrainParams p) {
             vnext[k] = (rv[k] && t >= 2) ? p.Vgen[(long long)toks[rq[k] * p.L + (t - 2 < len[rq[k]] ? t - 2 : 0)] * R + rr_[k]] : 0.0f;
         }
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             if (sv[k]) {
                 const int li = sq[k] * SP + ss[k];
                 if (t <= len[sq[k]]) {
@@ -764,7 +764,7 @@ train_backward_kernel(const TrainParams p) {
         matvec2_partial<LDSW>(pc, z, SP, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
         wg_barrier_lds();
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             if (rv[k]) {
                 float dd = 0.0f;
                 if (t <= len[rq[k]]) {
@@ -784,7 +784,7 @@ train_backward_kernel(const TrainParams p) {
         matvec2_partial<LDSW>(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
         wg_barrier_lds();
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
                 const float dfp = part2_sum(pc, S, sq[k], ss[k], nw) + part2_sum(pa, S, sq[k], ss[k], nw);
                 float dhb;                                             // adjoint of the (unmasked) chain input
@@ -816,7 +816,7 @@ train_backward_kernel(const TrainParams p) {
             }
             wg_barrier_lds();
 #pragma unroll
-            for (int k = 0; k < TR_VPT; k++) {
+            for (int k = 0; k < VPT; k++) {
                 if (sv[k] && t <= len[sq[k]]) {
                     float dh = dhk[k] + part2_sum(pa, S, sq[k], ss[k], nw);
                     if (farnn == 2) dh += part2_sum(pc, S, sq[k], ss[k], nw);
@@ -830,14 +830,14 @@ train_backward_kernel(const TrainParams p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < TR_VPT; k++) {
+        for (int k = 0; k < VPT; k++) {
             hcur[k] = hprev[k]; hprev[k] = hpp[k]; gs[k] = gsn[k]; pr[k] = prn[k]; vcur[k] = vnext[k];
             zc[k] = zn[k]; rc[k] = rn[k]; cc[k] = cn[k];
         }
         wg_barrier_lds();
     }
 #pragma unroll
-    for (int k = 0; k < TR_VPT; k++) {
+    for (int k = 0; k < VPT; k++) {
         if (sv[k]) {
             const float g0 = gacc[k] + G_base[srow[k]] + dhin[k];
             if (g0 != 0.0f) atomicAdd((dir == 0 ? p.dh0 : p.dhT) + ss[k], g0);
