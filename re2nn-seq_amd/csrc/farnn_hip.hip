@@ -1374,34 +1374,29 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     p.threshold = c->d.threshold; p.inv_tokens = 1.0f / (float)valid_tokens;
 
     FARNN_HIP_TRY(hipMemsetAsync(c->ws, 0, need * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->loss, 0, sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dVgen, 0, V * R * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dS1, 0, S * R * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dS2, 0, S * R * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dW, 0, S * S * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dC, 0, K * S * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dh0, 0, S * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(o->dhT, 0, S * sizeof(float), s));
-    FARNN_HIP_TRY(hipMemsetAsync(c->dOsum, 0, S * sizeof(float), s));
-    if (farnn) {
-        FARNN_HIP_TRY(hipMemsetAsync(o->dWss1, 0, S * S * sizeof(float), s));
-        FARNN_HIP_TRY(hipMemsetAsync(o->dWrs1, 0, R * S * sizeof(float), s));
-        FARNN_HIP_TRY(hipMemsetAsync(o->dbs1, 0, S * sizeof(float), s));
-        transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->Wss1, c->Wss1T, (int)S, (int)S);
-        transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->Wrs1, c->Wrs1T, (int)R, (int)S);
-        if (farnn == 2) {
-            FARNN_HIP_TRY(hipMemsetAsync(o->dWss2, 0, S * S * sizeof(float), s));
-            FARNN_HIP_TRY(hipMemsetAsync(o->dWrs2, 0, R * S * sizeof(float), s));
-            FARNN_HIP_TRY(hipMemsetAsync(o->dbs2, 0, S * sizeof(float), s));
-            transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->Wss2, c->Wss2T, (int)S, (int)S);
-            transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->Wrs2, c->Wrs2T, (int)R, (int)S);
+    {
+        PrepJobs pj;
+        memset(&pj, 0, sizeof(pj));
+        auto add = [&](int kind, const float *src, float *dst, size_t rows, size_t cols) {
+            PrepJob &j = pj.j[pj.n++];
+            j.kind = kind; j.src = src; j.dst = dst; j.rows = (int)rows; j.cols = (int)cols; j.e0 = pj.total;
+            pj.total += (int)(kind == 2 ? cols : rows * cols);
+        };
+        add(0, nullptr, o->loss, 1, 1); add(0, nullptr, o->dVgen, V, R); add(0, nullptr, o->dS1, S, R);
+        add(0, nullptr, o->dS2, S, R); add(0, nullptr, o->dW, S, S); add(0, nullptr, o->dC, K, S);
+        add(0, nullptr, o->dh0, 1, S); add(0, nullptr, o->dhT, 1, S); add(0, nullptr, c->dOsum, 1, S);
+        add(1, w->S1, c->S1T, S, R); add(1, w->S2, c->S2T, S, R); add(1, w->W, c->WT, S, S);
+        add(2, w->C, c->Osum, K, S);
+        if (farnn) {
+            add(0, nullptr, o->dWss1, S, S); add(0, nullptr, o->dWrs1, R, S); add(0, nullptr, o->dbs1, 1, S);
+            add(1, w->Wss1, c->Wss1T, S, S); add(1, w->Wrs1, c->Wrs1T, R, S);
+            if (farnn == 2) {
+                add(0, nullptr, o->dWss2, S, S); add(0, nullptr, o->dWrs2, R, S); add(0, nullptr, o->dbs2, 1, S);
+                add(1, w->Wss2, c->Wss2T, S, S); add(1, w->Wrs2, c->Wrs2T, R, S);
+            }
         }
+        train_prep_kernel<<<(pj.total + 255) / 256, 256, 0, s>>>(pj);
     }
-
-    transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S1, c->S1T, (int)S, (int)R);
-    transpose_kernel<<<(unsigned)((S * R + 255) / 256), 256, 0, s>>>(w->S2, c->S2T, (int)S, (int)R);
-    transpose_kernel<<<(unsigned)((S * S + 255) / 256), 256, 0, s>>>(w->W, c->WT, (int)S, (int)S);
-    column_sum_kernel<<<(unsigned)((S + 255) / 256), 256, 0, s>>>(w->C, c->Osum, (int)K, (int)S);
 
     const size_t SR = S > R ? S : R;
     const size_t SPd0 = ((S + 3) & ~(size_t)3) + 8;

@@ -174,6 +174,36 @@ __global__ void column_sum_kernel(const float *__restrict__ C, float *__restrict
     Osum[s] = (a0 + a1) + (a2 + a3);
 }
 
+// ---- step preparation in one launch: zero the gradient outputs, transpose the matrices, column-sum C -----------
+// (fifteen-odd memsets and tiny kernels cost ~5 us of launch each on the stream)
+constexpr int PREP_MAX_JOBS = 28;
+struct PrepJob { const float *src; float *dst; int rows, cols, kind, e0; };   // kind 0 zero, 1 transpose, 2 column sum
+struct PrepJobs { PrepJob j[PREP_MAX_JOBS]; int n, total; };
+
+__global__ void __launch_bounds__(256)
+train_prep_kernel(const PrepJobs jobs) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= jobs.total) return;
+    int ji = 0;
+    while (ji + 1 < jobs.n && idx >= jobs.j[ji + 1].e0) ji++;
+    const PrepJob &jb = jobs.j[ji];
+    const int e = idx - jb.e0;
+    if (jb.kind == 0) jb.dst[e] = 0.0f;
+    else if (jb.kind == 1) {
+        const int r = e / jb.cols, c = e - r * jb.cols;
+        jb.dst[(long long)c * jb.rows + r] = jb.src[e];
+    } else {                                                           // e = column; rows summed in four chains
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+        int c = 0;
+        for (; c + 4 <= jb.rows; c += 4) {
+            a0 += jb.src[(long long)c * jb.cols + e]; a1 += jb.src[(long long)(c + 1) * jb.cols + e];
+            a2 += jb.src[(long long)(c + 2) * jb.cols + e]; a3 += jb.src[(long long)(c + 3) * jb.cols + e];
+        }
+        for (; c < jb.rows; c++) a0 += jb.src[(long long)c * jb.cols + e];
+        jb.dst[e] = (a0 + a1) + (a2 + a3);
+    }
+}
+
 // ---- forward chains with the stash ------------------------------------------------------------------------
 // grid (ceil(B/2), 2): blockIdx.y = 0 forward, 1 backward chain; TR_NSEQ sequences per workgroup.  LDSW: the three
 // matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
