@@ -232,13 +232,15 @@ def run_train(a, world, rank, dev, dist):
     tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=0, device=dev.index or 0, use_crf=a.crf,
                            farnn=a.farnn, sigmoid_exponent=5.0)
     params = list(p.values())
+    ntok_local = int(lengths.sum())
     opt = torch.optim.Adam(params, lr=1e-4)
 
     def step():
         opt.zero_grad(set_to_none=True)
         Vgen = p['V_embed'] * beta + torch.tanh(p['E'] @ p['G']) * (1 - beta)
         loss, _ = decomp_ifst_train_step(tc, Vgen, p['S1'], p['S2'], p['W'], p['C'], p['h0'], p['hT'], None, xd, ld, lab,
-                                         crf_trans=p.get('trans'), gates=tuple(p[n] for n in gate_names))
+                                         crf_trans=p.get('trans'), gates=tuple(p[n] for n in gate_names),
+                                         valid_tokens=ntok_local)
         loss.backward()
         if world > 1:
             flat = torch.cat([q.grad.reshape(-1) for q in params])

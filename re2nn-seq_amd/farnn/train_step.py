@@ -22,7 +22,7 @@ GATE_NAMES = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
 
 class _DecompIfstTrainStep(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, tc, x, lengths, labels, P, Vgen, S1, S2, W, Cmat, h0, hT, trans, *gates):
+    def forward(ctx, tc, ntok, x, lengths, labels, P, Vgen, S1, S2, W, Cmat, h0, hT, trans, *gates):
         dev = Vgen.device
         if dev.type != 'cuda':
             raise _lib.FarnnError('the training step runs on the HIP device only (no CPU fallback)')
@@ -30,11 +30,12 @@ class _DecompIfstTrainStep(torch.autograd.Function):
         Pc = None if P is None else P.detach().contiguous().float()
         tr = None if trans is None else trans.detach().contiguous().float()
         gs = [g.detach().contiguous().float() for g in gates]
+        B, L = x.shape
+        if ntok is None:            # counted on the host when the lengths live there (no device round trip in the step)
+            ntok = int(lengths.clamp(0, L).sum())
         x = x.to(dev).contiguous()
         lengths = lengths.to(dev).contiguous()
         labels = labels.to(dev).contiguous()
-        B, L = x.shape
-        ntok = int(lengths.clamp(0, L).sum())
         if ntok <= 0:
             raise ValueError('empty batch')
         grads = [torch.empty_like(t) for t in ws]
@@ -71,10 +72,13 @@ class _DecompIfstTrainStep(torch.autograd.Function):
             gtr = saved[k] * gloss
             k += 1
         ggs = [g * gloss for g in saved[k:k + ctx.n_gates]]
-        return (None, None, None, None, None) + tuple(grads) + (gtr,) + tuple(ggs)
+        return (None, None, None, None, None, None) + tuple(grads) + (gtr,) + tuple(ggs)
 
 
-def decomp_ifst_train_step(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels, crf_trans=None, gates=()):
+def decomp_ifst_train_step(tc, Vgen, S1, S2, W, Cmat, h0, hT, P, x, lengths, labels, crf_trans=None, gates=(),
+                           valid_tokens=None):
     """Returns (loss scalar tensor with grad, tags int32 [B,L] with -1 at pads).  gates: the tensors Wss1, Wrs1, bs1
-    (farnn = 1) followed by Wss2, Wrs2, bs2 (farnn = 2), in that order."""
-    return _DecompIfstTrainStep.apply(tc, x, lengths, labels, P, Vgen, S1, S2, W, Cmat, h0, hT, crf_trans, *gates)
+    (farnn = 1) followed by Wss2, Wrs2, bs2 (farnn = 2), in that order.  valid_tokens: sum of the clamped lengths if
+    the caller already has it (device-resident lengths would otherwise cost a synchronising read per step)."""
+    return _DecompIfstTrainStep.apply(tc, valid_tokens, x, lengths, labels, P, Vgen, S1, S2, W, Cmat, h0, hT, crf_trans,
+                                      *gates)
