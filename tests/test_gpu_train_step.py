@@ -86,6 +86,8 @@ def test_train_step_matches_reference_loss_and_gradients(k):
     (23, 70, 9, 50, 7, 9, 'relutanh', True),       # rank above the state count
     (5, 3, 4, 11, 3, 6, 'none', False),
     (64, 64, 130, 40, 4, 33, 'relu', True),        # more score columns than a wavefront
+    (7, 5, 3, 9, 1, 1, 'tanh', False),             # one sequence of one token
+    (130, 9, 5, 20, 3, 2, 'tanh', True),           # more states than two wavefronts' columns, odd rank
 ])
 def test_train_step_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
     """The C-ABI entry point directly, with empty and full-length sequences, against the oracle."""
@@ -104,7 +106,7 @@ def test_train_step_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
          'priority_mat': torch.from_numpy((np.eye(K) + (rng.rand(K, K) < 0.05) * 0.5).astype(np.float32))}
     lengths = rng.randint(1, L + 1, size=B).astype(np.int64)
     lengths[0] = L
-    if B > 2:
+    if B > 3:
         lengths[1] = 0
     x = rng.randint(0, V, size=(B, L)).astype(np.int64)
     labels = rng.randint(0, K, size=(B, L)).astype(np.int64)
