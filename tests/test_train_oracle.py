@@ -47,3 +47,28 @@ def test_train_oracle_matches_reference_loss_and_gradients(k):
         ref = g[pre + 'g.' + n]
         got = grads[n].numpy()
         np.testing.assert_allclose(got, ref, rtol=2e-4, atol=2e-6 * max(1.0, float(np.abs(ref).max())), err_msg=n)
+
+
+@pytest.mark.parametrize('k', range(10))
+def test_batched_train_oracle_equals_the_per_sequence_one(k):
+    """The batch-vectorised form (used at full size and as the CPU baseline) against the per-sequence restatement."""
+    meta, g, base = load()
+    cfg = meta['configs'][k]
+    pre = 'c{}.'.format(k)
+    p = {n: torch.from_numpy(g[pre + 'w.' + n]) for n in PARAMS}
+    p['priority_mat'] = torch.from_numpy(g[pre + 'w.priority_mat'])
+    if cfg.get('use_crf'):
+        p['crf.transitions'] = torch.from_numpy(g[pre + 'w.crf.transitions'])
+    for n in GATES:
+        if pre + 'w.' + n in g.files:
+            p[n] = torch.from_numpy(g[pre + 'w.' + n])
+    x, lengths, labels = torch.from_numpy(base['x']), torch.from_numpy(base['lengths']), torch.from_numpy(g['labels'])
+    kw = dict(nl=cfg['update_nonlinear'], additional_nonlinear=cfg.get('additional_nonlinear', 'none'),
+              use_priority=bool(cfg.get('use_priority', 0)), farnn=cfg.get('farnn', 0),
+              sig_k=float(cfg.get('sigmoid_exponent', 5)))
+    l1, g1, _ = to.train_step(p, x, lengths, labels, **kw)
+    l2, g2, _ = to.train_step_batched(p, x, lengths, labels, **kw)
+    assert abs(float(l1) - float(l2)) < 1e-5 * max(1.0, abs(float(l1)))
+    assert set(g1) == set(g2)
+    for n in g1:
+        np.testing.assert_allclose(g2[n].numpy(), g1[n].numpy(), rtol=2e-4, atol=2e-6 * max(1.0, float(g1[n].abs().max())), err_msg=n)
