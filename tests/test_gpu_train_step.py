@@ -365,3 +365,68 @@ def test_train_step_full_size_vs_batched_oracle(farnn, crf):
         close(out['d' + n].cpu().numpy(), grads_ref[key].numpy().reshape(out['d' + n].shape), 'd' + n, rtol=5e-3)
     if crf:
         close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), 'dtrans', rtol=5e-3)
+
+
+def test_train_step_random_configurations_soak():
+    """Random shapes x gates x loss x nonlinearity x priority against the vectorised oracle
+    (FARNN_TRAIN_SOAK_ITERS configurations, default 8; 2 x 150 with two seeds ran clean)."""
+    from re2nn_seq_amd import _lib
+    iters = int(os.environ.get('FARNN_TRAIN_SOAK_ITERS', '8'))
+    rng = np.random.RandomState(int(os.environ.get('FARNN_TRAIN_SOAK_SEED', '123')))
+    dev = torch.device('cuda')
+    for it in range(iters):
+        S, R = int(rng.randint(2, 140)), int(rng.randint(1, 90))
+        crf = bool(rng.rand() < 0.4)
+        K = int(rng.randint(4 if crf else 2, 90))
+        V, B, L, D = int(rng.randint(3, 200)), int(rng.randint(1, 20)), int(rng.randint(1, 40)), 5
+        farnn = int(rng.randint(0, 3))
+        nl = ['none', 'relu', 'tanh', 'relutanh'][rng.randint(0, 4)]
+        prio = bool(rng.rand() < 0.3)
+        f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
+        Cm = np.zeros((K, S), np.float32)
+        Cm[rng.randint(0, max(K - (2 if crf else 0), 1), size=S), np.arange(S)] = (rng.rand(S) < 0.8)
+        fs = 0.7 / np.sqrt(max(S, R))              # contractive for every nonlinearity (a linear recurrence explodes otherwise)
+        p = {'S1': f(S, R, sc=fs), 'S2': f(S, R, sc=fs), 'V_embed': f(V, R, sc=0.8),
+             'embed_r_generalized': f(D, R), 'C_output_mat': torch.from_numpy(Cm + (rng.rand(K, S) * 0.02).astype(np.float32)),
+             'wildcard_mat': torch.from_numpy(((rng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)),
+             'h0': f(S, sc=0.5), 'hT': f(S, sc=0.5), 'beta_vec': torch.full((R,), 0.7), 'embedding.weight': f(V, D),
+             'priority_mat': torch.from_numpy((np.eye(K) + (rng.rand(K, K) < 0.05) * 0.3).astype(np.float32))}
+        gate_names = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')[:3 * farnn]
+        for n in gate_names:
+            p[n] = f(1, S, sc=0.5) if n.startswith('bs') else (f(S, S, sc=0.5 / np.sqrt(S)) if n.startswith('Wss') else f(R, S, sc=0.5 / np.sqrt(R)))
+        if crf:
+            tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+            tr[:, K - 2] = -10000.0
+            tr[K - 1, :] = -10000.0
+            p['crf.transitions'] = torch.from_numpy(tr)
+        lengths = rng.randint(0, L + 1, size=B).astype(np.int64)
+        lengths[rng.randint(0, B)] = L
+        x = rng.randint(0, V, size=(B, L)).astype(np.int64)
+        labels = rng.randint(0, max(K - (2 if crf else 0), 1), size=(B, L)).astype(np.int64)
+        xt, lt, lab = torch.from_numpy(x), torch.from_numpy(lengths), torch.from_numpy(labels)
+        loss_ref, grads_ref, _ = to.train_step_batched(p, xt, lt, lab, nl=nl, use_priority=prio, farnn=farnn, sig_k=2.0)
+        w = {'Vgen': to.generalized_table(p).to(dev), 'S1': p['S1'].to(dev), 'S2': p['S2'].to(dev), 'W': p['wildcard_mat'].to(dev),
+             'C': p['C_output_mat'].to(dev), 'h0': p['h0'].to(dev), 'hT': p['hT'].to(dev)}
+        w.update({n: p[n].to(dev).contiguous() for n in gate_names})
+        P = p['priority_mat'].to(dev) if prio else None
+        trd = p['crf.transitions'].to(dev) if crf else None
+        tc = _lib.TrainContext(V, S, R, K, nl=nl, threshold=0.5, o_idx=0, use_crf=crf, farnn=farnn, sigmoid_exponent=2.0)
+        out = {'d' + n: torch.empty_like(t) for n, t in w.items()}
+        dtr = torch.empty_like(trd) if crf else None
+        loss = torch.empty(1, device=dev)
+        tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+        xd, ld, labd = xt.to(dev), lt.to(dev), lab.to(dev)
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None if P is None else P.data_ptr(),
+                     crf_trans=None if trd is None else trd.data_ptr()),
+                xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr(),
+                     dtrans=None if dtr is None else dtr.data_ptr()))
+        torch.cuda.synchronize()
+        tag = 'iteration {}: S={} R={} K={} V={} B={} L={} farnn={} crf={} nl={} prio={}'.format(it, S, R, K, V, B, L, farnn, crf, nl, prio)
+        assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref))), tag
+        for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')) + \
+                tuple((n, n) for n in gate_names):
+            close(out['d' + n].cpu().numpy(), grads_ref[key].numpy().reshape(out['d' + n].shape), tag + ' d' + n, rtol=5e-3)
+        if crf:
+            close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), tag + ' dtrans', rtol=5e-3)
+        tc.close()
