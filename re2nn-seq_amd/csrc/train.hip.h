@@ -499,60 +499,78 @@ train_crf_kernel(const TrainParams p) {
     const float *F = fl;
     const int64_t *y = p.labels + (long long)b * p.L;
     // forward messages and the Viterbi recursion on the clamped emissions (association as in :123,:145)
-    for (int j = tid; j < K; j += nt) {
-        const float f0 = F[j];
-        al[j] = f0 + tr[START * K1 + j];
-        vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * K1 + j];
+    // red[4..7]: per-wavefront maxima of the newest forward (later backward) message: the next step's scale comes from
+    // four broadcast reads instead of a pass over the K messages by every thread
+    const int wv = tid >> 6, lane_ = tid & 63;
+    {
+        float vmax = -INFINITY;
+        for (int j = tid; j < K; j += nt) {
+            const float f0 = F[j], a0 = f0 + tr[START * K1 + j];
+            al[j] = a0;
+            vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * K1 + j];
+            vmax = fmaxf(vmax, a0);
+        }
+        for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, WAVE));
+        if (lane_ == 0) red[4 + wv] = vmax;
     }
     __syncthreads();
     for (int t = 0; t < n; t++) {
-        // scale of step t: amax_t and ea_t = exp(al_t - amax_t)
+        // scale of step t: amax_t (from the wavefront maxima) and ea_t = exp(al_t - amax_t)
         const float *at = al + (long long)t * K;
-        // four independent chains: a single dependent max/fma chain over LDS reads runs at ~105 cycles per element, four
-        // chains unrolled by 16 at ~12 (scripts/probe/lds_rate.hip)
-        float mx;
-        {
-            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
-            int i = 0;
-#pragma unroll 4
-            for (; i + 4 <= K; i += 4) { m0 = fmaxf(m0, at[i]); m1 = fmaxf(m1, at[i + 1]); m2 = fmaxf(m2, at[i + 2]); m3 = fmaxf(m3, at[i + 3]); }
-            for (; i < K; i++) m0 = fmaxf(m0, at[i]);
-            mx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        }
+        const float mx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         for (int j = tid; j < K; j += nt) ea[(long long)t * K + j] = __expf(at[j] - mx);
         if (tid == 0) am[t] = mx;
         __syncthreads();
         if (t + 1 < n) {
+            // threads 0..127 do the sum recursion, 128..255 the max recursion (Viterbi): half the work per thread.
+            // Four independent chains per loop: a single dependent chain over LDS reads runs at ~105 cycles per element,
+            // four chains at ~12 (scripts/probe/lds_rate.hip)
             const float *et = ea + (long long)t * K, *vp = vit + (t & 1) * K;
-            for (int j = tid; j < K; j += nt) {
-                const float ft = F[(long long)(t + 1) * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
-                float s4[4] = {0.f, 0.f, 0.f, 0.f}, b4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-                int i4[4] = {0, 0, 0, 0};
-                int i = 0;
+            const int half = tid >> 7, lt = tid & 127;
+            float vmax = -INFINITY;
+            if (half == 0) {
+                for (int j = lt; j < K; j += 128) {
+                    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+                    int i = 0;
 #pragma unroll 4
-                for (; i + 4 <= K; i += 4) {
+                    for (; i + 4 <= K; i += 4) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        s4[u] = fmaf(et[i + u], etr[(i + u) * K1 + j], s4[u]);
-                        const float cand = (fc + tr[(i + u) * K1 + j]) + vp[i + u];
-                        if (cand > b4[u]) { b4[u] = cand; i4[u] = i + u; }
+                        for (int u = 0; u < 4; u++) s4[u] = fmaf(et[i + u], etr[(i + u) * K1 + j], s4[u]);
                     }
+                    for (; i < K; i++) s4[0] = fmaf(et[i], etr[i * K1 + j], s4[0]);
+                    const float an = mx + __logf((s4[0] + s4[1]) + (s4[2] + s4[3])) + F[(long long)(t + 1) * K + j];
+                    al[(long long)(t + 1) * K + j] = an;
+                    vmax = fmaxf(vmax, an);
                 }
-                for (; i < K; i++) {
-                    s4[0] = fmaf(et[i], etr[i * K1 + j], s4[0]);
-                    const float cand = (fc + tr[i * K1 + j]) + vp[i];
-                    if (cand > b4[0]) { b4[0] = cand; i4[0] = i; }
-                }
-                const float se = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-                float bv = b4[0];
-                int bi = i4[0];
+            } else {
+                for (int j = lt; j < K; j += 128) {
+                    const float ft = F[(long long)(t + 1) * K + j], fc = j == K - 3 ? fminf(ft, p.threshold) : ft;
+                    float b4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    int i4[4] = {0, 0, 0, 0};
+                    int i = 0;
+#pragma unroll 4
+                    for (; i + 4 <= K; i += 4) {
 #pragma unroll
-                for (int u = 1; u < 4; u++)                                  // first maximum over i, like torch.max (:149)
-                    if (b4[u] > bv || (b4[u] == bv && i4[u] < bi)) { bv = b4[u]; bi = i4[u]; }
-                al[(long long)(t + 1) * K + j] = mx + __logf(se) + ft;
-                vit[((t + 1) & 1) * K + j] = bv;
-                bp[(long long)(t + 1) * K + j] = (unsigned char)bi;
+                        for (int u = 0; u < 4; u++) {
+                            const float cand = (fc + tr[(i + u) * K1 + j]) + vp[i + u];
+                            if (cand > b4[u]) { b4[u] = cand; i4[u] = i + u; }
+                        }
+                    }
+                    for (; i < K; i++) {
+                        const float cand = (fc + tr[i * K1 + j]) + vp[i];
+                        if (cand > b4[0]) { b4[0] = cand; i4[0] = i; }
+                    }
+                    float bv = b4[0];
+                    int bi = i4[0];
+#pragma unroll
+                    for (int u = 1; u < 4; u++)                              // first maximum over i, like torch.max (:149)
+                        if (b4[u] > bv || (b4[u] == bv && i4[u] < bi)) { bv = b4[u]; bi = i4[u]; }
+                    vit[((t + 1) & 1) * K + j] = bv;
+                    bp[(long long)(t + 1) * K + j] = (unsigned char)bi;
+                }
             }
+            for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, WAVE));
+            if (lane_ == 0) red[4 + wv] = vmax;                               // -inf from the Viterbi wavefronts
             __syncthreads();
         }
     }
@@ -583,7 +601,17 @@ train_crf_kernel(const TrainParams p) {
         }
     }
     for (int t = n + tid; t < p.L; t += nt) p.tags[(long long)b * p.L + t] = -1;
-    for (int i = tid; i < K; i += nt) bt[((n - 1) & 1) * K + i] = tr[i * K1 + STOP];      // backward message at the last token
+    {
+        float vmax = -INFINITY;
+        for (int i = tid; i < K; i += nt) {
+            const float bv = tr[i * K1 + STOP];
+            bt[((n - 1) & 1) * K + i] = bv;                                      // backward message at the last token
+            vmax = fmaxf(vmax, F[(long long)(n - 1) * K + i] + bv);
+        }
+        for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, WAVE));
+        __syncthreads();                                                         // the forward loop's last reads of red[4..7]
+        if (lane_ == 0) red[4 + wv] = vmax;
+    }
     __syncthreads();
     const float logZ = red[0];
     // backward messages, marginals and expected transition counts
@@ -592,19 +620,7 @@ train_crf_kernel(const TrainParams p) {
         float *bn = bt + ((t + 1) & 1) * K;                                     // becomes beta_{t-1}
         const float *at = al + (long long)t * K;
         // scale of the backward side at step t: bmax over f_t + beta_t, eb = exp(f_t + beta_t - bmax)
-        float bmx;
-        {
-            const float *ft = F + (long long)t * K;
-            float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
-            int j = 0;
-#pragma unroll 4
-            for (; j + 4 <= K; j += 4) {
-                m0 = fmaxf(m0, ft[j] + bc[j]); m1 = fmaxf(m1, ft[j + 1] + bc[j + 1]);
-                m2 = fmaxf(m2, ft[j + 2] + bc[j + 2]); m3 = fmaxf(m3, ft[j + 3] + bc[j + 3]);
-            }
-            for (; j < K; j++) m0 = fmaxf(m0, ft[j] + bc[j]);
-            bmx = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
-        }
+        const float bmx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
         for (int j = tid; j < K; j += nt) {
             eb[j] = __expf(F[(long long)t * K + j] + bc[j] - bmx);
             const float m = __expf(at[j] + bc[j] - logZ);
@@ -619,7 +635,7 @@ train_crf_kernel(const TrainParams p) {
             const float *ep = ea + (long long)(t - 1) * K;
             const float scale = __expf(am[t - 1] + bmx - logZ);                 // xi_{t-1}(i,j) = ea[i] etr[i][j] eb[j] scale
             // thread (row group r0, column j): rows r0, r0 + rstep, ... -- no divisions, all reads of a round independent
-            {
+            if (K1 <= nt) {
                 const int cj = tid % K1, r0 = tid / K1, rstep = nt / K1;        // K1 columns per row in LDS (the pad column is skipped)
                 if (cj < K && r0 < rstep) {
                     const float ebj = eb[cj];
@@ -627,7 +643,13 @@ train_crf_kernel(const TrainParams p) {
                     for (int i = r0; i < K; i += rstep)
                         ex[i * K1 + cj] = fmaf(ep[i] * scale, etr[i * K1 + cj] * ebj, ex[i * K1 + cj]);
                 }
+            } else {
+                for (int e = tid; e < K * K; e += nt) {
+                    const int i = e / K, j = e - i * K;
+                    ex[i * K1 + j] = fmaf(ep[i] * scale, etr[i * K1 + j] * eb[j], ex[i * K1 + j]);
+                }
             }
+            float vmax = -INFINITY;
             for (int i = tid; i < K; i += nt) {                                 // beta_{t-1}[i] = bmax + log sum_j etr[i][j] eb[j]
                 float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
                 int j = 0;
@@ -638,8 +660,12 @@ train_crf_kernel(const TrainParams p) {
                 }
                 for (; j < K; j++) s0 = fmaf(etr[i * K1 + j], eb[j], s0);
                 const float se = (s0 + s1) + (s2 + s3);
-                bn[i] = bmx + __logf(se);
+                const float bnew = bmx + __logf(se);
+                bn[i] = bnew;
+                vmax = fmaxf(vmax, F[(long long)(t - 1) * K + i] + bnew);
             }
+            for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, WAVE));
+            if (lane_ == 0) red[4 + wv] = vmax;                                   // read after the barrier below
         }
         __syncthreads();
     }
