@@ -1225,6 +1225,7 @@ struct farnn_train_ctx {
     int wsB = 0, wsL = 0;
     float *S1T = nullptr, *S2T = nullptr, *WT = nullptr, *Osum = nullptr, *dOsum = nullptr;
     float *Wss1T = nullptr, *Wss2T = nullptr, *Wrs1T = nullptr, *Wrs2T = nullptr;   // gate transposes (farnn > 0)
+    float *VgenT = nullptr, *GV = nullptr;   // [R][V] and 2 x [V][S]: the gates' input halves Vgen Wrs (farnn > 0)
     float *ones = nullptr;        // [ones_n] of 1.0f: bias gradients as a product with a column of ones
     size_t ones_n = 0;
     int profiling = 0;
@@ -1251,6 +1252,16 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
         return fail(FARNN_ENOMEM, "train_create: out of device memory%s%s");
     }
     c->S1T = blk; c->S2T = blk + S * R; c->WT = c->S2T + S * R; c->Osum = c->WT + S * S; c->dOsum = c->Osum + S;
+    if (d->farnn) {
+        const size_t Vv = d->V;
+        if (hipMalloc((void **)&c->VgenT, Vv * R * sizeof(float)) != hipSuccess ||
+            hipMalloc((void **)&c->GV, 2 * Vv * S * sizeof(float)) != hipSuccess) {
+            if (c->VgenT) (void)hipFree(c->VgenT);
+            (void)hipFree(blk);
+            delete c;
+            return fail(FARNN_ENOMEM, "train_create: out of device memory%s%s");
+        }
+    }
     if (d->farnn) { c->Wss1T = c->dOsum + S; c->Wss2T = c->Wss1T + S * S; c->Wrs1T = c->Wss2T + S * S; c->Wrs2T = c->Wrs1T + S * R; }
     *out = c;
     return FARNN_OK;
@@ -1264,6 +1275,8 @@ extern "C" void farnn_train_destroy(farnn_train_ctx *c) {
     if (c->ws) (void)hipFree(c->ws);
     if (c->part) (void)hipFree(c->part);
     if (c->ones) (void)hipFree(c->ones);
+    if (c->VgenT) (void)hipFree(c->VgenT);
+    if (c->GV) (void)hipFree(c->GV);
     if (c->S1T) (void)hipFree(c->S1T);
     delete c;
 }
@@ -1390,12 +1403,32 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         if (farnn) {
             add(0, nullptr, o->dWss1, S, S); add(0, nullptr, o->dWrs1, R, S); add(0, nullptr, o->dbs1, 1, S);
             add(1, w->Wss1, c->Wss1T, S, S); add(1, w->Wrs1, c->Wrs1T, R, S);
+            add(1, w->Vgen, c->VgenT, V, R); add(0, nullptr, c->GV, (farnn == 2 ? 2 : 1) * V, S);
             if (farnn == 2) {
                 add(0, nullptr, o->dWss2, S, S); add(0, nullptr, o->dWrs2, R, S); add(0, nullptr, o->dbs2, 1, S);
                 add(1, w->Wss2, c->Wss2T, S, S); add(1, w->Wrs2, c->Wrs2T, R, S);
             }
         }
         train_prep_kernel<<<(pj.total + 255) / 256, 256, 0, s>>>(pj);
+    }
+    if (farnn) {
+        // GV = Vgen Wrs as A^T B with the rank as the reduction index: A = Vgen^T [R][V], B = Wrs [R][S]
+        AtbJobs gj;
+        memset(&gj, 0, sizeof(gj));
+        gj.chunk = 128;
+        atb_add(gj, c->VgenT, w->Wrs1, c->GV, (long long)R, (int)V, (int)S);
+        if (farnn == 2) atb_add(gj, c->VgenT, w->Wrs2, c->GV + V * S, (long long)R, (int)V, (int)S);
+        const size_t gpf = atb_partial_floats(gj);
+        if (gpf > c->part_floats) {
+            if (c->part) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->part); c->part = nullptr; c->part_floats = 0; }
+            if (hipMalloc((void **)&c->part, gpf * sizeof(float)) != hipSuccess)
+                return fail(FARNN_ENOMEM, "train_step: out of device memory for the gate-input products%s%s");
+            c->part_floats = gpf;
+        }
+        gj.partial = c->part;
+        atb_partial_kernel<<<gj.total_wgs, 256, 0, s>>>(gj);
+        atb_reduce_kernel<<<(gj.total_out + 255) / 256, 256, 0, s>>>(gj);
+        p.GV1 = c->GV; p.GV2 = c->GV + V * S;
     }
 
     const size_t SR = S > R ? S : R;
@@ -1406,7 +1439,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t nwv = TR_THREADS / 64;
     const size_t SPd = ((S + 3) & ~(size_t)3) + 8, RPd = ((R + 3) & ~(size_t)3) + 8;
     const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
-                          (farnn ? 2 * SPd + 2 * RPd + 4 * 2 * nwv * S : 0)) * sizeof(float);
+                          (farnn ? 2 * SPd + 2 * 2 * nwv * S : 0)) * sizeof(float);
     const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
                           (farnn ? 4 * SPd + 2 * nwv * SR : 0)) * sizeof(float);
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);

@@ -44,6 +44,7 @@ struct TrainParams {
     float *DAZf, *DAZb, *DARf, *DARb;                       // [.][S] adjoints of the gate pre-activations
     float *VRf, *VRb;                                       // [.][R] v_t rows (for d Wrs)
     float *HBARf;                                           // [.][S] forward chain input hbar_t (= f_{t-1} without gates)
+    const float *GV1, *GV2;                                 // [V][S] Vgen Wrs1, Vgen Wrs2: the input halves of the gates, hoisted out of the recurrences
     const float *trans;       // [K][K] CRF transitions (CRF mode) and the per-sequence partials of their gradient
     float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
@@ -233,14 +234,14 @@ train_forward_kernel(const TrainParams p) {
     // the token of every step, in step order, so that no step waits for an index load
     int *toks = (int *)(part2 + nw * 2 * S);                  // [TR_NSEQ][L]
     // gated steps: raw state and v_t as matvec inputs, four more partial buffers
-    float *hv = (float *)(toks + TR_NSEQ * p.L), *vv = hv + 2 * SP, *pg = vv + 2 * RP;
+    float *hv = (float *)(toks + TR_NSEQ * p.L), *pg = hv + 2 * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
     for (int e = tid; e < 2 * SP + 2 * RP; e += nt) f[e] = 0.0f;          // f | tv contiguous: pads stay zero
-    if (farnn) for (int e = tid; e < 2 * SP + 2 * RP; e += nt) hv[e] = 0.0f;   // hv | vv contiguous
+    if (farnn) for (int e = tid; e < 2 * SP; e += nt) hv[e] = 0.0f;
     __syncthreads();
     for (int e = tid; e < TR_NSEQ * S; e += nt) {
         const int q = e / S, s = e - q * S;
@@ -273,31 +274,42 @@ train_forward_kernel(const TrainParams p) {
         hk[k] = hin[k]; zk[k] = 1.0f; rk[k] = 1.0f;
     }
     float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
+    float g1c[VPT], g2c[VPT], g1n[VPT], g2n[VPT];
+#pragma unroll
+    for (int k = 0; k < VPT; k++) {
+        const bool ok = farnn && sv[k] && maxlen >= 1;
+        const long long go = ok ? (long long)toks[sq[k] * p.L] * S + ss[k] : 0;
+        g1c[k] = ok ? p.GV1[go] : 0.0f;
+        g2c[k] = (ok && farnn == 2) ? p.GV2[go] : 0.0f;
+        g1n[k] = g2n[k] = 0.0f;
+    }
     for (int t = 1; t <= maxlen; t++) {
 #pragma unroll
-        for (int k = 0; k < VPT; k++)
+        for (int k = 0; k < VPT; k++) {
             vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(long long)toks[rq[k] * p.L + t] * R + rr_[k]] : 0.0f;
-        if (farnn) {
-            // z = sigma(k (h Wss1 + v Wrs1 + bs1)), r likewise (:146-149); hbar = (1-r) h_init + r h (:150-151)
-#pragma unroll
-            for (int k = 0; k < VPT; k++) if (rv[k]) vv[rq[k] * RP + rr_[k]] = vcur[k];
-            wg_barrier_lds();
-            matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
-            matvec2_partial<false>(pg + nw * 2 * S, vv, RP, p.Wrs1, R, S, tid, nt);
-            if (farnn == 2) {
-                matvec2_partial<false>(pg + 2 * nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
-                matvec2_partial<false>(pg + 3 * nw * 2 * S, vv, RP, p.Wrs2, R, S, tid, nt);
+            if (farnn) {
+                const bool ok = sv[k] && t < maxlen;
+                const long long go = ok ? (long long)toks[sq[k] * p.L + t] * S + ss[k] : 0;
+                g1n[k] = ok ? p.GV1[go] : 0.0f;
+                g2n[k] = (ok && farnn == 2) ? p.GV2[go] : 0.0f;
             }
+        }
+        if (farnn) {
+            // z = sigma(k (h Wss1 + v Wrs1 + bs1)), r likewise (:146-149); hbar = (1-r) h_init + r h (:150-151).  The input
+            // halves v Wrs do not depend on the state: they are rows of GV = Vgen Wrs (one product per step for the whole
+            // vocabulary, before the recurrences), fetched one step ahead like v itself -- the two largest products of
+            // the gate phase (K = R) leave the sequential loop
+            matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
+            if (farnn == 2) matvec2_partial<false>(pg + nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
                 if (sv[k]) {
-                    const float az = part2_sum(pg, S, sq[k], ss[k], nw) + part2_sum(pg + nw * 2 * S, S, sq[k], ss[k], nw) + p.bs1[ss[k]];
+                    const float az = part2_sum(pg, S, sq[k], ss[k], nw) + g1c[k] + p.bs1[ss[k]];
                     zk[k] = 1.0f / (1.0f + expf(-p.sig_k * az));
                     float hbar = hk[k];
                     if (farnn == 2) {
-                        const float ar = part2_sum(pg + 2 * nw * 2 * S, S, sq[k], ss[k], nw) +
-                                         part2_sum(pg + 3 * nw * 2 * S, S, sq[k], ss[k], nw) + p.bs2[ss[k]];
+                        const float ar = part2_sum(pg + nw * 2 * S, S, sq[k], ss[k], nw) + g2c[k] + p.bs2[ss[k]];
                         rk[k] = 1.0f / (1.0f + expf(-p.sig_k * ar));
                         hbar = (1.0f - rk[k]) * hin[k] + rk[k] * hk[k];
                     }
@@ -336,7 +348,7 @@ train_forward_kernel(const TrainParams p) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < VPT; k++) vcur[k] = vnext[k];
+        for (int k = 0; k < VPT; k++) { vcur[k] = vnext[k]; g1c[k] = g1n[k]; g2c[k] = g2n[k]; }
         wg_barrier_lds();
     }
 }
