@@ -1255,7 +1255,7 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
     if (d->farnn) {
         const size_t Vv = d->V;
         if (hipMalloc((void **)&c->VgenT, Vv * R * sizeof(float)) != hipSuccess ||
-            hipMalloc((void **)&c->GV, 2 * Vv * S * sizeof(float)) != hipSuccess) {
+            hipMalloc((void **)&c->GV, 6 * Vv * S * sizeof(float)) != hipSuccess) {
             if (c->VgenT) (void)hipFree(c->VgenT);
             (void)hipFree(blk);
             delete c;
@@ -1403,7 +1403,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         if (farnn) {
             add(0, nullptr, o->dWss1, S, S); add(0, nullptr, o->dWrs1, R, S); add(0, nullptr, o->dbs1, 1, S);
             add(1, w->Wss1, c->Wss1T, S, S); add(1, w->Wrs1, c->Wrs1T, R, S);
-            add(1, w->Vgen, c->VgenT, V, R); add(0, nullptr, c->GV, (farnn == 2 ? 2 : 1) * V, S);
+            add(1, w->Vgen, c->VgenT, V, R); add(0, nullptr, c->GV, 4 * V, S);      // GV1 | GV2 | dGV1 | dGV2
             if (farnn == 2) {
                 add(0, nullptr, o->dWss2, S, S); add(0, nullptr, o->dWrs2, R, S); add(0, nullptr, o->dbs2, 1, S);
                 add(1, w->Wss2, c->Wss2T, S, S); add(1, w->Wrs2, c->Wrs2T, R, S);
@@ -1428,7 +1428,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         gj.partial = c->part;
         atb_partial_kernel<<<gj.total_wgs, 256, 0, s>>>(gj);
         atb_reduce_kernel<<<(gj.total_out + 255) / 256, 256, 0, s>>>(gj);
-        p.GV1 = c->GV; p.GV2 = c->GV + V * S;
+        p.GV1 = c->GV; p.GV2 = c->GV + V * S; p.dGV1 = c->GV + 2 * V * S; p.dGV2 = c->GV + 3 * V * S;
     }
 
     const size_t SR = S > R ? S : R;
@@ -1441,7 +1441,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
                           (farnn ? 2 * SPd + 2 * 2 * nwv * S : 0)) * sizeof(float);
     const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
-                          (farnn ? 4 * SPd + 2 * nwv * SR : 0)) * sizeof(float);
+                          (farnn ? 4 * SPd : 0)) * sizeof(float);
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
     const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
     const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
@@ -1492,6 +1492,18 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     if (ldsw_b) FARNN_TRAIN_CHAIN(train_backward_kernel, true, lds_b);
     else        FARNN_TRAIN_CHAIN(train_backward_kernel, false, lds_b);
 #undef FARNN_TRAIN_CHAIN
+    float *dGVT = nullptr;
+    if (farnn) {                                       // dGV^T ([S][V]) as the A operand of dVgen += dGV Wrs^T
+        dGVT = c->GV + 4 * V * S;
+        PrepJobs tj;
+        memset(&tj, 0, sizeof(tj));
+        for (int gsel = 0; gsel < farnn; gsel++) {
+            PrepJob &j = tj.j[tj.n++];
+            j.kind = 1; j.src = c->GV + (2 + gsel) * V * S; j.dst = dGVT + gsel * S * V; j.rows = (int)V; j.cols = (int)S; j.e0 = tj.total;
+            tj.total += (int)(V * S);
+        }
+        train_prep_kernel<<<(tj.total + 255) / 256, 256, 0, s>>>(tj);
+    }
     // parameter gradients = tall-skinny products over the per-token rows (rows of non-tokens are zero)
     AtbJobs jobs;
     memset(&jobs, 0, sizeof(jobs));
@@ -1512,15 +1524,15 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         // gates read the raw previous state (stash shifted by one row) and v_t: dWss = h_{t-1}^T da, dWrs = v^T da, dbs = 1^T da
         atb_add(jobs, p.A, p.DAZf + S, o->dWss1, (long long)N1 - 1, (int)S, (int)S);
         atb_add(jobs, p.Bk, p.DAZb + S, o->dWss1, (long long)N1 - 1, (int)S, (int)S);
-        atb_add(jobs, p.VRf, p.DAZf, o->dWrs1, (long long)N1, (int)R, (int)S);
-        atb_add(jobs, p.VRb, p.DAZb, o->dWrs1, (long long)N1, (int)R, (int)S);
+        atb_add(jobs, w->Vgen, p.dGV1, o->dWrs1, (long long)V, (int)R, (int)S);             // dWrs = Vgen^T dGV
+        atb_add(jobs, dGVT, c->Wrs1T, o->dVgen, (long long)S, (int)V, (int)R);              // dVgen += dGV Wrs^T
         atb_add(jobs, c->ones, p.DAZf, o->dbs1, (long long)N1, 1, (int)S);
         atb_add(jobs, c->ones, p.DAZb, o->dbs1, (long long)N1, 1, (int)S);
         if (farnn == 2) {
             atb_add(jobs, p.A, p.DARf + S, o->dWss2, (long long)N1 - 1, (int)S, (int)S);
             atb_add(jobs, p.Bk, p.DARb + S, o->dWss2, (long long)N1 - 1, (int)S, (int)S);
-            atb_add(jobs, p.VRf, p.DARf, o->dWrs2, (long long)N1, (int)R, (int)S);
-            atb_add(jobs, p.VRb, p.DARb, o->dWrs2, (long long)N1, (int)R, (int)S);
+            atb_add(jobs, w->Vgen, p.dGV2, o->dWrs2, (long long)V, (int)R, (int)S);
+            atb_add(jobs, dGVT + S * V, c->Wrs2T, o->dVgen, (long long)S, (int)V, (int)R);
             atb_add(jobs, c->ones, p.DARf, o->dbs2, (long long)N1, 1, (int)S);
             atb_add(jobs, c->ones, p.DARb, o->dbs2, (long long)N1, 1, (int)S);
         }

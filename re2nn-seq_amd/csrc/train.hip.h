@@ -45,6 +45,7 @@ struct TrainParams {
     float *VRf, *VRb;                                       // [.][R] v_t rows (for d Wrs)
     float *HBARf;                                           // [.][S] forward chain input hbar_t (= f_{t-1} without gates)
     const float *GV1, *GV2;                                 // [V][S] Vgen Wrs1, Vgen Wrs2: the input halves of the gates, hoisted out of the recurrences
+    float *dGV1, *dGV2;                                     // [V][S] their adjoints (rows of the words that occur)
     const float *trans;       // [K][K] CRF transitions (CRF mode) and the per-sequence partials of their gradient
     float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
@@ -727,7 +728,7 @@ train_backward_kernel(const TrainParams p) {
     }
     int *toks = (int *)(pc + nw * 2 * S);                     // [TR_NSEQ][L] tokens in step order
     // gated steps: the gate pre-activation adjoints as matvec inputs and a fourth partial buffer
-    float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP, *pd = darv + 2 * SP;
+    float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
@@ -756,7 +757,7 @@ train_backward_kernel(const TrainParams p) {
     }
     float hin[VPT], dhin[VPT], zc[VPT], zn[VPT], rc[VPT], rn[VPT], cc[VPT], cn[VPT], dhk[VPT];
     const float *ZG = dir == 0 ? p.ZGf : p.ZGb, *RG = dir == 0 ? p.RGf : p.RGb, *CD = dir == 0 ? p.CDf : p.CDb;
-    float *DAZ = dir == 0 ? p.DAZf : p.DAZb, *DAR = dir == 0 ? p.DARf : p.DARb, *VR = dir == 0 ? p.VRf : p.VRb;
+    float *DAZ = dir == 0 ? p.DAZf : p.DAZb, *DAR = dir == 0 ? p.DARf : p.DARb;
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         hin[k] = (farnn && sv[k]) ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
@@ -804,6 +805,7 @@ train_backward_kernel(const TrainParams p) {
                         const float daz = gt * (cc[k] - hp) * p.sig_k * zc[k] * (1.0f - zc[k]);
                         dazv[li] = daz;
                         DAZ[row] = daz;
+                        atomicAdd(p.dGV1 + (long long)toks[sq[k] * p.L + t - 1] * S + ss[k], daz);   // az = h Wss1 + GV1[token] + bs1
                         if (farnn == 2) hp = (1.0f - rc[k]) * hin[k] + rc[k] * hp;          // hbar (:150-151)
                     } else {
                         yy = gt * nl_grad_from_output(hcur[k], p.nl);
@@ -842,7 +844,6 @@ train_backward_kernel(const TrainParams p) {
                     dd = uv * vv;
                     D1o[row] = dd;
                     To[row] = vv * rvv;
-                    if (farnn) VR[row] = vv;
                     atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], uv * rvv);   // d v_t = u * rr
                 }
                 d1[rq[k] * RP + rr_[k]] = dd;
@@ -866,6 +867,7 @@ train_backward_kernel(const TrainParams p) {
                         dhin[k] = fmaf(dhb, 1.0f - rc[k], dhin[k]);
                         dhk[k] = fmaf(dhb, rc[k], dhk[k]);
                         DAR[srow[k] + (long long)t * S] = dar;
+                        atomicAdd(p.dGV2 + (long long)toks[sq[k] * p.L + t - 1] * S + ss[k], dar);
                     } else {
                         dhk[k] += dhb;
                     }
@@ -874,14 +876,12 @@ train_backward_kernel(const TrainParams p) {
             }
         }
         if (farnn) {
-            // the gates read the raw h_{t-1} and v_t: d h_{t-1} += daz Wss1^T + dar Wss2^T, d v_t += daz Wrs1^T + dar Wrs2^T
+            // the gates read the raw h_{t-1}: d h_{t-1} += daz Wss1^T + dar Wss2^T.  Their input halves were hoisted
+            // (GV = Vgen Wrs): the adjoints daz, dar go to the word's rows of dGV, and d Vgen += dGV Wrs^T, d Wrs = Vgen^T dGV
+            // are products over the vocabulary after the loop
             wg_barrier_lds();
             matvec2_partial<false>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
-            matvec2_partial<false>(pb, dazv, SP, p.Wrs1T, S, R, tid, nt);
-            if (farnn == 2) {
-                matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
-                matvec2_partial<false>(pd, darv, SP, p.Wrs2T, S, R, tid, nt);
-            }
+            if (farnn == 2) matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
@@ -889,11 +889,6 @@ train_backward_kernel(const TrainParams p) {
                     float dh = dhk[k] + part2_sum(pa, S, sq[k], ss[k], nw);
                     if (farnn == 2) dh += part2_sum(pc, S, sq[k], ss[k], nw);
                     gacc[k] = dh;
-                }
-                if (rv[k] && t <= len[rq[k]]) {
-                    float dv = part2_sum(pb, R, rq[k], rr_[k], nw);
-                    if (farnn == 2) dv += part2_sum(pd, R, rq[k], rr_[k], nw);
-                    atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], dv);
                 }
             }
         }
