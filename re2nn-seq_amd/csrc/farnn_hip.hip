@@ -1445,7 +1445,13 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
     const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
     const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
-    const size_t lds_f = vec_f + (ldsw_f ? mat_f : 0), lds_b = vec_b + (ldsw_b ? mat_b : 0);
+    // through-L2 kernels keep as many of their S x S matrices in LDS as fit (wildcard matrix, then the gates' Wss)
+    const size_t ssb = S * S * sizeof(float), lds_cap = 156 * 1024;
+    const size_t want_ss = farnn == 2 ? 3 : (farnn == 1 ? 2 : 1);
+    p.nss_f = ldsw_f || vec_f + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_f - 16) / ssb);
+    p.nss_b = ldsw_b || vec_b + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_b - 16) / ssb);
+    if (env_int("FARNN_TRAIN_NOLDS", 0) > 1) p.nss_f = p.nss_b = 0;
+    const size_t lds_f = vec_f + (ldsw_f ? mat_f : 16 + p.nss_f * ssb), lds_b = vec_b + (ldsw_b ? mat_b : 16 + p.nss_b * ssb);
     const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
     // instantiation: weights in LDS or through L2, with or without the gate state, one or two slots per thread

@@ -46,6 +46,7 @@ struct TrainParams {
     float *HBARf;                                           // [.][S] forward chain input hbar_t (= f_{t-1} without gates)
     const float *GV1, *GV2;                                 // [V][S] Vgen Wrs1, Vgen Wrs2: the input halves of the gates, hoisted out of the recurrences
     float *dGV1, *dGV2;                                     // [V][S] their adjoints (rows of the words that occur)
+    int nss_f, nss_b;         // through-L2 chain kernels: how many of their S x S matrices still fit in LDS (0..3)
     const float *trans;       // [K][K] CRF transitions (CRF mode) and the per-sequence partials of their gradient
     float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
@@ -237,6 +238,14 @@ train_forward_kernel(const TrainParams p) {
     // gated steps: raw state and v_t as matvec inputs, four more partial buffers
     float *hv = (float *)(toks + TR_NSEQ * p.L), *pg = hv + 2 * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
+    // through-L2 instantiation: the S x S matrices that still fit stay in LDS (W first, then the gates' Wss)
+    float *ssl = smem + (((int)((GATED ? pg + 2 * nw * 2 * S : hv) - smem) + 3) & ~3);  // offsets in floats: keeps the LDS address space
+    const int nss = LDSW ? 0 : p.nss_f;
+    const float *M2l = ssl, *G1l = ssl + S * S, *G2l = ssl + 2 * S * S;
+    const bool l_m2 = nss >= 1, l_g1 = GATED && nss >= 2, l_g2 = GATED && nss >= 3;
+    if (l_m2) stage_matrix(ssl, M2, S * S, tid, nt);
+    if (l_g1 && farnn) stage_matrix(ssl + S * S, p.Wss1, S * S, tid, nt);
+    if (l_g2 && farnn == 2) stage_matrix(ssl + 2 * S * S, p.Wss2, S * S, tid, nt);
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
@@ -300,8 +309,12 @@ train_forward_kernel(const TrainParams p) {
             // halves v Wrs do not depend on the state: they are rows of GV = Vgen Wrs (one product per step for the whole
             // vocabulary, before the recurrences), fetched one step ahead like v itself -- the two largest products of
             // the gate phase (K = R) leave the sequential loop
-            matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
-            if (farnn == 2) matvec2_partial<false>(pg + nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
+            if (l_g1) matvec2_partial<true>(pg, hv, SP, G1l, S, S, tid, nt);
+            else matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
+            if (farnn == 2) {
+                if (l_g2) matvec2_partial<true>(pg + nw * 2 * S, hv, SP, G2l, S, S, tid, nt);
+                else matvec2_partial<false>(pg + nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
+            }
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
@@ -321,7 +334,8 @@ train_forward_kernel(const TrainParams p) {
         }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
         matvec2_partial<LDSW>(part, f, SP, M1, S, R, tid, nt);
-        matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
+        if (l_m2) matvec2_partial<true>(part2, f, SP, M2l, S, S, tid, nt);
+        else matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++)
@@ -730,6 +744,14 @@ train_backward_kernel(const TrainParams p) {
     // gated steps: the gate pre-activation adjoints as matvec inputs and a fourth partial buffer
     float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
+    // through-L2 instantiation: the S x S matrices that still fit stay in LDS (W^T|W first, then the gates' Wss^T)
+    float *ssl = smem + (((int)((GATED ? darv + 2 * SP : dazv) - smem) + 3) & ~3);
+    const int nss = LDSW ? 0 : p.nss_b;
+    const float *Mcl = ssl, *G1l = ssl + S * S, *G2l = ssl + 2 * S * S;
+    const bool l_mc = nss >= 1, l_g1 = GATED && nss >= 2, l_g2 = GATED && nss >= 3;
+    if (l_mc) stage_matrix(ssl, Mc, S * S, tid, nt);
+    if (l_g1 && farnn) stage_matrix(ssl + S * S, p.Wss1T, S * S, tid, nt);
+    if (l_g2 && farnn == 2) stage_matrix(ssl + 2 * S * S, p.Wss2T, S * S, tid, nt);
     for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
@@ -831,7 +853,8 @@ train_backward_kernel(const TrainParams p) {
         wg_barrier_lds();
         matvec2_partial<LDSW>(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
         matvec2_partial<LDSW>(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
-        matvec2_partial<LDSW>(pc, z, SP, Mc, S, S, tid, nt);             // d fp through the wildcard matrix
+        if (l_mc) matvec2_partial<true>(pc, z, SP, Mcl, S, S, tid, nt);   // d fp through the wildcard matrix
+        else matvec2_partial<LDSW>(pc, z, SP, Mc, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
@@ -880,8 +903,12 @@ train_backward_kernel(const TrainParams p) {
             // (GV = Vgen Wrs): the adjoints daz, dar go to the word's rows of dGV, and d Vgen += dGV Wrs^T, d Wrs = Vgen^T dGV
             // are products over the vocabulary after the loop
             wg_barrier_lds();
-            matvec2_partial<false>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
-            if (farnn == 2) matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
+            if (l_g1) matvec2_partial<true>(pa, dazv, SP, G1l, S, S, tid, nt);
+            else matvec2_partial<false>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
+            if (farnn == 2) {
+                if (l_g2) matvec2_partial<true>(pc, darv, SP, G2l, S, S, tid, nt);
+                else matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
+            }
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {

@@ -430,3 +430,61 @@ def test_train_step_random_configurations_soak():
         if crf:
             close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), tag + ' dtrans', rtol=5e-3)
         tc.close()
+
+
+@pytest.mark.parametrize('mode', ['1', '2'])
+@pytest.mark.parametrize('k', [0, 6, 8, 9])
+def test_train_step_through_l2_kernels_match_reference(k, mode, monkeypatch):
+    """The chain kernels that read their matrices through L2 (what large ranks use): FARNN_TRAIN_NOLDS=1 keeps the
+    S x S matrices that fit in LDS, =2 none.  Same fixtures, same bar."""
+    monkeypatch.setenv('FARNN_TRAIN_NOLDS', mode)
+    test_train_step_matches_reference_loss_and_gradients(k)
+
+
+def test_train_step_rank_250_gated_crf_vs_batched_oracle(monkeypatch):
+    """The shipped configurations' shape (rank 250, gates, CRF) on a small batch: the instantiation bench.py times."""
+    from re2nn_seq_amd import _lib
+    rng = np.random.RandomState(250)
+    V, S, R, K, B, L, D, farnn = 120, 104, 250, 75, 6, 17, 8, 2
+    f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
+    Cm = np.zeros((K, S), np.float32)
+    Cm[rng.randint(0, K - 2, size=S), np.arange(S)] = (rng.rand(S) < 0.8)
+    fs = 0.7 / np.sqrt(R)
+    p = {'S1': f(S, R, sc=fs), 'S2': f(S, R, sc=fs), 'V_embed': f(V, R, sc=0.8), 'embed_r_generalized': f(D, R),
+         'C_output_mat': torch.from_numpy(Cm + (rng.rand(K, S) * 0.02).astype(np.float32)),
+         'wildcard_mat': torch.from_numpy(((rng.rand(S, S) < 1.0 / S) * 0.5).astype(np.float32)),
+         'h0': f(S, sc=0.5), 'hT': f(S, sc=0.5), 'beta_vec': torch.full((R,), 0.7), 'embedding.weight': f(V, D),
+         'priority_mat': torch.eye(K)}
+    gate_names = ('Wss1', 'Wrs1', 'bs1', 'Wss2', 'Wrs2', 'bs2')
+    for n in gate_names:
+        p[n] = f(1, S, sc=0.5) if n.startswith('bs') else (f(S, S, sc=0.5 / np.sqrt(S)) if n.startswith('Wss') else f(R, S, sc=0.5 / np.sqrt(R)))
+    tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    p['crf.transitions'] = torch.from_numpy(tr)
+    lengths = rng.randint(1, L + 1, size=B).astype(np.int64)
+    lengths[0] = L
+    x = rng.randint(0, V, size=(B, L)).astype(np.int64)
+    labels = rng.randint(0, K - 2, size=(B, L)).astype(np.int64)
+    xt, lt, lab = torch.from_numpy(x), torch.from_numpy(lengths), torch.from_numpy(labels)
+    loss_ref, grads_ref, _ = to.train_step_batched(p, xt, lt, lab, nl='tanh', farnn=farnn, sig_k=3.0)
+    dev = torch.device('cuda')
+    w = {'Vgen': to.generalized_table(p).to(dev), 'S1': p['S1'].to(dev), 'S2': p['S2'].to(dev), 'W': p['wildcard_mat'].to(dev),
+         'C': p['C_output_mat'].to(dev), 'h0': p['h0'].to(dev), 'hT': p['hT'].to(dev)}
+    w.update({n: p[n].to(dev).contiguous() for n in gate_names})
+    trd = p['crf.transitions'].to(dev)
+    tc = _lib.TrainContext(V, S, R, K, nl='tanh', threshold=0.5, o_idx=1, use_crf=True, farnn=farnn, sigmoid_exponent=3.0)
+    out = {'d' + n: torch.empty_like(t) for n, t in w.items()}
+    dtr = torch.empty_like(trd)
+    loss = torch.empty(1, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    xd, ld, labd = xt.to(dev), lt.to(dev), lab.to(dev)
+    tc.step(dict({n: t.data_ptr() for n, t in w.items()}, P=None, crf_trans=trd.data_ptr()),
+            xd.data_ptr(), ld.data_ptr(), labd.data_ptr(), B, L, int(lengths.sum()),
+            dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr(), dtrans=dtr.data_ptr()))
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_ref)) < 1e-4 * max(1.0, abs(float(loss_ref)))
+    for n, key in (('S1', 'S1'), ('S2', 'S2'), ('W', 'wildcard_mat'), ('C', 'C_output_mat'), ('h0', 'h0'), ('hT', 'hT')) + \
+            tuple((n, n) for n in gate_names):
+        close(out['d' + n].cpu().numpy(), grads_ref[key].numpy().reshape(out['d' + n].shape), 'd' + n, rtol=5e-3)
+    close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), 'dtrans', rtol=5e-3)
