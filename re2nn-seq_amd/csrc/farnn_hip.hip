@@ -1303,7 +1303,8 @@ extern "C" int farnn_train_time(farnn_train_ctx *c, double *total_ms, int64_t *s
 }
 
 static void atb_add(AtbJobs &jobs, const float *A, const float *Bm, float *out, long long N, int M, int J) {
-    if (N <= 0 || jobs.n >= ATB_MAX_JOBS) return;
+    if (N <= 0) return;
+    if (jobs.n >= ATB_MAX_JOBS) { jobs.total_wgs = -1; return; }       // checked by the caller: never drop a product silently
     AtbJob &j = jobs.j[jobs.n];
     j.A = A; j.B = Bm; j.out = out; j.N = N; j.M = M; j.J = J;
     j.tiles_m = (M + 63) / 64; j.tiles_j = (J + 63) / 64;
@@ -1391,9 +1392,12 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         PrepJobs pj;
         memset(&pj, 0, sizeof(pj));
         auto add = [&](int kind, const float *src, float *dst, size_t rows, size_t cols) {
+            if (pj.n >= PREP_MAX_JOBS) { pj.total = -1; return; }
             PrepJob &j = pj.j[pj.n++];
             j.kind = kind; j.src = src; j.dst = dst; j.rows = (int)rows; j.cols = (int)cols; j.e0 = pj.total;
-            pj.total += (int)(kind == 2 ? cols : rows * cols);
+            const size_t ne = kind == 2 ? cols : rows * cols;
+            if (pj.total < 0 || ne > (size_t)0x7fffffff - (size_t)pj.total) { pj.total = -1; return; }   // 32-bit element index
+            pj.total += (int)ne;
         };
         add(0, nullptr, o->loss, 1, 1); add(0, nullptr, o->dVgen, V, R); add(0, nullptr, o->dS1, S, R);
         add(0, nullptr, o->dS2, S, R); add(0, nullptr, o->dW, S, S); add(0, nullptr, o->dC, K, S);
@@ -1409,6 +1413,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
                 add(1, w->Wss2, c->Wss2T, S, S); add(1, w->Wrs2, c->Wrs2T, R, S);
             }
         }
+        if (pj.total < 0) return fail(FARNN_ERANGE, "train_step: too many preparation jobs%s%s");
         train_prep_kernel<<<(pj.total + 255) / 256, 256, 0, s>>>(pj);
     }
     if (farnn) {
@@ -1543,6 +1548,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
             atb_add(jobs, c->ones, p.DARb, o->dbs2, (long long)N1, 1, (int)S);
         }
     }
+    if (jobs.total_wgs < 0) return fail(FARNN_ERANGE, "train_step: too many gradient products for one launch%s%s");
     const size_t pf = atb_partial_floats(jobs);
     if (pf > c->part_floats) {
         if (c->part) { FARNN_HIP_TRY(hipDeviceSynchronize()); (void)hipFree(c->part); c->part = nullptr; c->part_floats = 0; }
