@@ -641,6 +641,20 @@ train_crf_kernel(const TrainParams p) {
     }
     __syncthreads();
     const float logZ = red[0];
+    // expected transition counts: thread (row group r0, column cj) owns rows r0, r0 + rstep, ... of column cj.  When that
+    // is at most CRF_XR rows, its counts and its exp(transition) entries live in registers for the whole backward pass
+    // (the LDS read-modify-write form costs four LDS instructions per element and step)
+    constexpr int CRF_XR = 32;
+    const int xcj = tid % K1, xr0 = tid / K1, xrstep = nt / K1 > 0 ? nt / K1 : 1;
+    const bool xreg = K1 <= nt && (K + xrstep - 1) / xrstep <= CRF_XR;
+    const bool xmine = xreg && xcj < K && xr0 < xrstep;
+    float exr[CRF_XR], etrr[CRF_XR];
+#pragma unroll
+    for (int u = 0; u < CRF_XR; u++) {
+        const int i = xr0 + u * xrstep;
+        exr[u] = 0.0f;
+        etrr[u] = (xmine && i < K) ? etr[i * K1 + xcj] : 0.0f;
+    }
     // backward messages, marginals and expected transition counts
     for (int t = n - 1; t >= 0; t--) {
         const float *bc = bt + (t & 1) * K;
@@ -662,7 +676,16 @@ train_crf_kernel(const TrainParams p) {
             const float *ep = ea + (long long)(t - 1) * K;
             const float scale = __expf(am[t - 1] + bmx - logZ);                 // xi_{t-1}(i,j) = ea[i] etr[i][j] eb[j] scale
             // thread (row group r0, column j): rows r0, r0 + rstep, ... -- no divisions, all reads of a round independent
-            if (K1 <= nt) {
+            if (xreg) {
+                if (xmine) {
+                    const float se = scale * eb[xcj];
+#pragma unroll
+                    for (int u = 0; u < CRF_XR; u++) {
+                        const int i = xr0 + u * xrstep;
+                        exr[u] = fmaf(ep[i < K ? i : 0] * se, etrr[u], exr[u]);          // etrr is 0 past the last row
+                    }
+                }
+            } else if (K1 <= nt) {
                 const int cj = tid % K1, r0 = tid / K1, rstep = nt / K1;        // K1 columns per row in LDS (the pad column is skipped)
                 if (cj < K && r0 < rstep) {
                     const float ebj = eb[cj];
@@ -696,6 +719,14 @@ train_crf_kernel(const TrainParams p) {
         }
         __syncthreads();
     }
+    if (xmine) {
+#pragma unroll
+        for (int u = 0; u < CRF_XR; u++) {
+            const int i = xr0 + u * xrstep;
+            if (i < K) ex[i * K1 + xcj] += exr[u];                              // each element has exactly one owner
+        }
+    }
+    __syncthreads();
     for (int e = tid; e < K * K; e += nt) dpart[e] = ex[(e / K) * K1 + e % K];
 }
 
