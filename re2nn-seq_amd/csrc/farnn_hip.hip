@@ -1395,7 +1395,9 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
             if (pj.n >= PREP_MAX_JOBS) { pj.total = -1; return; }
             PrepJob &j = pj.j[pj.n++];
             j.kind = kind; j.src = src; j.dst = dst; j.rows = (int)rows; j.cols = (int)cols; j.e0 = pj.total;
-            const size_t ne = kind == 2 ? cols : rows * cols;
+            // every job starts on a 256-thread block boundary; a transpose takes one block per 32x32 tile
+            const size_t ne = kind == 1 ? ((rows + 31) / 32) * ((cols + 31) / 32) * 256
+                                        : (((kind == 2 ? cols : rows * cols) + 255) / 256) * 256;
             if (pj.total < 0 || ne > (size_t)0x7fffffff - (size_t)pj.total) { pj.total = -1; return; }   // 32-bit element index
             pj.total += (int)ne;
         };
@@ -1511,7 +1513,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         for (int gsel = 0; gsel < farnn; gsel++) {
             PrepJob &j = tj.j[tj.n++];
             j.kind = 1; j.src = c->GV + (2 + gsel) * V * S; j.dst = dGVT + gsel * S * V; j.rows = (int)V; j.cols = (int)S; j.e0 = tj.total;
-            tj.total += (int)(V * S);
+            tj.total += (int)(((V + 31) / 32) * ((S + 31) / 32) * 256);
         }
         train_prep_kernel<<<(tj.total + 255) / 256, 256, 0, s>>>(tj);
     }

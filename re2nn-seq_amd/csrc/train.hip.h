@@ -185,17 +185,39 @@ struct PrepJobs { PrepJob j[PREP_MAX_JOBS]; int n, total; };
 
 __global__ void __launch_bounds__(256)
 train_prep_kernel(const PrepJobs jobs) {
+    __shared__ float tile[32][33];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= jobs.total) return;
+    if (blockIdx.x * blockDim.x >= jobs.total) return;
     int ji = 0;
-    while (ji + 1 < jobs.n && idx >= jobs.j[ji + 1].e0) ji++;
+    while (ji + 1 < jobs.n && (int)(blockIdx.x * blockDim.x) >= jobs.j[ji + 1].e0) ji++;   // jobs start on block boundaries
     const PrepJob &jb = jobs.j[ji];
     const int e = idx - jb.e0;
+    if (jb.kind == 1) {
+        // transpose through a 32x32 LDS tile: reads and writes both run along rows (a direct transpose writes 64
+        // different cache lines per wavefront: 54 us for the 11 k x 250 table)
+        const int tiles_c = (jb.cols + 31) >> 5, t = e >> 8, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+        if (r0 < jb.rows) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = r0 + ty + 8 * k, c = c0 + tx;
+                tile[ty + 8 * k][tx] = (r < jb.rows && c < jb.cols) ? jb.src[(long long)r * jb.cols + c] : 0.0f;
+            }
+        }
+        __syncthreads();
+        if (r0 < jb.rows) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int c = c0 + ty + 8 * k, r = r0 + tx;
+                if (r < jb.rows && c < jb.cols) jb.dst[(long long)c * jb.rows + r] = tile[tx][ty + 8 * k];
+            }
+        }
+        return;
+    }
+    const int n = jb.kind == 2 ? jb.cols : jb.rows * jb.cols;
+    if (e >= n) return;
     if (jb.kind == 0) jb.dst[e] = 0.0f;
-    else if (jb.kind == 1) {
-        const int r = e / jb.cols, c = e - r * jb.cols;
-        jb.dst[(long long)c * jb.rows + r] = jb.src[e];
-    } else {                                                           // e = column; rows summed in four chains
+    else {                                                             // e = column; rows summed in four chains
         float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
         int c = 0;
         for (; c + 4 <= jb.rows; c += 4) {
