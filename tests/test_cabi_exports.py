@@ -67,3 +67,32 @@ def test_product_never_imports_the_oracle():
                     text = f.read()
                 assert 'import oracle' not in text and 'from oracle' not in text, fn
                 assert 'farnn_oracle' not in text, fn
+
+
+def test_ctypes_struct_layouts_match_the_header(tmp_path):
+    """sizeof / offsetof of every struct the binding mirrors, as gcc sees include/farnn.h, against ctypes."""
+    import subprocess
+    from re2nn_seq_amd import _lib
+    pairs = {
+        'farnn_onehot_ifst_desc': _lib.OnehotIfstDesc, 'farnn_onehot_fst4_desc': _lib.OnehotFst4Desc,
+        'farnn_onehot_ind1_desc': _lib.OnehotInd1Desc, 'farnn_decomp_ifst_desc': _lib.DecompIfstDesc,
+        'farnn_decomp_ind1_desc': _lib.DecompInd1Desc, 'farnn_decomp_fst_desc': _lib.DecompFstDesc,
+        'farnn_edge_list': _lib.EdgeList, 'farnn_train_dims': _lib.TrainDims,
+        'farnn_train_weights': _lib.TrainWeights, 'farnn_train_outputs': _lib.TrainOutputs,
+    }
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "farnn.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        lines.append('  printf("%s sizeof %zu\\n", "{0}", sizeof({0}));'.format(cname))
+        for fname, _ in cls._fields_:              # a trailing underscore in the binding avoids a Python keyword
+            lines.append('  printf("%s.%s %zu\\n", "{0}", "{1}", offsetof({0}, {2}));'.format(cname, fname, fname.rstrip('_')))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.rsplit(' ', 1) for line in out.strip().splitlines())
+    for cname, cls in pairs.items():
+        assert int(got[cname + ' sizeof']) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got['{}.{}'.format(cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
