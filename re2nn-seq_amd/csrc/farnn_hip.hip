@@ -1462,16 +1462,17 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
     // instantiation: weights in LDS or through L2, with or without the gate state, one or two slots per thread
-    const bool two = 2 * SR > (size_t)TR_THREADS;
+    const bool twoS = 2 * S > (size_t)TR_THREADS, twoR = 2 * R > (size_t)TR_THREADS;
+#define FARNN_TRAIN_CHAIN2(KERN, LDSWV, G, LDSB)                                                                       \
+    do {                                                                                                             \
+        if (twoS)      { if ((rc = raise_lds_limit(KERN<LDSWV, G, 2, 2>, LDSB))) return rc; KERN<LDSWV, G, 2, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        else if (twoR) { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 2>, LDSB))) return rc; KERN<LDSWV, G, 1, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        else           { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 1>, LDSB))) return rc; KERN<LDSWV, G, 1, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+    } while (0)
 #define FARNN_TRAIN_CHAIN(KERN, LDSWV, LDSB)                                                              \
     do {                                                                                                  \
-        if (farnn) {                                                                                      \
-            if (two) { if ((rc = raise_lds_limit(KERN<LDSWV, true, 2>, LDSB))) return rc; KERN<LDSWV, true, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); }   \
-            else     { if ((rc = raise_lds_limit(KERN<LDSWV, true, 1>, LDSB))) return rc; KERN<LDSWV, true, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); }   \
-        } else {                                                                                          \
-            if (two) { if ((rc = raise_lds_limit(KERN<LDSWV, false, 2>, LDSB))) return rc; KERN<LDSWV, false, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
-            else     { if ((rc = raise_lds_limit(KERN<LDSWV, false, 1>, LDSB))) return rc; KERN<LDSWV, false, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
-        }                                                                                                 \
+        if (farnn) FARNN_TRAIN_CHAIN2(KERN, LDSWV, true, LDSB);                                           \
+        else       FARNN_TRAIN_CHAIN2(KERN, LDSWV, false, LDSB);                                          \
     } while (0)
     if (ldsw_f) FARNN_TRAIN_CHAIN(train_forward_kernel, true, lds_f);
     else        FARNN_TRAIN_CHAIN(train_forward_kernel, false, lds_f);
@@ -1505,6 +1506,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     if (ldsw_b) FARNN_TRAIN_CHAIN(train_backward_kernel, true, lds_b);
     else        FARNN_TRAIN_CHAIN(train_backward_kernel, false, lds_b);
 #undef FARNN_TRAIN_CHAIN
+#undef FARNN_TRAIN_CHAIN2
     float *dGVT = nullptr;
     if (farnn) {                                       // dGV^T ([S][V]) as the A operand of dVgen += dGV Wrs^T
         dGVT = c->GV + 4 * V * S;

@@ -233,9 +233,10 @@ train_prep_kernel(const PrepJobs jobs) {
 // grid (ceil(B/2), 2): blockIdx.y = 0 forward, 1 backward chain; TR_NSEQ sequences per workgroup.  LDSW: the three
 // matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
 // LDS: [M1 | M2 | M3] f[2][S] tv[2][R] part[4][2][max(S,R)] part2[4][2][S]
-template <bool LDSW, bool GATED, int VPT>
+template <bool LDSW, bool GATED, int VPS, int VPR>
 __global__ void __launch_bounds__(TR_THREADS)
 train_forward_kernel(const TrainParams p) {
+    constexpr int VPT = VPS > VPR ? VPS : VPR;       // slots per thread: VPS cover 2 S states, VPR cover 2 R ranks
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
     const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
@@ -291,8 +292,9 @@ train_forward_kernel(const TrainParams p) {
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
-        sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
-        rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        // slot k of a kind that needs fewer slots than the other is dead at compile time (VPS, VPR): its registers vanish
+        sv[k] = k < VPS && e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = k < VPR && e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         srow[k] = (long long)(b0 + sq[k]) * (p.L + 1) * S + ss[k];
     }
     float *stash_out = dir == 0 ? p.A : p.Bk;
@@ -767,9 +769,10 @@ __global__ void crf_reduce_kernel(const float *__restrict__ part, float *dtrans,
 // grid (ceil(B/2), 2), TR_NSEQ sequences per workgroup.  LDSW: the four matrices of this direction
 // (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
 // LDS: [Ma | Mb | Mc | Md] z fp [2][mv_pad(S)], d1 [2][mv_pad(R)], pa pb [8][2][max(S,R)], pc [8][2][S], toks [2][L]
-template <bool LDSW, bool GATED, int VPT>
+template <bool LDSW, bool GATED, int VPS, int VPR>
 __global__ void __launch_bounds__(TR_THREADS)
 train_backward_kernel(const TrainParams p) {
+    constexpr int VPT = VPS > VPR ? VPS : VPR;       // slots per thread: VPS cover 2 S states, VPR cover 2 R ranks
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
     const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
@@ -821,8 +824,9 @@ train_backward_kernel(const TrainParams p) {
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
-        sv[k] = e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
-        rv[k] = e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        // slot k of a kind that needs fewer slots than the other is dead at compile time (VPS, VPR): its registers vanish
+        sv[k] = k < VPS && e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = k < VPR && e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         sv[k] = sv[k] && b0 + sq[k] < p.B;
         rv[k] = rv[k] && b0 + rq[k] < p.B;
         srow[k] = (long long)(b0 + (sv[k] ? sq[k] : 0)) * (p.L + 1) * S + ss[k];

@@ -441,11 +441,13 @@ def test_train_step_through_l2_kernels_match_reference(k, mode, monkeypatch):
     test_train_step_matches_reference_loss_and_gradients(k)
 
 
-def test_train_step_rank_250_gated_crf_vs_batched_oracle(monkeypatch):
-    """The shipped configurations' shape (rank 250, gates, CRF) on a small batch: the instantiation bench.py times."""
+@pytest.mark.parametrize('R', [250, 300])
+def test_train_step_rank_250_gated_crf_vs_batched_oracle(R):
+    """The shipped configurations' shape (rank 250, gates, CRF) on a small batch: the instantiation bench.py times;
+    rank 300 needs two rank slots per thread (2 R > 512 threads) but one state slot."""
     from re2nn_seq_amd import _lib
-    rng = np.random.RandomState(250)
-    V, S, R, K, B, L, D, farnn = 120, 104, 250, 75, 6, 17, 8, 2
+    rng = np.random.RandomState(R)
+    V, S, K, B, L, D, farnn = 120, 104, 75, 6, 17, 8, 2
     f = lambda *shape, sc=0.3: torch.from_numpy((rng.randn(*shape) * sc).astype(np.float32))   # noqa: E731
     Cm = np.zeros((K, S), np.float32)
     Cm[rng.randint(0, K - 2, size=S), np.arange(S)] = (rng.rand(S) < 0.8)
