@@ -1226,6 +1226,7 @@ struct farnn_train_ctx {
     float *S1T = nullptr, *S2T = nullptr, *WT = nullptr, *Osum = nullptr, *dOsum = nullptr;
     float *Wss1T = nullptr, *Wss2T = nullptr, *Wrs1T = nullptr, *Wrs2T = nullptr;   // gate transposes (farnn > 0)
     float *VgenT = nullptr, *GV = nullptr;   // [R][V] and 2 x [V][S]: the gates' input halves Vgen Wrs (farnn > 0)
+    int n_cu = 256;               // compute units of the device
     float *ones = nullptr;        // [ones_n] of 1.0f: bias gradients as a product with a column of ones
     size_t ones_n = 0;
     int profiling = 0;
@@ -1245,6 +1246,10 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
     if ((rc = select_device(device))) return rc;
     farnn_train_ctx *c = new farnn_train_ctx();
     c->d = *d; c->device = device;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) c->n_cu = ncu;
+    }
     const size_t S = d->S, R = d->R;
     float *blk = nullptr;
     if (hipMalloc((void **)&blk, (2 * S * R + S * S + 2 * S + (d->farnn ? 2 * S * S + 2 * S * R : 0)) * sizeof(float)) != hipSuccess) {
@@ -1445,37 +1450,57 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t lds_l = lds_lw + (clds ? lds_lc : 0);
     const size_t nwv = TR_THREADS / 64;
     const size_t SPd = ((S + 3) & ~(size_t)3) + 8, RPd = ((R + 3) & ~(size_t)3) + 8;
-    const size_t vec_f = (2 * SPd + 2 * RPd + 2 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
-                          (farnn ? 2 * SPd + 2 * 2 * nwv * S : 0)) * sizeof(float);
-    const size_t vec_b = (4 * SPd + 2 * RPd + 4 * nwv * SR + 2 * nwv * S + 2 * (size_t)L +
-                          (farnn ? 4 * SPd : 0)) * sizeof(float);
+    // LDS of the vectors, partial sums and token lists of a chain workgroup with ns sequences
+    auto vecf = [&](size_t ns) { return (ns * SPd + ns * RPd + ns * nwv * SR + ns * nwv * S + ns * (size_t)L +
+                                         (farnn ? ns * SPd + 2 * ns * nwv * S : 0)) * sizeof(float); };
+    auto vecb = [&](size_t ns) { return (2 * ns * SPd + ns * RPd + 2 * ns * nwv * SR + ns * nwv * S + ns * (size_t)L +
+                                         (farnn ? 2 * ns * SPd : 0)) * sizeof(float); };
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
-    const bool ldsw_f = vec_f + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
-    const bool ldsw_b = vec_b + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    const bool ldsw_f = vecf(TR_NSEQ) + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    const bool ldsw_b = vecb(TR_NSEQ) + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    // sequences per workgroup: two with the matrices in LDS; four when they are read through L2 every step (that mode
+    // is bound by the L2 rate, and every element read then feeds four sequences) if the batch still fills the chip
+    const size_t lds_cap = 156 * 1024;
+    auto pick_ns = [&](bool ldsw, size_t vec4) -> int {
+        const int forced = env_int("FARNN_TRAIN_NSEQ", 0);
+        if (ldsw) return TR_NSEQ;
+        const bool fits = TR_NSEQ_L2 * SR <= (size_t)TR_VPT * TR_THREADS && vec4 + 16 <= lds_cap;
+        if (forced == 2 || !fits) return TR_NSEQ;
+        // measured at rank 250: with 256 sequences four per workgroup leave half the CUs idle (2.98 vs 2.63 ms per step),
+        // with 1024 they win (6.5 vs 8.3 ms): four once two-sequence workgroups would outnumber the CUs two to one
+        return (forced == 4 || (size_t)B >= 2 * (size_t)c->n_cu) ? TR_NSEQ_L2 : TR_NSEQ;
+    };
+    const int ns_f = pick_ns(ldsw_f, vecf(TR_NSEQ_L2)), ns_b = pick_ns(ldsw_b, vecb(TR_NSEQ_L2));
+    const size_t vec_f = vecf(ns_f), vec_b = vecb(ns_b);
     // through-L2 kernels keep as many of their S x S matrices in LDS as fit (wildcard matrix, then the gates' Wss)
-    const size_t ssb = S * S * sizeof(float), lds_cap = 156 * 1024;
+    const size_t ssb = S * S * sizeof(float);
     const size_t want_ss = farnn == 2 ? 3 : (farnn == 1 ? 2 : 1);
     p.nss_f = ldsw_f || vec_f + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_f - 16) / ssb);
     p.nss_b = ldsw_b || vec_b + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_b - 16) / ssb);
     if (env_int("FARNN_TRAIN_NOLDS", 0) > 1) p.nss_f = p.nss_b = 0;
     const size_t lds_f = vec_f + (ldsw_f ? mat_f : 16 + p.nss_f * ssb), lds_b = vec_b + (ldsw_b ? mat_b : 16 + p.nss_b * ssb);
-    const dim3 cgrid((B + TR_NSEQ - 1) / TR_NSEQ, 2);
     int rc;
-    // instantiation: weights in LDS or through L2, with or without the gate state, one or two slots per thread
-    const bool twoS = 2 * S > (size_t)TR_THREADS, twoR = 2 * R > (size_t)TR_THREADS;
-#define FARNN_TRAIN_CHAIN2(KERN, LDSWV, G, LDSB)                                                                       \
+    // instantiation: weights in LDS or through L2, with or without the gate state, slots per thread, sequences per workgroup
+#define FARNN_TRAIN_CHAIN3(KERN, LDSWV, G, NSV, LDSB)                                                                  \
     do {                                                                                                             \
-        if (twoS)      { if ((rc = raise_lds_limit(KERN<LDSWV, G, 2, 2>, LDSB))) return rc; KERN<LDSWV, G, 2, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
-        else if (twoR) { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 2>, LDSB))) return rc; KERN<LDSWV, G, 1, 2><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
-        else           { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 1>, LDSB))) return rc; KERN<LDSWV, G, 1, 1><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        const dim3 cgrid((B + NSV - 1) / NSV, 2);                                                                    \
+        const bool twoS = NSV * S > (size_t)TR_THREADS, twoR = NSV * R > (size_t)TR_THREADS;                        \
+        if (twoS)      { if ((rc = raise_lds_limit(KERN<LDSWV, G, 2, 2, NSV>, LDSB))) return rc; KERN<LDSWV, G, 2, 2, NSV><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        else if (twoR) { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 2, NSV>, LDSB))) return rc; KERN<LDSWV, G, 1, 2, NSV><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
+        else           { if ((rc = raise_lds_limit(KERN<LDSWV, G, 1, 1, NSV>, LDSB))) return rc; KERN<LDSWV, G, 1, 1, NSV><<<cgrid, TR_THREADS, LDSB, s>>>(p); } \
     } while (0)
-#define FARNN_TRAIN_CHAIN(KERN, LDSWV, LDSB)                                                              \
+#define FARNN_TRAIN_CHAIN(KERN, LDSWV, NSR, LDSB)                                                         \
     do {                                                                                                  \
-        if (farnn) FARNN_TRAIN_CHAIN2(KERN, LDSWV, true, LDSB);                                           \
-        else       FARNN_TRAIN_CHAIN2(KERN, LDSWV, false, LDSB);                                          \
+        if (LDSWV || NSR == TR_NSEQ) {                                                                    \
+            if (farnn) FARNN_TRAIN_CHAIN3(KERN, LDSWV, true, TR_NSEQ, LDSB);                              \
+            else       FARNN_TRAIN_CHAIN3(KERN, LDSWV, false, TR_NSEQ, LDSB);                             \
+        } else {                                                                                          \
+            if (farnn) FARNN_TRAIN_CHAIN3(KERN, false, true, TR_NSEQ_L2, LDSB);                           \
+            else       FARNN_TRAIN_CHAIN3(KERN, false, false, TR_NSEQ_L2, LDSB);                          \
+        }                                                                                                 \
     } while (0)
-    if (ldsw_f) FARNN_TRAIN_CHAIN(train_forward_kernel, true, lds_f);
-    else        FARNN_TRAIN_CHAIN(train_forward_kernel, false, lds_f);
+    if (ldsw_f) FARNN_TRAIN_CHAIN(train_forward_kernel, true, ns_f, lds_f);
+    else        FARNN_TRAIN_CHAIN(train_forward_kernel, false, ns_f, lds_f);
     {
         int dev = 0, ncu = 0;
         (void)hipGetDevice(&dev);
@@ -1503,10 +1528,10 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         }
 #undef FARNN_LAUNCH_LOSS
     }
-    if (ldsw_b) FARNN_TRAIN_CHAIN(train_backward_kernel, true, lds_b);
-    else        FARNN_TRAIN_CHAIN(train_backward_kernel, false, lds_b);
+    if (ldsw_b) FARNN_TRAIN_CHAIN(train_backward_kernel, true, ns_b, lds_b);
+    else        FARNN_TRAIN_CHAIN(train_backward_kernel, false, ns_b, lds_b);
 #undef FARNN_TRAIN_CHAIN
-#undef FARNN_TRAIN_CHAIN2
+#undef FARNN_TRAIN_CHAIN3
     float *dGVT = nullptr;
     if (farnn) {                                       // dGV^T ([S][V]) as the A operand of dVgen += dGV Wrs^T
         dGVT = c->GV + 4 * V * S;

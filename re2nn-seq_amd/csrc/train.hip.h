@@ -66,7 +66,9 @@ __device__ __forceinline__ float nl_grad_from_output(float y, int nl) {
 
 constexpr int TR_THREADS = 512;  // chain kernels: 8 wavefronts split every matrix-vector product's reduction index
 constexpr int TR_VPT = 2;        // per-thread slots covering 2 R (R <= 512) and 2 S (S <= 512) values
-constexpr int TR_NSEQ = 2;      // sequences per workgroup of the chain kernels: every weight element read feeds both
+constexpr int TR_NSEQ = 2;      // sequences per workgroup of the chain kernels when the matrices sit in LDS (every element read
+                                 // feeds both); TR_NSEQ_L2 when they are read through L2 every step (that mode is L2-rate bound)
+constexpr int TR_NSEQ_L2 = 4;
 
 // part[(wave*2+q)*J + j] = sum over this wavefront's share of k of in[q][k] M[k][j]  (M row-major [K][J], in LDS
 // or global memory; `in` = two vectors of stride ldin in LDS).  The caller adds the wavefronts' shares after a barrier.
@@ -81,7 +83,7 @@ __device__ __forceinline__ int mv_pad(int n) { return ((n + 3) & ~3) + 8; }     
 // two vectors of stride ldin = mv_pad(K) in LDS, 16-byte aligned, zero beyond K).  Measured on the first version (one
 // LDS read per operand): 5.8 k cycles for the two products of a step, 2/3 of the LDS instructions being broadcast reads
 // of `in` -- those are 16-byte reads here, and the shares start at multiples of 4.
-template <bool INLDS>
+template <bool INLDS, int NS>
 __device__ __forceinline__ void matvec2_partial(float *part, const float *in, int ldin, const float *__restrict__ M, int K,
                                                 int J, int tid, int /*nthreads*/) {
     const int njb = (J + 63) >> 6, nks = mv_nks(J);
@@ -93,43 +95,53 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
     const int k0 = 4 * ((K4 * ks) / nks), k1r = 4 * ((K4 * (ks + 1)) / nks), k1 = k1r < K ? k1r : K;
     const bool jok = j < J;
     const int jc = jok ? j : J - 1;
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+    float a[NS][4];
+#pragma unroll
+    for (int q = 0; q < NS; q++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) a[q][e] = 0.0f;
     // 32-bit offsets stepped by J (64-bit index arithmetic per operand cost more than the reads).  A round past the
     // end of the share is masked after the reads; the matrix rows it touches are read unguarded when the matrix is
-    // in LDS (they stay inside the allocation) and clamped to the last row otherwise.
+    // in LDS (they stay inside the allocation) and clamped to the last row otherwise.  Every matrix element read
+    // feeds the NS sequences of the workgroup.
     int off = k0 * J + jc;
     const int last = (K - 1) * J + jc;
     for (int k = k0; k < k1; k += 8, off += 8 * J) {
         float m[8];
-        v4f x0a = *(const v4f *)(in + k), x0b = *(const v4f *)(in + k + 4);
-        v4f x1a = *(const v4f *)(in + ldin + k), x1b = *(const v4f *)(in + ldin + k + 4);
+        v4f xa[NS], xb[NS];
+#pragma unroll
+        for (int q = 0; q < NS; q++) { xa[q] = *(const v4f *)(in + q * ldin + k); xb[q] = *(const v4f *)(in + q * ldin + k + 4); }
 #pragma unroll
         for (int u = 0; u < 8; u++) {
             const int o = off + u * J;
             m[u] = M[INLDS ? o : (o < last ? o : last)];
         }
         const int left = k1 - k;                          // wave-uniform
-        if (left < 8) {                                   // both operands: whatever sits past the share (another share's
-#pragma unroll                                            // inputs, LDS beyond the matrix -- possibly NaN) must not count
-            for (int u = 0; u < 4; u++) {
-                if (u >= left) { x0a[u] = 0.0f; x1a[u] = 0.0f; m[u] = 0.0f; }
-                if (4 + u >= left) { x0b[u] = 0.0f; x1b[u] = 0.0f; m[4 + u] = 0.0f; }
-            }
+        if (left < 8) {                                   // whatever sits past the share (another share's inputs, LDS beyond
+#pragma unroll                                            // the matrix -- possibly NaN) must not count: the matrix side is zeroed
+            for (int u = 0; u < 8; u++) if (u >= left) m[u] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < NS; q++)
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (u >= left) xa[q][u] = 0.0f;
+                    if (4 + u >= left) xb[q][u] = 0.0f;
+                }
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] = fmaf(x0a[u], m[u], a[u]); c[u] = fmaf(x1a[u], m[u], c[u]);
-        }
+        for (int q = 0; q < NS; q++) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            a[u] = fmaf(x0b[u], m[4 + u], a[u]); c[u] = fmaf(x1b[u], m[4 + u], c[u]);
+            for (int u = 0; u < 4; u++) a[q][u] = fmaf(xa[q][u], m[u], a[q][u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[q][u] = fmaf(xb[q][u], m[4 + u], a[q][u]);
         }
     }
     if (jok) {
-        part[(ks * 2 + 0) * J + j] = (a[0] + a[1]) + (a[2] + a[3]);
-        part[(ks * 2 + 1) * J + j] = (c[0] + c[1]) + (c[2] + c[3]);
+#pragma unroll
+        for (int q = 0; q < NS; q++) part[(ks * NS + q) * J + j] = (a[q][0] + a[q][1]) + (a[q][2] + a[q][3]);
     }
 }
+template <int NS>
 __device__ __forceinline__ float part2_sum(const float *part, int J, int q, int j, int /*nw*/) {
     // all shares are read before any is added (at most 8): a read-add chain over LDS costs ~105 cycles per element
     // (scripts/probe/lds_rate.hip), independent reads ~12
@@ -137,7 +149,7 @@ __device__ __forceinline__ float part2_sum(const float *part, int J, int q, int 
     const int nks = mv_nks(J);
     float v[NW];
 #pragma unroll
-    for (int w = 0; w < NW; w++) v[w] = w < nks ? part[((w < nks ? w : 0) * 2 + q) * J + j] : 0.0f;
+    for (int w = 0; w < NW; w++) v[w] = w < nks ? part[((w < nks ? w : 0) * NS + q) * J + j] : 0.0f;
     float s = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; w++) s += v[w];
@@ -233,17 +245,17 @@ train_prep_kernel(const PrepJobs jobs) {
 // grid (ceil(B/2), 2): blockIdx.y = 0 forward, 1 backward chain; TR_NSEQ sequences per workgroup.  LDSW: the three
 // matrices of this direction (2 S R + S S floats) are staged in LDS once; otherwise they are read through L2.
 // LDS: [M1 | M2 | M3] f[2][S] tv[2][R] part[4][2][max(S,R)] part2[4][2][S]
-template <bool LDSW, bool GATED, int VPS, int VPR>
+template <bool LDSW, bool GATED, int VPS, int VPR, int NS>
 __global__ void __launch_bounds__(TR_THREADS)
 train_forward_kernel(const TrainParams p) {
     constexpr int VPT = VPS > VPR ? VPS : VPR;       // slots per thread: VPS cover 2 S states, VPR cover 2 R ranks
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
-    const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
+    const int b0 = blockIdx.x * NS, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
     float *wl = smem;
     const int SP = mv_pad(S), RP = mv_pad(R);                  // strides of the two sequences' vectors (zero pads)
-    float *f = smem + (LDSW ? ((2 * S * R + S * S + 3) & ~3) : 0), *tv = f + 2 * SP, *part = tv + 2 * RP, *part2 = part + nw * 2 * SR;
+    float *f = smem + (LDSW ? ((2 * S * R + S * S + 3) & ~3) : 0), *tv = f + NS * SP, *part = tv + NS * RP, *part2 = part + nw * NS * SR;
     const float *M1 = dir == 0 ? p.S1 : p.S2, *M2 = dir == 0 ? p.W : p.WT, *M3 = dir == 0 ? p.S2T : p.S1T;
     if (LDSW) {
         stage_matrix(wl, M1, S * R, tid, nt);
@@ -251,32 +263,32 @@ train_forward_kernel(const TrainParams p) {
         stage_matrix(wl + S * R + S * S, M3, R * S, tid, nt);
         M1 = wl; M2 = wl + S * R; M3 = wl + S * R + S * S;
     }
-    int len[TR_NSEQ], maxlen = 0;
-    for (int q = 0; q < TR_NSEQ; q++) {
+    int len[NS], maxlen = 0;
+    for (int q = 0; q < NS; q++) {
         len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
         maxlen = len[q] > maxlen ? len[q] : maxlen;
     }
     // the token of every step, in step order, so that no step waits for an index load
-    int *toks = (int *)(part2 + nw * 2 * S);                  // [TR_NSEQ][L]
+    int *toks = (int *)(part2 + nw * NS * S);                  // [NS][L]
     // gated steps: raw state and v_t as matvec inputs, four more partial buffers
-    float *hv = (float *)(toks + TR_NSEQ * p.L), *pg = hv + 2 * SP;
+    float *hv = (float *)(toks + NS * p.L), *pg = hv + NS * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     // through-L2 instantiation: the S x S matrices that still fit stay in LDS (W first, then the gates' Wss)
-    float *ssl = smem + (((int)((GATED ? pg + 2 * nw * 2 * S : hv) - smem) + 3) & ~3);  // offsets in floats: keeps the LDS address space
+    float *ssl = smem + (((int)((GATED ? pg + 2 * nw * NS * S : hv) - smem) + 3) & ~3);  // offsets in floats: keeps the LDS address space
     const int nss = LDSW ? 0 : p.nss_f;
     const float *M2l = ssl, *G1l = ssl + S * S, *G2l = ssl + 2 * S * S;
     const bool l_m2 = nss >= 1, l_g1 = GATED && nss >= 2, l_g2 = GATED && nss >= 3;
     if (l_m2) stage_matrix(ssl, M2, S * S, tid, nt);
     if (l_g1 && farnn) stage_matrix(ssl + S * S, p.Wss1, S * S, tid, nt);
     if (l_g2 && farnn == 2) stage_matrix(ssl + 2 * S * S, p.Wss2, S * S, tid, nt);
-    for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
+    for (int e = tid; e < NS * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
-    for (int e = tid; e < 2 * SP + 2 * RP; e += nt) f[e] = 0.0f;          // f | tv contiguous: pads stay zero
-    if (farnn) for (int e = tid; e < 2 * SP; e += nt) hv[e] = 0.0f;
+    for (int e = tid; e < NS * SP + NS * RP; e += nt) f[e] = 0.0f;          // f | tv contiguous: pads stay zero
+    if (farnn) for (int e = tid; e < NS * SP; e += nt) hv[e] = 0.0f;
     __syncthreads();
-    for (int e = tid; e < TR_NSEQ * S; e += nt) {
+    for (int e = tid; e < NS * S; e += nt) {
         const int q = e / S, s = e - q * S;
         const float h = dir == 0 ? p.h0[s] : p.hT[s];
         if (b0 + q < p.B) (dir == 0 ? p.A : p.Bk)[(long long)(b0 + q) * (p.L + 1) * S + s] = h;
@@ -293,8 +305,8 @@ train_forward_kernel(const TrainParams p) {
     for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
         // slot k of a kind that needs fewer slots than the other is dead at compile time (VPS, VPR): its registers vanish
-        sv[k] = k < VPS && e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
-        rv[k] = k < VPR && e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        sv[k] = k < VPS && e < NS * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = k < VPR && e < NS * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         srow[k] = (long long)(b0 + sq[k]) * (p.L + 1) * S + ss[k];
     }
     float *stash_out = dir == 0 ? p.A : p.Bk;
@@ -333,21 +345,21 @@ train_forward_kernel(const TrainParams p) {
             // halves v Wrs do not depend on the state: they are rows of GV = Vgen Wrs (one product per step for the whole
             // vocabulary, before the recurrences), fetched one step ahead like v itself -- the two largest products of
             // the gate phase (K = R) leave the sequential loop
-            if (l_g1) matvec2_partial<true>(pg, hv, SP, G1l, S, S, tid, nt);
-            else matvec2_partial<false>(pg, hv, SP, p.Wss1, S, S, tid, nt);
+            if (l_g1) matvec2_partial<true, NS>(pg, hv, SP, G1l, S, S, tid, nt);
+            else matvec2_partial<false, NS>(pg, hv, SP, p.Wss1, S, S, tid, nt);
             if (farnn == 2) {
-                if (l_g2) matvec2_partial<true>(pg + nw * 2 * S, hv, SP, G2l, S, S, tid, nt);
-                else matvec2_partial<false>(pg + nw * 2 * S, hv, SP, p.Wss2, S, S, tid, nt);
+                if (l_g2) matvec2_partial<true, NS>(pg + nw * NS * S, hv, SP, G2l, S, S, tid, nt);
+                else matvec2_partial<false, NS>(pg + nw * NS * S, hv, SP, p.Wss2, S, S, tid, nt);
             }
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
                 if (sv[k]) {
-                    const float az = part2_sum(pg, S, sq[k], ss[k], nw) + g1c[k] + p.bs1[ss[k]];
+                    const float az = part2_sum<NS>(pg, S, sq[k], ss[k], nw) + g1c[k] + p.bs1[ss[k]];
                     zk[k] = 1.0f / (1.0f + expf(-p.sig_k * az));
                     float hbar = hk[k];
                     if (farnn == 2) {
-                        const float ar = part2_sum(pg + nw * 2 * S, S, sq[k], ss[k], nw) + g2c[k] + p.bs2[ss[k]];
+                        const float ar = part2_sum<NS>(pg + nw * NS * S, S, sq[k], ss[k], nw) + g2c[k] + p.bs2[ss[k]];
                         rk[k] = 1.0f / (1.0f + expf(-p.sig_k * ar));
                         hbar = (1.0f - rk[k]) * hin[k] + rk[k] * hk[k];
                     }
@@ -357,20 +369,20 @@ train_forward_kernel(const TrainParams p) {
             wg_barrier_lds();
         }
         // rr = f . (S1 | S2) and the wildcard part f . (W | W^T): both depend on f only
-        matvec2_partial<LDSW>(part, f, SP, M1, S, R, tid, nt);
-        if (l_m2) matvec2_partial<true>(part2, f, SP, M2l, S, S, tid, nt);
-        else matvec2_partial<LDSW>(part2, f, SP, M2, S, S, tid, nt);
+        matvec2_partial<LDSW, NS>(part, f, SP, M1, S, R, tid, nt);
+        if (l_m2) matvec2_partial<true, NS>(part2, f, SP, M2l, S, S, tid, nt);
+        else matvec2_partial<LDSW, NS>(part2, f, SP, M2, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++)
-            if (rv[k]) tv[rq[k] * RP + rr_[k]] = vcur[k] * part2_sum(part, R, rq[k], rr_[k], nw);     // temp = V_vec * _RR
+            if (rv[k]) tv[rq[k] * RP + rr_[k]] = vcur[k] * part2_sum<NS>(part, R, rq[k], rr_[k], nw);     // temp = V_vec * _RR
         wg_barrier_lds();
-        matvec2_partial<LDSW>(part, tv, RP, M3, R, S, tid, nt);                              // temp . (S2^T | S1^T)
+        matvec2_partial<LDSW, NS>(part, tv, RP, M3, R, S, tid, nt);                              // temp . (S2^T | S1^T)
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
-                const float pre = part2_sum(part, S, sq[k], ss[k], nw) + part2_sum(part2, S, sq[k], ss[k], nw);
+                const float pre = part2_sum<NS>(part, S, sq[k], ss[k], nw) + part2_sum<NS>(part2, S, sq[k], ss[k], nw);
                 const long long row = srow[k] + (long long)t * S;
                 float h;
                 if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * osum[k], p.nl); }      // (:181)
@@ -769,18 +781,18 @@ __global__ void crf_reduce_kernel(const float *__restrict__ part, float *dtrans,
 // grid (ceil(B/2), 2), TR_NSEQ sequences per workgroup.  LDSW: the four matrices of this direction
 // (3 S R + S S floats) live in LDS.  The forward chain's pre-activation is read from the stash (PRE), not recomputed.
 // LDS: [Ma | Mb | Mc | Md] z fp [2][mv_pad(S)], d1 [2][mv_pad(R)], pa pb [8][2][max(S,R)], pc [8][2][S], toks [2][L]
-template <bool LDSW, bool GATED, int VPS, int VPR>
+template <bool LDSW, bool GATED, int VPS, int VPR, int NS>
 __global__ void __launch_bounds__(TR_THREADS)
 train_backward_kernel(const TrainParams p) {
     constexpr int VPT = VPS > VPR ? VPS : VPR;       // slots per thread: VPS cover 2 S states, VPR cover 2 R ranks
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, nw = nt >> 6;
-    const int b0 = blockIdx.x * TR_NSEQ, dir = blockIdx.y;
+    const int b0 = blockIdx.x * NS, dir = blockIdx.y;
     const int S = p.S, R = p.R, SR = S > R ? S : R;
     float *wl = smem;
     const int SP = mv_pad(S), RP = mv_pad(R);                  // strides of the matvec inputs z, fp, d1 (zero pads)
-    float *z = smem + (LDSW ? ((3 * S * R + S * S + 3) & ~3) : 0), *fp = z + 2 * SP, *d1 = fp + 2 * SP;
-    float *pa = d1 + 2 * RP, *pb = pa + nw * 2 * SR, *pc = pb + nw * 2 * SR;
+    float *z = smem + (LDSW ? ((3 * S * R + S * S + 3) & ~3) : 0), *fp = z + NS * SP, *d1 = fp + NS * SP;
+    float *pa = d1 + NS * RP, *pb = pa + nw * NS * SR, *pc = pb + nw * NS * SR;
     // rr = fp . Ma, u = z . Mb, d fp = z . Mc + d1 . Md
     const float *Ma = dir == 0 ? p.S1 : p.S2, *Mb = dir == 0 ? p.S2 : p.S1, *Mc = dir == 0 ? p.WT : p.W,
                 *Md = dir == 0 ? p.S1T : p.S2T;
@@ -791,29 +803,29 @@ train_backward_kernel(const TrainParams p) {
         stage_matrix(wl + 2 * S * R + S * S, Md, R * S, tid, nt);
         Ma = wl; Mb = wl + S * R; Mc = wl + 2 * S * R; Md = wl + 2 * S * R + S * S;
     }
-    int len[TR_NSEQ], maxlen = 0;
-    for (int q = 0; q < TR_NSEQ; q++) {
+    int len[NS], maxlen = 0;
+    for (int q = 0; q < NS; q++) {
         len[q] = b0 + q < p.B ? clamp_len(p.len[b0 + q], p.L) : 0;
         maxlen = len[q] > maxlen ? len[q] : maxlen;
     }
-    int *toks = (int *)(pc + nw * 2 * S);                     // [TR_NSEQ][L] tokens in step order
+    int *toks = (int *)(pc + nw * NS * S);                     // [NS][L] tokens in step order
     // gated steps: the gate pre-activation adjoints as matvec inputs and a fourth partial buffer
-    float *dazv = (float *)(toks + TR_NSEQ * p.L), *darv = dazv + 2 * SP;
+    float *dazv = (float *)(toks + NS * p.L), *darv = dazv + NS * SP;
     const int farnn = GATED ? p.farnn : 0;             // the ungated instantiation carries none of the gate state
     // through-L2 instantiation: the S x S matrices that still fit stay in LDS (W^T|W first, then the gates' Wss^T)
-    float *ssl = smem + (((int)((GATED ? darv + 2 * SP : dazv) - smem) + 3) & ~3);
+    float *ssl = smem + (((int)((GATED ? darv + NS * SP : dazv) - smem) + 3) & ~3);
     const int nss = LDSW ? 0 : p.nss_b;
     const float *Mcl = ssl, *G1l = ssl + S * S, *G2l = ssl + 2 * S * S;
     const bool l_mc = nss >= 1, l_g1 = GATED && nss >= 2, l_g2 = GATED && nss >= 3;
     if (l_mc) stage_matrix(ssl, Mc, S * S, tid, nt);
     if (l_g1 && farnn) stage_matrix(ssl + S * S, p.Wss1T, S * S, tid, nt);
     if (l_g2 && farnn == 2) stage_matrix(ssl + 2 * S * S, p.Wss2T, S * S, tid, nt);
-    for (int e = tid; e < TR_NSEQ * p.L; e += nt) {
+    for (int e = tid; e < NS * p.L; e += nt) {
         const int q = e / p.L, i = e - q * p.L;
         toks[e] = i < len[q] ? clamp_tok(p.x[(long long)(b0 + q) * p.L + (dir == 0 ? i : len[q] - 1 - i)], p.V) : 0;
     }
-    for (int e = tid; e < 4 * SP + 2 * RP; e += nt) z[e] = 0.0f;          // z fp d1 contiguous: pads stay zero
-    if (farnn) for (int e = tid; e < 4 * SP; e += nt) dazv[e] = 0.0f;       // dazv | darv contiguous
+    for (int e = tid; e < 2 * NS * SP + NS * RP; e += nt) z[e] = 0.0f;          // z fp d1 contiguous: pads stay zero
+    if (farnn) for (int e = tid; e < 2 * NS * SP; e += nt) dazv[e] = 0.0f;       // dazv | darv contiguous
     __syncthreads();
     // per-thread slots, fixed for the whole kernel (no divisions in the time loop); g, y and dOsum of a slot are only
     // ever touched by its owner, so they live in registers
@@ -825,8 +837,8 @@ train_backward_kernel(const TrainParams p) {
     for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
         // slot k of a kind that needs fewer slots than the other is dead at compile time (VPS, VPR): its registers vanish
-        sv[k] = k < VPS && e < TR_NSEQ * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
-        rv[k] = k < VPR && e < TR_NSEQ * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
+        sv[k] = k < VPS && e < NS * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
+        rv[k] = k < VPR && e < NS * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         sv[k] = sv[k] && b0 + sq[k] < p.B;
         rv[k] = rv[k] && b0 + rq[k] < p.B;
         srow[k] = (long long)(b0 + (sv[k] ? sq[k] : 0)) * (p.L + 1) * S + ss[k];
@@ -908,10 +920,10 @@ train_backward_kernel(const TrainParams p) {
             }
         }
         wg_barrier_lds();
-        matvec2_partial<LDSW>(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
-        matvec2_partial<LDSW>(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
-        if (l_mc) matvec2_partial<true>(pc, z, SP, Mcl, S, S, tid, nt);   // d fp through the wildcard matrix
-        else matvec2_partial<LDSW>(pc, z, SP, Mc, S, S, tid, nt);
+        matvec2_partial<LDSW, NS>(pa, fp, SP, Ma, S, R, tid, nt);            // rr  = fp . (S1 | S2)
+        matvec2_partial<LDSW, NS>(pb, z, SP, Mb, S, R, tid, nt);             // u   = z . (S2 | S1)
+        if (l_mc) matvec2_partial<true, NS>(pc, z, SP, Mcl, S, S, tid, nt);   // d fp through the wildcard matrix
+        else matvec2_partial<LDSW, NS>(pc, z, SP, Mc, S, S, tid, nt);
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
@@ -919,7 +931,7 @@ train_backward_kernel(const TrainParams p) {
                 float dd = 0.0f;
                 if (t <= len[rq[k]]) {
                     const long long row = rrow[k] + (long long)t * R;
-                    const float rvv = part2_sum(pa, R, rq[k], rr_[k], nw), uv = part2_sum(pb, R, rq[k], rr_[k], nw);
+                    const float rvv = part2_sum<NS>(pa, R, rq[k], rr_[k], nw), uv = part2_sum<NS>(pb, R, rq[k], rr_[k], nw);
                     const float vv = vcur[k];
                     dd = uv * vv;
                     D1o[row] = dd;
@@ -930,12 +942,12 @@ train_backward_kernel(const TrainParams p) {
             }
         }
         wg_barrier_lds();
-        matvec2_partial<LDSW>(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
+        matvec2_partial<LDSW, NS>(pa, d1, RP, Md, R, S, tid, nt);            // d fp through the language factors
         wg_barrier_lds();
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
-                const float dfp = part2_sum(pc, S, sq[k], ss[k], nw) + part2_sum(pa, S, sq[k], ss[k], nw);
+                const float dfp = part2_sum<NS>(pc, S, sq[k], ss[k], nw) + part2_sum<NS>(pa, S, sq[k], ss[k], nw);
                 float dhb;                                             // adjoint of the (unmasked) chain input
                 if (dir == 0) dhb = dfp;
                 else { dOacc[k] = fmaf(dfp, yk[k], dOacc[k]); dhb = dfp * osum[k]; }       // d Osum += d bbar * (unmasked input)
@@ -960,18 +972,18 @@ train_backward_kernel(const TrainParams p) {
             // (GV = Vgen Wrs): the adjoints daz, dar go to the word's rows of dGV, and d Vgen += dGV Wrs^T, d Wrs = Vgen^T dGV
             // are products over the vocabulary after the loop
             wg_barrier_lds();
-            if (l_g1) matvec2_partial<true>(pa, dazv, SP, G1l, S, S, tid, nt);
-            else matvec2_partial<false>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
+            if (l_g1) matvec2_partial<true, NS>(pa, dazv, SP, G1l, S, S, tid, nt);
+            else matvec2_partial<false, NS>(pa, dazv, SP, p.Wss1T, S, S, tid, nt);
             if (farnn == 2) {
-                if (l_g2) matvec2_partial<true>(pc, darv, SP, G2l, S, S, tid, nt);
-                else matvec2_partial<false>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
+                if (l_g2) matvec2_partial<true, NS>(pc, darv, SP, G2l, S, S, tid, nt);
+                else matvec2_partial<false, NS>(pc, darv, SP, p.Wss2T, S, S, tid, nt);
             }
             wg_barrier_lds();
 #pragma unroll
             for (int k = 0; k < VPT; k++) {
                 if (sv[k] && t <= len[sq[k]]) {
-                    float dh = dhk[k] + part2_sum(pa, S, sq[k], ss[k], nw);
-                    if (farnn == 2) dh += part2_sum(pc, S, sq[k], ss[k], nw);
+                    float dh = dhk[k] + part2_sum<NS>(pa, S, sq[k], ss[k], nw);
+                    if (farnn == 2) dh += part2_sum<NS>(pc, S, sq[k], ss[k], nw);
                     gacc[k] = dh;
                 }
             }

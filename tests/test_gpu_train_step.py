@@ -432,12 +432,15 @@ def test_train_step_random_configurations_soak():
         tc.close()
 
 
-@pytest.mark.parametrize('mode', ['1', '2'])
+@pytest.mark.parametrize('mode', ['1', '2', '1n4'])
 @pytest.mark.parametrize('k', [0, 6, 8, 9])
 def test_train_step_through_l2_kernels_match_reference(k, mode, monkeypatch):
     """The chain kernels that read their matrices through L2 (what large ranks use): FARNN_TRAIN_NOLDS=1 keeps the
-    S x S matrices that fit in LDS, =2 none.  Same fixtures, same bar."""
-    monkeypatch.setenv('FARNN_TRAIN_NOLDS', mode)
+    S x S matrices that fit in LDS, =2 none; 'n4' forces four sequences per workgroup (what batches of 512+ sequences
+    use).  Same fixtures, same bar."""
+    monkeypatch.setenv('FARNN_TRAIN_NOLDS', mode[0])
+    if mode.endswith('n4'):
+        monkeypatch.setenv('FARNN_TRAIN_NSEQ', '4')
     test_train_step_matches_reference_loss_and_gradients(k)
 
 
