@@ -1092,11 +1092,16 @@ atb_reduce_kernel(const AtbJobs jobs) {
     const int e = idx - jb.out0;
     const long long mj = (long long)jb.M * jb.J;
     const float *po = jobs.partial + jb.part_off + e;
-    float s0 = 0.0f, s1 = 0.0f;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;    // eight loads in flight, four chains
     int sp = 0;
-    for (; sp + 1 < jb.nsplit; sp += 2) { s0 += po[sp * mj]; s1 += po[(sp + 1) * mj]; }
-    if (sp < jb.nsplit) s0 += po[sp * mj];
-    atomicAdd(jb.out + e, s0 + s1);                      // two products may share an output (both chains add into dS1, dS2, dW)
+    for (; sp + 8 <= jb.nsplit; sp += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = po[(long long)(sp + u) * mj];
+        s0 += v[0] + v[4]; s1 += v[1] + v[5]; s2 += v[2] + v[6]; s3 += v[3] + v[7];
+    }
+    for (; sp < jb.nsplit; sp++) s0 += po[(long long)sp * mj];
+    atomicAdd(jb.out + e, (s0 + s1) + (s2 + s3));        // two products may share an output (both chains add into dS1, dS2, dW)
 }
 
 // dC[c][s] += dOsum[s] for every label row (Osum = C.sum(0))
