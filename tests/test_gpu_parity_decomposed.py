@@ -272,6 +272,50 @@ def test_decomposed_independent1_scoring_geometries_vs_oracle(S, RO, K, B, L, pr
     np.testing.assert_allclose(gf[valid], scores.cpu().numpy()[valid], rtol=2e-4, atol=2e-4)
 
 
+def test_decomposed_independent1_scoring_soak():
+    """Random shapes of the independent=1 scoring (MFMA path and generic fallback) against the oracle
+    (FARNN_D1_SOAK_ITERS configurations, default 6; 300 ran clean)."""
+    from re2nn_seq_amd import _lib, synth
+    iters = int(os.environ.get('FARNN_D1_SOAK_ITERS', '6'))
+    rng = np.random.RandomState(int(os.environ.get('FARNN_D1_SOAK_SEED', '31')))
+    for it in range(iters):
+        S, RO, K = int(rng.randint(2, 125)), int(rng.randint(1, 90)), int(rng.randint(2, 140))
+        V, R, B, L = int(rng.randint(3, 80)), int(rng.randint(1, 20)), int(rng.randint(1, 40)), int(rng.randint(1, 30))
+        prio = bool(rng.rand() < 0.4)
+        p = {'Vgen': (rng.randn(V, R) * 0.4).astype(np.float32), 'S1': (rng.randn(S, R) * 0.3).astype(np.float32),
+             'S2': (rng.randn(S, R) * 0.3).astype(np.float32), 'W': (rng.rand(S, S) < 0.1).astype(np.float32) * 0.5,
+             'Cout': (rng.randn(K, RO) * 0.5).astype(np.float32), 'S1o': (rng.randn(S, RO) * 0.1).astype(np.float32),
+             'S2o': (rng.randn(S, RO) * 0.1).astype(np.float32), 'Wo': None,
+             'h0': np.eye(S, dtype=np.float32)[0], 'hT': (rng.rand(S) < 0.3).astype(np.float32),
+             'farnn': 0, 'nl': fo.NL_CODES['tanh'], 'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+        P = (np.eye(K) + (rng.rand(K, K) < 0.05) * 0.5).astype(np.float32) if prio else None
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        lengths[rng.randint(0, B)] = L
+        if B > 2:
+            lengths[rng.randint(0, B)] = 0
+        full = bool(rng.rand() < 0.3)
+        h = _lib.create_decomp_ind1(p['Vgen'], p['S1'], p['S2'], p['W'], p['Cout'], p['S1o'], p['S2o'],
+                                    p['h0'], p['hT'], P=P, nl='tanh', threshold=0.5, o_idx=1)
+        xd, ld = _t(x).cuda(), _t(lengths).cuda()
+        tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+        scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_FULL if full else _lib.MODE_LOCAL, tags.data_ptr(), None,
+              scores.data_ptr())
+        torch.cuda.synchronize()
+        tag = 'iteration {}: S={} RO={} K={} V={} R={} B={} L={} prio={} full={}'.format(it, S, RO, K, V, R, B, L, prio, full)
+        Lmax = max(int(lengths.max()), 1)
+        ref = fo.decomp_ind1_scores(p, x, lengths, P=P)
+        got = scores.cpu().numpy()
+        mask = np.arange(L)[None, :] < lengths[:, None]
+        np.testing.assert_allclose(got[:, :Lmax][mask[:, :Lmax]], ref[mask[:, :Lmax]], rtol=2e-4, atol=2e-4, err_msg=tag)
+        assert np.isfinite(got).all(), tag
+        if not full:
+            assert (got[~mask] == 0).all() and (tags.cpu().numpy()[~mask] == -1).all(), tag
+        want = fo.forward_local_tags(got[:, :Lmax], lengths, 0.5, 1)
+        assert np.array_equal(tags.cpu().numpy()[mask], want), tag
+        h.close()
+
+
 # ---------------------------------------------------------------- decomposed independent=0 (a15)
 def _fst_configs():
     with open(os.path.join(GOLDEN, 'decomp_fst_small.json')) as f:
