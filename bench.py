@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
 """Benchmark of the FA-RNN forward tagging path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload ifst|ifst_crf|fst4|decomp]
+    python bench.py --gpus N --steps K --warmup W [--workload ifst|ifst_crf|fst4|decomp|...]
 
-A "step" is one pass of the hot path (farnn_tag through the C-ABI: recurrence chain +
-score/decode kernels, plus the RCCL gather of tag ids when N > 1) over one batch of synthetic
-input already resident in HBM.  Default workload = BASELINE.json configs[1]: ATIS-BIO-sized
-onehot i-FST (V=950, S=71, C=128), batch 256 x seqlen 64 per GPU, lengths ~ U[5,64] with one
-full-length row.  Weak scaling: every rank tags its own 256-sequence
-shard; `value` = valid (non-pad) tokens tagged by all ranks per second.
+A "step" is one pass of the hot path (farnn_tag through the C-ABI: recurrence + score/decode,
+plus the RCCL gather of tag ids when N > 1) over one batch of synthetic input already resident
+in HBM.  Default workload = BASELINE.json configs[1]: ATIS-BIO-sized onehot i-FST (V=950, S=71,
+C=128), batch 256 x seqlen 64 per GPU, lengths ~ U[5,64] with one full-length row (BASELINE.md
+section 3).  Weak scaling: every rank tags its own 256-sequence shard; `value` = valid (non-pad)
+tokens tagged by all ranks per second.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process (which never touches the
+GPU) starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N bench.py ...`),
+relays rank 0's JSON line and exits with the children's status.  Under an external torchrun
+(WORLD_SIZE set) the process is one of the ranks.
 
 Rank 0 prints ONE JSON line (contract in the task statement), carrying
-  roofline     the dominant kernel (chain_kernel) priced against the HBM peak: algorithmic bytes
-               per launch ((2*S*S*4+12) per valid token) / its mean duration measured
-               with HIP events on the launch stream inside the timed region;
-  cpu_baseline the C port of the oracle (oracle/farnn_oracle.c, OpenMP over sequences) timed on
-               this host's cores on the same batch (N=1, rank 0 only) -- also used to re-check
-               the GPU tags after the timed region.
+  roofline      the dominant kernel of the workload against the ceiling that really bounds it (see
+                roofline_for): HBM stream, Infinity-Cache/L2 row gather, f32 VALU or f32 MFMA; its mean
+                duration is measured with HIP events on the launch stream inside the timed region;
+  cpu_baseline  the C port of the oracle (oracle/farnn_oracle.c, OpenMP over sequence-directions, T+W
+                hoisted: the "fair" CPU number) on this host's cores, same batch (N=1, rank 0 only);
+  cpu_baseline_faithful   the numpy restatement of the reference's own algorithm (re-adds T+W every call,
+                walks all L pad steps, batched einsum like model_onehot.py:366-403);
+  parity        the GPU tags (and scores, for the float paths) of the batch that was timed, re-checked
+                against the oracle AFTER the timed region, for whichever workload ran;
+  other_configs (default invocation only) the other single-GPU BASELINE configs -- ifst_crf, decomp
+                (rank 50), fst4 -- timed for a few hundred ms each with their own roofline and parity.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,8 +42,12 @@ os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
-F32_MFMA_PEAK_TFLOPS = 157.3   # dense f32 MFMA peak (64 FLOP/clk/SIMD; MI355X_MICROARCH.md)
+# ceilings (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0            # HBM3E spec peak; ~6300 achievable with a float4 copy
+IC_GATHER_GBS = 8600.0           # "Indexed rows: gather into LDS": 38 MB table, random rows, Infinity Cache
+L2_GATHER_GBS = 16800.0          # same section: rows served by the XCD's L2 (lower figure of 16.8-18.8 TB/s)
+INFINITY_CACHE_BYTES = 256 << 20
+F32_PEAK_TFLOPS = 157.3          # dense f32 peak, vector and matrix alike (64 FLOP/clk/SIMD)
 
 WORKLOADS = {
     # name: (description, V, S, C)
@@ -48,6 +63,8 @@ WORKLOADS = {
     'synth512': ('synthetic onehot i-FST V=20k S=512 C=256 (T = 21 GB fp32 per GPU, + transposed copy)',
                  20000, 512, 256),
 }
+# the other single-GPU BASELINE configs the default invocation also times: (workload, steps, warmup)
+OTHER_CONFIGS = (('ifst_crf', 2000, 50), ('decomp', 1500, 50), ('fst4', 60, 5))
 
 
 def parse():
@@ -69,17 +86,61 @@ def parse():
                     help='in-flight batches for the main timed region: steps alternate over this many '
                          'HIP streams, each with its own model handle and workspace')
     ap.add_argument('--no-pipelined', action='store_true', help='skip the extra 2-streams measurement')
+    ap.add_argument('--no-other-configs', action='store_true',
+                    help='default workload only: skip the ifst_crf / decomp / fst4 side measurements')
+    ap.add_argument('--no-parity', action='store_true', help='skip the post-run oracle check')
     ap.add_argument('--graph', type=int, default=0,
                     help='N > 0: capture N consecutive steps into one HIP graph and replay it (steps must be a '
                          'multiple of N); 0 = plain stream launches')
-    ap.add_argument('--event-stride', type=int, default=16,
-                    help='time the kernels of every N-th step with HIP events (0 = never)')
+    ap.add_argument('--event-stride', type=int, default=-1,
+                    help='time the kernels of every N-th step with HIP events (0 = never; default: chosen from '
+                         '--steps so that at least 8 launches are timed, at most every 16th step)')
     return ap.parse_args()
 
 
+def auto_event_stride(steps):
+    """>= 8 timed launches whenever steps >= 8; never denser than needed (an event pair costs launch latency)."""
+    return max(1, min(16, steps // 8))
+
+
+# ------------------------------------------------------------------------------------------ N > 1 launcher
+def launch_ranks(a):
+    """`bench.py --gpus N` without an external torchrun: start the N ranks from this process, which has not
+    touched the GPU (no exec of a GPU-initialised process), relay rank 0's JSON line, exit with their status."""
+    import socket
+    one_dev = os.environ.get('FARNN_BENCH_ONE_DEVICE') == '1'
+    if not one_dev:
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU
+        if have < a.gpus:
+            raise SystemExit('bench.py --gpus {}: only {} GPU(s) visible (FARNN_BENCH_ONE_DEVICE=1 runs every rank '
+                             'on cuda:0 over gloo, for tests)'.format(a.gpus, have))
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(a.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        raise SystemExit('bench.py: the ranks exited cleanly but printed no result line')
+    sys.exit(p.returncode)
+
+
+# ------------------------------------------------------------------------------------------ workloads
 def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring='sum'):
     """Returns (handle, x, lengths, extras).  Weights use one seed on every rank (replicated
-    model); the batch is seeded per rank (each rank owns a different shard)."""
+    model); the batch is seeded per rank (each rank owns a different shard).  `extras` keeps the host
+    copies the post-run oracle check needs."""
     from re2nn_seq_amd import _lib, synth
     _, V, S, C = WORKLOADS[name]
     wrng = np.random.RandomState(1234)
@@ -114,28 +175,34 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
             tr[:, K - 2] = -10000.0
             tr[K - 1, :] = -10000.0
         h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=crf, crf_trans=tr, device=dev)
-        extras.update(Tf=T + W, O=O, h0=h0, hT=hT)
+        extras.update(T=T, W=W, Tf=T + W, O=O, h0=h0, hT=hT, tr=tr)
     elif name == 'fst4':
         T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
         # the 4-D layout of the same automaton: label c lives on the edges into states with O[c,j]=1
         T4 = np.einsum('vsj,cj->vcsj', T, O).astype(np.float32)
         W4 = np.einsum('sj,cj->csj', W, O).astype(np.float32)
         h = _lib.create_onehot_fst4(T4, W4, h0, hT, device=dev)
-        del T4
+        extras.update(T4=T4, W4=W4, h0=h0, hT=hT)
     elif name in ('decomp1', 'decomp0'):
         p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
         RO = 70
         f = lambda *shape, sc=0.2: (wrng.randn(*shape) * sc).astype(np.float32)      # noqa: E731
+        q = {'Vgen': p['V_embed'].astype(np.float32), 'S1': p['S1'].astype(np.float32),
+             'S2': p['S2'].astype(np.float32), 'h0': p['start_vector'].astype(np.float32),
+             'hT': p['final_vector'].astype(np.float32), 'farnn': 0, 'nl': 2, 'semiring': 1 if semiring == 'max' else 0,
+             'sig_k': 5}
         if name == 'decomp1':
             # the scoring GEMM of one token: U = abw[S,S] . S2o[S,RO], the a b~ scaling and br = sum S1o . U
             extras['mfma_flops_per_token'] = 2.0 * S * S * RO + 2.0 * S * S + 2.0 * S * RO
-            h = _lib.create_decomp_ind1(p['V_embed'], p['S1'], p['S2'], p['wildcard_mat'], f(C, RO, sc=0.5),
-                                        f(S, RO), f(S, RO), p['start_vector'], p['final_vector'], nl='tanh',
-                                        semiring=semiring, device=dev)
+            q.update(W=p['wildcard_mat'].astype(np.float32), Cout=f(C, RO, sc=0.5), S1o=f(S, RO), S2o=f(S, RO))
+            h = _lib.create_decomp_ind1(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['S1o'], q['S2o'],
+                                        q['h0'], q['hT'], nl='tanh', semiring=semiring, device=dev)
         else:
-            h = _lib.create_decomp_fst(p['V_embed'], f(C, cp_rank, sc=0.5), p['S1'], p['S2'], f(C, RO, sc=0.5),
-                                       f(S, RO), f(S, RO), p['wildcard_mat'], p['start_vector'],
-                                       p['final_vector'], nl='tanh', semiring=semiring, device=dev)
+            q.update(C=f(C, cp_rank, sc=0.5), Cw=f(C, RO, sc=0.5), S1w=f(S, RO), S2w=f(S, RO),
+                     WW=p['wildcard_mat'].astype(np.float32))
+            h = _lib.create_decomp_fst(q['Vgen'], q['C'], q['S1'], q['S2'], q['Cw'], q['S1w'], q['S2w'], q['WW'],
+                                       q['h0'], q['hT'], nl='tanh', semiring=semiring, device=dev)
+        extras['q'] = q
     else:
         p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
         Vgen = p['V_embed']          # beta = 1: the generalized table is V_embed itself
@@ -144,9 +211,16 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
             gates = {'Wss1': wrng.randn(S, S) * 0.1, 'Wrs1': wrng.randn(cp_rank, S) * 0.1, 'bs1': np.full(S, 1.0)}
             if farnn == 2:
                 gates.update(Wss2=wrng.randn(S, S) * 0.1, Wrs2=wrng.randn(cp_rank, S) * 0.1, bs2=np.full(S, 1.0))
+            gates = {k: v.astype(np.float32) for k, v in gates.items()}
         h = _lib.create_decomp_ifst(Vgen, p['S1'], p['S2'], p['wildcard_mat'], p['C_output_mat'],
                                     p['start_vector'], p['final_vector'], nl='tanh', farnn=farnn, gates=gates,
                                     sigmoid_exponent=5, semiring=semiring, device=dev)
+        q = {'Vgen': Vgen.astype(np.float32), 'S1': p['S1'].astype(np.float32), 'S2': p['S2'].astype(np.float32),
+             'W': p['wildcard_mat'].astype(np.float32), 'Cout': p['C_output_mat'].astype(np.float32),
+             'h0': p['start_vector'].astype(np.float32), 'hT': p['final_vector'].astype(np.float32),
+             'farnn': farnn, 'nl': 2, 'semiring': 1 if semiring == 'max' else 0, 'sig_k': 5}
+        q.update(gates or {})
+        extras['q'] = q
     x, lengths = synth.random_batch(V, B, L, brng)
     if full_length:
         lengths[:] = L
@@ -161,17 +235,91 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
     return h, x, lengths, extras
 
 
-def cpu_baseline(extras, x, lengths, gpu_tags, seconds):
-    """Time the C port of the oracle on this host's cores on the same batch (bounded sample) and
-    re-check the GPU tags against it.  OpenMP over the 256 sequences does not scale to every
-    host's full thread count (a 256-thread box runs it slower than 32 threads), so a short sweep
-    picks the fastest thread count first and `cores` reports the threads actually used."""
+# ------------------------------------------------------------------------------------------ parity (after the timed region)
+def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
+    """Oracle check of the batch that was timed: the tags the LAST timed step left in HBM (`gpu_tags`,
+    int32 [B,L], -1 at pads) and, for the floating-point paths, a fresh call that also returns scores.
+    Heavy oracles (4-D gather, independent=0/1 scoring) check the first few sequences only; sequences
+    are independent, so a prefix of the batch is a valid sub-batch."""
+    from oracle import farnn_oracle as fo
+    from re2nn_seq_amd import _lib
+    B, L = x.shape
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    out = {'tags_equal': None, 'sequences_checked': B, 'max_score_err': None}
+
+    def gpu_scores(n):
+        xs = torch.from_numpy(np.ascontiguousarray(x[:n])).to(dev)
+        ls = torch.from_numpy(np.ascontiguousarray(lengths[:n])).to(dev)
+        K = h.num_columns()
+        sc = torch.empty((n, L, K), dtype=torch.float32, device=dev)
+        tg = torch.empty((n, L), dtype=torch.int32, device=dev)
+        h.tag(xs.data_ptr(), ls.data_ptr(), n, L, _lib.MODE_LOCAL, tg.data_ptr(), None, sc.data_ptr())
+        torch.cuda.synchronize(dev)
+        return sc.cpu().numpy(), tg.cpu().numpy()
+
+    def float_compare(ref, n, crf_tr=None):
+        """ref [n, Lmax, K] oracle scores: scores to 1e-4, tags equal wherever the oracle's decision margin
+        exceeds 1e-3 (argmax paths) / everywhere (the check the tests apply at this size)."""
+        sc, tg = gpu_scores(n)
+        Lmax = ref.shape[1]
+        m = mask[:n, :Lmax]
+        err = float(np.abs(sc[:, :Lmax][m] - ref[m]).max())
+        out['max_score_err'] = err
+        out['sequences_checked'] = n
+        rt = fo.decode_argmax(ref, 0.5, 0)
+        refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
+        top2 = np.sort(refc[m], axis=1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 1e-3
+        same_fresh = np.array_equal(tg[:, :Lmax][m][safe], rt[m][safe])
+        same_timed = np.array_equal(gpu_tags[:n, :Lmax][m][safe], rt[m][safe])
+        out['tags_equal'] = bool(same_fresh and same_timed and err <= 1e-4 * max(1.0, float(np.abs(ref[m]).max())))
+        out['tags_compared'] = int(safe.sum())
+        out['tags_within_margin_skipped'] = int((~safe).sum())
+
+    if name in ('ifst', 'ifst_crf'):
+        from oracle import c_port
+        tags, scores, _ = c_port.onehot_ifst_tag(extras['Tf'], extras['O'], extras['h0'], extras['hT'], x, lengths,
+                                                 want_scores=(name == 'ifst_crf'), nthreads=min(os.cpu_count() or 1, 16))
+        if name == 'ifst':
+            out['tags_equal'] = bool(np.array_equal(tags, gpu_tags))
+            out['oracle'] = 'C port of the oracle, every position of every sequence, bit-exact'
+        else:
+            ext = fo.onehot_crf_extension_scores(scores)
+            ref = fo.decode_crf(ext, lengths, extras['tr'], 0.5, 0)
+            out['tags_equal'] = bool(np.array_equal(ref[mask], gpu_tags.astype(np.int64)[mask]))
+            out['oracle'] = 'C-port scores + numpy Viterbi (crf.py:102-195), every valid position, bit-exact'
+    elif name == 'decomp':
+        ref = fo.decomp_ifst_scores(extras['q'], x, lengths)
+        float_compare(ref, B)
+        out['oracle'] = 'numpy oracle decomp_ifst_scores, whole batch: scores <= 1e-4, tags outside 1e-3 margins'
+    elif name in ('decomp1', 'decomp0'):
+        n = min(B, 8)
+        fn = fo.decomp_ind1_scores if name == 'decomp1' else fo.decomp_fst_scores
+        ref = fn(extras['q'], x[:n], lengths[:n])
+        float_compare(ref, n)
+        out['oracle'] = 'numpy oracle, first {} sequences: scores <= 1e-4, tags outside 1e-3 margins'.format(n)
+    elif name == 'fst4':
+        n = min(B, 6)
+        ref = fo.onehot_fst4_scores(extras['T4'], extras['W4'], extras['h0'], extras['hT'], x[:n], lengths[:n])
+        rt = fo.decode_argmax(ref, 0.5, 0)
+        out['tags_equal'] = bool(np.array_equal(rt[mask[:n]], gpu_tags[:n].astype(np.int64)[mask[:n]]))
+        out['sequences_checked'] = n
+        out['oracle'] = 'numpy oracle onehot_fst4_scores, first {} sequences, bit-exact tags'.format(n)
+    else:
+        out['oracle'] = 'none at this size (weights exist on the device only); covered by tests/test_gpu_fullsize_properties.py'
+        out['sequences_checked'] = 0
+    return out
+
+
+# ------------------------------------------------------------------------------------------ CPU baselines
+def cpu_baseline(extras, x, lengths, seconds):
+    """The C port of the oracle on this host's cores, same batch, bounded sample: the "fair" CPU number
+    (T+W hoisted, stops at len).  Parallel over (sequence, direction) chains, then over sequences for the
+    scoring; a short sweep picks the fastest thread count and `cores` reports the threads actually used."""
     from oracle import c_port
     c_port.load(native=True)
     ncpu = os.cpu_count() or 1
     args = (extras['Tf'], extras['O'], extras['h0'], extras['hT'], x, lengths)
-    tags, _, _ = c_port.onehot_ifst_tag(*args, nthreads=min(ncpu, 8))      # warm-up + check
-    parity = bool(np.array_equal(tags, gpu_tags))
     tok = int(lengths.sum())
 
     def rate(nthreads, budget):
@@ -185,12 +333,120 @@ def cpu_baseline(extras, x, lengths, gpu_tags, seconds):
                 return tok * n / el, n, el
 
     cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16, 8) if 1 <= c <= ncpu})
-    best = max(cands, key=lambda c: rate(c, 0.6)[0])
+    best = max(cands, key=lambda c: rate(c, 0.5)[0])
     value, n, el = rate(best, seconds)
-    return {'value': value, 'unit': 'tokens/s', 'cores': int(best), 'kind': 'port',
+    return {'value': value, 'unit': 'tokens/s', 'cores': int(best), 'host_threads': ncpu, 'kind': 'port',
             'sample': '{} passes of the same {}x{} batch ({} valid tokens) in {:.1f} s; C port of the '
-                      'oracle (T+W hoisted, OpenMP over sequences), best of thread counts {} on a '
-                      '{}-thread host'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu)}, parity
+                      'oracle (T+W hoisted, OpenMP over sequence-directions), best of thread counts {} on a '
+                      '{}-thread host'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu)}
+
+
+def cpu_baseline_faithful(extras, x, lengths, seconds):
+    """The reference's own algorithm (model_onehot.py:366-403) as the numpy oracle restates it: re-adds T+W on
+    every call, gathers B x S x S blocks per step, walks all L padded steps, batched einsum on the host BLAS
+    threads -- the "reference-faithful" CPU number of BASELINE.md section 3 (the PyTorch reference itself
+    cannot travel to the GPU box)."""
+    from oracle import farnn_oracle as fo
+    tok = int(lengths.sum())
+    args = (extras['T'], extras['W'], extras['O'], extras['h0'], extras['hT'], x, lengths)
+    fo.decode_argmax(fo.onehot_ifst_scores(*args), 0.5, 0)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fo.decode_argmax(fo.onehot_ifst_scores(*args), 0.5, 0)
+        n += 1
+        el = time.perf_counter() - t0
+        if el + el / n > seconds:
+            break
+    return {'value': tok * n / el, 'unit': 'tokens/s', 'cores': os.cpu_count() or 1, 'kind': 'port',
+            'sample': '{} passes of the same batch in {:.1f} s; numpy float32 restatement of the reference algorithm '
+                      '(T+W re-added per call, all L steps, B x S x S gathers; numpy/BLAS threads of a {}-thread '
+                      'host)'.format(n, el, os.cpu_count() or 1)}
+
+
+# ------------------------------------------------------------------------------------------ roofline
+def load_traffic(name, a):
+    """Measured fabric-side bytes per launch of the dominant kernel (profiles/traffic.json, separate PMC passes),
+    valid only for the shape it was measured on."""
+    shape_ok = {'ifst': (256, 64), 'fst4': (256, 64), 'synth512': (1024, 128)}.get(name)
+    if shape_ok != (a.batch, a.seqlen) or a.full_length:
+        return None
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if not os.path.exists(tpath):
+        return None
+    with open(tpath) as f:
+        return json.load(f).get(name, {}).get('hbm_bytes_per_launch')
+
+
+def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_timed):
+    """The dominant kernel (by measured time) against the ceiling that bounds it.
+      dense-block recurrence / 4-D scoring stream : bytes.  Working set above the 256 MiB Infinity Cache ->
+          HBM (8.0 TB/s spec).  Below it the blocks are served by L2 and the Infinity Cache and never by HBM:
+          the ceiling is the guide's row-gather rates, split by the measured fabric traffic (bytes that left L2
+          at the 8.6 TB/s Infinity-Cache gather rate, the rest at the 16.8 TB/s L2 gather rate); the HBM-side
+          rate actually measured is reported beside it as hbm_frac_measured.
+      decomposed recurrences, Viterbi : shared weights in LDS, ~R*4 bytes per token from HBM -> not a bandwidth
+          problem by construction; priced in f32 VALU flops against the 157.3 TFLOP/s vector
+          peak, with the per-step latency (the real bound of a 64-step serial chain) beside it.
+      independent=1 scoring : f32 MFMA."""
+    from re2nn_seq_amd import _lib
+    _, V, S, C = WORKLOADS[name]
+    dom = _lib.KERN_SCORE if score_avg_s > chain_avg_s else _lib.KERN_CHAIN
+    dom_s = score_avg_s if dom == _lib.KERN_SCORE else chain_avg_s
+    kname = h.kernel_name(dom)
+    rf = {'kernel': kname, 'kernel_avg_us': dom_s * 1e6, 'launches_timed': n_timed,
+          'chain_avg_us': chain_avg_s * 1e6, 'score_decode_avg_us': score_avg_s * 1e6, 'traffic': None}
+    if dom_s <= 0:
+        rf.update(bound='hbm', achieved=0.0, peak=HBM_PEAK_GBS, unit='GB/s', frac=0.0)
+        return rf
+    L = a.seqlen
+    byte_bound = ('chain_kernel' in kname and dom == _lib.KERN_CHAIN) or 'fst4' in kname
+    if byte_bound:
+        alg = h.kernel_algorithmic_bytes(dom, tok_local)
+        achieved = alg / dom_s / 1e9
+        traffic = load_traffic(name, a)
+        SP = (S + 3) // 4 * 4
+        ws = (2.0 * V * S * SP * 4) if 'chain' in kname else (1.0 * V * C * S * SP * 4)
+        rf.update(achieved=achieved, unit='GB/s', traffic=traffic, algorithmic_bytes_per_launch=alg,
+                  working_set_bytes=ws)
+        if ws > INFINITY_CACHE_BYTES:
+            rf.update(bound='hbm', peak=HBM_PEAK_GBS)
+        else:
+            peak = IC_GATHER_GBS
+            if traffic is not None and 0 < traffic < alg:
+                t_floor = (alg - traffic) / (L2_GATHER_GBS * 1e9) + traffic / (IC_GATHER_GBS * 1e9)
+                peak = alg / t_floor / 1e9
+                rf['peak_note'] = ('working set {:.0f} MB is L2/Infinity-Cache resident: {:.0f} MB per launch leave L2 '
+                                   '(measured, Infinity-Cache gather 8.6 TB/s), the other {:.0f} MB are L2 hits (L2 gather '
+                                   '16.8 TB/s); HBM is not on the path'.format(ws / 1e6, traffic / 1e6, (alg - traffic) / 1e6))
+            rf.update(bound='infinity_cache', peak=peak)
+        if traffic is not None:
+            rf['hbm_frac_measured'] = traffic / dom_s / 1e9 / HBM_PEAK_GBS
+        rf['frac'] = achieved / rf['peak']
+        return rf
+    if dom == _lib.KERN_SCORE and 'mfma_flops_per_token' in extras and 'mfma' in kname:
+        fl = extras['mfma_flops_per_token'] * tok_local
+        ach = fl / dom_s / 1e12
+        rf.update(bound='mfma', achieved=ach, peak=F32_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F32_PEAK_TFLOPS,
+                  algorithmic_flops_per_launch=fl)
+        return rf
+    # latency-bound kernels: VALU flops of the dominant kernel per valid token (SURVEY.md 8d)
+    R, K = a.rank, h.num_columns()
+    if dom == _lib.KERN_CHAIN:            # decomposed recurrence, both directions
+        fl_tok = 2.0 * (4 * S * R + 2 * S * S)
+        if a.farnn >= 1:
+            fl_tok += (2.0 if a.farnn == 2 else 1.0) * (2 * S * S + 2 * S * R) * 2
+        per_step_us = dom_s * 1e6 / max(1, L)
+        note = ('weights shared by all sequences and LDS-resident; {:.0f} B per token from HBM: not bandwidth-bound by '
+                'construction. The bound is the serial chain: {} steps per direction'.format(R * 4 + 12, L))
+    else:                                 # score GEMM (+ Viterbi DP: 2 adds + 1 max per tag pair)
+        fl_tok = 2.0 * K * S + (3.0 * K * K if 'viterbi' in kname else 0.0)
+        per_step_us = dom_s * 1e6 / max(1, L)
+        note = 'scores stay on-chip; the DP is serial over the {} positions of a sequence'.format(L)
+    fl = fl_tok * tok_local
+    ach = fl / dom_s / 1e12
+    rf.update(bound='valu_f32', achieved=ach, peak=F32_PEAK_TFLOPS, unit='TFLOP/s', frac=ach / F32_PEAK_TFLOPS,
+              algorithmic_flops_per_launch=fl, step_latency_us=per_step_us, note=note)
+    return rf
 
 
 def run_train(a, world, rank, dev, dist):
@@ -279,11 +535,16 @@ def run_train(a, world, rank, dev, dist):
     lib_ms, lib_n = tc.time()
     if rank == 0:
         tok_local = int(lengths.sum())
-        # algorithmic bytes of the library part per valid token: the state stash, the per-token adjoint rows and
-        # the score-side rows, each written once and read once
-        alg = (2.0 * (16 * S + 6 * R + 2 * K) * 4) * tok_local
+        # VALU flops of the library part per valid token: forward recurrence 2(4SR+2S^2) + scoring 2KS, the
+        # backward pass about twice that (BPTT products + the parameter-gradient outer products), gates on top
+        fwd = 2.0 * (4 * S * R + 2 * S * S) + 2.0 * K * S
+        if a.farnn:
+            fwd += (2.0 if a.farnn == 2 else 1.0) * (2 * S * S + 2 * S * R) * 2
+        if a.crf:
+            fwd += 4.0 * K * K            # forward-backward recursions of the CRF: two dot products per tag pair
+        flops = 3.0 * fwd * tok_local
         lib_s = (lib_ms / max(lib_n, 1)) * 1e-3
-        achieved = alg / lib_s / 1e9 if lib_s > 0 else 0.0
+        achieved = flops / lib_s / 1e12 if lib_s > 0 else 0.0
         out = {
             'metric': 'trained tokens/sec @ batch=256, seqlen=64 (decomposed i-FST, one optimizer step per batch)',
             'value': tok_total * a.steps / el, 'unit': 'tokens/s', 'n_gpus': world, 'steps': a.steps,
@@ -294,12 +555,13 @@ def run_train(a, world, rank, dev, dist):
                        'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
                        'parallelism': 'data parallel x{}{}'.format(world, ', one RCCL all-reduce of the gradients' if world > 1 else ''),
                        'final_loss': float(loss.detach())},
-            'roofline': {'bound': 'hbm', 'kernel': 'train_backward_kernel (+train_forward_kernel, train_loss_kernel, atb_*)',
-                         'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': None, 'algorithmic_bytes_per_launch': alg,
+            'roofline': {'bound': 'valu_f32', 'kernel': 'train_backward_kernel (+train_forward_kernel, train_loss_kernel, atb_*)',
+                         'achieved': achieved, 'peak': F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': achieved / F32_PEAK_TFLOPS,
+                         'traffic': None, 'algorithmic_flops_per_launch': flops,
                          'kernel_avg_us': lib_s * 1e6, 'launches_timed': lib_n,
+                         'step_latency_us': lib_s * 1e6 / (2 * L),
                          'note': 'the library part of the step is bound by the latency of 64 sequential recurrence '
-                                 'steps per direction, not by bandwidth'},
+                                 'steps per direction (forward, then backward in time), not by bandwidth or flops'},
         }
         if world == 1 and not a.no_cpu_baseline and not a.crf and not a.farnn:
             out['cpu_baseline'] = train_cpu_baseline(p, beta, x, lengths, labels, a.cpu_seconds)
@@ -332,42 +594,21 @@ def train_cpu_baseline(p, beta, x, lengths, labels, budget_s):
                       'the same batch in {:.1f} s; the reference itself takes 0.73 s per step on 8 cores (DESIGN.md)'.format(n, el)}
 
 
-def main():
-    a = parse()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
-    # test hook (single-GPU boxes): FARNN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo, to exercise
-    # the N>1 code path where RCCL (one rank per device) cannot be used
-    one_dev = os.environ.get('FARNN_BENCH_ONE_DEVICE') == '1'
-    if one_dev:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        if one_dev:
-            dist.init_process_group('gloo')
-        else:
-            dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+# ------------------------------------------------------------------------------------------ the tagging measurement
+def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, event_stride, headline):
+    """Build `name`, time `steps` steps (contract: barrier + sync on both sides, max over ranks), then -- after
+    the timed region -- re-check the batch against the oracle.  Returns the result dict on rank 0, else None."""
     from re2nn_seq_amd import _lib
-
     B, L = a.batch, a.seqlen
-    if a.workload == 'train':
-        return run_train(a, world, rank, dev, dist)
-    if a.workload == 'synth512':
-        a.no_pipelined = True            # a second 63 GB replica of the weights is pointless here
-    h, x, lengths, extras = build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring)
-    n_pipe = max(a.streams, 1 if a.no_pipelined else 2)
-    handles = [h] + [build_workload(a.workload, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring)[0]
-                     for _ in range(n_pipe - 1)]
+    n_main = max(a.streams, 1) if headline else 1
+    n_pipe = max(n_main, 2 if want_pipelined else 1)
+    built = [build_workload(name, B, L, rank, a.rank, a.full_length, a.farnn, a.semiring) for _ in range(n_pipe)]
+    h, x, lengths, extras = built[0]
+    handles = [b[0] for b in built]
+    del built
     xd = torch.from_numpy(x).to(dev)
     ld = torch.from_numpy(lengths).to(dev)
-    tags_bufs = [torch.empty((B, L), dtype=torch.int32, device=dev) for _ in handles]
-    tags = tags_bufs[0]
+    tags_bufs = [torch.full((B, L), -7, dtype=torch.int32, device=dev) for _ in handles]
     # N > 1: the tag ids of step i are gathered (RCCL all-gather over xGMI, on RCCL's own stream) while
     # step i+1 computes (re2nn_seq_amd.dist.OverlappedGather: two blocks in rotation)
     og = None
@@ -378,9 +619,7 @@ def main():
         hh.reserve(B, L)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in handles[1:]]
 
-    def timed_region(n_streams, steps, warmup, event_stride):
-        """barrier + sync, `steps` steps alternating over `n_streams` streams, sync + barrier;
-        returns (elapsed max-over-ranks is taken by the caller, per-kernel event sums)."""
+    def timed_region(n_streams, steps, warmup, stride):
         counter = [0]
 
         def step():
@@ -406,7 +645,7 @@ def main():
         drain()
         torch.cuda.synchronize(dev)
         graph = None
-        if a.graph > 0 and world == 1 and n_streams == 1 and event_stride == 0:
+        if a.graph > 0 and world == 1 and n_streams == 1 and stride == 0:
             # the whole step (every kernel farnn_tag enqueues) recorded once, replayed steps/N times
             side = torch.cuda.Stream(dev)
             graph = torch.cuda.CUDAGraph()
@@ -416,10 +655,10 @@ def main():
                                    None, None, torch.cuda.current_stream(dev).cuda_stream)
             graph.replay()
             torch.cuda.synchronize(dev)
+        for hh in handles[:n_streams]:
+            hh.set_profiling(stride)            # HIP events around the kernels of every N-th step
         if world > 1:
             dist.barrier()
-        for hh in handles[:n_streams]:
-            hh.set_profiling(event_stride)     # HIP events around the kernels of every N-th step
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         if graph is not None:
@@ -446,12 +685,12 @@ def main():
             el = float(t.item())
         return el, sums
 
-    elapsed, (chain_ms, chain_n, score_ms, score_n) = timed_region(a.streams, a.steps, a.warmup, a.event_stride)
+    elapsed, (chain_ms, chain_n, score_ms, score_n) = timed_region(n_main, steps, warmup, event_stride)
     pipelined = None
-    if not a.no_pipelined and a.streams == 1:
+    if want_pipelined and n_main == 1:
         # same K steps with two batches in flight (two streams, two handles): the score/decode kernel
         # of one batch overlaps the recurrence of the next.  Reported beside `value`, never as it.
-        pel, _ = timed_region(2, a.steps, a.warmup, 0)
+        pel, _ = timed_region(2, steps, warmup, 0)
         pipelined = (2, pel)
 
     tok_local = int(lengths.sum())
@@ -461,59 +700,102 @@ def main():
         tok_total = int(n.item())
     else:
         tok_total = tok_local
+    if rank != 0:
+        for hh in handles:
+            hh.close()
+        return None
 
+    desc, V, S, C = WORKLOADS[name]
+    chain_avg_s = (chain_ms / max(chain_n, 1)) * 1e-3
+    score_avg_s = (score_ms / max(score_n, 1)) * 1e-3
+    out = {
+        'value': tok_total * steps / elapsed,
+        'unit': 'tokens/s',
+        'steps': steps, 'warmup': warmup,
+        'ms_per_step': elapsed / steps * 1e3,
+        'config': {'workload': '{}: V={} S={} C={}{}, batch {} x seqlen {} per GPU, lengths {}'
+                               .format(desc, V, S, C,
+                                       ' R={} farnn={}'.format(a.rank, a.farnn) if name.startswith('decomp') else '',
+                                       B, L, 'all {}'.format(L) if a.full_length else 'U[5,{}]'.format(L)),
+                   'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
+                   'parallelism': 'batch-sharded x{} (weights replicated{}){}'.format(
+                       world, ', RCCL all_gather of tag ids' if world > 1 else '',
+                       ', {} batches in flight per GPU'.format(n_main) if n_main > 1 else '')},
+        'roofline': roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, chain_n),
+    }
+    if pipelined:
+        out['pipelined'] = {'streams': pipelined[0], 'value': tok_total * steps / pipelined[1],
+                            'unit': 'tokens/s', 'ms_per_step': pipelined[1] / steps * 1e3,
+                            'note': 'same K steps with two batches in flight on two HIP streams'}
+    if world == 1 and not a.no_parity:
+        # the last timed step wrote tags_bufs[(steps - 1) % n_main]
+        got = tags_bufs[(steps - 1) % n_main].cpu().numpy()
+        out['parity'] = parity_check(name, h, extras, x, lengths, got, dev)
+        if out['parity']['tags_equal'] is False:
+            print('WARNING: {}: GPU results differ from the oracle'.format(name), file=sys.stderr)
+    if headline and world == 1 and not a.no_cpu_baseline and name == 'ifst':
+        out['cpu_baseline'] = cpu_baseline(extras, x, lengths, a.cpu_seconds)
+        out['cpu_baseline_faithful'] = cpu_baseline_faithful(extras, x, lengths, min(a.cpu_seconds, 6.0))
+    for hh in handles:
+        hh.close()
+    del extras
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    a = parse()
+    if 'WORLD_SIZE' not in os.environ and a.gpus > 1:
+        return launch_ranks(a)                 # this process never initialises the GPU
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus:
+        raise SystemExit('bench.py: --gpus {} but WORLD_SIZE={} (launch with torchrun --nproc-per-node {} or '
+                         'let bench.py start the ranks itself)'.format(a.gpus, world, a.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback for the product path)')
+    # test hook (single-GPU boxes): FARNN_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 over gloo, to exercise
+    # the N>1 code path where RCCL (one rank per device) cannot be used
+    one_dev = os.environ.get('FARNN_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+    from re2nn_seq_amd import _lib  # noqa: F401
+
+    if a.workload == 'train':
+        return run_train(a, world, rank, dev, dist)
+    stride = a.event_stride if a.event_stride >= 0 else auto_event_stride(a.steps)
+    want_pipe = not a.no_pipelined and a.streams == 1 and a.workload != 'synth512'   # no second 63 GB replica
+    res = run_tagging(a, a.workload, a.steps, a.warmup, world, rank, dev, dist, want_pipe, stride, True)
     if rank == 0:
-        desc, V, S, C = WORKLOADS[a.workload]
-        # the dominant kernel of this workload (by time) is the one priced against the roofline
-        chain_avg_s = (chain_ms / max(chain_n, 1)) * 1e-3
-        score_avg_s = (score_ms / max(score_n, 1)) * 1e-3
-        dom = _lib.KERN_SCORE if score_avg_s > chain_avg_s else _lib.KERN_CHAIN
-        dom_avg_s = score_avg_s if dom == _lib.KERN_SCORE else chain_avg_s
-        alg_bytes = h.kernel_algorithmic_bytes(dom, tok_local)
-        achieved = alg_bytes / dom_avg_s / 1e9 if dom_avg_s > 0 else 0.0
-        bound, peak, unit = 'hbm', HBM_PEAK_GBS, 'GB/s'
-        if dom == _lib.KERN_SCORE and 'mfma_flops_per_token' in extras and 'mfma' in h.kernel_name(dom):
-            # the per-token scoring GEMM on the f32 matrix cores: priced against the dense f32 MFMA peak
-            bound, peak, unit = 'mfma', F32_MFMA_PEAK_TFLOPS, 'TFLOP/s'
-            alg_bytes = extras['mfma_flops_per_token'] * tok_local          # algorithmic FLOPs per launch
-            achieved = alg_bytes / dom_avg_s / 1e12 if dom_avg_s > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = json.load(f).get(a.workload, {}).get('hbm_bytes_per_launch')
-        out = {
-            'metric': 'tagged tokens/sec @ batch=256, seqlen=64; achieved HBM GB/s vs peak',
-            'value': tok_total * a.steps / elapsed,
-            'unit': 'tokens/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-            'ms_per_step': elapsed / a.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '{}: V={} S={} C={}, batch {} x seqlen {} per GPU, lengths {}'
-                                   .format(desc, V, S, C, B, L,
-                                           'all {}'.format(L) if a.full_length else 'U[5,{}]'.format(L)),
-                       'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
-                       'parallelism': 'batch-sharded x{} (weights replicated{}){}'.format(
-                           world, ', RCCL all_gather of tag ids' if world > 1 else '',
-                           ', {} batches in flight per GPU'.format(a.streams) if a.streams > 1 else '')},
-            'roofline': {'bound': bound, 'kernel': h.kernel_name(dom),
-                         'achieved': achieved, 'peak': peak, 'unit': unit,
-                         'frac': achieved / peak, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch' if bound == 'hbm' else 'algorithmic_flops_per_launch': alg_bytes,
-                         'kernel_avg_us': dom_avg_s * 1e6, 'launches_timed': chain_n,
-                         'chain_avg_us': chain_avg_s * 1e6, 'score_decode_avg_us': score_avg_s * 1e6},
-        }
-        if pipelined:
-            out['pipelined'] = {'streams': pipelined[0], 'value': tok_total * a.steps / pipelined[1],
-                                'unit': 'tokens/s', 'ms_per_step': pipelined[1] / a.steps * 1e3,
-                                'note': 'same K steps with two batches in flight on two HIP streams'}
-        if world == 1 and not a.no_cpu_baseline and 'Tf' in extras and a.workload == 'ifst':
-            cb, parity = cpu_baseline(extras, x, lengths, tags.cpu().numpy(), a.cpu_seconds)
-            out['cpu_baseline'] = cb
-            out['parity_vs_cpu_port'] = parity
-            if not parity:
-                print('WARNING: GPU tags differ from the CPU port of the oracle', file=sys.stderr)
+        out = {'metric': 'tagged tokens/sec @ batch=256, seqlen=64; achieved HBM GB/s vs peak',
+               'value': res.pop('value'), 'unit': res.pop('unit'), 'n_gpus': world,
+               'steps': res.pop('steps'), 'warmup': res.pop('warmup'), 'ms_per_step': res.pop('ms_per_step'),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+        out.update(res)
+        defaults = (a.batch, a.seqlen, a.rank, a.farnn, a.semiring, a.full_length, a.streams, a.graph) == \
+                   (256, 64, 50, 0, 'sum', False, 1, 0)
+        if world == 1 and a.workload == 'ifst' and defaults and not a.no_other_configs:
+            others = []
+            for name, st, wu in OTHER_CONFIGS:
+                t0 = time.perf_counter()
+                try:
+                    r = run_tagging(a, name, st, wu, 1, 0, dev, None, False, auto_event_stride(st), False)
+                    r['workload'] = name
+                    r['wall_s'] = time.perf_counter() - t0
+                except Exception as e:          # a side measurement must not take the headline line down
+                    r = {'workload': name, 'error': '{}: {}'.format(type(e).__name__, e)}
+                others.append(r)
+            out['other_configs'] = others
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

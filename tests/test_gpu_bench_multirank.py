@@ -33,3 +33,50 @@ def test_bench_two_ranks_on_one_device(extra):
     assert d['n_gpus'] == 2 and d['steps'] == 5 and d['warmup'] == 2 and d['value'] > 0 and d['scaling'] == 'weak'
     assert d['config']['valid_tokens_per_step'] > 8000          # both ranks' shards are counted
     assert 'roofline' in d and d['roofline']['frac'] > 0
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun around it (the form the round driver may use): the parent
+    starts the two ranks itself, relays ONE JSON line with n_gpus = 2 and both shards counted."""
+    env = dict(os.environ, FARNN_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '5', '--warmup', '2',
+           '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 5 and d['value'] > 0
+    assert d['config']['valid_tokens_per_step'] > 2 * 8000
+    assert d['config']['padded_tokens_per_step'] == 2 * 256 * 64
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    env = dict(os.environ, FARNN_BENCH_ONE_DEVICE='1', WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2'], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_bench_default_line_carries_every_single_gpu_config():
+    """The default invocation: headline = configs[1] with a roofline fraction <= 1 against the ceiling that bounds
+    it, a post-run oracle check, both CPU baselines, and the other single-GPU configs with their own checks."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5',
+                        '--cpu-seconds', '2'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    rf = d['roofline']
+    assert rf['launches_timed'] >= 8 and 0 < rf['frac'] <= 1.0 and rf['bound'] in ('infinity_cache', 'hbm')
+    assert d['parity']['tags_equal'] is True
+    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
+    names = [o['workload'] for o in d['other_configs']]
+    assert names == ['ifst_crf', 'decomp', 'fst4']
+    for o in d['other_configs']:
+        assert 'error' not in o, o
+        assert o['value'] > 0 and o['parity']['tags_equal'] is True, o
+        assert 0 < o['roofline']['frac'] <= 1.0

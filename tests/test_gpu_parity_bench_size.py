@@ -1,0 +1,135 @@
+"""GPU parity AT THE SIZES bench.py times (BASELINE.json configs[2] and configs[3]), through the C-ABI:
+the batch geometry matters -- two-round / paired scheduling of the decomposed recurrence over 512 chains,
+the in-kernel length-rank selection at B = 256, the 11 000-row word-table gather, the K = 73 / K = 130 score
+tiles -- so the small-geometry tests do not stand in for these.
+
+    config 2   SNIPS-BIO-sized decomposed i-FST: V=11 000, S=104, C=73, B=256, L=64, lengths U[5,64]
+               (i)  rank 50, farnn 0, tanh                (what `bench.py --workload decomp` times)
+               (ii) rank 250, farnn 2, use_crf=1          (the shape of the shipped example `.res` configurations)
+    config 3   ATIS-BIO-sized onehot i-FST + fused Viterbi: V=950, S=71, C=128 (+2), B=256, L=64
+
+Oracle: oracle/farnn_oracle.py (pinned to the reference by tests/test_oracle_golden.py).  Bar: scores within
+1e-4 (north_star), tags equal wherever the oracle's decision margin exceeds 1e-3; bit-exact for the onehot path.
+Reference: model_decompose_single.py:207-304, model_decompose.py:339-371, crf.py:102-195."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import farnn_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _snips_model(R, farnn, crf, seed=1234):
+    """The generator bench.py uses for `--workload decomp` (same seed), plus gates / CRF rows on demand."""
+    from re2nn_seq_amd import synth
+    V, S, C = 11000, 104, 73
+    wrng = np.random.RandomState(seed)
+    p = synth.random_decomposed_params(V, S, C, R, 100, wrng)
+    f = lambda a: np.asarray(a, np.float32)                       # noqa: E731
+    Cout = f(p['C_output_mat'])
+    tr = None
+    if crf:            # two extra rows for START / STOP (model_decompose_single.py:78-79), small random values
+        Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
+        K = C + 2
+        tr = fo.crf_default_transitions(C) + (wrng.randn(K, K) * 0.3).astype(np.float32)
+    q = {'Vgen': f(p['V_embed']), 'S1': f(p['S1']), 'S2': f(p['S2']), 'W': f(p['wildcard_mat']), 'Cout': Cout,
+         'h0': f(p['start_vector']), 'hT': f(p['final_vector']), 'farnn': farnn, 'nl': fo.NL_TANH,
+         'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+    gates = None
+    if farnn:
+        gates = {'Wss1': f(wrng.randn(S, S) * 0.1), 'Wrs1': f(wrng.randn(R, S) * 0.1), 'bs1': f(np.full(S, 1.0))}
+        if farnn == 2:
+            gates.update(Wss2=f(wrng.randn(S, S) * 0.1), Wrs2=f(wrng.randn(R, S) * 0.1), bs2=f(np.full(S, 1.0)))
+        q.update(gates)
+    return V, q, gates, tr
+
+
+@pytest.mark.parametrize('R,farnn,crf', [(50, 0, False), (250, 2, True), (100, 1, False)])
+def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf):
+    from re2nn_seq_amd import _lib, synth
+    B, L = 256, 64
+    V, q, gates, tr = _snips_model(R, farnn, crf)
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4321))       # bench.py's rank-0 batch
+    assert lengths.min() >= 5 and lengths.max() == L
+    K = q['Cout'].shape[0]
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn,
+                                gates=gates, sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0,
+                                use_crf=crf, crf_trans=tr)
+    assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), scores.data_ptr())
+    # the call bench.py times: tags only (no score tensor: the fused score+Viterbi kernel when CRF is on)
+    tags2 = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags2.data_ptr(), None, None)
+    torch.cuda.synchronize()
+
+    ref = fo.decomp_ifst_scores(q, x, lengths)                    # [B, L, K]
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    got = scores.cpu().numpy()
+    np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    assert (got[~mask] == 0).all()
+    tg, tg2 = tags.cpu().numpy(), tags2.cpu().numpy()
+    assert (tg[~mask] == -1).all() and (tg2[~mask] == -1).all()
+    if not crf:
+        rt = fo.decode_argmax(ref, 0.5, 0)
+        refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
+        top2 = np.sort(refc[mask], axis=1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 1e-3
+        assert safe.mean() > 0.9                                   # the comparison is not vacuous
+        assert np.array_equal(tg[mask][safe], rt[mask][safe])
+        assert np.array_equal(tg2[mask][safe], rt[mask][safe])
+        assert np.array_equal(flat.cpu().numpy()[safe], fo.forward_local_tags(ref, lengths, 0.5, 0)[safe])
+    else:
+        # Viterbi on the GPU's own scores must equal the oracle's Viterbi on those scores bit for bit (the DP is
+        # the same f32 expression); against the oracle's scores a path may differ only where the two totals tie
+        # within float noise, so hold whole sequences equal and allow a handful of near-tie sequences
+        own = fo.decode_crf(got, lengths, tr, 0.5, 0)
+        assert np.array_equal(own[mask], tg[mask].astype(np.int64))
+        assert np.array_equal(own[mask], tg2[mask].astype(np.int64))       # fused kernel == score kernel + Viterbi
+        assert np.array_equal(fo.flatten(own, lengths), flat.cpu().numpy())
+        want = fo.decode_crf(ref, lengths, tr, 0.5, 0)
+        seq_equal = np.array([np.array_equal(want[b, :lengths[b]], tg[b, :lengths[b]]) for b in range(B)])
+        assert seq_equal.mean() >= 0.97, seq_equal.mean()
+    h.close()
+
+
+def test_onehot_ifst_crf_at_bench_size_vs_oracle():
+    """BASELINE configs[3] exactly as `bench.py --workload ifst_crf` builds it: V=950, S=71, C=128, K=130,
+    B=256, L=64, random transitions.  Integer scores: the decoded paths are bit-identical."""
+    from oracle import c_port
+    from re2nn_seq_amd import _lib, synth
+    V, S, C, B, L = 950, 71, 128, 256, 64
+    wrng = np.random.RandomState(1234)
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
+    K = C + 2
+    tr = (wrng.randn(K, K) * 0.1).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4321))
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=True, crf_trans=tr)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None)   # fused
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    tags_u = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_u.data_ptr(), None, scores.data_ptr())  # unfused
+    torch.cuda.synchronize()
+    _, sc, _ = c_port.onehot_ifst_tag(T + W, O, h0, hT, x, lengths, want_scores=True, nthreads=8)
+    ext = fo.onehot_crf_extension_scores(sc)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    assert np.array_equal(scores.cpu().numpy()[mask], ext[mask])
+    want = fo.decode_crf(ext, lengths, tr, 0.5, 0)
+    assert np.array_equal(want[mask], tags.cpu().numpy().astype(np.int64)[mask])
+    assert np.array_equal(want[mask], tags_u.cpu().numpy().astype(np.int64)[mask])
+    assert np.array_equal(fo.flatten(want, lengths), flat.cpu().numpy())
+    assert (tags.cpu().numpy()[~mask] == -1).all()
+    h.close()
