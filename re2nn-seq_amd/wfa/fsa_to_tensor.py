@@ -18,7 +18,9 @@ Quirks preserved on purpose (SURVEY.md 8b "loader quirks"):
     0..24 (ref :47-56, :63-66) -- the onehot driver never passes the kwarg;
   * the label of an edge is attached to its DESTINATION state in the i-FST layout (ref :586);
   * ``final_vector`` / ``start_vector`` are indexed with the raw state ids (ref :606-610);
-  * a rule word missing from the vocabulary is reported and skipped (ref :603).
+  * a rule word missing from the vocabulary is reported and its language-tensor entry skipped
+    (ref :603); its LABEL is still written to output_mat / output_tensor (ref :515, :586), and the 4-D
+    layout, which has no separate label array, drops the edge entirely (ref :463-465).
 All outputs are float64, like the reference's.
 """
 import numpy as np
@@ -89,7 +91,11 @@ def _walk_edges(automata, word2idx, slot2idx, dataset, strict_oo):
                 elif word in word2idx:
                     edges.append(([word2idx[word]], col, fi, ti, [word]))
                 else:
+                    # the reference writes the edge's label BEFORE it looks the word up (:120, :515, :586), so an
+                    # out-of-vocabulary rule word still labels output_mat / output_tensor; only the language
+                    # tensor entry is skipped.  An empty word list is exactly that: label only.
                     print('OOV word: {} in rule'.format(word))
+                    edges.append(([], col, fi, ti, []))
     return state2idx, edges
 
 

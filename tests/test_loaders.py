@@ -52,11 +52,34 @@ def test_default_dataset_kwarg_is_mitr_quirk():
     assert f2t.is_number('2021') and f2t.is_number('9.5') and not f2t.is_number('w3')
 
 
-def test_oov_rule_word_is_skipped(capsys):
+def test_oov_rule_word_keeps_its_label(capsys):
+    """A rule word outside the vocabulary: the reference writes the edge's label before the vocabulary lookup
+    (fsa_to_tensor.py:515, :586), so output_mat / output_tensor keep it and only the language tensor skips the
+    edge; the 4-D layout drops it.  Fixture captured from the reference loaders (make_golden_oov.py)."""
+    edges = [(0, 1, 'notaword<:>b-e1'), (2, 3, 'alsomissing<:>i-e2'), (1, 1, 'nope<:>oo')]   # = make_golden_oov.OOV_EDGES
     automaton, t2i, s2i = _automaton()
-    automaton['transitions'].setdefault(0, {}).setdefault(1, set()).add('notaword<:>o')
-    f2t.dfa_to_tensor_slot_single_wildcard(automaton, t2i, s2i)
+    for fr, to, lab in edges:
+        automaton['transitions'].setdefault(fr, {}).setdefault(to, set()).add(lab)
+    g = load_golden('loader_oov')
+    r = f2t.dfa_to_tensor_slot_single_wildcard(automaton, t2i, s2i)
     assert 'OOV word: notaword in rule' in capsys.readouterr().out
+    assert np.array_equal(r[0], g['single.T']) and np.array_equal(r[2], g['single.W'])
+    assert np.array_equal(r[3], g['single.O'])
+    base = f2t.dfa_to_tensor_slot_single_wildcard(_automaton()[0], t2i, s2i)
+    assert not np.array_equal(base[3], g['single.O'])            # the fixture discriminates: labels were added
+    assert np.array_equal(base[0], g['single.T'])                # ... and no language-tensor entry was
+    r = f2t.dfa_to_tensor_slot_independent_wildcard(automaton, t2i, s2i)
+    assert np.array_equal(r[0], g['ind.T']) and np.array_equal(r[2], g['ind.W']) and np.array_equal(r[3], g['ind.Oten'])
+    a4 = {**automaton, 'transitions': {f: {t: {e for e in es if e != 'nope<:>oo'} for t, es in d.items()}
+                                       for f, d in automaton['transitions'].items()}}
+    r = f2t.dfa_to_tensor_slot_new_wildcard(a4, t2i, s2i)
+    assert np.array_equal(r[0], g['new.T4']) and np.array_equal(r[2], g['new.W4'])
+    # the device-side builders get the same label-only entries (word = -2)
+    w, fr_, to_, lab, _, _, _ = f2t.dfa_to_edges_slot_single_wildcard(automaton, t2i, s2i)
+    assert (w == -2).sum() >= len(edges)
+    O = np.zeros_like(g['single.O'])
+    O[lab[lab >= 0], to_[lab >= 0]] = 1
+    assert np.array_equal(O, g['single.O'])
 
 
 def test_synthetic_automaton_has_ifst_property():
