@@ -1233,6 +1233,8 @@ struct farnn_train_ctx {
     double prof_ms = 0.0;
     int64_t prof_n = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    volatile int *err_host = nullptr;   // pinned, device-mapped: the kernels set bit 0 on a bad label (only then is it touched)
+    int *err_dev = nullptr;             // the device's address of err_host
 };
 
 extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_train_ctx **out) {
@@ -1240,7 +1242,10 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
     *out = nullptr;
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0) return fail(FARNN_EINVAL, "train_create: bad dimensions%s%s");
     if (d->nl < FARNN_NL_NONE || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "train_create: bad nonlinearity%s%s");
-    if (d->use_crf && (d->K < 4 || d->K > 256)) return fail(FARNN_ERANGE, "train_create: CRF needs 4..256 score columns%s%s");
+    // the CRF loss kernel keeps exp(transitions) in LDS: K = 190 is the hard limit (L = 4); at L = 64 it is K = 140
+    // (checked per call, farnn_decomp_ifst_train_step returns FARNN_ERANGE before enqueuing anything)
+    if (d->use_crf && (d->K < 4 || train_crf_lds_bytes(d->K, 4, true) > 160 * 1024))
+        return fail(FARNN_ERANGE, "train_create: CRF needs 4..190 score columns%s%s");
     if (d->farnn < 0 || d->farnn > 2) return fail(FARNN_EINVAL, "train_create: farnn must be 0, 1 or 2%s%s");
     int rc;
     if ((rc = select_device(device))) return rc;
@@ -1268,6 +1273,12 @@ extern "C" int farnn_train_create(const farnn_train_dims *d, int device, farnn_t
         }
     }
     if (d->farnn) { c->Wss1T = c->dOsum + S; c->Wss2T = c->Wss1T + S * S; c->Wrs1T = c->Wss2T + S * S; c->Wrs2T = c->Wrs1T + S * R; }
+    if (hipHostMalloc((void **)&c->err_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->err_dev, (void *)c->err_host, 0) != hipSuccess) {
+        farnn_train_destroy(c);
+        return fail(FARNN_ENOMEM, "train_create: out of memory%s%s");
+    }
+    *c->err_host = 0;
     *out = c;
     return FARNN_OK;
 }
@@ -1283,6 +1294,7 @@ extern "C" void farnn_train_destroy(farnn_train_ctx *c) {
     if (c->VgenT) (void)hipFree(c->VgenT);
     if (c->GV) (void)hipFree(c->GV);
     if (c->S1T) (void)hipFree(c->S1T);
+    if (c->err_host) (void)hipHostFree((void *)c->err_host);
     delete c;
 }
 
@@ -1342,10 +1354,19 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     if (farnn == 2 && (!w->Wss2 || !w->Wrs2 || !w->bs2 || !o->dWss2 || !o->dWrs2 || !o->dbs2))
         return fail(FARNN_EINVAL, "train_step: reset-gate weights / gradients missing%s%s");
     if (B <= 0 || L <= 0 || valid_tokens <= 0) return fail(FARNN_EINVAL, "train_step: B, L and valid_tokens must be positive%s%s");
+    // checked before anything is enqueued: the CRF kernel keeps exp(transitions) [K][K+1] and two message tables
+    // [L][K] in LDS (K = 130 at L = 64: 144 KiB; K = 140 is the limit at L = 64, K = 190 at L = 4)
+    if (crf && train_crf_lds_bytes(c->d.K, L, true) > 160 * 1024)
+        return fail(FARNN_ERANGE, "train_step: CRF tag set too large for this sequence length (K(K+1)*4 + 9*L*K + ... bytes of LDS must fit 160 KiB)%s%s");
     if (c->d.S > TR_VPT * TR_THREADS / TR_NSEQ || c->d.R > TR_VPT * TR_THREADS / TR_NSEQ)
         return fail(FARNN_ERANGE, "train_step: more than 512 states or rank above 512%s%s");
     FARNN_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (*c->err_host) {        // set by an earlier step's kernels straight in pinned host memory (no sync here)
+        FARNN_HIP_TRY(hipStreamSynchronize(s));
+        *c->err_host = 0;
+        return fail(FARNN_EINVAL, "train_step: an earlier step saw a label outside 0..K-1 at a valid position (torch's CrossEntropyLoss raises on it); that step counted it as label 0%s%s");
+    }
     const size_t S = c->d.S, R = c->d.R, K = c->d.K, V = c->d.V;
     const size_t N1 = (size_t)B * (L + 1), N0 = (size_t)B * L;
     const size_t need = N1 * (8 * S + 4 * R) + N0 * (K + S) + (crf ? N0 * K + (size_t)B * K * K : 0) +
@@ -1363,7 +1384,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     memset(&p, 0, sizeof(p));
     p.Vgen = w->Vgen; p.S1 = w->S1; p.S2 = w->S2; p.W = w->W; p.C = w->C; p.h0 = w->h0; p.hT = w->hT; p.P = w->P;
     p.S1T = c->S1T; p.S2T = c->S2T; p.WT = c->WT; p.Osum = c->Osum;
-    p.x = x; p.len = lengths; p.labels = labels;
+    p.x = x; p.len = lengths; p.labels = labels; p.err = c->err_dev;
     float *q = c->ws;
     p.A = q; q += N1 * S; p.Bk = q; q += N1 * S; p.GA = q; q += N1 * S; p.GB = q; q += N1 * S;
     p.Zf = q; q += N1 * S; p.Zb = q; q += N1 * S; p.BBAR = q; q += N1 * S; p.PRE = q; q += N1 * S;
@@ -1519,10 +1540,15 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         } else {
             // emissions -> CRF forward-backward (loss, d loss / d emissions, transition counts, Viterbi tags) -> adjoints
             FARNN_LAUNCH_LOSS(1)
-            const size_t K1 = K + 1;
-            const size_t lds_c = (3 * K * K1 + 3 * (size_t)L * K + (size_t)L + 5 * K + 8) * sizeof(float) + (((size_t)L * K + 3) & ~(size_t)3);
-            if ((rc = raise_lds_limit(train_crf_kernel, lds_c))) return rc;
-            train_crf_kernel<<<B, 256, lds_c, s>>>(p);
+            if (train_crf_lds_bytes(K, L, false) <= 160 * 1024) {
+                const size_t lds_c = train_crf_lds_bytes(K, L, false);
+                if ((rc = raise_lds_limit(train_crf_kernel<false>, lds_c))) return rc;
+                train_crf_kernel<false><<<B, 256, lds_c, s>>>(p);
+            } else {        // large tag sets: transitions, expected counts and emissions stay in global memory
+                const size_t lds_c = train_crf_lds_bytes(K, L, true);
+                if ((rc = raise_lds_limit(train_crf_kernel<true>, lds_c))) return rc;
+                train_crf_kernel<true><<<B, 256, lds_c, s>>>(p);
+            }
             crf_reduce_kernel<<<(unsigned)((K * K + 255) / 256), 256, 0, s>>>(p.dtrans_part, o->dtrans, B, (int)(K * K));
             FARNN_LAUNCH_LOSS(2)
         }

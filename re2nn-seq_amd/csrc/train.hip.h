@@ -51,6 +51,7 @@ struct TrainParams {
     float *dtrans_part;       // [B][K][K]
     float *dVgen, *dOsum, *dh0, *dhT, *loss;
     int32_t *tags;
+    int *err;                 // sticky device flag: bit 0 = a label outside 0..K-1 at a valid position
     int B, L, V, S, R, K, nl, o_idx;
     float threshold, inv_tokens;
 };
@@ -475,9 +476,13 @@ train_loss_kernel(const TrainParams p) {
             float se = 0.0f;
             for (int c = lane; c < K; c += WAVE) se += expf(sc[c] - mx);
             for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, WAVE);
-            const int lab = (int)p.labels[pos];
+            // a label outside 0..K-1 (torch's CrossEntropyLoss raises on it): counted as label 0 in the loss AND in the
+            // gradient, and reported through the sticky flag (the next call returns FARNN_EINVAL)
+            const long long lab64 = p.labels[pos];
+            const int lab = (lab64 < 0 || lab64 >= K) ? 0 : (int)lab64;
+            if (lane == 0 && lab64 != lab) atomicOr(p.err, 1);
             const float lse = mx + logf(se);
-            loss_acc += lse - sc[lab < 0 || lab >= K ? 0 : lab];
+            loss_acc += lse - sc[lab];
             {
                 float bv = -INFINITY; int bi = 0x7ffffffe;
                 for (int c = lane; c < K; c += WAVE) {
@@ -533,33 +538,48 @@ train_loss_kernel(const TrainParams p) {
 // version evaluated expf K^2 times per step: 1.85 ms for 256 sequences).
 // LDS: tr, etr, ex [K][K+1]; al[L][K] log-messages; ea[L][K] = exp(al - amax_t); am[L]; bt[2][K]; eb[K]; red[8];
 //      vit[2][K]; fl[L][K] emissions; bp[L][K] bytes
+template <bool BIG>
 __global__ void __launch_bounds__(256)
 train_crf_kernel(const TrainParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, nt = blockDim.x, b = blockIdx.x;
     const int K = p.K, K1 = K + 1, START = K - 2, STOP = K - 1;
     const int n = clamp_len(p.len[b], p.L);
-    float *tr = smem, *etr = tr + K * K1, *ex = etr + K * K1, *al = ex + K * K1, *ea = al + (long long)p.L * K;
+    // BIG (tag sets whose three tables + messages exceed the 160 KiB of LDS, e.g. K = 130 at L = 64): only
+    // exp(transitions) and the messages stay in LDS; the transitions are read from global memory (L2-resident, the
+    // Viterbi half and the gold score use them), the expected counts accumulate in this sequence's slice of
+    // dtrans_part (every element has one owning thread) and the emissions are read where the loss kernel left them.
+    const int TS = BIG ? K : K1;                                               // row stride of tr / ex
+    float *etr = smem, *lds_tr = etr + K * K1, *lds_ex = lds_tr + (BIG ? 0 : K * K1);
+    float *al = lds_ex + (BIG ? 0 : K * K1), *ea = al + (long long)p.L * K;
     float *am = ea + (long long)p.L * K, *bt = am + p.L, *eb = bt + 2 * K, *red = eb + K, *vit = red + 8;
-    float *fl = vit + 2 * K;                                                   // [L][K] this sequence's emissions
-    unsigned char *bp = (unsigned char *)(fl + (long long)p.L * K);
+    float *fl = vit + 2 * K;                                                   // [L][K] this sequence's emissions (!BIG)
+    unsigned char *bp = (unsigned char *)(fl + (BIG ? 0 : (long long)p.L * K));
     float *dpart = p.dtrans_part + (long long)b * K * K;
+    const float *tr;
+    float *ex;
+    if constexpr (BIG) { tr = p.trans; ex = dpart; } else { tr = lds_tr; ex = lds_ex; }
     for (int e = tid; e < K * K; e += nt) {
         const int o = (e / K) * K1 + e % K;
         const float t = p.trans[e];
-        tr[o] = t; etr[o] = __expf(t); ex[o] = 0.0f;
+        etr[o] = __expf(t);
+        if constexpr (BIG) { dpart[e] = 0.0f; } else { lds_tr[o] = t; lds_ex[o] = 0.0f; }
     }
     __syncthreads();
     if (n == 0) {
-        for (int e = tid; e < K * K; e += nt) dpart[e] = 0.0f;
+        if constexpr (!BIG)
+            for (int e = tid; e < K * K; e += nt) dpart[e] = 0.0f;
         return;
     }
-    {
+    const float *F;
+    if constexpr (BIG) {
+        F = p.SC + (long long)b * p.L * K;
+    } else {
         const float *Fg = p.SC + (long long)b * p.L * K;
         for (int e = tid; e < n * K; e += nt) fl[e] = Fg[e];
+        F = fl;
     }
     __syncthreads();
-    const float *F = fl;
     const int64_t *y = p.labels + (long long)b * p.L;
     // forward messages and the Viterbi recursion on the clamped emissions (association as in :123,:145)
     // red[4..7]: per-wavefront maxima of the newest forward (later backward) message: the next step's scale comes from
@@ -568,9 +588,9 @@ train_crf_kernel(const TrainParams p) {
     {
         float vmax = -INFINITY;
         for (int j = tid; j < K; j += nt) {
-            const float f0 = F[j], a0 = f0 + tr[START * K1 + j];
+            const float f0 = F[j], a0 = f0 + tr[START * TS + j];
             al[j] = a0;
-            vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * K1 + j];
+            vit[j] = (j == K - 3 ? fminf(f0, p.threshold) : f0) + tr[START * TS + j];
             vmax = fmaxf(vmax, a0);
         }
         for (int o = 32; o; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, WAVE));
@@ -615,12 +635,12 @@ train_crf_kernel(const TrainParams p) {
                     for (; i + 4 <= K; i += 4) {
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
-                            const float cand = (fc + tr[(i + u) * K1 + j]) + vp[i + u];
+                            const float cand = (fc + tr[(i + u) * TS + j]) + vp[i + u];
                             if (cand > b4[u]) { b4[u] = cand; i4[u] = i + u; }
                         }
                     }
                     for (; i < K; i++) {
-                        const float cand = (fc + tr[i * K1 + j]) + vp[i];
+                        const float cand = (fc + tr[i * TS + j]) + vp[i];
                         if (cand > b4[0]) { b4[0] = cand; i4[0] = i; }
                     }
                     float bv = b4[0];
@@ -647,17 +667,17 @@ train_crf_kernel(const TrainParams p) {
         float gold = 0.0f;
         for (int t = 0; t < n; t++) {
             int yt = (int)y[t];
-            yt = yt < 0 || yt >= K ? 0 : yt;
-            gold += F[(long long)t * K + yt] + tr[prev * K1 + yt];
-            ex[prev * K1 + yt] -= 1.0f;                                         // gold transition counts
+            if (y[t] < 0 || y[t] >= K) { yt = 0; atomicOr(p.err, 1); }         // same clamp as the marginals below
+            gold += F[(long long)t * K + yt] + tr[prev * TS + yt];
+            ex[prev * TS + yt] -= 1.0f;                                         // gold transition counts
             prev = yt;
         }
-        gold += tr[prev * K1 + STOP];
-        ex[prev * K1 + STOP] -= 1.0f;
+        gold += tr[prev * TS + STOP];
+        ex[prev * TS + STOP] -= 1.0f;
         red[0] = logZ;
         atomicAdd(p.loss, logZ - gold);
         float bv = -INFINITY; int ptr = 0;
-        for (int i = 0; i < K; i++) { const float c = vp[i] + tr[i * K1 + STOP]; if (c > bv) { bv = c; ptr = i; } }
+        for (int i = 0; i < K; i++) { const float c = vp[i] + tr[i * TS + STOP]; if (c > bv) { bv = c; ptr = i; } }
         for (int t = n - 1; t >= 0; t--) {
             p.tags[(long long)b * p.L + t] = ptr == K - 3 ? p.o_idx : ptr;
             if (t > 0) ptr = bp[(long long)t * K + ptr];
@@ -667,7 +687,7 @@ train_crf_kernel(const TrainParams p) {
     {
         float vmax = -INFINITY;
         for (int i = tid; i < K; i += nt) {
-            const float bv = tr[i * K1 + STOP];
+            const float bv = tr[i * TS + STOP];
             bt[((n - 1) & 1) * K + i] = bv;                                      // backward message at the last token
             vmax = fmaxf(vmax, F[(long long)(n - 1) * K + i] + bv);
         }
@@ -704,8 +724,8 @@ train_crf_kernel(const TrainParams p) {
             int yt = (int)y[t];
             yt = yt < 0 || yt >= K ? 0 : yt;
             p.DS[((long long)b * p.L + t) * K + j] = m - (j == yt ? 1.0f : 0.0f);
-            if (t == 0) ex[START * K1 + j] += m;
-            if (t == n - 1) ex[j * K1 + STOP] += m;
+            if (t == 0) ex[START * TS + j] += m;
+            if (t == n - 1) ex[j * TS + STOP] += m;
         }
         __syncthreads();                                                        // eb ready; START row / STOP column settled
         if (t > 0) {
@@ -727,12 +747,12 @@ train_crf_kernel(const TrainParams p) {
                     const float ebj = eb[cj];
 #pragma unroll 4
                     for (int i = r0; i < K; i += rstep)
-                        ex[i * K1 + cj] = fmaf(ep[i] * scale, etr[i * K1 + cj] * ebj, ex[i * K1 + cj]);
+                        ex[i * TS + cj] = fmaf(ep[i] * scale, etr[i * K1 + cj] * ebj, ex[i * TS + cj]);
                 }
             } else {
                 for (int e = tid; e < K * K; e += nt) {
                     const int i = e / K, j = e - i * K;
-                    ex[i * K1 + j] = fmaf(ep[i] * scale, etr[i * K1 + j] * eb[j], ex[i * K1 + j]);
+                    ex[i * TS + j] = fmaf(ep[i] * scale, etr[i * K1 + j] * eb[j], ex[i * TS + j]);
                 }
             }
             float vmax = -INFINITY;
@@ -759,11 +779,18 @@ train_crf_kernel(const TrainParams p) {
 #pragma unroll
         for (int u = 0; u < CRF_XR; u++) {
             const int i = xr0 + u * xrstep;
-            if (i < K) ex[i * K1 + xcj] += exr[u];                              // each element has exactly one owner
+            if (i < K) ex[i * TS + xcj] += exr[u];                              // each element has exactly one owner
         }
     }
     __syncthreads();
-    for (int e = tid; e < K * K; e += nt) dpart[e] = ex[(e / K) * K1 + e % K];
+    for (int e = tid; e < K * K; e += nt) dpart[e] = ex[(e / K) * TS + e % K];
+}
+
+// LDS bytes of train_crf_kernel<BIG> (its carve, above)
+inline size_t train_crf_lds_bytes(size_t K, size_t L, bool big) {
+    const size_t K1 = K + 1;
+    const size_t floats = (big ? 1 : 3) * K * K1 + (big ? 2 : 3) * L * K + L + 5 * K + 8;
+    return floats * sizeof(float) + ((L * K + 3) & ~(size_t)3);
 }
 
 // dtrans[e] = sum_b dtrans_part[b][e]

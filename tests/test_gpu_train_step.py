@@ -192,6 +192,8 @@ def test_training_loop_reduces_the_loss_and_tagging_sees_the_update():
 @pytest.mark.parametrize('S,R,K,V,B,L,nl,prio', [
     (104, 50, 75, 200, 9, 40, 'tanh', False),      # SNIPS-sized label set + START/STOP
     (20, 8, 6, 30, 5, 7, 'relu', True),
+    (71, 30, 130, 120, 6, 64, 'tanh', False),      # ATIS-sized label set (C=128 + 2) at L=64: the CRF kernel's large-K form
+    (40, 20, 140, 60, 3, 64, 'relu', False),       # the largest tag set that fits at L=64
 ])
 def test_train_step_crf_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
     """CRF mode of the C-ABI entry point (loss = sum of log Z - gold score) against the oracle, with an empty and a
@@ -496,3 +498,53 @@ def test_train_step_rank_250_gated_crf_vs_batched_oracle(R):
             tuple((n, n) for n in gate_names):
         close(out['d' + n].cpu().numpy(), grads_ref[key].numpy().reshape(out['d' + n].shape), 'd' + n, rtol=5e-3)
     close(dtr.cpu().numpy(), grads_ref['crf.transitions'].numpy(), 'dtrans', rtol=5e-3)
+
+
+def test_train_step_reports_out_of_range_labels_and_crf_size_limits():
+    """a label outside 0..K-1 at a valid position is counted as label 0 in loss AND gradient (they stay
+    consistent) and the NEXT call returns FARNN_EINVAL (torch's CrossEntropyLoss raises on such a target); a CRF tag
+    set that cannot fit the LDS is refused before anything is enqueued."""
+    from re2nn_seq_amd import _lib
+    rng = np.random.RandomState(3)
+    V, S, R, K, B, L = 30, 12, 6, 7, 4, 5
+    dev = torch.device('cuda')
+    f = lambda *shape: torch.from_numpy((rng.randn(*shape) * 0.3).astype(np.float32)).to(dev)   # noqa: E731
+    w = {'Vgen': f(V, R), 'S1': f(S, R), 'S2': f(S, R), 'W': f(S, S), 'C': f(K, S), 'h0': f(S), 'hT': f(S)}
+    out = {'d' + n: torch.zeros_like(t) for n, t in w.items()}
+    loss = torch.zeros(1, device=dev)
+    tags = torch.empty((B, L), dtype=torch.int32, device=dev)
+    x = torch.from_numpy(rng.randint(0, V, size=(B, L))).to(dev)
+    lengths = torch.tensor([5, 3, 1, 4], device=dev)
+    good = torch.from_numpy(rng.randint(0, K, size=(B, L))).to(dev)
+    bad = good.clone(); bad[1, 1] = K + 3
+    zero = good.clone(); zero[1, 1] = 0
+    padbad = good.clone(); padbad[1, 4] = -5            # a pad position: never read
+    tc = _lib.TrainContext(V, S, R, K, nl='tanh')
+
+    def step(lab):
+        tc.step({n: t.data_ptr() for n, t in w.items()}, x.data_ptr(), lengths.data_ptr(), lab.data_ptr(), B, L, 13,
+                dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(), tags=tags.data_ptr()))
+        torch.cuda.synchronize()
+        return float(loss), {n: t.clone() for n, t in out.items()}
+
+    l0, g0 = step(zero)
+    step(padbad)                                        # fine: the next call does not raise
+    l1, g1 = step(bad)
+    assert l1 == l0 and all(torch.equal(g0[n], g1[n]) for n in g0)      # counted as label 0, consistently
+    with pytest.raises(_lib.FarnnError, match='label outside'):
+        step(good)
+    step(good)                                          # the flag is reported once
+    tc.close()
+    # CRF size limits: K = 200 cannot keep exp(transitions) in LDS at all; K = 150 fails at L = 64 only
+    with pytest.raises(_lib.FarnnError, match='4..190'):
+        _lib.TrainContext(V, S, R, 200, nl='tanh', use_crf=True)
+    tc = _lib.TrainContext(V, S, R, 150, nl='tanh', use_crf=True)
+    w['C'] = f(150, S); out['dC'] = torch.zeros_like(w['C'])
+    tr = f(150, 150); dtr = torch.zeros_like(tr)
+    x64 = torch.from_numpy(rng.randint(0, V, size=(B, 64))).to(dev)
+    lab64 = torch.zeros((B, 64), dtype=torch.int64, device=dev)
+    with pytest.raises(_lib.FarnnError, match='too large'):
+        tc.step(dict({n: t.data_ptr() for n, t in w.items()}, crf_trans=tr.data_ptr()), x64.data_ptr(), lengths.data_ptr(),
+                lab64.data_ptr(), B, 64, 13, dict({n: t.data_ptr() for n, t in out.items()}, loss=loss.data_ptr(),
+                                                  tags=tags.data_ptr(), dtrans=dtr.data_ptr()))
+    tc.close()
