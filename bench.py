@@ -184,7 +184,7 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
         h = _lib.create_onehot_fst4(T4, W4, h0, hT, device=dev)
         extras.update(T4=T4, W4=W4, h0=h0, hT=hT)
     elif name in ('decomp1', 'decomp0'):
-        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
+        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng, contractive=True)
         RO = 70
         f = lambda *shape, sc=0.2: (wrng.randn(*shape) * sc).astype(np.float32)      # noqa: E731
         q = {'Vgen': p['V_embed'].astype(np.float32), 'S1': p['S1'].astype(np.float32),
@@ -204,13 +204,13 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
                                        q['h0'], q['hT'], nl='tanh', semiring=semiring, device=dev)
         extras['q'] = q
     else:
-        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng)
+        p = synth.random_decomposed_params(V, S, C, cp_rank, 100, wrng, contractive=True)
         Vgen = p['V_embed']          # beta = 1: the generalized table is V_embed itself
         gates = None
         if farnn:
-            gates = {'Wss1': wrng.randn(S, S) * 0.1, 'Wrs1': wrng.randn(cp_rank, S) * 0.1, 'bs1': np.full(S, 1.0)}
+            gates = {'Wss1': wrng.randn(S, S) * 0.03, 'Wrs1': wrng.randn(cp_rank, S) * 0.03, 'bs1': np.full(S, 1.0)}
             if farnn == 2:
-                gates.update(Wss2=wrng.randn(S, S) * 0.1, Wrs2=wrng.randn(cp_rank, S) * 0.1, bs2=np.full(S, 1.0))
+                gates.update(Wss2=wrng.randn(S, S) * 0.03, Wrs2=wrng.randn(cp_rank, S) * 0.03, bs2=np.full(S, 1.0))
             gates = {k: v.astype(np.float32) for k, v in gates.items()}
         h = _lib.create_decomp_ifst(Vgen, p['S1'], p['S2'], p['wildcard_mat'], p['C_output_mat'],
                                     p['start_vector'], p['final_vector'], nl='tanh', farnn=farnn, gates=gates,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
@@ -62,6 +63,21 @@ __device__ __forceinline__ int clamp_tok(long long v, int V) { return (v < 0 || 
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+
+// Agent-scope (write-through / L1-bypassing) 8-byte accesses for data handed from one workgroup to another inside a
+// launch: relaxed agent-scope atomics lower to `global_store_dwordx2 ... sc1` / `global_load_dwordx2 ... sc1`
+// (MI355X_MICROARCH.md, inter-workgroup visibility).  `p` must be 8-byte aligned.
+__device__ __forceinline__ void st2_agent(float *p, float a, float b) {
+    const unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ld4_agent(const float *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float((unsigned)lo), __uint_as_float((unsigned)(lo >> 32)),
+                       __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
+}
 
 // (value desc, index asc) combine for first-index argmax, matching torch.max tie-breaking.
 __device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int oi) {

@@ -1,6 +1,7 @@
 // libfarnn_hip.so -- C-ABI entry points (include/farnn.h) of the MI355X-native FA-RNN tagging path.
 // gfx950 only; no CPU fallback lives here (the CPU oracle is test infrastructure under oracle/).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdlib.h>
 #include <map>
 #include <new>
@@ -27,8 +28,14 @@ enum { KERN_CHAIN = 0, KERN_SCORE = 1, KERN_PREP = 2, KERN_COUNT = 3 };
 
 struct Prof {
     std::vector<hipEvent_t> ev[KERN_COUNT];   // (start, stop) pairs
+    std::vector<hipEvent_t> pool;             // events created ahead of the timed region (farnn_set_profiling)
     double ms[KERN_COUNT] = {0, 0, 0};
     long long n[KERN_COUNT] = {0, 0, 0};
+    hipEvent_t get() {
+        hipEvent_t e = nullptr;
+        if (!pool.empty()) { e = pool.back(); pool.pop_back(); return e; }
+        return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+    }
 };
 
 struct farnn_model {
@@ -58,12 +65,15 @@ struct farnn_model {
     float *d1_br = nullptr;                 // [B*L][MT][NT*16] per-row-tile partial output-rank vectors (decomposed independent=1)
     int64_t *offs = nullptr;
     int *order = nullptr;
+    int *pair_cnt = nullptr;                // [2][B] arrival counters of the fused chain+score launch (monotonic) and tile claims
+    int epoch = 0;                          // launches of the fused kernel so far
     int wsB = 0, wsL = 0;
     ChainGeom geom;
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
     bool dense_decomp = false;              // decomposed model served by dense per-word blocks + chain_kernel
     bool order_valid = false;
+    bool last_fused = false;                // the last farnn_tag ran the single-launch form (chain + score/decode epilogue)
     int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
     long long calls = 0;
     int prof_this_call = 0;
@@ -247,16 +257,19 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     if (m->A) {
         FARNN_HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); (void)hipFree(m->order);
+        if (m->pair_cnt) (void)hipFree(m->pair_cnt);
         if (m->crf_scores) (void)hipFree(m->crf_scores);
         if (m->d1_br) (void)hipFree(m->d1_br);
     }
     m->d1_br = nullptr;
-    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->wsB = m->wsL = 0;
+    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->pair_cnt = nullptr; m->wsB = m->wsL = 0;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
+    FARNN_HIP_TRY(hipMalloc((void **)&m->pair_cnt, (size_t)2 * nB * sizeof(int)));
+    FARNN_HIP_TRY(hipMemset(m->pair_cnt, 0, (size_t)2 * nB * sizeof(int)));
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     if (m->d1_BSSp)
@@ -271,13 +284,18 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
 // ---- profiling -------------------------------------------------------------------------------
 struct KernelTimer {
     farnn_model *m; int which; hipStream_t s; hipEvent_t e0 = nullptr, e1 = nullptr;
-    KernelTimer(farnn_model *m_, int w, hipStream_t s_) : m(m_), which(w), s(s_) {
-        if (m->prof_this_call && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess)
-            (void)hipEventRecord(e0, s);
+    // ext = true: the events ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL start/stop events): no
+    // extra packets on the stream, so a timed step costs the same as an untimed one; the caller passes e0/e1 to the launch
+    bool ext;
+    KernelTimer(farnn_model *m_, int w, hipStream_t s_, bool ext_ = false) : m(m_), which(w), s(s_), ext(ext_) {
+        if (m->prof_this_call) {
+            e0 = m->prof.get(); e1 = m->prof.get();
+            if (e0 && e1 && !ext) (void)hipEventRecord(e0, s);
+        }
     }
     ~KernelTimer() {
         if (e0 && e1) {
-            (void)hipEventRecord(e1, s);
+            if (!ext) (void)hipEventRecord(e1, s);
             m->prof.ev[which].push_back(e0);
             m->prof.ev[which].push_back(e1);
         }
@@ -293,7 +311,7 @@ static void prof_fold(farnn_model *m) {
                 hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) {
                 m->prof.ms[k] += ms; m->prof.n[k] += 1;
             }
-            (void)hipEventDestroy(v[i]); (void)hipEventDestroy(v[i + 1]);
+            m->prof.pool.push_back(v[i]); m->prof.pool.push_back(v[i + 1]);
         }
         v.clear();
     }
@@ -302,7 +320,14 @@ static void prof_fold(farnn_model *m) {
 extern "C" int farnn_set_profiling(farnn_model *m, int32_t enable) {
     if (!m) return fail(FARNN_EINVAL, "null model%s%s");
     prof_fold(m);
-    if (enable) for (int k = 0; k < KERN_COUNT; k++) { m->prof.ms[k] = 0; m->prof.n[k] = 0; }
+    if (enable) {
+        for (int k = 0; k < KERN_COUNT; k++) { m->prof.ms[k] = 0; m->prof.n[k] = 0; }
+        while (m->prof.pool.size() < 256) {       // events exist before the timed region starts
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            m->prof.pool.push_back(e);
+        }
+    }
     m->profiling = enable > 0 ? enable : 0;
     m->calls = 0;
     return FARNN_OK;
@@ -320,6 +345,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
         case KERN_CHAIN:
+            if (m->last_fused) return "chain_kernel<fused score+decode epilogue>";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
                 return m->rows.ok ? "decomp_rows_kernel" : "decomp_chain_kernel";
@@ -353,9 +379,12 @@ static int raise_lds_limit(KernelT kern, size_t bytes) {
     return FARNN_OK;
 }
 
+// fuse_sp != nullptr: ask for the fused launch (scores + argmax decode as the chain kernel's epilogue); *fused tells
+// whether the geometry allowed it (else the caller launches the score kernel itself)
 static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, int B, int L, int full,
-                        hipStream_t s) {
+                        hipStream_t s, const ScoreParams *fuse_sp = nullptr, bool *fused = nullptr) {
     const ChainGeom &g = m->geom;
+    if (fused) *fused = false;
     ChainParams p;
     p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
@@ -371,17 +400,50 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         return fail(FARNN_ERANGE, "chain kernel: LDS ring does not fit (sequence too long for this S)%s%s");
     p.KS = ks; p.NQP = nqp; p.PPS = (g.NQ + nqp - 1) / nqp;
     const size_t lds = g.lds_bytes(m->wsL, ks, nqp);
-    const dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);   // compute + loader + writer wavefronts
+    dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);         // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
+    ScoreParams sp;
+    memset(&sp, 0, sizeof(sp));
+    // the fused form needs eight wavefronts for the epilogue, the one-chunk-per-lane geometries (S <= 256), the
+    // sequence's score tile + output matrix inside the (then idle) DMA ring, and the arrival counters
+    const bool six_wave_fast = block.x <= 384 && g.NCH == 1 && p.PPS == 1 && g.NQ > 3;   // keeps its own fast path
+    const bool do_fuse = fuse_sp && m->pair_cnt && g.NCH == 1 && g.NW + g.NLD + 1 <= SCORE_WAVES && !six_wave_fast &&
+                         score_lds_bytes(m->S, m->SP, m->Kc, m->P ? 1 : 0, 1) <= (size_t)ks * g.phase_bytes(nqp) &&
+                         !env_int("FARNN_NOFUSE", 0);
+    if (do_fuse) {
+        sp = *fuse_sp;
+        block = dim3(SCORE_WAVES * 64);
+        p.pair_cnt = m->pair_cnt;
+        p.claim = m->pair_cnt + m->wsB;
+        p.epoch = ++m->epoch;
+        p.spin = env_int("FARNN_FUSE_SPIN", 160);
+        p.flat_in_kernel = (sp.flat && !sp.offs) ? 1 : 0;
+        p.fence = env_int("FARNN_FUSE_FENCE", 0);
+        if (fused) *fused = true;
+    } else {
+        p.pair_cnt = nullptr; p.claim = nullptr; p.epoch = 0; p.spin = 0; p.fence = 0; p.flat_in_kernel = 0;
+        if (env_int("FARNN_CHAIN_HELPER", 0) && block.x < 512) block = dim3(block.x + 64);     // experiment: an idle eighth wavefront
+    }
+#define FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, FU)                                                 \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ, FU>, lds))) return rc;            \
+        if (kt.e0 && kt.e1)                                                                   \
+            hipExtLaunchKernelGGL((chain_kernel<NCH, MX, FQ, FU>), grid, block, (uint32_t)lds, s, kt.e0, kt.e1, 0, ka); \
+        else                                                                                  \
+            chain_kernel<NCH, MX, FQ, FU><<<grid, block, lds, s>>>(ka);                    \
+    } while (0)
 #define FARNN_LAUNCH_CHAIN(NCH, MX, FQ)                                                       \
     do {                                                                                      \
-        if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ>, lds))) return rc;                \
-        chain_kernel<NCH, MX, FQ><<<grid, block, lds, s>>>(p);                                \
+        if constexpr (NCH == 1 && FQ <= 3) {                                                  \
+            if (do_fuse) FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, true); else FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, false); \
+        } else FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, false);                                      \
     } while (0)
 #define FARNN_LAUNCH_CHAIN_MX(NCH, FQ)                                                        \
     do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true, FQ); else FARNN_LAUNCH_CHAIN(NCH, false, FQ); } while (0)
-    KernelTimer kt(m, KERN_CHAIN, s);
+    ChainKernelArgs ka;
+    ka.p = p; ka.sp = sp;
+    KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
     const int fq_max = block.x <= 384 ? 6 : 3;
     const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= fq_max && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
     if (g.NCH == 1) {
@@ -397,6 +459,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     else return fail(FARNN_ERANGE, "unsupported state count%s%s");
 #undef FARNN_LAUNCH_CHAIN_MX
 #undef FARNN_LAUNCH_CHAIN
+#undef FARNN_LAUNCH_CHAIN_F
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -609,9 +672,10 @@ static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t 
     return FARNN_OK;
 }
 
-static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
-                               int64_t *flat, float *scores, hipStream_t s) {
+static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
+                                     int64_t *flat, float *scores) {
     ScoreParams p;
+    memset(&p, 0, sizeof(p));
     p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
     p.offs = (flat && !m->prep_in_kernel) ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
     p.crf_scores = m->crf_scores;
@@ -619,6 +683,17 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     p.dbg = env_int("FARNN_DBG", 0);
+    return p;
+}
+
+// the dense-block recurrence followed by scores + decode: ONE launch (the decode is the chain kernel's epilogue) when
+// the decode is the threshold/argmax one and the geometry allows it, else the chain kernel + the score / Viterbi kernels
+static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64_t *len, int B, int L, int full,
+                                   int32_t *tags, int64_t *flat, float *scores, hipStream_t s);
+
+static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int full, int32_t *tags,
+                               int64_t *flat, float *scores, hipStream_t s) {
+    ScoreParams p = make_score_params(m, len, B, full, tags, flat, scores);
     if (viterbi_can_fuse(m, p)) {          // stash -> scores -> Viterbi -> tags in one kernel
         KernelTimer kt(m, KERN_SCORE, s);
         return launch_viterbi(m, p, B, s, true);
@@ -649,6 +724,19 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf && (rc = launch_viterbi(m, p, B, s))) return rc;
     return FARNN_OK;
+}
+
+static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64_t *len, int B, int L, int full,
+                                   int32_t *tags, int64_t *flat, float *scores, hipStream_t s) {
+    int rc;
+    if (!m->use_crf) {
+        const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
+        bool fused = false;
+        if ((rc = launch_chain(m, x, len, B, L, full, s, &sp, &fused))) return rc;
+        m->last_fused = fused;
+        if (fused) return FARNN_OK;
+    } else if ((rc = launch_chain(m, x, len, B, L, full, s))) return rc;
+    return launch_score_decode(m, len, B, full, tags, flat, scores, s);
 }
 
 extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
@@ -694,8 +782,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     }
     switch (m->kind) {
         case KIND_IFST:
-            if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
-            return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+            return launch_chain_and_decode(m, x, lengths, B, L, full, tags, flat_tags, scores, s);
         case KIND_FST4:
             if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
             {
@@ -713,9 +800,8 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                                          m->o_idx, m->threshold, m->Oten, m->V, s);
             }
         case KIND_DECOMP: {
-            if (m->dense_decomp) {
-                if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
-            } else {
+            if (m->dense_decomp) return launch_chain_and_decode(m, x, lengths, B, L, full, tags, flat_tags, scores, s);
+            {
                 KernelTimer kt(m, KERN_CHAIN, s);
                 if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
             }
@@ -1204,11 +1290,13 @@ extern "C" void farnn_destroy(farnn_model *m) {
     (void)hipSetDevice(m->device);
     (void)hipDeviceSynchronize();
     prof_fold(m);
+    for (hipEvent_t e : m->prof.pool) (void)hipEventDestroy(e);
     for (void *p : m->owned) (void)hipFree(p);
     if (m->A) (void)hipFree(m->A);
     if (m->Bk) (void)hipFree(m->Bk);
     if (m->offs) (void)hipFree(m->offs);
     if (m->order) (void)hipFree(m->order);
+    if (m->pair_cnt) (void)hipFree(m->pair_cnt);
     if (m->crf_scores) (void)hipFree(m->crf_scores);
     if (m->d1_br) (void)hipFree(m->d1_br);
     delete m;
@@ -1657,7 +1745,8 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     if (which == KERN_CHAIN) {
         if (!m->dense_decomp && (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0))
             return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
-        return (2.0 * S * S * 4 + 8) * n;                 // one block per direction + the token id
+        // one block per direction + the token id (+ the tag when the decode is this kernel's epilogue)
+        return (2.0 * S * S * 4 + 8 + (m->last_fused ? 4 : 0)) * n + (m->last_fused ? K * S * 4 : 0);
     }
     if (which == KERN_SCORE) {
         switch (m->kind) {

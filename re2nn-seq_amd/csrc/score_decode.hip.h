@@ -46,28 +46,39 @@ constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 // KCH = label columns per lane (K <= 64*KCH): compile-time so that the register-blocked loops are
 // fully unrolled with no per-column guards (with a runtime bound hipcc emitted one scalar branch
 // per column and the GEMM loop ran 3x slower).
-template <bool OT_LDS, int KCH>
-__global__ void __launch_bounds__(SCORE_WAVES * 64)
-score_tile_kernel(const ScoreParams p) {
-    extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+//
+// score_tiles: the tiles tile_first, tile_first + tile_step, ... (32 tokens each) of sequence b, by the 8 wavefronts
+// of the calling workgroup (every thread calls it; `smem` = 16-byte aligned LDS of score_lds_bytes()).  The output
+// matrix is staged once for all the tiles.  SC1: the stash is read with agent-scope (sc1) loads -- the form the
+// fused epilogue of chain_kernel needs, where another workgroup of the same launch wrote half of it.
+// where score_tiles keeps the transposed output matrix inside `smem`
+__device__ __forceinline__ float *score_ot_lds(float *smem, int SP, int Kc, bool has_P) {
+    return smem + SCORE_TT * SP + (has_P ? SCORE_WAVES * Kc : 0);
+}
+
+// LDS-DMA of the transposed output matrix into its place (1 KiB pieces, round-robin over the eight wavefronts); the
+// issuing wavefront's next `s_waitcnt vmcnt(0)` covers its pieces, a workgroup barrier behind that everybody's
+__device__ __forceinline__ void score_stage_ot(const float *OT, float *otl, int S, int Kc, int w, int lane) {
+    const unsigned ot_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)otl);
+    const int pieces = (S * Kc * 4 + 1023) / 1024;
+    const char *obase = reinterpret_cast<const char *>(OT);
+    for (int k = w; k < pieces; k += SCORE_WAVES)
+        lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, obase, ot_lds + (unsigned)k * 1024u);
+}
+
+// foff_pre >= 0: the sequence's offset in the flat output is already known; ot_prestaged: the caller issued
+// score_stage_ot() itself (from these same wavefronts) -- both let the fused epilogue overlap them with its hand-off
+template <bool OT_LDS, int KCH, bool SC1>
+__device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, const int tile_first, const int tile_step,
+                                            float *smem, const int tid, const long long foff_pre = -1,
+                                            const bool ot_prestaged = false) {
+    const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = SCORE_WAVES * 64;
-    const int b = blockIdx.y, t0 = blockIdx.x * SCORE_TT;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc;
-    const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
-    const int ntL = min(SCORE_TT, p.L - t0);             // tokens of this tile that exist
-
-    if (nt <= 0) {      // a tile of pads only (LOCAL mode)
-        for (int i = t0 + w; i < t0 + ntL; i += SCORE_WAVES) {
-            if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
-            if (p.scores)
-                for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
-        }
-        return;
-    }
+    const int ntiles = (p.L + SCORE_TT - 1) / SCORE_TT;
 
     // ---- LDS carve ---------------------------------------------------------------------------
     float *ab = smem;                                    // [TT][SP]  alpha*beta of the tile
@@ -75,47 +86,16 @@ score_tile_kernel(const ScoreParams p) {
     float *scw = nullptr;                                // [waves][Kc] one score row per wave (P)
     if (p.P) { scw = cur; cur += SCORE_WAVES * Kc; }
     float *otl = cur;                                    // [S][Kc] rounded up to whole DMA pieces
-    if (OT_LDS && !(p.dbg & 16)) {
-        // LDS-DMA: 1 KiB pieces, round-robin over the wavefronts; lands while phase 1 runs
-        const unsigned ot_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)otl);
-        const int pieces = (S * Kc * 4 + 1023) / 1024;
-        const char *obase = reinterpret_cast<const char *>(p.OT);
-        for (int k = w; k < pieces; k += SCORE_WAVES)
-            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, obase, ot_lds + (unsigned)k * 1024u);
-    }
-
-    const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
-    const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
-    const int SP4 = SP >> 2;
-    // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
-    // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
-    for (int idx0 = 0; idx0 < SCORE_TT * SP4; idx0 += 2 * nthreads) {
-        float4 a4[2], b4[2];
-        int tokv[2], s4v[2];
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int idx = idx0 + r * nthreads + tid;
-            const int tok = idx / SP4;
-            tokv[r] = tok; s4v[r] = (idx - tok * SP4) * 4;
-            a4[r] = make_float4(0.f, 0.f, 0.f, 0.f); b4[r] = a4[r];
-            if (tok < nt) {
-                const int i = t0 + tok;
-                const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
-                a4[r] = ld4(Ab + (long long)(i + 1) * SP + s4v[r]);
-                b4[r] = ld4(Bb + (long long)bidx * SP + s4v[r]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 2; r++)
-            if (tokv[r] < SCORE_TT)
-                st4(ab + tokv[r] * SP + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
-                                                             a4[r].z * b4[r].z, a4[r].w * b4[r].w));
+    bool dma_pending = ot_prestaged;
+    if (OT_LDS && !ot_prestaged && !(p.dbg & 16) && tile_first * SCORE_TT < nsteps) {
+        score_stage_ot(p.OT, otl, S, Kc, w, lane);       // lands while phase 1 runs
+        dma_pending = true;
     }
     // no prepared offsets: where this sequence starts in the flat output = sum of the lengths before it
     // (utils.py:153-164); B <= 1024 here, two loads per thread, hidden behind the DMA
     __shared__ int foff_w[SCORE_WAVES];
-    int foff_s = 0;
-    if (!p.offs && p.flat) {
+    long long foff = foff_pre >= 0 ? foff_pre : (p.offs ? p.offs[b] : 0);
+    if (foff_pre < 0 && !p.offs && p.flat) {
         int part = 0;
         for (int j = tid; j < b; j += nthreads) {
             const int v = (int)p.len[j];
@@ -124,109 +104,165 @@ score_tile_kernel(const ScoreParams p) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
         if (lane == 0) foff_w[w] = part;
-    }
-    if (OT_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wavefront's DMA pieces landed
-    __syncthreads();
-    if (!p.offs && p.flat) {
+        __syncthreads();
+        int foff_s = 0;
 #pragma unroll
         for (int ww = 0; ww < SCORE_WAVES; ww++) foff_s += foff_w[ww];
+        foff = (long long)foff_s;
     }
 
-    // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ----------
-    const int tg = w * 4;
-    if (tg >= nt && tg >= ntL) return;
+    const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
+    const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
+    const int SP4 = SP >> 2;
     const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
-    long long foff = p.offs ? p.offs[b] : 0;
-    if (!p.offs && p.flat) foff = (long long)foff_s;
-    float acc[4][KCH];
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-#pragma unroll
-        for (int k = 0; k < KCH; k++) acc[j][k] = 0.0f;
-    if (tg < nt && !(p.dbg & 32)) {
-        const float *abw = ab + tg * SP;
-        const float *otb = (OT_LDS ? otl : p.OT) + lane;
-        for (int s0 = 0; s0 < S; s0 += 4) {
-            float av[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const float4 a4 = ld4(abw + j * SP + s0);              // LDS broadcast
-                av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
+    for (int tile = tile_first; tile < ntiles; tile += tile_step) {
+        const int t0 = tile * SCORE_TT;
+        const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
+        const int ntL = min(SCORE_TT, p.L - t0);             // tokens of this tile that exist
+        if (nt <= 0) {      // a tile of pads only (LOCAL mode); uniform over the workgroup
+            for (int i = t0 + w; i < t0 + ntL; i += SCORE_WAVES) {
+                if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
+                if (p.scores)
+                    for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
             }
-            float ov[4][KCH];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int srow = (s0 + u < S) ? s0 + u : S - 1;        // ab pad columns are zero
-#pragma unroll
-                for (int k = 0; k < KCH; k++)
-                    ov[u][k] = otb[(long long)srow * Kc + 64 * k];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-                for (int k = 0; k < KCH; k++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov[u][k], acc[j][k]);
+            continue;
         }
-    }
+        // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
+        // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
+        for (int idx0 = 0; idx0 < SCORE_TT * SP4; idx0 += 2 * nthreads) {
+            float4 a4[2], b4[2];
+            int tokv[2], s4v[2];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int i = t0 + tg + j;
-        if (tg + j < nt) {
-            float sc[KCH];
+            for (int r = 0; r < 2; r++) {
+                const int idx = idx0 + r * nthreads + tid;
+                const int tok = idx / SP4;
+                tokv[r] = tok; s4v[r] = (idx - tok * SP4) * 4;
+                a4[r] = make_float4(0.f, 0.f, 0.f, 0.f); b4[r] = a4[r];
+                if (tok < nt) {
+                    const int i = t0 + tok;
+                    const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
+                    if (SC1) {
+                        a4[r] = ld4_agent(Ab + (long long)(i + 1) * SP + s4v[r]);
+                        b4[r] = ld4_agent(Bb + (long long)bidx * SP + s4v[r]);
+                    } else {
+                        a4[r] = ld4(Ab + (long long)(i + 1) * SP + s4v[r]);
+                        b4[r] = ld4(Bb + (long long)bidx * SP + s4v[r]);
+                    }
+                }
+            }
 #pragma unroll
-            for (int k = 0; k < KCH; k++) sc[k] = acc[j][k];
-            if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
-                float *sr = scw + w * Kc;
+            for (int r = 0; r < 2; r++)
+                if (tokv[r] < SCORE_TT)
+                    st4(ab + tokv[r] * SP + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
+                                                                 a4[r].z * b4[r].z, a4[r].w * b4[r].w));
+        }
+        if (dma_pending) {                                   // this wavefront's DMA pieces landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            dma_pending = false;
+        }
+        __syncthreads();
+
+        // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ----------
+        const int tg = w * 4;
+        float acc[4][KCH];
 #pragma unroll
-                for (int k = 0; k < KCH; k++) sr[lane + 64 * k] = sc[k];
-                __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
-                for (int cc = 0; cc < K; cc++) {
-                    const float sv = sr[cc];
-                    const float *prow = p.P + (long long)cc * Kc + lane;
+            for (int k = 0; k < KCH; k++) acc[j][k] = 0.0f;
+        if (tg < nt && !(p.dbg & 32)) {
+            const float *abw = ab + tg * SP;
+            const float *otb = (OT_LDS ? otl : p.OT) + lane;
+            for (int s0 = 0; s0 < S; s0 += 4) {
+                float av[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const float4 a4 = ld4(abw + j * SP + s0);              // LDS broadcast
+                    av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
+                }
+                float ov[4][KCH];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int srow = (s0 + u < S) ? s0 + u : S - 1;        // ab pad columns are zero
 #pragma unroll
                     for (int k = 0; k < KCH; k++)
-                        sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                        ov[u][k] = otb[(long long)srow * Kc + 64 * k];
                 }
-                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int k = 0; k < KCH; k++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov[u][k], acc[j][k]);
             }
-            if (p.scores) {
-                float *so = p.scores + ((long long)b * p.L + i) * K;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = t0 + tg + j;
+            if (tg + j < nt) {
+                float sc[KCH];
+#pragma unroll
+                for (int k = 0; k < KCH; k++) sc[k] = acc[j][k];
+                if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
+                    float *sr = scw + w * Kc;
+#pragma unroll
+                    for (int k = 0; k < KCH; k++) sr[lane + 64 * k] = sc[k];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
+                    for (int cc = 0; cc < K; cc++) {
+                        const float sv = sr[cc];
+                        const float *prow = p.P + (long long)cc * Kc + lane;
+#pragma unroll
+                        for (int k = 0; k < KCH; k++)
+                            sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (p.scores) {
+                    float *so = p.scores + ((long long)b * p.L + i) * K;
+#pragma unroll
+                    for (int k = 0; k < KCH; k++) {
+                        const int col = lane + 64 * k;
+                        if (col < K) so[col] = sc[k];
+                    }
+                }
+                // threshold clamp of the `oo` column, then decode
+                float bv = -INFINITY; int bi = 0x7ffffffe;
 #pragma unroll
                 for (int k = 0; k < KCH; k++) {
                     const int col = lane + 64 * k;
-                    if (col < K) so[col] = sc[k];
+                    if (col < K) {
+                        float v = sc[k] + 0.0f;                      // -0.0 -> +0.0 (torch: -0 == +0)
+                        if (col == clamp_col) v = fminf(v, p.threshold);
+                        if (p.use_crf) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
+                        if (v > bv) { bv = v; bi = col; }
+                    }
                 }
-            }
-            // threshold clamp of the `oo` column, then decode
-            float bv = -INFINITY; int bi = 0x7ffffffe;
-#pragma unroll
-            for (int k = 0; k < KCH; k++) {
-                const int col = lane + 64 * k;
-                if (col < K) {
-                    float v = sc[k] + 0.0f;                      // -0.0 -> +0.0 (torch: -0 == +0)
-                    if (col == clamp_col) v = fminf(v, p.threshold);
-                    if (p.use_crf) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
-                    if (v > bv) { bv = v; bi = col; }
+                if (!p.use_crf) {
+                    if (!(p.dbg & 64)) bi = wave_argmax_dpp(bv, bi);
+                    if (lane == 0) {
+                        if (bi >= K) bi = 0;                        // all-NaN row: torch returns 0
+                        const int tag = (bi == K - 1) ? p.o_idx : bi;
+                        if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                        if (p.flat && i < len) p.flat[foff + i] = tag;
+                    }
                 }
+            } else if (tg + j < ntL) {      // pad position inside a partly valid tile (LOCAL mode)
+                if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
+                if (p.scores)
+                    for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
             }
-            if (!p.use_crf) {
-                if (!(p.dbg & 64)) bi = wave_argmax_dpp(bv, bi);
-                if (lane == 0) {
-                    if (bi >= K) bi = 0;                        // all-NaN row: torch returns 0
-                    const int tag = (bi == K - 1) ? p.o_idx : bi;
-                    if (p.tags) p.tags[(long long)b * p.L + i] = tag;
-                    if (p.flat && i < len) p.flat[foff + i] = tag;
-                }
-            }
-        } else if (tg + j < ntL) {      // pad position inside a partly valid tile (LOCAL mode)
-            if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
-            if (p.scores)
-                for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
         }
+        if (tile + tile_step < ntiles) __syncthreads();      // the next tile overwrites ab
     }
+    if (dma_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // never leave DMA in flight into freed LDS
+}
+
+template <bool OT_LDS, int KCH>
+__global__ void __launch_bounds__(SCORE_WAVES * 64)
+score_tile_kernel(const ScoreParams p) {
+    extern __shared__ __align__(16) float smem[];
+    score_tiles<OT_LDS, KCH, false>(p, blockIdx.y, blockIdx.x, gridDim.x, smem, threadIdx.x);
 }
 
 inline size_t score_lds_bytes(int S, int SP, int Kc, int has_P, int ot_in_lds) {
@@ -271,7 +307,7 @@ viterbi_kernel(const ScoreParams p) {
     const int nthreads = blockDim.x;
     const int b = blockIdx.x;
     const int n = clamp_len(p.len[b], p.L);
-    const int nsteps = p.full ? p.L : n;
+    (void)p.full;
     const int K = p.K, Kp = p.Kp;
     const int PW = 4 * IB;                               // padded partition width (>= K)
     float *part = smem;                                  // [2][PW], pad entries -inf
@@ -345,7 +381,7 @@ viterbi_kernel(const ScoreParams p) {
         }
     }
     if (p.tags)
-        for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
+        for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
 }
 
 // History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
@@ -369,7 +405,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     const int nthreads = blockDim.x;
     const int b = blockIdx.x;
     const int n = clamp_len(p.len[b], p.L);
-    const int nsteps = p.full ? p.L : n;
+    (void)p.full;
     const int K = p.K, Kp = p.Kp;
     const int PW = 4 * IB;                               // padded partition width (>= K)
     float *hist = smem;                                  // [L][PW] partitions of every step, pads -inf
@@ -528,7 +564,7 @@ viterbi_hist_kernel(const ScoreParams p) {
         }
     }
     if (p.tags)
-        for (int i = n + tid; i < nsteps; i += nthreads) p.tags[(long long)b * p.L + i] = -1;
+        for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
 }
 
 // the instantiated block size (in float4s) for K tags: ceil(ceil(K/4)/4) rounded up to a built one

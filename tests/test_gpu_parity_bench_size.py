@@ -29,22 +29,22 @@ def _snips_model(R, farnn, crf, seed=1234):
     from re2nn_seq_amd import synth
     V, S, C = 11000, 104, 73
     wrng = np.random.RandomState(seed)
-    p = synth.random_decomposed_params(V, S, C, R, 100, wrng)
+    p = synth.random_decomposed_params(V, S, C, R, 100, wrng, contractive=True)
     f = lambda a: np.asarray(a, np.float32)                       # noqa: E731
     Cout = f(p['C_output_mat'])
     tr = None
     if crf:            # two extra rows for START / STOP (model_decompose_single.py:78-79), small random values
         Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
         K = C + 2
-        tr = fo.crf_default_transitions(C) + (wrng.randn(K, K) * 0.3).astype(np.float32)
+        tr = fo.crf_default_transitions(C) + (wrng.randn(K, K) * 1.0).astype(np.float32)
     q = {'Vgen': f(p['V_embed']), 'S1': f(p['S1']), 'S2': f(p['S2']), 'W': f(p['wildcard_mat']), 'Cout': Cout,
          'h0': f(p['start_vector']), 'hT': f(p['final_vector']), 'farnn': farnn, 'nl': fo.NL_TANH,
          'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
     gates = None
     if farnn:
-        gates = {'Wss1': f(wrng.randn(S, S) * 0.1), 'Wrs1': f(wrng.randn(R, S) * 0.1), 'bs1': f(np.full(S, 1.0))}
+        gates = {'Wss1': f(wrng.randn(S, S) * 0.03), 'Wrs1': f(wrng.randn(R, S) * 0.03), 'bs1': f(np.full(S, 1.0))}
         if farnn == 2:
-            gates.update(Wss2=f(wrng.randn(S, S) * 0.1), Wrs2=f(wrng.randn(R, S) * 0.1), bs2=f(np.full(S, 1.0)))
+            gates.update(Wss2=f(wrng.randn(S, S) * 0.03), Wrs2=f(wrng.randn(R, S) * 0.03), bs2=f(np.full(S, 1.0)))
         q.update(gates)
     return V, q, gates, tr
 
