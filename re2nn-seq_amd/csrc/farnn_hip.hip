@@ -16,6 +16,7 @@
 #include "decomp_chain.hip.h"
 #include "decomp1_score.hip.h"
 #include "decomp_rows.hip.h"
+#include "decomp_regs.hip.h"
 #include "train.hip.h"
 
 namespace farnn {
@@ -73,6 +74,7 @@ struct farnn_model {
     bool prep_in_kernel = false, sort_in_kernel = false;
     bool dense_decomp = false;              // decomposed model served by dense per-word blocks + chain_kernel
     bool order_valid = false;
+    bool last_wave = false;                 // the last decomposed recurrence ran on decomp_regs_kernel
     bool last_fused = false;                // the last farnn_tag ran the single-launch form (chain + score/decode epilogue)
     int profiling = 0;          // 0 off, N>0: time every N-th farnn_tag call
     long long calls = 0;
@@ -348,7 +350,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
             if (m->last_fused) return "chain_kernel<fused score+decode epilogue>";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
-                return m->rows.ok ? "decomp_rows_kernel" : "decomp_chain_kernel";
+                return m->rows.ok ? ((m->last_wave || (m->calls == 0 && m->dw.farnn == 0 && m->dw.R <= DG_ROWS && !getenv("FARNN_DECOMP_NOREGS"))) ? "decomp_regs_kernel" : "decomp_rows_kernel") : "decomp_chain_kernel";
             return "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
@@ -532,6 +534,17 @@ static int build_rows_pack(farnn_model *m) {
 static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int64_t *lengths, int B, int full,
                                     hipStream_t s) {
     const int *order = m->order_valid ? m->order : nullptr;
+    if (m->n_cu <= 0) {
+        int dev = 0, ncu = 0;
+        FARNN_HIP_TRY(hipGetDevice(&dev));
+        FARNN_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        m->n_cu = ncu > 0 ? ncu : 256;
+    }
+    RegsPlan rp;
+    m->last_wave = m->rows.ok && regs_plan(m->rows, m->dw, m->wsL, rp);
+    if (m->last_wave)        // farnn = 0, rank <= 64: four wavefronts per chain, the packed rows in registers
+        return launch_decomp_regs(m->rows, m->dw, rp, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B, m->wsL,
+                                  full, s);
     RowsPlan pl;
     if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->wsL, pl))
         return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B,

@@ -60,7 +60,7 @@ def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf):
     h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn,
                                 gates=gates, sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0,
                                 use_crf=crf, crf_trans=tr)
-    assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+    assert h.kernel_name(_lib.KERN_CHAIN) in ('decomp_rows_kernel', 'decomp_regs_kernel')
     xd, ld = _t(x).cuda(), _t(lengths).cuda()
     scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
     tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
