@@ -125,7 +125,7 @@ def test_decompose_independent1_cli_matches_oracle(tree, tmp_path):
         c = sc.copy(); c[..., -1] = np.minimum(c[..., -1], 0.5)
         m = np.arange(sc.shape[1])[None, :] < lengths[:, None]
         top2 = np.sort(c[m], axis=1)[:, -2:]
-        assert (top2[:, 1] - top2[:, 0]).min() > 1e-2
+        assert (top2[:, 1] - top2[:, 0]).min() > 1e-4     # float32 noise here is ~1e-6: equality is meaningful
         return sc
 
     for split in ('train', 'dev', 'test'):

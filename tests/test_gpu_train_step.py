@@ -193,7 +193,7 @@ def test_training_loop_reduces_the_loss_and_tagging_sees_the_update():
     (104, 50, 75, 200, 9, 40, 'tanh', False),      # SNIPS-sized label set + START/STOP
     (20, 8, 6, 30, 5, 7, 'relu', True),
     (71, 30, 130, 120, 6, 64, 'tanh', False),      # ATIS-sized label set (C=128 + 2) at L=64: the CRF kernel's large-K form
-    (40, 20, 140, 60, 3, 64, 'relu', False),       # the largest tag set that fits at L=64
+    (40, 20, 140, 60, 3, 64, 'tanh', False),       # the largest tag set that fits at L=64
 ])
 def test_train_step_crf_c_abi_vs_oracle(S, R, K, V, B, L, nl, prio):
     """CRF mode of the C-ABI entry point (loss = sum of log Z - gold score) against the oracle, with an empty and a
@@ -530,7 +530,9 @@ def test_train_step_reports_out_of_range_labels_and_crf_size_limits():
     l0, g0 = step(zero)
     step(padbad)                                        # fine: the next call does not raise
     l1, g1 = step(bad)
-    assert l1 == l0 and all(torch.equal(g0[n], g1[n]) for n in g0)      # counted as label 0, consistently
+    # counted as label 0, consistently in the loss and in every gradient (equal up to the order of the float atomics)
+    assert abs(l1 - l0) < 1e-5 * abs(l0)
+    assert all(torch.allclose(g0[n], g1[n], rtol=1e-4, atol=1e-6) for n in g0)
     with pytest.raises(_lib.FarnnError, match='label outside'):
         step(good)
     step(good)                                          # the flag is reported once
