@@ -286,7 +286,7 @@ chain_kernel(const ChainKernelArgs args) {
                 if (FUSED && !(p.dbg & 256)) {
                     for (int j = 2 * lane; j < SP; j += 2 * WAVE) st2_agent(srow + j, src[j], src[j + 1]);
                 } else {
-                    for (int j = lane; j < S; j += WAVE) srow[j] = src[j];
+                    for (int j = lane; j < SP; j += WAVE) srow[j] = src[j];     // pad columns: hfull's stay zero
                 }
             }
         }

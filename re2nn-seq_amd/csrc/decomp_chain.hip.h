@@ -69,6 +69,9 @@ decomp_chain_kernel(const DecompParams p) {
     const float *hinit = dir == 0 ? w.h0 : w.hT;
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     for (int j = tid; j < SP; j += nt) { float t = j < S ? hinit[j] : 0.0f; h[j] = t; stash[j] = t; }
+    // pad columns of every row this chain will write (the workspace is strided with the call's L and not re-zeroed)
+    if (SP > S)
+        for (int q = tid; q < nsteps * (SP - S); q += nt) stash[(long long)(1 + q / (SP - S)) * SP + S + q % (SP - S)] = 0.0f;
     __syncthreads();
 
     const float *Sa = dir == 0 ? w.S1 : w.S2;        // hb . Sa            [S][Rp]

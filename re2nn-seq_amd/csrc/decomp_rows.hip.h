@@ -217,10 +217,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
             stash_base[(long long)bseq[s] * (p.L + 1) * SP + j] = hv;
         }
     }
-    for (int j = S + tid; j < SP; j += DR_THREADS)
+    // pad columns of every row the chains will write (the workspace is strided with the call's L and not re-zeroed)
+    if (SP > S) {
 #pragma unroll
         for (int s = 0; s < NSEQ; s++)
-            if (nst[s] >= 0) stash_base[(long long)bseq[s] * (p.L + 1) * SP + j] = 0.0f;
+            for (int q = tid; q < (nst[s] + 1) * (SP - S); q += DR_THREADS)
+                stash_base[((long long)bseq[s] * (p.L + 1) + q / (SP - S)) * SP + S + q % (SP - S)] = 0.0f;
+    }
 
     // per-token vectors: element e of sequence s at step t
     auto tv_load = [&](int s, int e, int t) -> float {

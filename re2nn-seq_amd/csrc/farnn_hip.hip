@@ -68,7 +68,8 @@ struct farnn_model {
     int *order = nullptr;
     int *pair_cnt = nullptr;                // [2][B] arrival counters of the fused chain+score launch (monotonic) and tile claims
     int epoch = 0;                          // launches of the fused kernel so far
-    int wsB = 0, wsL = 0;
+    int wsB = 0, wsL = 0;                   // workspace CAPACITY: sequences, positions
+    int curL = 0;                           // the current call's L: every stride of the workspace arrays
     ChainGeom geom;
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
@@ -392,16 +393,15 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
     p.order = m->order_valid ? m->order : nullptr;
     p.sort = m->sort_in_kernel ? 1 : 0;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR; p.V = m->V;
+    p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR; p.V = m->V;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
     p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
-    (void)L;
     // ring shape: a whole step per phase when it fits, KS phases deep
     int ks = 2, nqp = g.NQ;
-    if (!g.pick_ring(m->wsL, m->chain_ks, ks, nqp))
+    if (!g.pick_ring(m->curL, m->chain_ks, ks, nqp))
         return fail(FARNN_ERANGE, "chain kernel: LDS ring does not fit (sequence too long for this S)%s%s");
     p.KS = ks; p.NQP = nqp; p.PPS = (g.NQ + nqp - 1) / nqp;
-    const size_t lds = g.lds_bytes(m->wsL, ks, nqp);
+    const size_t lds = g.lds_bytes(m->curL, ks, nqp);
     dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);         // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
@@ -541,15 +541,15 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
         m->n_cu = ncu > 0 ? ncu : 256;
     }
     RegsPlan rp;
-    m->last_wave = m->rows.ok && regs_plan(m->rows, m->dw, m->wsL, rp);
+    m->last_wave = m->rows.ok && regs_plan(m->rows, m->dw, m->curL, rp);
     if (m->last_wave)        // farnn = 0, rank <= 64: four wavefronts per chain, the packed rows in registers
-        return launch_decomp_regs(m->rows, m->dw, rp, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B, m->wsL,
+        return launch_decomp_regs(m->rows, m->dw, rp, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B, m->curL,
                                   full, s);
     RowsPlan pl;
-    if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->wsL, pl))
+    if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->curL, pl))
         return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B,
-                                  m->wsL, full, s);
-    return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->wsL, full, s);
+                                  m->curL, full, s);
+    return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->curL, full, s);
 }
 
 // fused: the Viterbi kernel computes the scores itself (no score_tile launch went before it)
@@ -597,7 +597,7 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
     p.S1o = m->d1_S1o; p.S2o = m->d1_S2o; p.CoutT = m->d1_CoutT; p.P = m->P;
     p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
     p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RO = m->RO; p.ROp = m->ROp;
+    p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RO = m->RO; p.ROp = m->ROp;
     p.V = m->V;
     p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
@@ -650,7 +650,7 @@ static int launch_decomp1_score(farnn_model *m, const int64_t *x, const int64_t 
         ScoreParams v;
         memset(&v, 0, sizeof(v));
         v.trT = m->tr; v.len = len; v.offs = flat ? m->offs : nullptr; v.tags = tags; v.flat = flat;
-        v.crf_scores = m->crf_scores; v.B = B; v.L = m->wsL; v.K = m->K; v.Kp = m->Kp;
+        v.crf_scores = m->crf_scores; v.B = B; v.L = m->curL; v.K = m->K; v.Kp = m->Kp;
         v.full = full; v.use_crf = 1; v.o_idx = m->o_idx; v.threshold = m->threshold;
         if ((rc = launch_viterbi(m, v, B, s))) return rc;
     }
@@ -664,7 +664,7 @@ static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t 
     p.S1w = m->d0_S1w; p.S2w = m->d0_S2w; p.CwT = m->d0_CwT; p.P = m->P;
     p.x = x; p.len = len; p.offs = flat ? m->offs : nullptr;
     p.tags = tags; p.flat = flat; p.scores = scores; p.crf_scores = m->crf_scores;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RW = m->RW; p.RWp = m->RWp;
+    p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.R = m->R; p.Rp = m->Rp; p.RW = m->RW; p.RWp = m->RWp;
     p.V = m->V;
     p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
@@ -678,7 +678,7 @@ static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t 
         ScoreParams v;
         memset(&v, 0, sizeof(v));
         v.trT = m->tr; v.len = len; v.offs = flat ? m->offs : nullptr; v.tags = tags; v.flat = flat;
-        v.crf_scores = m->crf_scores; v.B = B; v.L = m->wsL; v.K = m->K; v.Kp = m->Kp;
+        v.crf_scores = m->crf_scores; v.B = B; v.L = m->curL; v.K = m->K; v.Kp = m->Kp;
         v.full = full; v.use_crf = 1; v.o_idx = m->o_idx; v.threshold = m->threshold;
         if ((rc = launch_viterbi(m, v, B, s))) return rc;
     }
@@ -692,7 +692,7 @@ static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, 
     p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
     p.offs = (flat && !m->prep_in_kernel) ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
     p.crf_scores = m->crf_scores;
-    p.B = B; p.L = m->wsL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
+    p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     p.dbg = env_int("FARNN_DBG", 0);
@@ -760,13 +760,11 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     FARNN_HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
-    // the stash is indexed with the workspace's L; keep it equal to the call's L
-    if (B > m->wsB || L != m->wsL) {
-        if (L != m->wsL && m->A) { m->wsB = 0; }
-        int keepB = m->wsB;
-        m->wsL = 0;
-        if ((rc = farnn_reserve(m, B > keepB ? B : keepB, L))) return rc;
-    }
+    // the workspace arrays are strided with the CALL's L (every kernel writes whatever it later reads, pad columns
+    // included), so (B, L) only have to fit the capacity: a loop whose batches vary in size or length allocates once
+    if (B > m->wsB || L > m->wsL)
+        if ((rc = farnn_reserve(m, B, L))) return rc;
+    m->curL = L;
     const int full = mode == FARNN_MODE_FULL;
     m->prof_this_call = m->profiling > 0 && (m->calls++ % m->profiling) == 0;
     // batch preparation: flat-output offsets and the length-sorted launch order (full mode runs
@@ -801,7 +799,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
             {
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->A4, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
-                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
+                                         tags, flat_tags, scores, B, m->curL, m->S, m->SP, m->C, m->Kc, full,
                                          m->o_idx, m->threshold, /*Oten*/ nullptr, m->V, s);
             }
         case KIND_IND1:
@@ -809,7 +807,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
             {
                 KernelTimer kt(m, KERN_SCORE, s);
                 return launch_fst4_score(m->Ms, m->A, m->Bk, m->P, x, lengths, flat_tags ? m->offs : nullptr,
-                                         tags, flat_tags, scores, B, m->wsL, m->S, m->SP, m->C, m->Kc, full,
+                                         tags, flat_tags, scores, B, m->curL, m->S, m->SP, m->C, m->Kc, full,
                                          m->o_idx, m->threshold, m->Oten, m->V, s);
             }
         case KIND_DECOMP: {
@@ -832,7 +830,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
                 if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
             } else {
                 KernelTimer kt(m, KERN_CHAIN, s);
-                if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->wsL, full, s))) return rc;
+                if ((rc = launch_decomp_chain(m->dw, x, lengths, nullptr, m->A, m->Bk, B, m->curL, full, s))) return rc;
             }
             return launch_decomp1_score(m, x, lengths, B, full, tags, flat_tags, scores, s);
         }

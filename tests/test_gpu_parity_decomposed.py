@@ -466,3 +466,41 @@ def test_materialised_modes_run_on_dense_blocks():
     ref = fo.decomp_ifst_scores(q, x, lengths)
     mask = np.arange(Lmax)[None, :] < lengths[:, None]
     np.testing.assert_allclose(scores.cpu().numpy()[:, :Lmax][mask], ref[mask], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('farnn,semiring,R', [(0, 'sum', 50), (2, 'sum', 40), (1, 'max', 12), (0, 'sum', 90)])
+def test_one_handle_serves_varying_batch_shapes(farnn, semiring, R):
+    """the workspace is a capacity, strided with the call's (B, L): a loop whose batches vary in length
+    (the decomposed mirrors clip every batch to lengths.max()) allocates once, and results do not depend on what an
+    earlier, differently shaped call left behind (pad columns, longer rows).  Register kernel (farnn 0, rank <= 64), rows
+    kernel (gated / rank 90) and the generic kernel (gated max semiring) alike; S = 21 has pad columns (SP = 24)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(11 + farnn)
+    V, S, K = 80, 21, 7
+    p = synth.random_decomposed_params(V, S, K, R, 16, rng, contractive=True)
+    f = lambda a: np.asarray(a, np.float32)                    # noqa: E731
+    q = {'Vgen': f(p['V_embed']), 'S1': f(p['S1']), 'S2': f(p['S2']), 'W': f(p['wildcard_mat']), 'Cout': f(p['C_output_mat']),
+         'h0': f(p['start_vector']), 'hT': f(p['final_vector']), 'farnn': farnn, 'nl': fo.NL_CODES['tanh'],
+         'semiring': fo.SEMIRING_MAX if semiring == 'max' else fo.SEMIRING_SUM, 'sig_k': 5}
+    gates = None
+    if farnn:
+        gates = {'Wss1': f(rng.randn(S, S) * 0.1), 'Wrs1': f(rng.randn(R, S) * 0.1), 'bs1': f(np.full(S, 0.3))}
+        if farnn == 2:
+            gates.update(Wss2=f(rng.randn(S, S) * 0.1), Wrs2=f(rng.randn(R, S) * 0.1), bs2=f(np.full(S, 0.2)))
+        q.update(gates)
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn, gates=gates,
+                                sigmoid_exponent=5, nl='tanh', semiring=semiring, o_idx=2)
+    for B, L in [(9, 20), (5, 7), (12, 20), (3, 33), (9, 20)]:
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        xd, ld = _t(x).cuda(), _t(lengths).cuda()
+        scores = torch.full((B, L, K), 7.0, dtype=torch.float32, device='cuda')
+        flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), scores.data_ptr())
+        torch.cuda.synchronize()
+        ref = fo.decomp_ifst_scores(q, x, lengths)
+        Lmax = ref.shape[1]
+        mask = np.arange(Lmax)[None, :] < lengths[:, None]
+        got = scores.cpu().numpy()[:, :Lmax]
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4, err_msg='B={} L={}'.format(B, L))
+        assert (scores.cpu().numpy()[:, :Lmax][~mask] == 0).all()
+    h.close()

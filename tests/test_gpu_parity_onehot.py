@@ -419,3 +419,39 @@ def test_create_destroy_does_not_leak_device_memory():
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 8 << 20, 'leaked {} bytes'.format(free0 - free1)
+
+
+@pytest.mark.parametrize('fuse', ['1', '0'])
+def test_one_handle_serves_varying_batch_shapes(fuse, monkeypatch):
+    """The workspace is a capacity: calls of different (B, L) on one handle -- smaller, larger, back again -- each
+    bit-exact against the oracle (no reallocation / device-wide stall when L changes; S = 23 has a pad
+    column, so stale rows of an earlier stride would show).  Fused single-launch form and the two-kernel form."""
+    monkeypatch.setenv('FARNN_NOFUSE', '0' if fuse == '1' else '1')
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(2)
+    V, S, C = 50, 23, 9
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=1)
+    for B, L, mode in [(9, 20, _lib.MODE_LOCAL), (5, 7, _lib.MODE_LOCAL), (12, 40, _lib.MODE_FULL), (3, 33, _lib.MODE_LOCAL),
+                       (9, 20, _lib.MODE_LOCAL), (300, 12, _lib.MODE_LOCAL), (9, 70, _lib.MODE_LOCAL)]:
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+        scores = torch.full((B, L, C), 7.0, dtype=torch.float32, device='cuda')
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(), flat.data_ptr(), scores.data_ptr())
+        tags2 = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags2.data_ptr(), None, None)       # the tags-only call
+        torch.cuda.synchronize()
+        ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+        mask = np.arange(L)[None, :] < lengths[:, None]
+        got = scores.cpu().numpy()
+        want_tags = fo.decode_argmax(ref, 0.5, 1)
+        if mode == _lib.MODE_LOCAL:
+            assert np.array_equal(got[mask], ref[mask]) and (got[~mask] == 0).all()
+            assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, 1))
+            assert np.array_equal(tags.cpu().numpy()[mask], want_tags[mask]) and (tags.cpu().numpy()[~mask] == -1).all()
+        else:
+            assert np.array_equal(got, ref) and np.array_equal(tags.cpu().numpy(), want_tags)
+        assert np.array_equal(tags.cpu().numpy(), tags2.cpu().numpy())
+    h.close()
