@@ -363,6 +363,49 @@ def cpu_baseline_faithful(extras, x, lengths, seconds):
                       'host)'.format(n, el, os.cpu_count() or 1)}
 
 
+def host_inclusive(extras, x, lengths, seconds=0.4):
+    """The boundary's own calling convention (reference val.py:17-31): CPU tensors in, CPU tensors out through the
+    model mirror FARNN_S_O_I_S -- H2D copies of x / lengths, the tagging launch, the D2H copy of the flat predictions and
+    the label flatten, per batch.  Two forms: one synchronous forward_local() per batch, and the eval loop's form with
+    two batches in flight (submit_local / result).  PCIe-inclusive, so never `value`."""
+    import argparse as ap
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    a = ap.Namespace(rand_constant=0.0, threshold=0.5, train_mode='sum', local_loss_func='CE1', use_priority=0,
+                     independent=2, update_nonlinear='none')
+    S = extras['h0'].shape[0]
+    m = FARNN_S_O_I_S(extras['T'], extras['O'], extras['W'], np.zeros(S), extras['hT'], extras['h0'], None, a, o_idx=0)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    lab = torch.zeros_like(xt)
+    tok = int(lengths.sum())
+    for _ in range(20):
+        m.forward_local(xt, lab, lt, train=False)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            m.forward_local(xt, lab, lt, train=False)
+        n += 50
+    sync_el = time.perf_counter() - t0
+    import collections
+    q, n2, t0 = collections.deque(), 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(50):
+            q.append(m.submit_local(xt, lab, lt))
+            if len(q) > m.pipeline_depth:
+                q.popleft().result()
+        n2 += 50
+    while q:
+        last = q.popleft().result()
+    pipe_el = time.perf_counter() - t0
+    ok = bool(np.array_equal(last[1].numpy(), m.forward_local(xt, lab, lt, train=False)[1].numpy()))
+    m.invalidate()
+    return {'value': tok * n2 / pipe_el, 'unit': 'tokens/s', 'us_per_batch': pipe_el / n2 * 1e6,
+            'batches_in_flight': m.pipeline_depth,
+            'synchronous': {'value': tok * n / sync_el, 'us_per_batch': sync_el / n * 1e6},
+            'same_predictions': ok,
+            'note': 'CPU tensors in / out through FARNN_S_O_I_S.forward_local (farnn_tag_host_submit / _wait: mapped pinned staging, a staging kernel, the tagging launch storing its flat predictions into mapped host memory); PCIe-inclusive, '
+                    'never the headline value'}
+
+
 # ------------------------------------------------------------------------------------------ roofline
 def load_traffic(name, a):
     """Measured fabric-side bytes per launch of the dominant kernel (profiles/traffic.json, separate PMC passes),
@@ -736,6 +779,11 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
     if headline and world == 1 and not a.no_cpu_baseline and name == 'ifst':
         out['cpu_baseline'] = cpu_baseline(extras, x, lengths, a.cpu_seconds)
         out['cpu_baseline_faithful'] = cpu_baseline_faithful(extras, x, lengths, min(a.cpu_seconds, 6.0))
+    if headline and world == 1 and name == 'ifst' and not a.no_parity:
+        for hh in handles:
+            hh.close()
+        handles = []
+        out['host_inclusive'] = host_inclusive(extras, x, lengths)
     for hh in handles:
         hh.close()
     del extras

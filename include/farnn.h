@@ -238,6 +238,25 @@ int farnn_reserve(farnn_model *m, int32_t B, int32_t L);
 
 void farnn_destroy(farnn_model *m);
 
+/* ---- the same call with HOST buffers: what the reference's eval loop hands over (val.py:17-31) -----------------------
+ * model.forward_local(x, label, lengths, train=False) is called with CPU tensors and its flat predictions are read on
+ * the CPU.  farnn_tag_host_submit stages [x | lengths] through a pinned buffer the handle owns, enqueues ONE H2D copy,
+ * farnn_tag(FARNN_MODE_LOCAL) and the D2H copy of the flat predictions on a stream of the handle, and returns a ticket at
+ * once; farnn_tag_host_wait blocks until that batch is done and copies its predictions out.  Up to FARNN_HOST_SLOTS
+ * batches may be in flight (the host prepares batch i+1 while batch i runs); tickets are waited for in submission order.
+ * x_host / len_host may be reused as soon as submit returns.  PCIe-inclusive path: bench.py reports it as
+ * `host_inclusive`, never as the headline value.
+ *   x_host    int64 [B,L]   (host)          len_host  int64 [B]  (host)
+ *   ticket    out: slot number to pass to farnn_tag_host_wait;  n_flat out (or NULL): sum(clamp(len, 0, L))
+ *   flat_out  int64 [n_flat] (host)         n_out (or NULL): how many were written
+ * farnn_flatten_host: utils.flatten (utils.py:153-164) of a host int64 [B,L] array (the flat gold labels the same
+ * call returns beside the predictions); returns the element count, -1 on a null argument. */
+#define FARNN_HOST_SLOTS 4
+int farnn_tag_host_submit(farnn_model *m, const int64_t *x_host, const int64_t *len_host, int32_t B, int32_t L,
+                          int32_t *ticket, int64_t *n_flat);
+int farnn_tag_host_wait(farnn_model *m, int32_t ticket, int64_t *flat_out, int64_t *n_out);
+int64_t farnn_flatten_host(const int64_t *a, const int64_t *len_host, int32_t B, int32_t L, int64_t *out);
+
 /* ---- training step of the decomposed i-FST -----------------------------------
  * Replaces FARNN_S_D_W_I_S.forward_local(train=True) + loss.backward()
  * (model_decompose_single.py:207-304, train_decompose.py:186-190) for farnn = 0/1/2, the sum semiring and the

@@ -15,6 +15,7 @@ OK = 0
 NL = {'none': 0, 'relu': 1, 'tanh': 2, 'relutanh': 3, 'sigmoid': 4}
 SEMIRING = {'sum': 0, 'max': 1}
 MODE_LOCAL, MODE_FULL = 0, 1
+HOST_SLOTS = 4                  # FARNN_HOST_SLOTS: batches the host-buffer path keeps in flight
 KERN_CHAIN, KERN_SCORE, KERN_PREP = 0, 1, 2
 
 _f32p = C.POINTER(C.c_float)
@@ -130,6 +131,9 @@ SIGNATURES = {
     'farnn_decomp_fst_create': (C.c_int, [C.POINTER(DecompFstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_tag': (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
     'farnn_reserve': (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    'farnn_tag_host_submit': (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
+    'farnn_flatten_host': (C.c_int64, [_vp, _vp, C.c_int32, C.c_int32, _vp]),
+    'farnn_tag_host_wait': (C.c_int, [_vp, C.c_int32, _vp, C.POINTER(C.c_int64)]),
     'farnn_destroy': (None, [_vp]),
     'farnn_abi_version': (C.c_int, []),
     'farnn_device_count': (C.c_int, []),
@@ -172,6 +176,11 @@ def check(rc, what=''):
         msg = load().farnn_last_error()
         raise FarnnError('{} failed with code {}: {}'.format(what or 'farnn call', rc,
                                                              msg.decode() if msg else ''))
+
+
+def flatten_host(a_ptr, len_ptr, B, L, out_ptr):
+    """utils.flatten of a host int64 [B,L] array into `out` (farnn_flatten_host); returns the element count."""
+    return load().farnn_flatten_host(a_ptr, len_ptr, B, L, out_ptr)
 
 
 def f32(a):
@@ -217,6 +226,17 @@ class Handle:
     def tag(self, x_ptr, len_ptr, B, L, mode, tags_ptr=None, flat_ptr=None, scores_ptr=None, stream=None):
         check(load().farnn_tag(self.raw, x_ptr, len_ptr, B, L, mode, tags_ptr, flat_ptr, scores_ptr,
                                stream), 'farnn_tag')
+
+    def tag_host_submit(self, x_ptr, len_ptr, B, L):
+        """Host buffers in (int64 [B,L], [B]); returns a ticket for tag_host_wait.  Work is enqueued, not awaited."""
+        t, n = C.c_int32(-1), C.c_int64(0)
+        check(load().farnn_tag_host_submit(self.raw, x_ptr, len_ptr, B, L, C.byref(t), C.byref(n)), 'farnn_tag_host_submit')
+        return t.value, n.value
+
+    def tag_host_wait(self, ticket, flat_ptr):
+        n = C.c_int64(0)
+        check(load().farnn_tag_host_wait(self.raw, ticket, flat_ptr, C.byref(n)), 'farnn_tag_host_wait')
+        return n.value
 
     def algorithmic_bytes(self, valid_tokens):
         return load().farnn_algorithmic_bytes(self.raw, int(valid_tokens))

@@ -3,6 +3,7 @@
 Same signature and result dict as the reference's ``val_onehot``.  The reference appends every
 predicted token to a Python list as a 0-d tensor and scores them in pure-Python loops; here the
 flat predictions stay tensors until one concatenation, and the metrics are vectorised."""
+import collections
 import time
 
 import torch
@@ -19,13 +20,32 @@ def val_onehot(dataloader, model, args, o_idx=0, i2s=None, i2t=None, is_cuda=Tru
     preds, trues = [], []
     n_tok, t0 = 0, time.perf_counter()
     model.eval()
+    # the reference calls forward_local and reads the result batch by batch (val.py:28-31); here up to
+    # `pipeline_depth` batches are in flight: the H2D copy and launch of batch i+1 are enqueued before the
+    # predictions of batch i-1 are read back (same calls, same order of results)
+    submit = getattr(model, 'submit_local', None)
+    depth = getattr(model, 'pipeline_depth', 0) if submit is not None and not getattr(model, 'training', False) else 0
+    pending = collections.deque()
+
+    def collect(item):
+        _, pred_label, true_label = item.result()
+        preds.append(pred_label.reshape(-1).cpu())
+        trues.append(true_label.reshape(-1).cpu())
+
     with torch.no_grad():
         for batch in dataloader:
             x, label, lengths = batch['x'], batch['s'], batch['l']
-            _, pred_label, true_label = model.forward_local(x, label, lengths, train=False)
-            preds.append(pred_label.reshape(-1).cpu())
-            trues.append(true_label.reshape(-1).cpu())
+            if depth > 0:
+                pending.append(submit(x, label, lengths))
+                if len(pending) > depth:
+                    collect(pending.popleft())
+            else:
+                _, pred_label, true_label = model.forward_local(x, label, lengths, train=False)
+                preds.append(pred_label.reshape(-1).cpu())
+                trues.append(true_label.reshape(-1).cpu())
             n_tok += int(lengths.sum())
+        while pending:
+            collect(pending.popleft())
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0

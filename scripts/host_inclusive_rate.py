@@ -27,15 +27,32 @@ t0 = time.perf_counter()
 for _ in range(n):
     _, pred, _ = m.forward_local(xt, lab, lt, train=False)
 el = time.perf_counter() - t0
-print('host-inclusive: {:.3e} valid tokens/s, {:.1f} us per batch ({} valid tokens)'.format(
+print('host-inclusive, one synchronous call per batch: {:.3e} valid tokens/s, {:.1f} us per batch ({} valid tokens)'.format(
     int(lengths.sum()) * n / el, el / n * 1e6, int(lengths.sum())))
+import collections
+for depth in (1, 2, 3):
+    m.pipeline_depth = depth
+    q = collections.deque()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        q.append(m.submit_local(xt, lab, lt))
+        if len(q) > depth:
+            q.popleft().result()
+    while q:
+        q.popleft().result()
+    el = time.perf_counter() - t0
+    print('host-inclusive, {} batches in flight: {:.3e} valid tokens/s, {:.1f} us per batch'.format(
+        depth, int(lengths.sum()) * n / el, el / n * 1e6))
 
 if os.environ.get('FARNN_HOST_PROFILE'):
     import cProfile
     import pstats
     pr = cProfile.Profile()
     pr.enable()
-    for _ in range(100):
-        m.forward_local(xt, lab, lt, train=False)
+    q = collections.deque()
+    for _ in range(200):
+        q.append(m.submit_local(xt, lab, lt))
+        if len(q) > 2:
+            q.popleft().result()
     pr.disable()
     pstats.Stats(pr).sort_stats('cumulative').print_stats(18)

@@ -455,3 +455,33 @@ def test_one_handle_serves_varying_batch_shapes(fuse, monkeypatch):
             assert np.array_equal(got, ref) and np.array_equal(tags.cpu().numpy(), want_tags)
         assert np.array_equal(tags.cpu().numpy(), tags2.cpu().numpy())
     h.close()
+
+
+def test_host_buffer_path_matches_the_device_path():
+    """farnn_tag_host_submit / _wait (what forward_local / val_onehot use for CPU tensors): batches in flight, results in
+    submission order, equal to the device-pointer path and to the oracle; shapes vary between submissions; a fifth
+    batch in flight is refused; the flat gold labels come from farnn_flatten_host."""
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(4)
+    V, S, C = 60, 23, 9
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, None, ns(), o_idx=1)
+    batches = []
+    for B, L in [(16, 12), (5, 30), (40, 7), (16, 12), (3, 3), (64, 20)]:
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        lab = rng.randint(0, C, size=(B, L)).astype(np.int64)
+        batches.append((torch.from_numpy(x), torch.from_numpy(lab), torch.from_numpy(lengths)))
+    pend = [m.submit_local(*b) for b in batches[:4]]
+    with pytest.raises(_lib.FarnnError):
+        m.submit_local(*batches[4])
+    outs = [p.result() for p in pend]
+    outs += [m.submit_local(*b).result() for b in batches[4:]]
+    for (x, lab, ln), (loss, pred, true) in zip(batches, outs):
+        ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x.numpy(), ln.numpy())
+        assert loss is None and pred.dtype == torch.int64 and pred.device.type == 'cpu'
+        assert np.array_equal(pred.numpy(), fo.forward_local_tags(ref, ln.numpy(), 0.5, 1))
+        assert np.array_equal(true.numpy(), fo.flatten(lab.numpy(), ln.numpy()))
+        _, pred_dev, true_dev = m.forward_local(x.cuda(), lab.cuda(), ln.cuda(), train=False)     # device tensors in
+        assert pred_dev.is_cuda and np.array_equal(pred_dev.cpu().numpy(), pred.numpy())
+        assert np.array_equal(true_dev.cpu().numpy(), true.numpy())
