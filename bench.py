@@ -776,6 +776,33 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         out['parity'] = parity_check(name, h, extras, x, lengths, got, dev)
         if out['parity']['tags_equal'] is False:
             print('WARNING: {}: GPU results differ from the oracle'.format(name), file=sys.stderr)
+    if headline and world == 1 and name in ('ifst', 'synth512') and h.has_compact():
+        # the compact form (bit-packed blocks + active-state walk) reported SEPARATELY; the contract
+        # number above stays fp32-dense.  Same batch, same handle; its tags must equal the dense kernel's.
+        dense_tags = tags_bufs[(steps - 1) % n_main].clone()
+        h.set_compact(True)
+        csteps = max(steps, 50) if name == 'ifst' else steps
+        for _ in range(5):
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[0].data_ptr(), None, None, streams[0].cuda_stream)
+        h.set_profiling(max(1, csteps // 8))
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(csteps):
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags_bufs[0].data_ptr(), None, None, streams[0].cuda_stream)
+        torch.cuda.synchronize(dev)
+        cel = time.perf_counter() - t0
+        cms, cn = h.kernel_time(_lib.KERN_CHAIN)
+        sms, sn = h.kernel_time(_lib.KERN_SCORE)
+        h.set_profiling(0)
+        out['compact'] = {'value': tok_local * csteps / cel, 'unit': 'tokens/s', 'ms_per_step': cel / csteps * 1e3, 'steps': csteps,
+                          'bytes_per_token': h.kernel_algorithmic_bytes(_lib.KERN_CHAIN, tok_local) / tok_local,
+                          'dense_bytes_per_token': 2.0 * S * S * 4 + 8,
+                          'kernel': h.kernel_name(_lib.KERN_CHAIN), 'kernel_avg_us': cms / max(cn, 1) * 1e3,
+                          'score_decode_avg_us': sms / max(sn, 1) * 1e3,
+                          'tags_equal_dense': bool(torch.equal(tags_bufs[0], dense_tags)),
+                          'note': 'bit-packed transition blocks, walk over the non-zero state entries only; latency-bound '
+                                  '(serial step chain), reported beside the fp32-dense contract number, never as it'}
+        h.set_compact(False)
     if headline and world == 1 and not a.no_cpu_baseline and name == 'ifst':
         out['cpu_baseline'] = cpu_baseline(extras, x, lengths, a.cpu_seconds)
         out['cpu_baseline_faithful'] = cpu_baseline_faithful(extras, x, lengths, min(a.cpu_seconds, 6.0))

@@ -98,6 +98,23 @@ typedef struct farnn_edge_list {
 int farnn_onehot_ifst_create_from_edges(const farnn_onehot_ifst_desc *base, const farnn_edge_list *edges,
                                         int device, farnn_model **out);
 
+/* ---- compact form of the onehot i-FST ----------------------------------------------------------
+ * With --rand_constant 0 (all main.py allows for --method onehot, :175-176) every entry of T and W is 0 or 1 and a
+ * word's S x S block holds a handful of edges; the loader still writes dense float64 tensors
+ * (wfa/fsa_to_tensor.py:546-615).  The compact form keeps a block as S rows of S bits (forward: sources of every
+ * destination; backward: destinations of every source) and the recurrence walks only the non-zero entries of the
+ * current state: 2*S*ceil(S/64)*8 bytes per token instead of 2*S*S*4, same results (bit-identical for `none` / `relu`,
+ * within rounding order for tanh).  Sum semiring, S <= 512, L <= 1024.  Contract numbers stay fp32-dense; bench.py
+ * reports this path separately (`compact`).
+ *   farnn_onehot_ifst_create / _create_from_edges build the bitmaps beside the dense blocks whenever the weights are
+ *   0/1 (farnn_has_compact); farnn_set_compact(m, 1) makes farnn_tag use them, (m, 0) goes back to the dense blocks.
+ *   farnn_onehot_ifst_create_compact builds ONLY the bitmaps, straight from the edge list (no dense tensor on the host
+ *   or in HBM: BASELINE's largest config is 0.66 GB instead of 2 x 21 GB); edge weights must be 1 (or val == NULL). */
+int farnn_has_compact(const farnn_model *m);
+int farnn_set_compact(farnn_model *m, int32_t enable);
+int farnn_onehot_ifst_create_compact(const farnn_onehot_ifst_desc *base, const farnn_edge_list *edges, int device,
+                                     farnn_model **out);
+
 /* ---- onehot FST 4-D: FARNN_S_O (reference model_onehot.py:8-129), --independent 0 ---- */
 typedef struct farnn_onehot_fst4_desc {
     int32_t V, S, C;

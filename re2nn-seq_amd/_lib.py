@@ -120,6 +120,10 @@ SIGNATURES = {
     'farnn_onehot_ifst_create': (C.c_int, [C.POINTER(OnehotIfstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_onehot_ifst_create_from_edges': (C.c_int, [C.POINTER(OnehotIfstDesc), C.POINTER(EdgeList), C.c_int,
                                                       C.POINTER(_vp)]),
+    'farnn_onehot_ifst_create_compact': (C.c_int, [C.POINTER(OnehotIfstDesc), C.POINTER(EdgeList), C.c_int,
+                                                   C.POINTER(_vp)]),
+    'farnn_has_compact': (C.c_int, [_vp]),
+    'farnn_set_compact': (C.c_int, [_vp, C.c_int32]),
     'farnn_onehot_fst4_create_from_edges': (C.c_int, [C.POINTER(OnehotFst4Desc), C.POINTER(EdgeList), C.c_int,
                                                       C.POINTER(_vp)]),
     'farnn_onehot_ind1_create_from_edges': (C.c_int, [C.POINTER(OnehotInd1Desc), C.POINTER(EdgeList), C.c_int,
@@ -238,6 +242,13 @@ class Handle:
         check(load().farnn_tag_host_wait(self.raw, ticket, flat_ptr, C.byref(n)), 'farnn_tag_host_wait')
         return n.value
 
+    def has_compact(self):
+        return bool(load().farnn_has_compact(self.raw))
+
+    def set_compact(self, enable=True):
+        """Bit-packed blocks + active-state walk instead of the dense fp32 blocks (0/1 automata; include/farnn.h)."""
+        check(load().farnn_set_compact(self.raw, int(bool(enable))), 'farnn_set_compact')
+
     def algorithmic_bytes(self, valid_tokens):
         return load().farnn_algorithmic_bytes(self.raw, int(valid_tokens))
 
@@ -325,6 +336,19 @@ def create_onehot_ifst_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, va
                           ptr(crf_trans), 0)
     return _create_from_edges('farnn_onehot_ifst_create_from_edges', base, edges, device,
                               keep + (h0, hT, P, crf_trans))
+
+
+def create_onehot_ifst_compact(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, nl='none', threshold=0.5,
+                               o_idx=0, use_crf=False, crf_trans=None, device=0):
+    """The i-FST in its compact form ONLY (bit-packed blocks scattered from the edge list; no dense tensor anywhere)."""
+    edges, keep = _edge_list(word, frm, to, label, val)
+    h0, hT = f32(h0), f32(hT)
+    P = None if P is None else f32(P)
+    crf_trans = None if crf_trans is None else f32(crf_trans)
+    base = OnehotIfstDesc(int(V), int(S), int(n_cols), None, None, None, ptr(h0), ptr(hT), ptr(P),
+                          NL[nl], SEMIRING['sum'], float(threshold), int(o_idx), int(bool(use_crf)),
+                          ptr(crf_trans), 0)
+    return _create_from_edges('farnn_onehot_ifst_create_compact', base, edges, device, keep + (h0, hT, P, crf_trans))
 
 
 def create_onehot_fst4_from_edges(V, S, n_cols, word, frm, to, label, h0, hT, val=None, P=None, semiring='sum',

@@ -17,6 +17,7 @@
 #include "decomp1_score.hip.h"
 #include "decomp_rows.hip.h"
 #include "decomp_regs.hip.h"
+#include "compact.hip.h"
 #include "train.hip.h"
 
 namespace farnn {
@@ -46,6 +47,9 @@ struct farnn_model {
     float threshold = 0.5f, sig_k = 1.0f;
     // device-resident, library-owned weights
     float *Mf = nullptr, *Mb = nullptr;     // chain blocks [V][S][SP] (+ transposed)
+    u64 *bmF = nullptr, *bmB = nullptr, *bmWF = nullptr, *bmWB = nullptr;   // compact form: bit-packed blocks (compact.hip.h)
+    int bmNS = 0;                           // 64-bit words per bitmap row; 0: no compact form
+    bool compact_on = false;                // farnn_set_compact: the recurrence walks the bitmaps instead of the dense blocks
     float *Ms = nullptr;                    // ind1: unmasked blocks for scoring
     float *A4 = nullptr;                    // fst4: [V][C][S][SP] premixed T4+W4
     float *Oten = nullptr;                  // ind1: [C][S][SP]
@@ -193,11 +197,47 @@ static int setup_crf(farnn_model *m, const float *crf_trans, int on_device) {
     return upload_transposed(m, &m->tr, crf_trans, m->K, m->K, m->Kp, on_device);
 }
 
+// ---- compact form of a 0/1 automaton (compact.hip.h): bit-packed blocks beside (or instead of) the dense ones ----------
+static int alloc_bitmaps(farnn_model *m) {
+    m->bmNS = (m->semiring == FARNN_SEMIRING_SUM) ? compact_ns(m->S) : 0;
+    if (!m->bmNS) return FARNN_OK;
+    const size_t nb = (size_t)m->V * m->S * m->bmNS * sizeof(u64), nw = (size_t)m->S * m->bmNS * sizeof(u64);
+    int rc;
+    if ((rc = dev_alloc(m, (void **)&m->bmF, nb)) || (rc = dev_alloc(m, (void **)&m->bmB, nb)) ||
+        (rc = dev_alloc(m, (void **)&m->bmWF, nw)) || (rc = dev_alloc(m, (void **)&m->bmWB, nw))) return rc;
+    FARNN_HIP_TRY(hipMemset(m->bmF, 0, nb)); FARNN_HIP_TRY(hipMemset(m->bmB, 0, nb));
+    FARNN_HIP_TRY(hipMemset(m->bmWF, 0, nw)); FARNN_HIP_TRY(hipMemset(m->bmWB, 0, nw));
+    return FARNN_OK;
+}
+
+static int finish_bitmaps(farnn_model *m, int *bad_dev) {
+    int bad = 0;
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipMemcpy(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(bad_dev);
+    if (bad) m->bmNS = 0;            // a weight other than 0 / 1: the dense blocks are the only form (the bitmaps stay unused)
+    return FARNN_OK;
+}
+
+static int build_bitmaps_from_dense(farnn_model *m, const float *T, const float *W) {
+    int rc = alloc_bitmaps(m);
+    if (rc || !m->bmNS) return rc;
+    int *bad = nullptr;
+    FARNN_HIP_TRY(hipMalloc((void **)&bad, sizeof(int)));
+    FARNN_HIP_TRY(hipMemset(bad, 0, sizeof(int)));
+    dense_to_bits_kernel<<<dim3((m->S * m->S + 255) / 256, m->V + 1), 256>>>(T, W, m->bmF, m->bmB, m->bmWF, m->bmWB, m->V, m->S,
+                                                                          m->bmNS, bad);
+    return finish_bitmaps(m, bad);
+}
+
 // ---- create: onehot i-FST --------------------------------------------------------------------
-extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int device, farnn_model **out) {
+struct DevEdges { const int32_t *word, *from, *to; const float *val; long long n; };     // device copies of an edge list
+
+// compact_edges != nullptr: build ONLY the compact form, from the edge list (no dense blocks; d->T / d->W unused)
+static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_model **out, const DevEdges *compact_edges) {
     if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
     *out = nullptr;
-    if (d->V <= 0 || d->S <= 0 || d->C <= 0 || !d->T || !d->W || !d->O || !d->h0 || !d->hT)
+    if (d->V <= 0 || d->S <= 0 || d->C <= 0 || ((!d->T || !d->W) && !compact_edges) || !d->O || !d->h0 || !d->hT)
         return fail(FARNN_EINVAL, "onehot_ifst: sizes must be positive and T/W/O/h0/hT non-null%s%s");
     if (d->nl < 0 || d->nl > FARNN_NL_RELUTANH) return fail(FARNN_EINVAL, "onehot_ifst: bad nl%s%s");
     if (d->semiring != FARNN_SEMIRING_SUM && d->semiring != FARNN_SEMIRING_MAX)
@@ -220,7 +260,20 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
     if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
     if (m->geom.NCH > 4) return bail(fail(FARNN_ERANGE, "more than 1024 states%s%s"));
 
-    {   // premix T+W once (the reference re-adds it on every call, model_onehot.py:366)
+    if (compact_edges) {
+        if ((rc = alloc_bitmaps(m))) return bail(rc);
+        if (!m->bmNS) return bail(fail(FARNN_ERANGE, "onehot_ifst compact form: needs the sum semiring and at most 512 states%s%s"));
+        int *bad = nullptr;
+        FARNN_HIP_TRY(hipMalloc((void **)&bad, sizeof(int)));
+        FARNN_HIP_TRY(hipMemset(bad, 0, sizeof(int)));
+        if (compact_edges->n > 0)
+            edges_to_bits_kernel<<<(unsigned)((compact_edges->n + 255) / 256), 256>>>(
+                compact_edges->word, compact_edges->from, compact_edges->to, compact_edges->val, compact_edges->n, m->bmF, m->bmB,
+                m->bmWF, m->bmWB, m->V, m->S, m->bmNS, bad);
+        if ((rc = finish_bitmaps(m, bad))) return bail(rc);
+        if (!m->bmNS) return bail(fail(FARNN_EINVAL, "onehot_ifst compact form: an edge is out of range or has a weight other than 1%s%s"));
+        m->compact_on = true;
+    } else {   // premix T+W once (the reference re-adds it on every call, model_onehot.py:366)
         const size_t nT = (size_t)m->V * m->S * m->S;
         TmpDev T, W;
         if ((rc = T.init(d->T, nT, od))) return bail(rc);
@@ -229,6 +282,7 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
         if ((rc = dev_alloc(m, (void **)&m->Mf, nM * 4))) return bail(rc);
         if ((rc = dev_alloc(m, (void **)&m->Mb, nM * 4))) return bail(rc);
         if ((rc = launch_premix(T.p, W.p, nullptr, m->Mf, m->Mb, m->V, m->S, m->SP, m->geom.SR))) return bail(rc);
+        if ((rc = build_bitmaps_from_dense(m, T.p, W.p))) return bail(rc);
     }
     // o = sum_c O[c,:]  (CE1, model_onehot.py:368); OT = O^T padded, with zero rows for START/STOP
     {
@@ -259,6 +313,21 @@ extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int dev
     } else if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
     *out = m;
+    return FARNN_OK;
+}
+
+extern "C" int farnn_onehot_ifst_create(const farnn_onehot_ifst_desc *d, int device, farnn_model **out) {
+    return ifst_create_impl(d, device, out, nullptr);
+}
+
+extern "C" int farnn_has_compact(const farnn_model *m) { return (m && m->bmNS > 0 && m->bmF) ? 1 : 0; }
+
+extern "C" int farnn_set_compact(farnn_model *m, int32_t enable) {
+    if (!m) return fail(FARNN_EINVAL, "set_compact: null model%s%s");
+    if (enable && !farnn_has_compact(m))
+        return fail(FARNN_EINVAL, "set_compact: this model has no compact form (i-FST with 0/1 weights, sum semiring, at most 512 states)%s%s");
+    if (!enable && !m->Mf) return fail(FARNN_EINVAL, "set_compact: this handle was created compact-only (no dense blocks)%s%s");
+    m->compact_on = enable != 0;
     return FARNN_OK;
 }
 
@@ -359,6 +428,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
     switch (which) {
         case KERN_CHAIN:
+            if (m->compact_on) return "compact_chain_kernel";
             if (m->last_fused) return "chain_kernel<fused score+decode epilogue>";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
@@ -804,6 +874,19 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
     }
     switch (m->kind) {
         case KIND_IFST:
+            if (m->compact_on) {
+                if (L > 1024) return fail(FARNN_ERANGE, "compact recurrence: more than 1024 positions%s%s");
+                CompactParams cp;
+                cp.bitsF = m->bmF; cp.bitsB = m->bmB; cp.wF = m->bmWF; cp.wB = m->bmWB; cp.o = m->o; cp.h0 = m->h0; cp.hT = m->hT;
+                cp.x = x; cp.len = lengths; cp.order = m->order_valid ? m->order : nullptr; cp.A = m->A; cp.Bk = m->Bk;
+                cp.B = B; cp.L = L; cp.S = m->S; cp.SP = m->SP; cp.V = m->V; cp.nl = m->nl; cp.full = full; cp.dbg = env_int("FARNN_DBG", 0);
+                m->last_fused = false;
+                {
+                    KernelTimer kt(m, KERN_CHAIN, s);
+                    if ((rc = launch_compact_chain(cp, m->bmNS, s))) return rc;
+                }
+                return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
+            }
             return launch_chain_and_decode(m, x, lengths, B, L, full, tags, flat_tags, scores, s);
         case KIND_FST4:
             if ((rc = launch_chain(m, x, lengths, B, L, full, s))) return rc;
@@ -926,6 +1009,44 @@ extern "C" int farnn_onehot_ifst_create_from_edges(const farnn_onehot_ifst_desc 
     }
     full.T = T; full.W = W; full.O = O; full.weights_on_device = 1;
     return farnn_onehot_ifst_create(&full, device, out);
+}
+
+extern "C" int farnn_onehot_ifst_create_compact(const farnn_onehot_ifst_desc *b, const farnn_edge_list *e, int device,
+                                                farnn_model **out) {
+    if (!b || !out || !e) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (b->V <= 0 || b->S <= 0 || b->C <= 0) return fail(FARNN_EINVAL, "ifst_create_compact: V, S, C must be positive%s%s");
+    if (e->n_edges < 0 || (e->n_edges > 0 && (!e->word || !e->from || !e->to)))
+        return fail(FARNN_EINVAL, "ifst_create_compact: edge arrays missing%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    EdgeTmp tmp;
+    float *O = nullptr;
+    if ((rc = tmp.zeros(&O, (size_t)b->C * b->S))) return rc;
+    if ((rc = scatter_edges(tmp, e, nullptr, nullptr, O, b->V, b->S, b->C, 0))) return rc;       // labels -> O only
+    // the edge arrays once more on the device, for the bitmap scatter
+    const size_t ne = (size_t)e->n_edges;
+    int32_t *dw = nullptr;
+    float *dv = nullptr;
+    if ((rc = tmp.get((void **)&dw, (ne ? ne : 1) * 3 * 4))) return rc;
+    if (ne) {
+        FARNN_HIP_TRY(hipMemcpy(dw, e->word, ne * 4, hipMemcpyHostToDevice));
+        FARNN_HIP_TRY(hipMemcpy(dw + ne, e->from, ne * 4, hipMemcpyHostToDevice));
+        FARNN_HIP_TRY(hipMemcpy(dw + 2 * ne, e->to, ne * 4, hipMemcpyHostToDevice));
+        if (e->val) {
+            if ((rc = tmp.get((void **)&dv, ne * 4))) return rc;
+            FARNN_HIP_TRY(hipMemcpy(dv, e->val, ne * 4, hipMemcpyHostToDevice));
+        }
+    }
+    DevEdges de{dw, dw + ne, dw + 2 * ne, dv, (long long)ne};
+    farnn_onehot_ifst_desc full = *b;
+    if (!b->weights_on_device) {
+        const size_t K = (size_t)b->C + (b->use_crf ? 2 : 0);
+        if ((rc = tmp.stage(full.h0, b->S)) || (rc = tmp.stage(full.hT, b->S)) ||
+            (rc = tmp.stage(full.P, (size_t)b->C * b->C)) || (rc = tmp.stage(full.crf_trans, K * K))) return rc;
+    }
+    full.T = nullptr; full.W = nullptr; full.O = O; full.weights_on_device = 1;
+    return ifst_create_impl(&full, device, out, &de);
 }
 
 extern "C" int farnn_onehot_fst4_create_from_edges(const farnn_onehot_fst4_desc *b, const farnn_edge_list *e,
@@ -1865,6 +1986,7 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     if (!m) return 0.0;
     const double S = m->S, C = m->C, R = m->R, K = m->K, n = (double)valid_tokens;
     if (which == KERN_CHAIN) {
+        if (m->compact_on) return (2.0 * S * m->bmNS * 8 + 8) * n;      // one bit-packed block per direction + the token id
         if (!m->dense_decomp && (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0))
             return (R * 4 + 8) * n + (2.0 * S * R + S * S) * 4;
         // one block per direction + the token id (+ the tag when the decode is this kernel's epilogue)

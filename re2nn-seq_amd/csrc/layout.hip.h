@@ -116,8 +116,8 @@ __global__ void scatter_edges_kernel(const int32_t *word, const int32_t *from, c
         else if (w == -1) W[((long long)l * S + f) * S + t] = v;
         return;
     }
-    if (w >= 0) T[((long long)w * S + f) * S + t] = v;
-    else if (w == -1) W[(long long)f * S + t] = v;          // w < -1: label only
+    if (w >= 0) { if (T) T[((long long)w * S + f) * S + t] = v; }           // (T == nullptr: labels only)
+    else if (w == -1) { if (W) W[(long long)f * S + t] = v; }                // w < -1: label only
     if (l >= 0) {
         if (mode == 0) O[(long long)l * S + t] = 1.0f;
         else O[((long long)l * S + f) * S + t] = 1.0f;

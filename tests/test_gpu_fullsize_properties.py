@@ -111,3 +111,29 @@ def test_fullsize_whole_sequences_vs_oracle(big):
     assert ref[mask].max() >= 1.0                           # non-trivial: accepting paths exist
     tags = _tag(big, x, lengths, _lib.MODE_LOCAL)[0][rows][:, :Lmax]
     assert np.array_equal(tags[mask].astype(np.int64), fo.decode_argmax(ref, 0.5, O_IDX)[mask])
+
+
+def test_fullsize_compact_form_equals_the_dense_blocks(big):
+    """SURVEY.md 8f2 at BASELINE's largest config: the bit-packed blocks (0.66 GB beside 2 x 21 GB of fp32) with the
+    active-state walk give the same scores and tags as the dense kernel, bit for bit (integer-valued states), in LOCAL
+    and FULL mode; the time of both is printed for the record."""
+    import time
+    from re2nn_seq_amd import _lib
+    h = big['h']
+    assert h.has_compact()
+    x, lengths = big['x'], big['lengths']
+    dense = {}
+    for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+        dense[mode] = _tag(big, x, lengths, mode, want_scores=True)
+    t0 = time.perf_counter(); _tag(big, x, lengths, _lib.MODE_LOCAL); t_dense = time.perf_counter() - t0
+    h.set_compact(True)
+    try:
+        assert h.kernel_name(_lib.KERN_CHAIN) == 'compact_chain_kernel'
+        for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+            tags, flat, scores = _tag(big, x, lengths, mode, want_scores=True)
+            assert np.array_equal(scores, dense[mode][2])
+            assert np.array_equal(tags, dense[mode][0]) and np.array_equal(flat, dense[mode][1])
+        t0 = time.perf_counter(); _tag(big, x, lengths, _lib.MODE_LOCAL); t_compact = time.perf_counter() - t0
+        print('config 5 shard, one batch incl. copies: dense {:.1f} ms, compact {:.1f} ms'.format(t_dense * 1e3, t_compact * 1e3))
+    finally:
+        h.set_compact(False)

@@ -485,3 +485,91 @@ def test_host_buffer_path_matches_the_device_path():
         _, pred_dev, true_dev = m.forward_local(x.cuda(), lab.cuda(), ln.cuda(), train=False)     # device tensors in
         assert pred_dev.is_cuda and np.array_equal(pred_dev.cpu().numpy(), pred.numpy())
         assert np.array_equal(true_dev.cpu().numpy(), true.numpy())
+
+
+@pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (64, 9, 17, 5), (65, 130, 9, 3), (71, 128, 64, 40),
+                                     (130, 70, 12, 4), (257, 40, 6, 3), (300, 256, 5, 2), (512, 256, 7, 3)])
+@pytest.mark.parametrize('nl', ['none', 'relu', 'tanh'])
+def test_compact_form_matches_dense_blocks_and_oracle(S, C, L, B, nl):
+    """bit-packed blocks + active-state walk.  Same handle, dense then compact: scores and tags equal bit
+    for bit for `none` / `relu` (integer-valued states), within 1e-4 for tanh; both against the oracle; every word-row
+    width (1, 2, 4, 8 64-bit words)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(S * 31 + C)
+    V = 29
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=max(2.0, S / 4), n_final=2)
+    W[0, min(1, S - 1)] = 1.0                  # a wildcard edge that coincides with word edges somewhere: T + W = 2
+    T[3 % V, 0, min(1, S - 1)] = 1.0
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, o_idx=1 % C)
+    assert h.has_compact()
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+    res = {}
+    for compact in (False, True):
+        h.set_compact(compact)
+        for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+            scores = torch.empty((B, L, C), dtype=torch.float32, device='cuda')
+            tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+            flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(),
+                  flat.data_ptr() if mode == _lib.MODE_LOCAL else None, scores.data_ptr())
+            torch.cuda.synchronize()
+            res[compact, mode] = (scores.cpu().numpy(), tags.cpu().numpy(), flat.cpu().numpy())
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths, nl=fo.NL_CODES[nl])
+    exact = nl != 'tanh'
+    for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+        d, c = res[False, mode], res[True, mode]
+        if exact:
+            assert np.array_equal(c[0], d[0]) and np.array_equal(c[1], d[1])
+        else:
+            np.testing.assert_allclose(c[0], d[0], rtol=1e-4, atol=1e-4)
+    if exact:
+        assert np.array_equal(res[True, _lib.MODE_FULL][0], ref)
+        assert np.array_equal(res[True, _lib.MODE_LOCAL][2], fo.forward_local_tags(ref, lengths, 0.5, 1 % C))
+    else:
+        np.testing.assert_allclose(res[True, _lib.MODE_FULL][0], ref, rtol=1e-4, atol=1e-4)
+    h.close()
+
+
+def test_compact_only_handle_from_the_edge_list_and_its_limits():
+    """farnn_onehot_ifst_create_compact: the automaton's edges go straight into bit-packed blocks (no dense tensor at
+    all); tags and scores equal the dense upload's and the reference loader + oracle.  Weighted edges, the max semiring
+    and switching a compact-only handle to dense are refused."""
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.wfa import fsa_to_tensor as f2t
+    dset, automaton, _ = synth.make_dataset(60, 4, 25, seed=3)
+    t2i = dict(dset['t2i']); t2i['<pad>'] = len(t2i)
+    s2i = dset['s2i']
+    word, frm, to, label, fin, sta, _ = f2t.dfa_to_edges_slot_single_wildcard(automaton, t2i, s2i)
+    T, _, W, O, _, fin2, sta2, _ = f2t.dfa_to_tensor_slot_single_wildcard(automaton, t2i, s2i)
+    V, S, C = len(t2i), len(automaton['states']), len(s2i) + 1
+    rng = np.random.RandomState(0)
+    q, _, lens = __import__('re2nn_seq_amd.utils', fromlist=['pad_dataset_1']).pad_dataset_1(dset['query_test'], 16, t2i['<pad>'])
+    x, lengths = np.stack(q).astype(np.int64), np.array(lens).astype(np.int64)
+    B, L = x.shape
+    h = _lib.create_onehot_ifst_compact(V, S, C, word, frm, to, label, sta, fin, o_idx=s2i['o'])
+    assert h.has_compact() and h.kernel_name(_lib.KERN_CHAIN) == 'compact_chain_kernel'
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+    scores = torch.empty((B, L, C), dtype=torch.float32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), scores.data_ptr())
+    torch.cuda.synchronize()
+    ref = fo.onehot_ifst_scores(T, W, O, sta2, fin2, x, lengths)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    assert np.array_equal(scores.cpu().numpy()[mask], ref[mask])
+    assert np.array_equal(flat.cpu().numpy(), fo.forward_local_tags(ref, lengths, 0.5, s2i['o']))
+    with pytest.raises(_lib.FarnnError, match='compact-only'):
+        h.set_compact(False)
+    h.close()
+    with pytest.raises(_lib.FarnnError, match='weight other than 1'):
+        _lib.create_onehot_ifst_compact(V, S, C, word, frm, to, label, sta, fin, val=np.full(len(word), 0.5, np.float32))
+    # dense uploads: weights other than 0 / 1 or the max semiring have no compact form
+    Tn = T.copy(); Tn[0, 0, 0] = 0.5
+    h = _lib.create_onehot_ifst(Tn, W, O, sta2, fin2)
+    assert not h.has_compact()
+    with pytest.raises(_lib.FarnnError, match='no compact form'):
+        h.set_compact(True)
+    h.close()
+    h = _lib.create_onehot_ifst(T, W, O, sta2, fin2, semiring='max')
+    assert not h.has_compact()
+    h.close()
