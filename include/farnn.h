@@ -178,6 +178,30 @@ typedef struct farnn_decomp_ifst_desc {
 
 int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *desc, int device, farnn_model **out);
 
+/* The same model with the word table -- and --normalize_automata -- computed ON THE DEVICE.  The
+ * reference recomputes get_generalized_v_embed_vec twice per time step (model_decompose_single.py:140-141):
+ *     Vgen[w] = V_embed[w] * beta + nl_add(E[w] @ G) * (1 - beta)                 (model_decompose.py:222-241)
+ * and its loader scales V_embed, S1, S2 by the averaged column norms on the host (init_params.py:285-297):
+ *     factor = cbrt(avg(V) avg(S1) avg(S2)),  M <- M * factor / avg(M),  avg(M)[c] = ||M[:, c]|| / rows  (utils.py:202-225).
+ * Here desc->Vgen is ignored: V_embed / E / G / beta go to the device once, the scaling (per-rank modes) and the fold
+ * run there, and nothing of size V x R comes back to the host.  G = pinv(E) @ V_embed (model_decompose_single.py:73-76)
+ * is given for the UN-normalised V_embed; its columns take V_embed's scale (the bridge is linear in them). */
+#define FARNN_NORM_NONE     0
+#define FARNN_NORM_L1_RANK  3      /* --normalize_automata l1-rank */
+#define FARNN_NORM_L2_RANK  4      /* --normalize_automata l2-rank (main.py:55 default) */
+typedef struct farnn_vgen_fold {
+    const float *V_embed;       /* [V,R]  (pad row included)                                                  */
+    const float *E;             /* [V,D]  embedding.weight                                                    */
+    const float *G;             /* [D,R]  embed_r_generalized                                                 */
+    const float *beta;          /* [R]    beta_vec                                                            */
+    int32_t D;
+    int32_t add_nl;             /* FARNN_NL_*: --additional_nonlinear                                         */
+    int32_t normalize;          /* FARNN_NORM_*: applied to V_embed (and G), desc->S1, desc->S2 before the fold */
+    int32_t on_device;          /* 1: V_embed / E / G / beta are device pointers                              */
+} farnn_vgen_fold;
+int farnn_decomp_ifst_create_folded(const farnn_decomp_ifst_desc *desc, const farnn_vgen_fold *fold, int device,
+                                    farnn_model **out);
+
 /* ---- decomposed independent=1: FARNN_S_D_W_I (reference model_decompose_independent.py:11-300) ---- */
 typedef struct farnn_decomp_ind1_desc {
     int32_t V, S, R, RO, K;     /* S incl. additional_states; RO = rank of the output factors        */

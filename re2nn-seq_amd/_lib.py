@@ -59,6 +59,14 @@ class DecompIfstDesc(C.Structure):
                 ('crf_trans', _f32p), ('weights_on_device', C.c_int32)]
 
 
+class VgenFold(C.Structure):
+    _fields_ = [('V_embed', _f32p), ('E', _f32p), ('G', _f32p), ('beta', _f32p), ('D', C.c_int32), ('add_nl', C.c_int32),
+                ('normalize', C.c_int32), ('on_device', C.c_int32)]
+
+
+NORM = {'none': 0, 'l1-rank': 3, 'l2-rank': 4}
+
+
 class DecompInd1Desc(C.Structure):
     _fields_ = [('V', C.c_int32), ('S', C.c_int32), ('R', C.c_int32), ('RO', C.c_int32), ('K', C.c_int32),
                 ('Vgen', _f32p), ('S1', _f32p), ('S2', _f32p), ('W', _f32p), ('Cout', _f32p),
@@ -131,6 +139,7 @@ SIGNATURES = {
     'farnn_onehot_fst4_create': (C.c_int, [C.POINTER(OnehotFst4Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_onehot_ind1_create': (C.c_int, [C.POINTER(OnehotInd1Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_ifst_create': (C.c_int, [C.POINTER(DecompIfstDesc), C.c_int, C.POINTER(_vp)]),
+    'farnn_decomp_ifst_create_folded': (C.c_int, [C.POINTER(DecompIfstDesc), C.POINTER(VgenFold), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_ind1_create': (C.c_int, [C.POINTER(DecompInd1Desc), C.c_int, C.POINTER(_vp)]),
     'farnn_decomp_fst_create': (C.c_int, [C.POINTER(DecompFstDesc), C.c_int, C.POINTER(_vp)]),
     'farnn_tag': (C.c_int, [_vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp]),
@@ -407,6 +416,30 @@ def create_decomp_ifst(Vgen, S1, S2, W, Cout, h0, hT, P=None, farnn=0, gates=Non
                        float(sigmoid_exponent), NL[nl], SEMIRING[semiring], float(threshold), int(o_idx),
                        int(bool(use_crf)), ptr(crf_trans), 0)
     return _create('farnn_decomp_ifst_create', d, device, (Vgen, S1, S2, W, Cout, h0, hT, P, crf_trans, g))
+
+
+def create_decomp_ifst_folded(V_embed, E, G, beta, S1, S2, W, Cout, h0, hT, add_nl='none', normalize='none', P=None,
+                              farnn=0, gates=None, sigmoid_exponent=5, nl='none', semiring='sum', threshold=0.5, o_idx=0,
+                              use_crf=False, crf_trans=None, device=0):
+    """create_decomp_ifst with the word table (and the per-rank --normalize_automata scaling of V_embed, S1, S2) computed on
+    the device: Vgen = V_embed * beta + nl_add(E @ G) * (1 - beta).  G is the bridge of the UN-normalised V_embed."""
+    V_embed, E, G, beta, S1, S2, W, Cout, h0, hT = (f32(a) for a in (V_embed, E, G, beta, S1, S2, W, Cout, h0, hT))
+    P = None if P is None else f32(P)
+    crf_trans = None if crf_trans is None else f32(crf_trans)
+    g = {k: f32(v) for k, v in (gates or {}).items()}
+    S, R = S1.shape
+    d = DecompIfstDesc(V_embed.shape[0], S, R, Cout.shape[0], None, ptr(S1), ptr(S2), ptr(W), ptr(Cout),
+                       ptr(h0), ptr(hT), ptr(P), int(farnn),
+                       ptr(g.get('Wss1')), ptr(g.get('Wrs1')), ptr(g.get('bs1')),
+                       ptr(g.get('Wss2')), ptr(g.get('Wrs2')), ptr(g.get('bs2')),
+                       float(sigmoid_exponent), NL[nl], SEMIRING[semiring], float(threshold), int(o_idx),
+                       int(bool(use_crf)), ptr(crf_trans), 0)
+    fd = VgenFold(ptr(V_embed), ptr(E), ptr(G), ptr(beta), E.shape[1], NL[add_nl], NORM[normalize], 0)
+    lib = load()
+    out = _vp()
+    check(lib.farnn_decomp_ifst_create_folded(C.byref(d), C.byref(fd), int(device), C.byref(out)),
+          'farnn_decomp_ifst_create_folded')
+    return Handle(out, (V_embed, E, G, beta, S1, S2, W, Cout, h0, hT, P, crf_trans, g))
 
 
 def create_decomp_ind1(Vgen, S1, S2, W, Cout, S1o, S2o, h0, hT, Wo=None, P=None, farnn=0, gates=None,

@@ -1232,7 +1232,8 @@ static int upload_ones_o(farnn_model *m) {
 }
 
 // ---- create: decomposed i-FST ------------------------------------------------------------------
-extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int device, farnn_model **out) {
+// od_vgen / od_s12: Vgen resp. S1, S2 are device pointers whatever d->weights_on_device says (the folded creator)
+static int decomp_ifst_create_impl(const farnn_decomp_ifst_desc *d, int device, farnn_model **out, int od_vgen, int od_s12) {
     if (!d || !out) return fail(FARNN_EINVAL, "null argument%s%s");
     *out = nullptr;
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || d->K <= 0 || !d->Vgen || !d->S1 || !d->S2 || !d->W ||
@@ -1256,7 +1257,7 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if (m->K > 64 * SCORE_KCH) return bail(fail(FARNN_ERANGE, "more than 256 label columns%s%s"));
     if (m->S > 1024 || m->R > 4096) return bail(fail(FARNN_ERANGE, "decomp_ifst: S<=1024, R<=4096%s%s"));
     DecompWeights &w = m->dw;
-    if ((rc = upload_chain_factors(m, d->Vgen, od, d->S1, d->S2, od, d->W, od, gates, od))) return bail(rc);
+    if ((rc = upload_chain_factors(m, d->Vgen, od | od_vgen, d->S1, d->S2, od | od_s12, d->W, od, gates, od))) return bail(rc);
     {   // o = sum_k Cout[k,:] (CE1, model_decompose_single.py:232); OT = Cout^T
         TmpDev Co;
         if ((rc = Co.init(d->Cout, (size_t)m->K * m->S, od))) return bail(rc);
@@ -1280,6 +1281,97 @@ extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int dev
     if ((rc = build_dense_blocks(m))) return bail(rc);
     *out = m;
     return FARNN_OK;
+}
+
+extern "C" int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *d, int device, farnn_model **out) {
+    return decomp_ifst_create_impl(d, device, out, 0, 0);
+}
+
+// ---- the word table and --normalize_automata on the device ------------------------------------------------
+// avg[c] = ||M[:, c]||_ord / rows   (utils.get_average, '-rank' modes; reference utils.py:202-225)
+__global__ void col_avg_norm_kernel(const float *M, int rows, int cols, int ld, int ord, float *avg) {
+    const int c = blockIdx.x;
+    __shared__ float red[256];
+    float acc = 0.0f;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const float v = M[(long long)r * ld + c];
+        acc += ord == 1 ? fabsf(v) : v * v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) avg[c] = (ord == 1 ? red[0] : sqrtf(red[0])) / (float)rows;
+}
+
+// factor = cbrt(v_avg s1_avg s2_avg); scale[0][c] = factor / v_avg, [1][c] = factor / s1_avg, [2][c] = factor / s2_avg  (init_params.py:285-297)
+__global__ void norm_scales_kernel(const float *avg /*[3][R]*/, float *scale /*[3][R]*/, int R) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= R) return;
+    const float f = cbrtf(avg[c] * avg[R + c] * avg[2 * R + c]);
+    scale[c] = f / avg[c]; scale[R + c] = f / avg[R + c]; scale[2 * R + c] = f / avg[2 * R + c];
+}
+
+__global__ void scale_cols_kernel(float *M, long long n, int cols, const float *scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) M[i] *= scale[i % cols];
+}
+
+// Vgen[w][r] = V[w][r] cv[r] beta[r] + nl_add( sum_d E[w][d] G[d][r] cv[r] ) (1 - beta[r])      (model_decompose.py:222-241)
+// cv = the normalisation scale of V_embed's columns (1 without): G = pinv(E) V_embed is linear in V_embed's columns
+__global__ void fold_vgen_kernel(const float *Vemb, const float *E, const float *G, const float *beta, const float *cv,
+                                 float *Vgen, int V, int R, int D, int add_nl) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)V * R) return;
+    const int w = (int)(idx / R), r = (int)(idx % R);
+    float g = 0.0f;
+    for (int d = 0; d < D; d++) g = fmaf(E[(long long)w * D + d], G[(long long)d * R + r], g);
+    const float c = cv ? cv[r] : 1.0f;
+    const float b = beta[r];
+    Vgen[idx] = Vemb[idx] * c * b + apply_nl(g * c, add_nl) * (1.0f - b);
+}
+
+extern "C" int farnn_decomp_ifst_create_folded(const farnn_decomp_ifst_desc *d, const farnn_vgen_fold *f, int device,
+                                               farnn_model **out) {
+    if (!d || !f || !out) return fail(FARNN_EINVAL, "null argument%s%s");
+    *out = nullptr;
+    if (d->V <= 0 || d->S <= 0 || d->R <= 0 || f->D <= 0 || !f->V_embed || !f->E || !f->G || !f->beta || !d->S1 || !d->S2)
+        return fail(FARNN_EINVAL, "decomp_ifst_create_folded: V_embed / E / G / beta / S1 / S2 and positive sizes needed%s%s");
+    if (f->add_nl < FARNN_NL_NONE || f->add_nl > FARNN_NL_SIGMOID) return fail(FARNN_EINVAL, "decomp_ifst_create_folded: bad add_nl%s%s");
+    if (f->normalize != FARNN_NORM_NONE && f->normalize != FARNN_NORM_L1_RANK && f->normalize != FARNN_NORM_L2_RANK)
+        return fail(FARNN_EINVAL, "decomp_ifst_create_folded: only the per-rank norms (l1-rank, l2-rank) are folded on the device%s%s");
+    int rc = select_device(device);
+    if (rc) return rc;
+    const size_t V = d->V, R = d->R, S = d->S, D = f->D;
+    EdgeTmp tmp;
+    float *Vd = nullptr, *S1d = nullptr, *S2d = nullptr, *Vgen = nullptr, *avg = nullptr;
+    TmpDev E, G, beta;
+    auto copy_in = [&](float **dst, const float *src, size_t n, int on_dev) -> int {
+        int r2 = tmp.get((void **)dst, n * 4);
+        if (r2) return r2;
+        FARNN_HIP_TRY(hipMemcpy(*dst, src, n * 4, on_dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+        return FARNN_OK;
+    };
+    if ((rc = copy_in(&Vd, f->V_embed, V * R, f->on_device)) || (rc = copy_in(&S1d, d->S1, S * R, d->weights_on_device)) ||
+        (rc = copy_in(&S2d, d->S2, S * R, d->weights_on_device)) || (rc = E.init(f->E, V * D, f->on_device)) ||
+        (rc = G.init(f->G, D * R, f->on_device)) || (rc = beta.init(f->beta, R, f->on_device)) ||
+        (rc = tmp.get((void **)&Vgen, V * R * 4)) || (rc = tmp.get((void **)&avg, 6 * R * 4))) return rc;
+    const float *cv = nullptr;
+    if (f->normalize != FARNN_NORM_NONE) {
+        const int ord = f->normalize == FARNN_NORM_L1_RANK ? 1 : 2;
+        col_avg_norm_kernel<<<(unsigned)R, 256>>>(Vd, (int)V, (int)R, (int)R, ord, avg);
+        col_avg_norm_kernel<<<(unsigned)R, 256>>>(S1d, (int)S, (int)R, (int)R, ord, avg + R);
+        col_avg_norm_kernel<<<(unsigned)R, 256>>>(S2d, (int)S, (int)R, (int)R, ord, avg + 2 * R);
+        norm_scales_kernel<<<(unsigned)((R + 255) / 256), 256>>>(avg, avg + 3 * R, (int)R);
+        scale_cols_kernel<<<(unsigned)((S * R + 255) / 256), 256>>>(S1d, (long long)(S * R), (int)R, avg + 4 * R);
+        scale_cols_kernel<<<(unsigned)((S * R + 255) / 256), 256>>>(S2d, (long long)(S * R), (int)R, avg + 5 * R);
+        cv = avg + 3 * R;
+    }
+    fold_vgen_kernel<<<(unsigned)((V * R + 255) / 256), 256>>>(Vd, E.p, G.p, beta.p, cv, Vgen, (int)V, (int)R, (int)D, f->add_nl);
+    FARNN_HIP_TRY(hipGetLastError());
+    FARNN_HIP_TRY(hipDeviceSynchronize());
+    farnn_decomp_ifst_desc full = *d;
+    full.Vgen = Vgen; full.S1 = S1d; full.S2 = S2d;
+    return decomp_ifst_create_impl(&full, device, out, 1, 1);
 }
 
 // ---- create: decomposed independent=1 ----------------------------------------------------------

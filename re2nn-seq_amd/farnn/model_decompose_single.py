@@ -157,9 +157,13 @@ class FARNN_S_D_W_I_S(NativeTagger):
         gates = {k: getattr(self, k).reshape(-1) if k.startswith('bs') else getattr(self, k)
                  for k in _GATE_KEYS if hasattr(self, k)}
         gates = {k: v.numpy() for k, v in gates.items()}
-        return _lib.create_decomp_ifst(
-            self.generalized_vocab_table().numpy(), self.S1.numpy(), self.S2.numpy(),
+        # the word table Vgen = V_embed * beta + nl_add(E @ G) * (1 - beta) is folded by the library on the device
+        # (farnn_decomp_ifst_create_folded); generalized_vocab_table() remains as the host statement of it
+        return _lib.create_decomp_ifst_folded(
+            self.V_embed.numpy(), self.embedding.numpy(), self.embed_r_generalized.numpy(), self.beta_vec.numpy(),
+            self.S1.numpy(), self.S2.numpy(),
             self.wildcard_mat.numpy(), self.C_output_mat.numpy(), self.h0.numpy(), self.hT.numpy(),
+            add_nl=a.additional_nonlinear,
             P=self.priority_full if a.use_priority else None, farnn=a.farnn, gates=gates,
             sigmoid_exponent=a.sigmoid_exponent, nl=a.update_nonlinear,
             semiring='max' if a.train_mode == 'max' else 'sum', threshold=a.threshold,

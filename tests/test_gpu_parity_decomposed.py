@@ -504,3 +504,50 @@ def test_one_handle_serves_varying_batch_shapes(farnn, semiring, R):
         np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4, err_msg='B={} L={}'.format(B, L))
         assert (scores.cpu().numpy()[:, :Lmax][~mask] == 0).all()
     h.close()
+
+
+@pytest.mark.parametrize('add_nl', ['none', 'relu', 'tanh', 'sigmoid', 'relutanh'])
+@pytest.mark.parametrize('normalize', ['none', 'l2-rank', 'l1-rank'])
+def test_word_table_and_normalisation_folded_on_the_device(add_nl, normalize):
+    """farnn_decomp_ifst_create_folded computes Vgen = V_embed*beta + nl_add(E@G)*(1-beta)
+    (model_decompose.py:222-241) and the per-rank --normalize_automata scaling (init_params.py:285-297) on the device.
+    Against the host statement of both (the oracle's generalized_vocab_table on factors normalised with
+    utils.get_average) through the regular creator: same scores."""
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.utils import get_average
+    rng = np.random.RandomState(5)
+    V, S, K, R, D, B, L = 90, 21, 7, 30, 12, 8, 14
+    p = synth.random_decomposed_params(V, S, K, R, D, rng, contractive=True)
+    Vemb, S1, S2, E = (np.asarray(p[k], np.float64) for k in ('V_embed', 'S1', 'S2', 'embed'))
+    G = np.linalg.pinv(E) @ Vemb                        # the bridge of the UN-normalised V_embed (:73-76)
+    beta = np.full(R, 0.6)
+    Vn, S1n, S2n, Gn = Vemb, S1, S2, G
+    if normalize != 'none':                             # init_params.py:285-297 on the host, float64 like the reference
+        va, s1a, s2a = get_average(Vemb, normalize), get_average(S1, normalize), get_average(S2, normalize)
+        fac = np.float_power(va * s1a * s2a, 1 / 3)
+        Vn, S1n, S2n = Vemb * (fac / va), S1 * (fac / s1a), S2 * (fac / s2a)
+        Gn = np.linalg.pinv(E) @ Vn                     # what the mirror's constructor computes from the normalised table
+    vg = fo.generalized_vocab_table(Vn, E, Gn, beta, add_nl=fo.NL_CODES[add_nl])
+    f = lambda a: np.asarray(a, np.float32)             # noqa: E731
+    common = dict(nl='tanh', o_idx=2)
+    W, Cout, h0, hT = f(p['wildcard_mat']), f(p['C_output_mat']), f(p['start_vector']), f(p['final_vector'])
+    h_host = _lib.create_decomp_ifst(vg, f(S1n), f(S2n), W, Cout, h0, hT, **common)
+    h_dev = _lib.create_decomp_ifst_folded(f(Vemb), f(E), f(G), f(beta), f(S1), f(S2), W, Cout, h0, hT, add_nl=add_nl,
+                                           normalize=normalize, **common)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    out = []
+    for h in (h_host, h_dev):
+        sc = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, None, sc.data_ptr())
+        torch.cuda.synchronize()
+        out.append(sc.cpu().numpy())
+        h.close()
+    assert np.abs(out[0]).max() > 0.1
+    np.testing.assert_allclose(out[1], out[0], rtol=2e-5, atol=2e-6)
+    with pytest.raises(_lib.FarnnError):
+        _lib.NORM['l2'] = 2                              # a whole-matrix norm: refused (spectral norm, host only)
+        try:
+            _lib.create_decomp_ifst_folded(f(Vemb), f(E), f(G), f(beta), f(S1), f(S2), W, Cout, h0, hT, normalize='l2')
+        finally:
+            del _lib.NORM['l2']
