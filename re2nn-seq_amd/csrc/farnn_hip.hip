@@ -1910,6 +1910,9 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         if (ldsw) return TR_NSEQ;
         const bool fits = TR_NSEQ_L2 * SR <= (size_t)TR_VPT * TR_THREADS && vec4 + 16 <= lds_cap;
         if (forced == 2 || !fits) return TR_NSEQ;
+        // the gated four-sequence kernels with two register slots per thread (4 R or 4 S above 512, e.g. the shipped rank
+        // 250) need more than the 256 VGPRs a 512-thread workgroup has and spill 80-320 bytes per lane: two sequences then
+        if (farnn && forced != 4 && (TR_NSEQ_L2 * S > (size_t)TR_THREADS || TR_NSEQ_L2 * R > (size_t)TR_THREADS)) return TR_NSEQ;
         // measured at rank 250: with 256 sequences four per workgroup leave half the CUs idle (2.98 vs 2.63 ms per step),
         // with 1024 they win (6.5 vs 8.3 ms): four once two-sequence workgroups would outnumber the CUs two to one
         return (forced == 4 || (size_t)B >= 2 * (size_t)c->n_cu) ? TR_NSEQ_L2 : TR_NSEQ;
