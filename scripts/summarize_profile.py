@@ -18,7 +18,10 @@ os.makedirs(dst, exist_ok=True)
 for f in glob.glob(os.path.join(src, 'bench_*.json')):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
-for sub, name in (('trace', 'ifst'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp')):
+for f in glob.glob(os.path.join(src, '*.txt')):
+    shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
+for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_two_kernels'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
+                  ('trace_fst4', 'fst4')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(dst, '{}_{}_kernel_stats.csv'.format(tag, name)))
@@ -43,7 +46,7 @@ runs = [('pmc_fetch', 'ifst ragged U[5,64]'), ('pmc_write', 'ifst ragged U[5,64]
         ('pmc_fetch_fst4', 'fst4')]
 for run, label in runs:
     for (k, c), (mean, n) in sorted(agg(run).items()):
-        if 'farnn::' in k and any(t in k for t in ('chain', 'score', 'viterbi')):
+        if 'farnn::' in k and any(t in k for t in ('chain', 'score', 'viterbi', 'decomp_regs', 'decomp_rows')):
             rows.append([label, k, c, '%.1f' % mean, n])
 with open(os.path.join(dst, tag + '_pmc_summary.csv'), 'w') as f:
     w = csv.writer(f)
@@ -71,6 +74,25 @@ if f_ is not None:
 f_ = pick('fst4', 'fst4_score', 'FETCH_SIZE')
 if f_ is not None:
     traffic['fst4'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'fst4_score_kernel', 'source': note + ' (reads only)'}
+# SQ counter groups (instruction mix, waits, LDS conflicts) of the dominant kernels
+sq = collections.defaultdict(lambda: [0.0, 0])
+for d in sorted(glob.glob(os.path.join(src, 'sq*_*'))):
+    if not os.path.isdir(d):
+        continue
+    wl = os.path.basename(d).split('_', 1)[1]
+    files = sorted(glob.glob(os.path.join(d, '*', '*_counter_collection.csv')), key=os.path.getmtime)
+    if not files:
+        continue
+    for row in csv.DictReader(open(files[-1])):
+        kn = row['Kernel_Name'].split('(')[0].replace('void ', '')
+        if 'farnn::' in kn and any(t in kn for t in ('chain_kernel', 'score_tile', 'viterbi', 'decomp_regs', 'decomp_rows')):
+            key = (wl, kn, row['Counter_Name'])
+            sq[key][0] += float(row['Counter_Value']); sq[key][1] += 1
+with open(os.path.join(dst, tag + '_pmc_sq.csv'), 'w') as f:
+    w = csv.writer(f)
+    w.writerow(['workload', 'kernel', 'counter', 'mean_per_dispatch', 'dispatches'])
+    for (wl, kn, c), (s_, n) in sorted(sq.items()):
+        w.writerow([wl, kn, c, '%.1f' % (s_ / n), n])
 with open(os.path.join(dst, 'traffic.json'), 'w') as f:
     json.dump(traffic, f, indent=1)
 for r in rows:
