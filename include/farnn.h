@@ -51,7 +51,9 @@ extern "C" {
 #define FARNN_SEMIRING_MAX 1
 /* farnn_tag() modes */
 #define FARNN_MODE_LOCAL   0   /* forward_local: valid positions only (model_onehot.py:131-146) */
-#define FARNN_MODE_FULL    1   /* forward_RE / forward_score: all L positions incl. pads (:148-160) */
+#define FARNN_MODE_FULL    1   /* forward_score: all L positions incl. pads, scores unclamped (:351-428) */
+#define FARNN_MODE_RE      2   /* forward_RE (:148-160): FULL, and the `oo` column (C-1) of `scores` comes back capped at the
+                                  threshold (:153-154); onehot models only */
 
 typedef struct farnn_model farnn_model;   /* opaque handle */
 

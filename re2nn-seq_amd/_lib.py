@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libfarnn_hip.so')
 OK = 0
 NL = {'none': 0, 'relu': 1, 'tanh': 2, 'relutanh': 3, 'sigmoid': 4}
 SEMIRING = {'sum': 0, 'max': 1}
-MODE_LOCAL, MODE_FULL = 0, 1
+MODE_LOCAL, MODE_FULL, MODE_RE = 0, 1, 2
 HOST_SLOTS = 4                  # FARNN_HOST_SLOTS: batches the host-buffer path keeps in flight
 KERN_CHAIN, KERN_SCORE, KERN_PREP = 0, 1, 2
 

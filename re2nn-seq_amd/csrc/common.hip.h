@@ -50,6 +50,7 @@ __device__ __forceinline__ float apply_nl(float v, int nl) {
 // global memory, two loops over typed pointers keep ds_read / global_load; a select between generic
 // pointers compiles to flat_load with a full vmcnt+lgkmcnt drain.
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef __attribute__((address_space(3))) const v4f lds_cv4f;
 typedef __attribute__((address_space(1))) const v4f glb_cv4f;
@@ -188,6 +189,46 @@ __device__ __forceinline__ int wave_argmax_dpp(float v, int idx) {
     dpp_max_step<0x142, 0xa>(hi, lo);      // row_bcast:15 into rows 1 and 3
     dpp_max_step<0x143, 0xc>(hi, lo);      // row_bcast:31 into rows 2 and 3
     return (int)~(unsigned)__builtin_amdgcn_readlane((int)lo, 63);
+}
+
+// wave maximum on the DPP network (wave-uniform result): one v_max with a DPP operand per level -- lanes without a
+// source lane (bound_ctrl off) keep their value.  Inline asm: the builtin form costs five instructions per level
+// (copy, DPP move, two canonicalising maxes, max).
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// first index (torch.max's rule) of the maximum of up to 256 candidates held as v[r] = candidate r*64 + lane (lanes
+// beyond the last candidate hold -inf): the wave maximum, then per row of 64 the lanes that equal it -- the lowest set
+// bit of the first non-empty row is the answer.  Wave-uniform result; 0 when nothing compares equal (all NaN).
+template <int NR>
+__device__ __forceinline__ int wave_first_argmax(const float (&v)[NR]) {
+    float best = v[0];
+#pragma unroll
+    for (int r = 1; r < NR; r++) best = fmaxf(best, v[r]);
+    const float m = wave_max_dpp(best);
+    int idx = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const unsigned long long hit = __ballot(v[r] == m);
+        if (!found && hit) { idx = r * 64 + __builtin_ctzll(hit); found = true; }
+    }
+    return idx;
 }
 
 }  // namespace farnn

@@ -635,32 +635,46 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
 
 // fused: the Viterbi kernel computes the scores itself (no score_tile launch went before it)
 static bool viterbi_can_fuse(const farnn_model *m, const ScoreParams &p) {
-    return m->use_crf && !p.scores && !p.P && p.A && p.OT &&
-           viterbi_hist_lds_bytes(m->K, m->Kp, p.L) <= 158 * 1024 && viterbi_fused_fits(m->K, p.SP, p.L) &&
+    return m->use_crf && !p.scores && !p.P && p.A && p.OT && m->K <= 256 &&
+           viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, true) <= 158 * 1024 &&
            !env_int("FARNN_VITERBI_BP", 0) && !env_int("FARNN_VITERBI_UNFUSED", 0);
 }
 
 static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s, bool fused = false) {
     int rc;
-    const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
-    int threads = round_up(4 * m->K, 64);
-    if (threads > 1024) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
-    const int ib4 = viterbi_ib4(m->K);
-    const size_t hlds = viterbi_hist_lds_bytes(m->K, m->Kp, p.L);
-    const bool hist = hlds <= 158 * 1024 && !env_int("FARNN_VITERBI_BP", 0);
-#define FARNN_LAUNCH_VIT(N)                                                                   \
-    do {                                                                                      \
-        if (hist && fused) {                                                                  \
+    if (m->K > 256) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
+    const size_t hlds = viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, fused);
+    if (hlds <= 158 * 1024 && !env_int("FARNN_VITERBI_BP", 0)) {
+        // partition history in LDS, back-pointers recomputed along the path
+        const int threads = viterbi_hist_threads(m->K);
+#define FARNN_LAUNCH_VITH(N)                                                                  \
+    case N:                                                                                   \
+        if (fused) {                                                                          \
             if ((rc = raise_lds_limit(viterbi_hist_kernel<N, true>, hlds))) return rc;        \
             viterbi_hist_kernel<N, true><<<dim3(B), dim3(threads), hlds, s>>>(p);             \
-        } else if (hist) {                                                                    \
+        } else {                                                                              \
             if ((rc = raise_lds_limit(viterbi_hist_kernel<N, false>, hlds))) return rc;       \
             viterbi_hist_kernel<N, false><<<dim3(B), dim3(threads), hlds, s>>>(p);            \
-        } else {                                                                              \
-            if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                   \
-            viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                        \
         }                                                                                     \
+        break;
+        switch (viterbi_hist_ib4(m->K)) {
+            FARNN_LAUNCH_VITH(0) FARNN_LAUNCH_VITH(1) FARNN_LAUNCH_VITH(2) FARNN_LAUNCH_VITH(3) FARNN_LAUNCH_VITH(4)
+            FARNN_LAUNCH_VITH(5) FARNN_LAUNCH_VITH(6) FARNN_LAUNCH_VITH(7) FARNN_LAUNCH_VITH(8)
+        }
+#undef FARNN_LAUNCH_VITH
+        FARNN_HIP_TRY(hipGetLastError());
+        return FARNN_OK;
+    }
+    if (fused) return fail(FARNN_EINVAL, "Viterbi: the fused form needs the history in LDS%s%s");
+    // long sequences: two partition rows + stored back-pointers
+    const size_t vlds = viterbi_lds_bytes(m->K, m->Kp, p.L);
+    const int threads = round_up(4 * m->K, 64);
+#define FARNN_LAUNCH_VIT(N)                                                                   \
+    do {                                                                                      \
+        if ((rc = raise_lds_limit(viterbi_kernel<N>, vlds))) return rc;                       \
+        viterbi_kernel<N><<<dim3(B), dim3(threads), vlds, s>>>(p);                            \
     } while (0)
+    const int ib4 = viterbi_ib4(m->K);
     if (ib4 == 2) FARNN_LAUNCH_VIT(2);            // K <= 32
     else if (ib4 == 4) FARNN_LAUNCH_VIT(4);       // K <= 64
     else if (ib4 == 9) FARNN_LAUNCH_VIT(9);       // K <= 144
@@ -833,11 +847,35 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
     return launch_score_decode(m, len, B, full, tags, flat, scores, s);
 }
 
+// forward_RE's view of the scores (model_onehot.py:153-154): the `oo` column (the last one) capped at the threshold
+__global__ void clamp_oo_column_kernel(float *scores, long long rows, int K, int col, float threshold) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < rows) scores[r * K + col] = fminf(scores[r * K + col], threshold);
+}
+
+static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
+                    int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream);
+
 extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
                          int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream) {
     if (!m || !x || !lengths) return fail(FARNN_EINVAL, "tag: null model / x / lengths%s%s");
     if (B <= 0 || L <= 0) return fail(FARNN_EINVAL, "tag: B and L must be positive%s%s");
-    if (mode != FARNN_MODE_LOCAL && mode != FARNN_MODE_FULL) return fail(FARNN_EINVAL, "tag: bad mode%s%s");
+    if (mode != FARNN_MODE_LOCAL && mode != FARNN_MODE_FULL && mode != FARNN_MODE_RE)
+        return fail(FARNN_EINVAL, "tag: bad mode%s%s");
+    if (mode != FARNN_MODE_RE) return tag_impl(m, x, lengths, B, L, mode, tags, flat_tags, scores, stream);
+    if (m->kind != KIND_IFST && m->kind != KIND_FST4 && m->kind != KIND_IND1)
+        return fail(FARNN_EINVAL, "tag: FARNN_MODE_RE exists on the onehot models only (model_onehot.py:148)%s%s");
+    int rc = tag_impl(m, x, lengths, B, L, FARNN_MODE_FULL, tags, flat_tags, scores, stream);
+    if (rc || !scores) return rc;
+    const long long rows = (long long)B * L;
+    clamp_oo_column_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, reinterpret_cast<hipStream_t>(stream)>>>(
+        scores, rows, m->K, m->C - 1, m->threshold);
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
+                    int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream) {
     FARNN_HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;

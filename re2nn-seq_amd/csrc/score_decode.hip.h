@@ -384,20 +384,40 @@ viterbi_kernel(const ScoreParams p) {
         for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
 }
 
+// floats of the history area of viterbi_hist_kernel: [L][Kp] partitions; the fused form first stages the [SP][L]
+// alpha*beta products there
+__host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, bool fused) {
+    const size_t a = (size_t)L * Kp, c = fused ? (size_t)SP * ((L + 3) & ~3) : 0;
+    return a > c ? a : c;
+}
+
 // History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
-// VALUES of every step (2 adds + 1 max per (i, j) instead of 2 adds + compare + 2 selects, and the
-// four lanes of a tag combine on the DPP network instead of two ds_bpermute round trips); the
-// back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE path the
-// backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
-// expression on the same values, so the path is bit-identical.  The transposed transition table
-// stays in LDS for that second pass.
+// VALUES of every step; the back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE
+// path the backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
+// expression on the same values, so the path is bit-identical.  The transposed transition table stays in LDS for
+// that second pass.
+// Forward pass layout (r02; FARNN_DBG=8192 prints the phase cycle counts).  The step is VALU-issue bound on the one CU
+// that owns the sequence: two adds (crf.py:123,145) and half a v_max3 per (source, tag), K*K pairs -- 660 cycles per step
+// at K = 130 if the four SIMDs were perfectly balanced, plus ~300 of LDS latency and barrier.  EIGHT lanes share a PAIR of
+// destination tags (j0, j0+1); lane g of the group owns the sources 32*k + 4*g .. +3 of every 32-source block k < IB4 (a
+// 16-byte LDS read per block, the eight lanes cover a contiguous 128 bytes: no bank conflicts) plus up to four leftover
+// sources 32*IB4 + g + 8x (K - 32*IB4 < 32): at most one wasted source slot per lane for any K (r01: four lanes per tag,
+// block sizes 8/16/36/52/64 -- K = 75 ran 36 slots per lane for 19 useful ones).  The two tags ride in the halves of
+// packed-f32 registers (v_pk_add_f32 issues at half rate on gfx950, so this saves registers and LDS reads, not issue
+// slots); the group is combined by three v_max with DPP operands per tag.  Tag pairs that do not fill a wavefront (K = 130:
+// the START/STOP pair) go to a TAIL wavefront that spreads them over all its lanes and runs at raised priority -- its
+// step is a short latency chain that otherwise runs behind the SIMD's older, issue-bound wavefronts.
+// Measured on the config-3 batch (K = 130, 64 positions; cycles at ~2.3 GHz): set-up + scores 25.6 k, forward pass
+// 1 190 per step (K = 128: 910), backtrace 590 per step (r01: 1 140 -- the keyed 64-bit DPP argmax).  Tried and dropped:
+// hoisting (f + tr) of the coming step behind the LDS write (no gain: the idle time there is ~100 cycles), conditional
+// leftover reads (waits inside branches: +130 per step).
 // FUSED: the workgroup also computes the clamped scores of its sequence (what score_tile_kernel would
 // have written to crf_scores) straight into LDS -- one kernel from stash to tags, no score round trip
 // through HBM: alpha*beta products staged transposed in the (not yet used) history area, then a
 // register-blocked [tokens x S].[S x K] product, 4 tokens x 4 tags per lane, against the L2-resident
 // transposed output matrix.  Same fmaf chain in s order as score_tile_kernel: identical bits.
 template <int IB4, bool FUSED>
-__global__ void __launch_bounds__(1024)
+__global__ void __launch_bounds__(IB4 < 7 ? 128 * IB4 + 128 : 1024)        // K < 32*IB4 + 32: 8 lanes per tag pair
 viterbi_hist_kernel(const ScoreParams p) {
     constexpr int IB = IB4 * 4;
     extern __shared__ __align__(16) float smem[];
@@ -407,16 +427,18 @@ viterbi_hist_kernel(const ScoreParams p) {
     const int n = clamp_len(p.len[b], p.L);
     (void)p.full;
     const int K = p.K, Kp = p.Kp;
-    const int PW = 4 * IB;                               // padded partition width (>= K)
-    float *hist = smem;                                  // [L][PW] partitions of every step, pads -inf
+    const int PW = Kp;                                   // partition row stride (K rounded up to 4), pads -inf
+    float *hist = smem;                                  // [L][PW] partitions of every step (FUSED: first the products)
     const int sc_pieces = (p.L * Kp * 4 + 1023) / 1024, tr_pieces = (K * Kp * 4 + 1023) / 1024;
-    float *scl = hist + (size_t)p.L * PW;                // [L][Kp] clamped scores of this sequence (whole KiB)
+    float *scl = hist + viterbi_hist_floats(Kp, p.SP, p.L, FUSED);   // [L][Kp] clamped scores of this sequence (whole KiB)
     float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
     const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
+    const bool probe = (p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
+    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0;
 
     // set-up without a register round trip: the scores and (behind them) the transition table stream
     // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
@@ -489,18 +511,52 @@ viterbi_hist_kernel(const ScoreParams p) {
         else score_tiles((glb_cv4f *)(p.OT + cg * 4), p.Kc >> 2);
         __syncthreads();                                 // abT (aliasing hist) is free again
     }
-    const int j = tid >> 2, q = tid & 3;
-    const bool owner = j < K;
-    float trr[IB];                                       // tr[i][j] for this lane's block of i
+    // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
+    // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
+    // that e.g. K = 130 (64 pairs + START/STOP) costs the ninth wavefront 3 source slots per lane instead of 17
+    const int npairs = (K + 1) >> 1, nfull = npairs >> 3, rem = npairs & 7;
+    const bool tail = wu >= nfull;                       // wave-uniform
+    const int GT = rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8;
+    const int g = tail ? (lane & (GT - 1)) : (tid & 7);  // lane of its group
+    const int grp = tail ? lane / GT : 0;
+    const int pair = tail ? nfull * 8 + grp : (tid >> 3);
+    const int j0 = 2 * pair;
+    const bool own0 = j0 < K && (!tail || grp < rem), own1 = own0 && j0 + 1 < K;
+    const bool writer = own0 && (tail ? g == GT - 1 : g == 0);
+    const int XS = (K - 8 * IB + 7) >> 3;                // full wavefronts: leftover source slots per lane (0..4)
+    const int nst = (K + GT - 1) / GT;                   // tail wavefront: source slots per lane (<= IB + 4)
+    constexpr int NSL = IB + 4;
+    v2f trs[NSL];                                        // tr[i][j0], tr[i][j0+1] of this lane's sources
+    int ixs[4];                                          // full: leftover sources (clamped into the row; their tr is -inf)
     {
-        const float *row = p.trT + (long long)(owner ? j : 0) * Kp + q * IB;   // 16-byte aligned; may run into
-#pragma unroll                                                                  // the next row: masked below
-        for (int k4 = 0; k4 < IB4; k4++) {
-            const float4 v = ld4(row + k4 * 4);
-            trr[k4 * 4 + 0] = v.x; trr[k4 * 4 + 1] = v.y; trr[k4 * 4 + 2] = v.z; trr[k4 * 4 + 3] = v.w;
+        const float *row0 = p.trT + (long long)(own0 ? j0 : 0) * Kp, *row1 = p.trT + (long long)(own1 ? j0 + 1 : 0) * Kp;
+        if (!tail) {
+#pragma unroll
+            for (int k4 = 0; k4 < IB4; k4++) {           // sources 32*k4 + 4*g + u: a 128-byte span per read, no bank conflicts
+                const float4 a = ld4(row0 + k4 * 32 + g * 4), c = ld4(row1 + k4 * 32 + g * 4);
+                trs[k4 * 4 + 0] = v2f{own0 ? a.x : ninf, own1 ? c.x : ninf}; trs[k4 * 4 + 1] = v2f{own0 ? a.y : ninf, own1 ? c.y : ninf};
+                trs[k4 * 4 + 2] = v2f{own0 ? a.z : ninf, own1 ? c.z : ninf}; trs[k4 * 4 + 3] = v2f{own0 ? a.w : ninf, own1 ? c.w : ninf};
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) {
+                const int i = 8 * IB + 8 * xk + g;
+                const bool ok = i < K;
+                ixs[xk] = ok ? i : K - 1;
+                trs[IB + xk] = v2f{(ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf};
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NSL; sl++) {
+                const int i = g + GT * sl;
+                const bool ok = i < K;
+                trs[sl] = v2f{(ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf};
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) ixs[xk] = 0;
         }
     }
-    const float t_start = (owner && q == 0) ? p.trT[(long long)j * Kp + START] : 0.0f;   // before the table DMA
+    const v2f t_start = writer ? v2f{p.trT[(long long)j0 * Kp + START], own1 ? p.trT[(long long)(j0 + 1) * Kp + START] : 0.0f}
+                               : v2f{0.f, 0.f};                                                  // before the table DMA
     int my_tr = 0;
     {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
@@ -509,65 +565,138 @@ viterbi_hist_kernel(const ScoreParams p) {
     }
     if (PW > K)
         for (int i = tid; i < n * (PW - K); i += nthreads) hist[(i / (PW - K)) * PW + K + i % (PW - K)] = ninf;
-    wait_vmcnt(my_tr);                                   // scores + this lane's transition block landed
-#pragma unroll
-    for (int k = 0; k < IB; k++) trr[k] = (owner && q * IB + k < K) ? trr[k] : ninf;
+    wait_vmcnt(my_tr);                                   // scores + this lane's transition entries landed
     wg_barrier_lds();                                    // (a __syncthreads would drain the table DMA)
-    if (owner && q == 0) hist[j] = scl[j] + t_start;                          // crf.py:135
+    // scores of this lane's two tags (a tag beyond K reads a finite pad column and its transitions are -inf)
+    const float *fcol = scl + (own0 ? j0 : 0);
+    auto scores_at = [&](int t) {                        // f_t[j0], f_t[j0+1]; nothing is read into a half without a tag
+        v2f f = *reinterpret_cast<const v2f *>(fcol + (size_t)t * Kp);
+        f.y = own1 ? f.y : 0.0f;
+        return f;
+    };
+    if (writer) {                                                             // crf.py:135
+        const v2f f0 = scores_at(0);
+        hist[j0] = f0.x + t_start.x;
+        if (own1) hist[j0 + 1] = f0.y + t_start.y;
+    }
     wg_barrier_lds();
+    if (probe) pc1 = (long long)__builtin_amdgcn_s_memtime();
+    // the tail wavefront's step is a short latency chain (LDS read, a few adds, six DPP levels, LDS write): at the default
+    // priority the SIMD's older wavefronts starve it until their own issue-bound step is over and the chain then runs
+    // behind them (K = 130: +330 cycles per step); first in line, it hides inside their step
+    if (tail) __builtin_amdgcn_s_setprio(3);
+    // One step: two adds (crf.py:123,145) and half a v_max3 per (source, tag).  The step is VALU-issue bound on the CU:
+    // hoisting the partition-independent add (f + tr) behind the step's LDS write was measured and bought nothing (the
+    // idle time around the write and the barrier is ~100 cycles, not the ~350 the first probe suggested), and
+    // v_pk_add_f32 issues at half rate on gfx950, so the packed form saves registers and LDS reads, not issue slots.
     for (int t = 1; t < n; t++) {
-        const float *pin = hist + (size_t)(t - 1) * PW + q * IB;
-        const float f = owner ? scl[(long long)t * Kp + j] : 0.0f;
-        float best = ninf;
+        const float *pin = hist + (size_t)(t - 1) * PW;
+        const v2f f = scores_at(t);
+        auto f_tr = [&](int sl) { return f + trs[sl]; };
+        v2f best = v2f{ninf, ninf};
+        if (!tail) {
+            float4 p4[IB4 > 0 ? IB4 : 1];
+            float px[4];                                 // leftover sources: read up front, no LDS wait inside a branch
 #pragma unroll
-        for (int k4 = 0; k4 < IB4; k4++) {
-            const float4 p4 = ld4(pin + k4 * 4);
-            const float v0 = (f + trr[k4 * 4 + 0]) + p4.x, v1 = (f + trr[k4 * 4 + 1]) + p4.y;   // crf.py:123,145
-            const float v2 = (f + trr[k4 * 4 + 2]) + p4.z, v3 = (f + trr[k4 * 4 + 3]) + p4.w;
-            best = fmaxf(fmaxf(best, v0), v1);
-            best = fmaxf(fmaxf(best, v2), v3);
+            for (int xk = 0; xk < 4; xk++) px[xk] = pin[ixs[xk]];
+#pragma unroll
+            for (int k4 = 0; k4 < IB4; k4++) {
+                p4[k4] = ld4(pin + k4 * 32 + g * 4);     // (the compiler pipelines these reads as the registers allow)
+                const v2f v0 = f_tr(k4 * 4 + 0) + v2f{p4[k4].x, p4[k4].x}, v1 = f_tr(k4 * 4 + 1) + v2f{p4[k4].y, p4[k4].y};
+                const v2f v2 = f_tr(k4 * 4 + 2) + v2f{p4[k4].z, p4[k4].z}, v3 = f_tr(k4 * 4 + 3) + v2f{p4[k4].w, p4[k4].w};
+                best.x = fmaxf(fmaxf(best.x, v0.x), v1.x); best.y = fmaxf(fmaxf(best.y, v0.y), v1.y);
+                best.x = fmaxf(fmaxf(best.x, v2.x), v3.x); best.y = fmaxf(fmaxf(best.y, v2.y), v3.y);
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++)
+                if (xk < XS) {
+                    const v2f v = f_tr(IB + xk) + v2f{px[xk], px[xk]};
+                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+                }
+            // the eight lanes of the group: xor 1, xor 2 inside the quad, then the mirrored quad of the half row
+            asm volatile("s_nop 1\n\t"
+                         "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1"
+                         : "+v"(best.x), "+v"(best.y));
+        } else {
+#pragma unroll
+            for (int s4 = 0; s4 < NSL; s4 += 4) {        // four slots at a time (slots beyond nst: -inf transitions)
+                if (s4 >= nst) continue;
+                float ps[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = g + GT * (s4 + u); ps[u] = pin[i < PW ? i : PW - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const v2f v = f_tr(s4 + u) + v2f{ps[u], ps[u]};
+                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+                }
+            }
+            // max scan over the GT lanes of the group: its last lane ends up with the group's maximum
+#define FARNN_SCAN2(CTRL) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 1" : "+v"(best.x), "+v"(best.y))
+            FARNN_SCAN2("row_shr:1 row_mask:0xf bank_mask:0xf");
+            FARNN_SCAN2("row_shr:2 row_mask:0xf bank_mask:0xf");
+            FARNN_SCAN2("row_shr:4 row_mask:0xf bank_mask:0xf");
+            if (GT >= 16) FARNN_SCAN2("row_shr:8 row_mask:0xf bank_mask:0xf");
+            if (GT >= 32) FARNN_SCAN2("row_bcast:15 row_mask:0xa bank_mask:0xf");
+            if (GT >= 64) FARNN_SCAN2("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef FARNN_SCAN2
         }
-        best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), 0xB1, 0xf, 0xf, false)));
-        best = fmaxf(best, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(best), 0x4E, 0xf, 0xf, false)));
-        if (owner && q == 0) hist[(size_t)t * PW + j] = best;
+        if (writer) *reinterpret_cast<v2f *>(hist + (size_t)t * PW + j0) = best;   // (j0 + 1 == K: -inf into the pad)
         wg_barrier_lds();
     }
+    if (tail) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transition table is in LDS
     __syncthreads();
+    if (probe) pc2 = (long long)__builtin_amdgcn_s_memtime();
     if (w == 0 && n > 0) {
-        const float *pin = hist + (size_t)(n - 1) * PW;
-        float bv = ninf; int bi = 0x7ffffffe;
-        for (int i = lane; i < K; i += WAVE) {
-            const float v = pin[i] + trl[(long long)STOP * Kp + i];            // crf.py:168-169
-            if (v > bv) { bv = v; bi = i; }
+        // One wavefront walks the path.  Candidate i of a step sits in lane i % 64, row i / 64 (NRB rows cover PW >= K);
+        // per step: one LDS round trip (the row of the table and the score the pointer selects), two adds per candidate,
+        // six v_max on the DPP network and a ballot per row (r01/r02 used the keyed argmax: 1 140 cycles per step, as much
+        // as the whole forward pass -- FARNN_DBG=8192 prints the phases).
+        constexpr int NRB = (32 * IB4 + 32 + 63) / 64;         // PW <= 32*IB4 + 32
+        int itr[NRB], ipp[NRB];                          // no guards in the loop: candidates >= K read a pad of the
+#pragma unroll                                           // partitions (-inf) and, harmlessly, the table's last valid entry
+        for (int r = 0; r < NRB; r++) {
+            const int i = r * 64 + lane;
+            itr[r] = i < K ? i : K - 1;
+            ipp[r] = i < PW ? i : PW - 1;
         }
-        int ptr = wave_argmax_dpp(bv, bi);
-        if (ptr >= K) ptr = 0;
+        auto first_argmax = [&](float f, const float *tr, const float *pp) {
+            float c[NRB];
+#pragma unroll
+            for (int r = 0; r < NRB; r++) c[r] = (f + tr[itr[r]]) + pp[ipp[r]];
+            return wave_first_argmax<NRB>(c);
+        };
+        int ptr = first_argmax(0.0f, trl + (long long)STOP * Kp, hist + (size_t)(n - 1) * PW);   // crf.py:168-169 (0 + x = x)
+        int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
         for (int t = n - 1; t >= 0; t--) {
-            if (lane == 0) {
-                const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
-                if (p.tags) p.tags[(long long)b * p.L + t] = tag;
-                if (p.flat) p.flat[foff + t] = tag;
+            const int tag = (ptr == K - 3) ? p.o_idx : ptr;                   // model_decompose.py:356
+            mytag = lane == (t & 63) ? tag : mytag;
+            if ((t & 63) == 0 && t + lane < n) {         // 64 positions at a time, coalesced
+                if (p.tags) p.tags[(long long)b * p.L + t + lane] = mytag;
+                if (p.flat) p.flat[foff + t + lane] = mytag;
             }
-            if (t > 0) {      // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed
-                const float f = scl[(long long)t * Kp + ptr];
-                const float *pp = hist + (size_t)(t - 1) * PW;
-                const float *tr = trl + (long long)ptr * Kp;
-                float v = ninf; int vi = 0x7ffffffe;
-                for (int i = lane; i < K; i += WAVE) {
-                    const float c = (f + tr[i]) + pp[i];
-                    if (c > v) { v = c; vi = i; }
-                }
-                ptr = wave_argmax_dpp(v, vi);
-                if (ptr >= K) ptr = 0;
-            }
+            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values
+            if (t > 0) ptr = first_argmax(scl[(long long)t * Kp + ptr], trl + (long long)ptr * Kp, hist + (size_t)(t - 1) * PW);
         }
+    }
+    if (probe && tid == 0) {
+        pc3 = (long long)__builtin_amdgcn_s_memtime();
+        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles, forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
+               b, n, nthreads, pc1 - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
     }
     if (p.tags)
         for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
 }
 
-// the instantiated block size (in float4s) for K tags: ceil(ceil(K/4)/4) rounded up to a built one
+// block size (in float4s) of viterbi_kernel (the back-pointer variant) for K tags: ceil(ceil(K/4)/4) rounded up to a built one
 inline int viterbi_ib4(int K) {
     const int need = ((K + 3) / 4 + 3) / 4;
     return need <= 2 ? 2 : need <= 4 ? 4 : need <= 9 ? 9 : need <= 13 ? 13 : 16;
@@ -575,12 +704,11 @@ inline int viterbi_ib4(int K) {
 inline size_t viterbi_lds_bytes(int K, int Kp, int L) {
     return (size_t)2 * 16 * viterbi_ib4(K) * 4 + (size_t)L * Kp * 4 + (size_t)L * Kp * 2;
 }
-// can the fused variant stage [SP][L] products in the history area?
-inline bool viterbi_fused_fits(int K, int SP, int L) {
-    return (size_t)SP * ((L + 3) & ~3) <= (size_t)L * 16 * viterbi_ib4(K);
-}
-inline size_t viterbi_hist_lds_bytes(int K, int Kp, int L) {
-    return (size_t)L * 16 * viterbi_ib4(K) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +
+// viterbi_hist_kernel: contiguous float4 blocks per lane (K = 32*IB4 + leftovers) and its thread count
+inline int viterbi_hist_ib4(int K) { return K / 32; }
+inline int viterbi_hist_threads(int K) { return round_up(((K + 1) / 2) * 8, 64); }
+inline size_t viterbi_hist_lds_bytes(int K, int Kp, int SP, int L, bool fused) {
+    return viterbi_hist_floats(Kp, SP, L, fused) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +
            ((size_t)K * Kp * 4 + 1023) / 1024 * 1024;
 }
 

@@ -192,8 +192,5 @@ class NativeTagger:
     def forward_RE(self, input, label, lengths, train=False):
         """(pred[B,L] int64, scores[B,L,K] with the `oo` column clamped); pads included
         (model_onehot.py:148-160)."""
-        r = self.run(input, lengths, _lib.MODE_FULL, want_tags=True, want_scores=True)
-        scores = r['scores']
-        K = scores.shape[2]
-        scores[:, :, K - 1].clamp_(max=float(self.args.threshold))
-        return r['tags'].to(torch.int64).to(input.device), scores.to(input.device)
+        r = self.run(input, lengths, _lib.MODE_RE, want_tags=True, want_scores=True)
+        return r['tags'].to(torch.int64).to(input.device), r['scores'].to(input.device)

@@ -3,8 +3,9 @@ decomposed-automaton pickle -> factors -> FARNN_S_D_W_I_S (``--independent 2``, 
 example configs use) or FARNN_S_D_W_I (``--independent 1``), INIT evaluation, `.res` record.
 ``--independent 0`` (FARNN_S_D_W) is wired like the reference's (:72-90) but, like there, cannot be
 reached from the CLI: main.py:127 forces local_loss_func='CE1' and :69-70 asserts independent != 0
-under CE1.  The epoch loop (:155-220) runs on the HIP training step for the decomposed i-FST with farnn 0 and
-no CRF (train_onehot.train_epochs); the other configurations are evaluated with --epoch 0."""
+under CE1.  The epoch loop (:155-220) runs on the HIP training step (csrc/train.hip.h through
+train_onehot.train_epochs) for the decomposed i-FST (``--independent 2``) with farnn 0/1/2, with or without the CRF,
+CE + CRF NLL losses; the KD / PR teacher terms and the other ``--independent`` settings are evaluated with --epoch 0."""
 from .farnn.model_decompose import FARNN_S_D_W
 from .farnn.model_decompose_independent import FARNN_S_D_W_I
 from .farnn.model_decompose_single import FARNN_S_D_W_I_S

@@ -121,6 +121,30 @@ def test_viterbi_atis_scale_vs_oracle(variant, monkeypatch):
     assert np.array_equal(pred.numpy(), fo.forward_local_tags(sc, lengths, 0.5, 3, crf_tr=tr))
 
 
+@pytest.mark.parametrize('variant', ['fused', 'history'])
+@pytest.mark.parametrize('C', [2, 3, 6, 13, 28, 29, 30, 31, 45, 62, 73, 94, 98, 125, 126, 127, 129, 135, 158, 198, 253, 254])
+def test_viterbi_tag_set_sizes_vs_oracle(C, variant, monkeypatch):
+    """Every shape of the Viterbi kernel's work split (csrc/score_decode.hip.h: eight lanes per tag pair, 32-source blocks +
+    0..4 leftover slots, the tail wavefront at 64 / 32 / 16 / 8 lanes per pair, K = C + 2 from 4 to 256), scores
+    computed inside the kernel and read from the score kernel's output, ragged lengths incl. 1: tags equal the oracle's
+    (crf.py:102-195) bit for bit."""
+    monkeypatch.setenv('FARNN_VITERBI_BP', '0')
+    monkeypatch.setenv('FARNN_VITERBI_UNFUSED', '0' if variant == 'fused' else '1')
+    from re2nn_seq_amd import synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(100 + C)
+    V, S, B, L = 60, 19 + C % 7, 9, 5 + C % 13
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=8.0)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    lengths[0] = 1
+    o_idx = C // 2
+    tr = fo.crf_default_transitions(C) + rng.randn(C + 2, C + 2).astype(np.float32)
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, None, ns(), o_idx=o_idx).enable_crf(tr)
+    _, pred, _ = m.forward_local(_t(x), torch.zeros_like(_t(x)), _t(lengths), train=False)
+    sc = fo.onehot_crf_extension_scores(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths))
+    assert np.array_equal(pred.numpy(), fo.forward_local_tags(sc, lengths, 0.5, o_idx, crf_tr=tr))
+
+
 # ---------------------------------------------------------------- decomposed independent=1 (a15)
 def _ind1_configs():
     with open(os.path.join(GOLDEN, 'decomp_ind1_small.json')) as f:

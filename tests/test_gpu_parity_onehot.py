@@ -573,3 +573,14 @@ def test_compact_only_handle_from_the_edge_list_and_its_limits():
     h = _lib.create_onehot_ifst(T, W, O, sta2, fin2, semiring='max')
     assert not h.has_compact()
     h.close()
+
+
+def test_fused_handoff_burst():
+    """Short form of tests/soak_fused_handoff.py: bursts of unsynchronised launches of the fused chain + decode kernel on two
+    streams, alternating batches, every tag of every launch against the C oracle (stale stash lines of an earlier launch
+    at the same address would show).  The long form ran 400 rounds x 48 launches clean."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('soak_fused_handoff', os.path.join(os.path.dirname(__file__), 'soak_fused_handoff.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(rounds=int(os.environ.get('FARNN_SOAK_ROUNDS', '6')), verbose=True) == 0
