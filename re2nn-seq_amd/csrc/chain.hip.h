@@ -165,13 +165,14 @@ struct ChainKernelArgs {      // ONE kernel argument, so that the epilogue can a
 };
 
 static_assert(sizeof(ScoreParams) % 4 == 0, "ScoreParams is copied word by word");
+template <class KARGS>
 __device__ __forceinline__ ScoreParams load_epilogue_params() {
     union { ScoreParams sp; unsigned w[sizeof(ScoreParams) / 4]; } u;
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef __attribute__((address_space(4))) const char kchar_t;
     typedef __attribute__((address_space(4))) const unsigned kword_t;
     kchar_t *ka = (kchar_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    kword_t *src = (kword_t *)(ka + offsetof(ChainKernelArgs, sp));
+    kword_t *src = (kword_t *)(ka + offsetof(KARGS, sp));
     asm volatile("" : "+s"(src));                    // the scalar loads below cannot move above this point
 #pragma unroll
     for (unsigned i = 0; i < sizeof(ScoreParams) / 4; i++) u.w[i] = src[i];
@@ -541,25 +542,19 @@ chain_kernel(const ChainKernelArgs args) {
             }
             arrive_s = __hip_atomic_fetch_add(p.pair_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // while the add is under way: the transposed output matrix streams into the (now idle) DMA ring.  Only for
-        // sequences of two or more tiles, whose both workgroups are likely to score; shorter ones stage it once they
-        // know they arrived second.  A workgroup that leaves without scoring drains its pieces first.
-        const ScoreParams sp = load_epilogue_params();
-        float *esm = reinterpret_cast<float *>(ring);                // ab tile + output matrix
+        const ScoreParams sp = load_epilogue_params<ChainKernelArgs>();
+        float *esm = reinterpret_cast<float *>(ring);                // products tile + score tile
         const int ntv = (nsteps + SCORE_TT - 1) / SCORE_TT;          // tiles that hold computed tokens
-        const bool prestaged = ntv >= 2 && !(p.dbg & (16 | 128 | 1024));
-        if (prestaged) score_stage_ot(sp.OT, score_ot_lds(esm, SP, sp.Kc, sp.P != nullptr), S, sp.Kc, w, lane);
         const long long foff_pre = (p.flat_in_kernel && !(p.dbg & 2048)) ? (long long)*foff_lds : -1;
         __syncthreads();                                             // the adding wave joins; nobody loads before it
         const int arrived = arrive_s;
         if (p.dbg & 128) return;                                     // ablation: no epilogue (wrong results)
-        bool staged = prestaged;                                     // the output matrix is (being) staged already
         auto run_tiles = [&](int first) {                            // tiles first, first + 2, ... of this sequence
             switch (sp.kch) {
-                case 1: score_tiles<true, 1, true>(sp, b, first, 2, esm, tid, foff_pre, staged); break;
-                case 2: score_tiles<true, 2, true>(sp, b, first, 2, esm, tid, foff_pre, staged); break;
-                case 3: score_tiles<true, 3, true>(sp, b, first, 2, esm, tid, foff_pre, staged); break;
-                default: score_tiles<true, 4, true>(sp, b, first, 2, esm, tid, foff_pre, staged); break;
+                case 1: score_tiles<1, true>(sp, b, first, 2, esm, tid, foff_pre); break;
+                case 2: score_tiles<2, true>(sp, b, first, 2, esm, tid, foff_pre); break;
+                case 3: score_tiles<3, true>(sp, b, first, 2, esm, tid, foff_pre); break;
+                default: score_tiles<4, true>(sp, b, first, 2, esm, tid, foff_pre); break;
             }
         };
         auto acquire = [&]() {
@@ -576,9 +571,8 @@ chain_kernel(const ChainKernelArgs args) {
         // resident longer than the bound, so the launch cannot deadlock; the claim (an exchange of the launch's epoch)
         // makes every tile scored exactly once.
         __shared__ int claim_s;
-        auto leave = [&]() { if (prestaged) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };   // no DMA into freed LDS
         if (!(arrived & 1)) {                                        // first of the two directions
-            if (ntv < 2 || p.spin <= 0) { leave(); return; }
+            if (ntv < 2 || p.spin <= 0) return;
             if (tid == 0) {
                 int seen = 0;
                 for (int it = 0; it < p.spin && !seen; it++) {
@@ -590,13 +584,12 @@ chain_kernel(const ChainKernelArgs args) {
                 claim_s = won;
             }
             __syncthreads();                                         // the polling wave joins; loads only behind it
-            if (!claim_s) { leave(); return; }
+            if (!claim_s) return;
         }
         acquire();
         // one call site for the tile code (four label-width variants of a large unrolled body)
         for (int first = (arrived & 1) ? 0 : 1;; first = 1) {
             run_tiles(first);
-            staged = true;                                           // (score_tiles waited for it; it stays in LDS)
             if (first == 1) break;
             if (ntv >= 2) {                                          // the odd tiles: still unclaimed?
                 __syncthreads();

@@ -61,12 +61,18 @@ __device__ __forceinline__ float dg_nl(float x, int nl) {
 
 // NCH2 / NCH3: 32-column chunks of the two input vectors (h: S columns; [rr | h]: Rp + S columns); NP3: passes of P3;
 // CS: leading chunks of [rr | h] that hold rr entries (they can only be read behind the step's first barrier)
+// (Tried in r02 and dropped: both chains of a sequence in one eight-wavefront workgroup with the scores + decode as its
+// epilogue -- one launch per step, but the two chains in step through shared barriers ran 63.5 us against 56.9, and the
+// two score tiles of the longest sequence, serial on one CU behind it, cost more than the separate launch: 76.5 us per
+// step against 69.1.)
 template <int NCH2, int NCH3, int NP3, int CS>
 __global__ void __launch_bounds__(DG_THREADS, 2)
 decomp_regs_kernel(const DecompRegsParams p) {
     extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int item = blockIdx.x, dir = item & 1;
+    const int wtid = threadIdx.x;
+    const int tid = wtid, lane = tid & 63;
+    const int dir = (int)blockIdx.x & 1;
+    const int seq = (int)blockIdx.x >> 1;
     const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp;
     constexpr int c2p = NCH2 * DR_CHUNK, c3p = NCH3 * DR_CHUNK;
     const int Lr = (p.L + 3) & ~3;
@@ -77,8 +83,8 @@ decomp_regs_kernel(const DecompRegsParams p) {
     int *tok = reinterpret_cast<int *>(X3 + 2 * c3p);         // [Lr]
     int *scratch = tok + Lr;                                  // select_by_length_rank: L + 17 ints
 
-    int b = p.order ? p.order[item >> 1] : (item >> 1);
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(item >> 1, p.B), scratch, tid, DG_THREADS);
+    int b = p.order ? p.order[seq] : seq;
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(seq, p.B), scratch, tid, DG_THREADS);
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
 
@@ -211,7 +217,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
         if (p.dbg & 4096) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[3] += c1 - c0; }
     }
     if ((p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)
-        printf("regs kernel wg %d wave %d: %d steps, cycles per step: A %lld  barrier %lld  B %lld  barrier %lld\n", (int)blockIdx.x, tid >> 6,
+        printf("regs kernel wg %d wave %d: %d steps, cycles per step: A %lld  barrier %lld  B %lld  barrier %lld\n", (int)blockIdx.x, wtid >> 6,
                nsteps, cyc[0] / nsteps, cyc[1] / nsteps, cyc[2] / nsteps, cyc[3] / nsteps);
 }
 

@@ -55,6 +55,7 @@ struct farnn_model {
     float *Oten = nullptr;                  // ind1: [C][S][SP]
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
+    float *OTm = nullptr; int c16 = 0;       // matrix-core image of OT for score_tiles (ot_to_mfma_kernel)
     DecompWeights dw;                       // decomposed model weights
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
@@ -198,6 +199,17 @@ static int setup_crf(farnn_model *m, const float *crf_trans, int on_device) {
 }
 
 // ---- compact form of a 0/1 automaton (compact.hip.h): bit-packed blocks beside (or instead of) the dense ones ----------
+// the matrix-core image of the transposed output matrix (call once m->OT is final)
+static int build_ot_image(farnn_model *m) {
+    int rc;
+    m->c16 = (m->S + 15) / 16;
+    const long long n = (long long)(m->Kc / 16) * m->c16 * 256;
+    if ((rc = dev_alloc(m, (void **)&m->OTm, (size_t)n * 4))) return rc;
+    ot_to_mfma_kernel<<<(unsigned)((n + 255) / 256), 256>>>(m->OT, m->OTm, m->S, m->Kc, m->c16);
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
 static int alloc_bitmaps(farnn_model *m) {
     m->bmNS = (m->semiring == FARNN_SEMIRING_SUM) ? compact_ns(m->S) : 0;
     if (!m->bmNS) return FARNN_OK;
@@ -296,6 +308,7 @@ static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_m
         int n = m->C * m->S;
         transpose_pad_kernel<<<(n + 255) / 256, 256>>>(O.p, m->OT, m->C, m->S, m->Kc);
         FARNN_HIP_TRY(hipGetLastError());
+        if ((rc = build_ot_image(m))) return bail(rc);
         FARNN_HIP_TRY(hipDeviceSynchronize());
     }
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
@@ -492,7 +505,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     // sequence's score tile + output matrix inside the (then idle) DMA ring, and the arrival counters
     const bool six_wave_fast = block.x <= 384 && g.NCH == 1 && p.PPS == 1 && g.NQ > 3;   // keeps its own fast path
     const bool do_fuse = fuse_sp && m->pair_cnt && g.NCH == 1 && g.NW + g.NLD + 1 <= SCORE_WAVES && !six_wave_fast &&
-                         score_lds_bytes(m->S, m->SP, m->Kc, m->P ? 1 : 0, 1) <= (size_t)ks * g.phase_bytes(nqp) &&
+                         score_lds_bytes(m->S, m->Kc) <= (size_t)ks * g.phase_bytes(nqp) &&
                          !env_int("FARNN_NOFUSE", 0);
     if (do_fuse) {
         sp = *fuse_sp;
@@ -784,7 +797,7 @@ static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, 
                                      int64_t *flat, float *scores) {
     ScoreParams p;
     memset(&p, 0, sizeof(p));
-    p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.P = m->P; p.trT = m->tr; p.len = len;
+    p.A = m->A; p.Bk = m->Bk; p.OT = m->OT; p.OTm = m->OTm; p.c16 = m->c16; p.P = m->P; p.trT = m->tr; p.len = len;
     p.offs = (flat && !m->prep_in_kernel) ? m->offs : nullptr; p.tags = tags; p.flat = flat; p.scores = scores;
     p.crf_scores = m->crf_scores;
     p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
@@ -806,28 +819,21 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
         KernelTimer kt(m, KERN_SCORE, s);
         return launch_viterbi(m, p, B, s, true);
     }
-    const int hasP = m->P ? 1 : 0;
-    const int ot = score_lds_bytes(m->S, m->SP, m->Kc, hasP, 1) <= 150 * 1024 ? 1 : 0;
-    const size_t lds = score_lds_bytes(m->S, m->SP, m->Kc, hasP, ot);
+    const size_t lds = score_lds_bytes(m->S, m->Kc);
     const dim3 grid((p.L + SCORE_TT - 1) / SCORE_TT, B), block(SCORE_WAVES * 64);
     int rc;
     KernelTimer kt(m, KERN_SCORE, s);
-#define FARNN_LAUNCH_SCORE(OT_, KCH_)                                                         \
+#define FARNN_LAUNCH_SCORE(KCH_)                                                              \
     do {                                                                                      \
-        if ((rc = raise_lds_limit(score_tile_kernel<OT_, KCH_>, lds))) return rc;             \
-        score_tile_kernel<OT_, KCH_><<<grid, block, lds, s>>>(p);                             \
+        if ((rc = raise_lds_limit(score_tile_kernel<KCH_>, lds))) return rc;                  \
+        score_tile_kernel<KCH_><<<grid, block, lds, s>>>(p);                                  \
     } while (0)
-#define FARNN_LAUNCH_SCORE_K(OT_)                                                             \
-    do {                                                                                      \
-        switch (p.kch) {                                                                      \
-            case 1: FARNN_LAUNCH_SCORE(OT_, 1); break;                                        \
-            case 2: FARNN_LAUNCH_SCORE(OT_, 2); break;                                        \
-            case 3: FARNN_LAUNCH_SCORE(OT_, 3); break;                                        \
-            default: FARNN_LAUNCH_SCORE(OT_, 4); break;                                       \
-        }                                                                                     \
-    } while (0)
-    if (ot) FARNN_LAUNCH_SCORE_K(true); else FARNN_LAUNCH_SCORE_K(false);
-#undef FARNN_LAUNCH_SCORE_K
+    switch (p.kch) {
+        case 1: FARNN_LAUNCH_SCORE(1); break;
+        case 2: FARNN_LAUNCH_SCORE(2); break;
+        case 3: FARNN_LAUNCH_SCORE(3); break;
+        default: FARNN_LAUNCH_SCORE(4); break;
+    }
 #undef FARNN_LAUNCH_SCORE
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf && (rc = launch_viterbi(m, p, B, s))) return rc;
@@ -1307,6 +1313,7 @@ static int decomp_ifst_create_impl(const farnn_decomp_ifst_desc *d, int device, 
         int n = m->K * m->S;
         transpose_pad_kernel<<<(n + 255) / 256, 256>>>(Co.p, m->OT, m->K, m->S, m->Kc);
         FARNN_HIP_TRY(hipGetLastError());
+        if ((rc = build_ot_image(m))) return bail(rc);
         FARNN_HIP_TRY(hipDeviceSynchronize());
         w.o = m->o;
     }

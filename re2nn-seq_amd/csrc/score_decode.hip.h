@@ -33,6 +33,8 @@ struct ScoreParams {
     int64_t *flat;          // [sum len] or nullptr
     float *scores;          // [B][L][K] or nullptr (unclamped, what forward_score returns)
     float *crf_scores;      // [B][L][Kp] workspace: clamped scores for the Viterbi kernel
+    const float *OTm;       // matrix-core image of OT (ot_to_mfma_kernel), c16 = ceil(S/16) state groups
+    int c16;
     int B, L, S, SP, K, Kp, Kc, kch;
     int full, use_crf, o_idx;
     float threshold;
@@ -43,56 +45,45 @@ constexpr int SCORE_KCH = 4;       // label columns per lane: K <= 256
 constexpr int SCORE_WAVES = 8;
 constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 
-// KCH = label columns per lane (K <= 64*KCH): compile-time so that the register-blocked loops are
-// fully unrolled with no per-column guards (with a runtime bound hipcc emitted one scalar branch
-// per column and the GEMM loop ran 3x slower).
+// KCH = label columns per lane in the decode (K <= 64*KCH), compile-time.
 //
 // score_tiles: the tiles tile_first, tile_first + tile_step, ... (32 tokens each) of sequence b, by the 8 wavefronts
-// of the calling workgroup (every thread calls it; `smem` = 16-byte aligned LDS of score_lds_bytes()).  The output
-// matrix is staged once for all the tiles.  SC1: the stash is read with agent-scope (sc1) loads -- the form the
-// fused epilogue of chain_kernel needs, where another workgroup of the same launch wrote half of it.
-// where score_tiles keeps the transposed output matrix inside `smem`
-__device__ __forceinline__ float *score_ot_lds(float *smem, int SP, int Kc, bool has_P) {
-    return smem + SCORE_TT * SP + (has_P ? SCORE_WAVES * Kc : 0);
-}
+// of the calling workgroup (every thread calls it; `smem` = 16-byte aligned LDS of score_lds_bytes()).  SC1: the stash
+// is read with agent-scope (sc1) loads -- the form a fused epilogue needs, where another workgroup of the same launch
+// wrote (part of) it.
+//
+// Per tile: (1) ab[tok][s] = alpha * beta products from the two stashes into LDS; (2) scores[32][Kc] = ab . O^T on the
+// f32 matrix cores: v_mfma_f32_16x16x4_f32 accumulates its four products in k order, i.e. the same ascending-s fmaf
+// chain the r01 VALU loop ran (bit-identical, MI355X_MICROARCH.md / tests) -- every wavefront owns KCH of the 2 x Kc/16
+// output blocks, its A fragments come from the LDS tile, its B fragments straight from the matrix-core image of the
+// output matrix in L2 (OTm: one 16-byte load per lane covers four k-steps; nothing is staged, r01/r02a moved the whole
+// 54 KB matrix into every workgroup's LDS), the accumulators go to an LDS score tile; (3) per token one wavefront reads
+// its row, applies the priority matrix / threshold clamp and finds the first maximum with a ballot per 64 columns.
+// Measured (FARNN_DBG=16384, one tile of the config-1 / config-2 batches, cycles): r02a VALU GEMM 5.8 k / 7.8 k and the
+// keyed-DPP decode 5.4 k; now ...
 
-// LDS-DMA of the transposed output matrix into its place (1 KiB pieces, round-robin over the eight wavefronts); the
-// issuing wavefront's next `s_waitcnt vmcnt(0)` covers its pieces, a workgroup barrier behind that everybody's
-__device__ __forceinline__ void score_stage_ot(const float *OT, float *otl, int S, int Kc, int w, int lane) {
-    const unsigned ot_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)otl);
-    const int pieces = (S * Kc * 4 + 1023) / 1024;
-    const char *obase = reinterpret_cast<const char *>(OT);
-    for (int k = w; k < pieces; k += SCORE_WAVES)
-        lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, obase, ot_lds + (unsigned)k * 1024u);
-}
-
-// foff_pre >= 0: the sequence's offset in the flat output is already known; ot_prestaged: the caller issued
-// score_stage_ot() itself (from these same wavefronts) -- both let the fused epilogue overlap them with its hand-off
-template <bool OT_LDS, int KCH, bool SC1>
+// foff_pre >= 0: the sequence's offset in the flat output is already known (the fused epilogue of chain_kernel computes
+// it during its hand-off)
+template <int KCH, bool SC1>
 __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, const int tile_first, const int tile_step,
-                                            float *smem, const int tid, const long long foff_pre = -1,
-                                            const bool ot_prestaged = false) {
+                                            float *smem, const int tid, const long long foff_pre = -1) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = SCORE_WAVES * 64;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, K = p.K, Kc = p.Kc;
+    const int SP = p.SP, K = p.K, Kc = p.Kc;
     const int ntiles = (p.L + SCORE_TT - 1) / SCORE_TT;
 
     // ---- LDS carve ---------------------------------------------------------------------------
-    float *ab = smem;                                    // [TT][SP]  alpha*beta of the tile
-    float *cur = ab + SCORE_TT * SP;
-    float *scw = nullptr;                                // [waves][Kc] one score row per wave (P)
-    if (p.P) { scw = cur; cur += SCORE_WAVES * Kc; }
-    float *otl = cur;                                    // [S][Kc] rounded up to whole DMA pieces
-    bool dma_pending = ot_prestaged;
-    if (OT_LDS && !ot_prestaged && !(p.dbg & 16) && tile_first * SCORE_TT < nsteps) {
-        score_stage_ot(p.OT, otl, S, Kc, w, lane);       // lands while phase 1 runs
-        dma_pending = true;
-    }
+    const int c16 = p.c16;                               // 16-state groups of the output matrix image
+    const int SPa = 16 * c16 + 4;                        // row stride of the products tile: whole groups (zero beyond SP), and
+                                                         // SPa/4 odd -- the 64 lanes of an A-fragment read hit 64 banks
+    float *ab = smem;                                    // [TT][SPa] alpha*beta of the tile
+    float *scl = ab + SCORE_TT * SPa;                    // [TT][Kc]  scores of the tile
+    float *scw = scl + SCORE_TT * Kc;                    // [waves][Kc] one score row per wave (P)
     // no prepared offsets: where this sequence starts in the flat output = sum of the lengths before it
-    // (utils.py:153-164); B <= 1024 here, two loads per thread, hidden behind the DMA
+    // (utils.py:153-164); B <= 1024 here, two loads per thread
     __shared__ int foff_w[SCORE_WAVES];
     long long foff = foff_pre >= 0 ? foff_pre : (p.offs ? p.offs[b] : 0);
     if (foff_pre < 0 && !p.offs && p.flat) {
@@ -115,6 +106,9 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
     const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
     const int SP4 = SP >> 2;
     const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
+    const int lr = lane & 15, lk = lane >> 4;            // MFMA fragment coordinates
+    const bool probe = (p.dbg & 16384) && nsteps == p.L && tid == 0;     // diagnostic: cycles of the phases
+    long long q0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (int tile = tile_first; tile < ntiles; tile += tile_step) {
         const int t0 = tile * SCORE_TT;
         const int nt = min(SCORE_TT, nsteps - t0);           // tokens of this tile that were computed
@@ -127,18 +121,34 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
             }
             continue;
         }
+        // B fragments of this wavefront's output blocks (block q: id = w*KCH + q; column block id >> 1, token half id & 1):
+        // a stream of 16-byte loads kept four groups ahead of the matrix cores; the first four fly while the
+        // products are formed.  All loops here are ROLLED: a tile runs this code once, and with the loops unrolled
+        // (r02a: 27-32 KB of straight-line code per tile) the tile's time was instruction fetch, not arithmetic.
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const f32x4 *otm = reinterpret_cast<const f32x4 *>(p.OTm) + lane;
+        const int c16p = (c16 + 3) & ~3;                     // the stream carries whole fours of groups per block (re-reads)
+        int lq = 0, lg = 0;                                  // load cursor: block, group
+        auto next_b = [&]() {
+            const int blk = w * KCH + (lq < KCH ? lq : KCH - 1);
+            const f32x4 v = otm[((long long)(blk >> 1) * c16 + (lg < c16 ? lg : c16 - 1)) * 64];
+            if (++lg == c16p) { lg = 0; lq++; }
+            return v;
+        };
+        f32x4 b0 = next_b(), b1 = next_b(), b2 = next_b(), b3 = next_b();
         // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
         // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
-        for (int idx0 = 0; idx0 < SCORE_TT * SP4; idx0 += 2 * nthreads) {
+        const int G4 = 4 * c16;                               // float4 columns of a tile row (those past SP stay zero)
+        for (int idx0 = 0; idx0 < SCORE_TT * G4; idx0 += 2 * nthreads) {
             float4 a4[2], b4[2];
             int tokv[2], s4v[2];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int idx = idx0 + r * nthreads + tid;
-                const int tok = idx / SP4;
-                tokv[r] = tok; s4v[r] = (idx - tok * SP4) * 4;
+                const int tok = idx / G4;
+                tokv[r] = tok; s4v[r] = (idx - tok * G4) * 4;
                 a4[r] = make_float4(0.f, 0.f, 0.f, 0.f); b4[r] = a4[r];
-                if (tok < nt) {
+                if (tok < nt && s4v[r] < SP) {
                     const int i = t0 + tok;
                     const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
                     if (SC1) {
@@ -153,60 +163,61 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 if (tokv[r] < SCORE_TT)
-                    st4(ab + tokv[r] * SP + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
-                                                                 a4[r].z * b4[r].z, a4[r].w * b4[r].w));
+                    st4(ab + tokv[r] * SPa + s4v[r], make_float4(a4[r].x * b4[r].x, a4[r].y * b4[r].y,
+                                                                  a4[r].z * b4[r].z, a4[r].w * b4[r].w));
         }
-        if (dma_pending) {                                   // this wavefront's DMA pieces landed
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            dma_pending = false;
-        }
+        long long q1 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
         __syncthreads();
+        long long q2 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
 
-        // ---- phase 2: 4 tokens per wavefront, register-blocked against the output matrix ----------
-        const int tg = w * 4;
-        float acc[4][KCH];
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-#pragma unroll
-            for (int k = 0; k < KCH; k++) acc[j][k] = 0.0f;
-        if (tg < nt && !(p.dbg & 32)) {
-            const float *abw = ab + tg * SP;
-            const float *otb = (OT_LDS ? otl : p.OT) + lane;
-            for (int s0 = 0; s0 < S; s0 += 4) {
-                float av[4][4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const float4 a4 = ld4(abw + j * SP + s0);              // LDS broadcast
-                    av[j][0] = a4.x; av[j][1] = a4.y; av[j][2] = a4.z; av[j][3] = a4.w;
+        // ---- phase 2: the wavefront's KCH output blocks on the matrix cores -----------------------------------------
+        if (!(p.dbg & 32)) {
+#pragma unroll 1
+            for (int q = 0; q < KCH; q++) {
+                const int blk = w * KCH + q;
+                const float *arow = ab + ((blk & 1) * 16 + lr) * SPa + lk;     // this lane's k of k-step 4g + e: 16g + 4e + lk
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                auto a_group = [&](int g, float (&a)[4]) {                     // A fragments of group g (clamped: unused past c16)
+                    const float *ap = arow + 16 * (g < c16 ? g : c16 - 1);
+                    a[0] = ap[0]; a[1] = ap[4]; a[2] = ap[8]; a[3] = ap[12];
+                };
+                auto mfma4 = [&](const float (&a)[4], const f32x4 &bb) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bb.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bb.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bb.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bb.w, acc, 0, 0, 0);
+                };
+                float ae[4], ao[4];                           // even / odd groups
+                a_group(0, ae);
+#pragma unroll 1
+                for (int g = 0; g < c16; g += 4) {            // slot = group % 4: a register is reloaded right after its use;
+                    a_group(g + 1, ao);                       // the next group's A fragments are read under this group's MFMAs
+                    mfma4(ae, b0); b0 = next_b();
+#define FARNN_SCORE_GROUP(K_, ACUR, ANEXT, BREG)                                                        \
+                    a_group(g + K_ + 1, ANEXT);                                                          \
+                    if (g + K_ < c16) mfma4(ACUR, BREG);                                                 \
+                    BREG = next_b();
+                    FARNN_SCORE_GROUP(1, ao, ae, b1) FARNN_SCORE_GROUP(2, ae, ao, b2) FARNN_SCORE_GROUP(3, ao, ae, b3)
+#undef FARNN_SCORE_GROUP
                 }
-                float ov[4][KCH];
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int srow = (s0 + u < S) ? s0 + u : S - 1;        // ab pad columns are zero
-#pragma unroll
-                    for (int k = 0; k < KCH; k++)
-                        ov[u][k] = otb[(long long)srow * Kc + 64 * k];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-#pragma unroll
-                    for (int k = 0; k < KCH; k++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) acc[j][k] = fmaf(av[j][u], ov[u][k], acc[j][k]);
+                // block done: rows lk*4 + r of the token half, column lr
+                float *dst = scl + ((blk & 1) * 16 + lk * 4) * Kc + (blk >> 1) * 16 + lr;
+                dst[0] = acc.x; dst[Kc] = acc.y; dst[2 * Kc] = acc.z; dst[3 * Kc] = acc.w;
             }
         }
-#pragma unroll
+        __syncthreads();
+        long long q3 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        // ---- phase 3: 4 tokens per wavefront: priority, outputs, clamp, decode ------------------------------------------
+        const int tg = w * 4;
+#pragma unroll 1
         for (int j = 0; j < 4; j++) {
             const int i = t0 + tg + j;
             if (tg + j < nt) {
                 float sc[KCH];
 #pragma unroll
-                for (int k = 0; k < KCH; k++) sc[k] = acc[j][k];
+                for (int k = 0; k < KCH; k++) sc[k] = scl[(tg + j) * Kc + lane + 64 * k];
                 if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
-                    float *sr = scw + w * Kc;
-#pragma unroll
-                    for (int k = 0; k < KCH; k++) sr[lane + 64 * k] = sc[k];
-                    __builtin_amdgcn_wave_barrier();
+                    const float *sr = scl + (tg + j) * Kc;
 #pragma unroll
                     for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
                     for (int cc = 0; cc < K; cc++) {
@@ -216,7 +227,6 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
                         for (int k = 0; k < KCH; k++)
                             sc[k] = fmaf(sv, prow[64 * k], sc[k]);
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
                 if (p.scores) {
                     float *so = p.scores + ((long long)b * p.L + i) * K;
@@ -226,22 +236,20 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
                         if (col < K) so[col] = sc[k];
                     }
                 }
-                // threshold clamp of the `oo` column, then decode
-                float bv = -INFINITY; int bi = 0x7ffffffe;
+                // threshold clamp of the `oo` column, then decode: column k*64 + lane is candidate row k of
+                // wave_first_argmax (first index of the maximum, torch.max's rule; an all-NaN row gives 0 like torch)
+                float cand[KCH];
 #pragma unroll
                 for (int k = 0; k < KCH; k++) {
                     const int col = lane + 64 * k;
-                    if (col < K) {
-                        float v = sc[k] + 0.0f;                      // -0.0 -> +0.0 (torch: -0 == +0)
-                        if (col == clamp_col) v = fminf(v, p.threshold);
-                        if (p.use_crf) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
-                        if (v > bv) { bv = v; bi = col; }
-                    }
+                    float v = sc[k] + 0.0f;                          // -0.0 -> +0.0 (torch: -0 == +0)
+                    if (col == clamp_col) v = fminf(v, p.threshold);
+                    if (p.use_crf && col < K) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
+                    cand[k] = col < K ? v : -INFINITY;
                 }
                 if (!p.use_crf) {
-                    if (!(p.dbg & 64)) bi = wave_argmax_dpp(bv, bi);
+                    const int bi = (p.dbg & 64) ? 0 : wave_first_argmax<KCH>(cand);
                     if (lane == 0) {
-                        if (bi >= K) bi = 0;                        // all-NaN row: torch returns 0
                         const int tag = (bi == K - 1) ? p.o_idx : bi;
                         if (p.tags) p.tags[(long long)b * p.L + i] = tag;
                         if (p.flat && i < len) p.flat[foff + i] = tag;
@@ -253,23 +261,40 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
                     for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
             }
         }
-        if (tile + tile_step < ntiles) __syncthreads();      // the next tile overwrites ab
+        if (probe) {
+            const long long q4 = (long long)__builtin_amdgcn_s_memtime();
+            printf("score tile %d of sequence %d: offsets+products %lld cycles, barrier %lld, GEMM %lld, decode %lld\n",
+                   tile, b, q1 - q0, q2 - q1, q3 - q2, q4 - q3);
+        }
+        if (tile + tile_step < ntiles) __syncthreads();      // the next tile overwrites ab and the score tile
+        if (probe) q0 = (long long)__builtin_amdgcn_s_memtime();
     }
-    if (dma_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // never leave DMA in flight into freed LDS
+    (void)scw;
 }
 
-template <bool OT_LDS, int KCH>
+template <int KCH>
 __global__ void __launch_bounds__(SCORE_WAVES * 64)
 score_tile_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
-    score_tiles<OT_LDS, KCH, false>(p, blockIdx.y, blockIdx.x, gridDim.x, smem, threadIdx.x);
+    score_tiles<KCH, false>(p, blockIdx.y, blockIdx.x, gridDim.x, smem, threadIdx.x);
 }
 
-inline size_t score_lds_bytes(int S, int SP, int Kc, int has_P, int ot_in_lds) {
-    size_t bytes = (size_t)SCORE_TT * SP * 4;
-    if (has_P) bytes += (size_t)SCORE_WAVES * Kc * 4;
-    if (ot_in_lds) bytes += ((size_t)S * Kc * 4 + 1023) / 1024 * 1024;
-    return bytes;
+inline size_t score_lds_bytes(int S, int Kc) {         // products tile (row stride 16*ceil(S/16) + 4) + score tile
+    return (size_t)SCORE_TT * (16 * ((S + 15) / 16) + 4) * 4 + (size_t)SCORE_TT * Kc * 4;
+}
+
+// Matrix-core image of the transposed output matrix OT[S][Kc]: OTm[Kc/16][c16][64 lanes][4], c16 = ceil(S/16): lane
+// (lr = lane % 16, lk = lane / 16) of column block cb holds, for the four k-steps 4g + e of state group g, the entries
+// OT[16g + 4e + lk][16cb + lr] (zero beyond S) -- the B operand of v_mfma_f32_16x16x4_f32, one 16-byte load per group.
+__global__ void ot_to_mfma_kernel(const float *OT, float *OTm, int S, int Kc, int c16) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long n = (long long)(Kc / 16) * c16 * 256;
+    if (i >= n) return;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+    const long long gi = i >> 8;
+    const int g = (int)(gi % c16), cb = (int)(gi / c16);
+    const int s = 16 * g + 4 * e + (lane >> 4);
+    OTm[i] = s < S ? OT[(long long)s * Kc + cb * 16 + (lane & 15)] : 0.0f;
 }
 
 // ---- Viterbi (crf.py:102-195) over the valid positions, one workgroup per sequence ------------
