@@ -183,8 +183,8 @@ __device__ __forceinline__ ScoreParams load_epilogue_params() {
 }
 
 template <int NCH, bool MAXSR, int FQ, bool FUSED>
-__global__ void __launch_bounds__(FQ > 3 ? 384 : CHAIN_MAX_THREADS)
-chain_kernel(const ChainKernelArgs args) {
+__global__ void __launch_bounds__(FQ > 3 ? 384 : CHAIN_MAX_THREADS, FUSED ? 4 : 1)   // fused (4 waves per SIMD = 128 VGPRs): the epilogue must not cost the
+chain_kernel(const ChainKernelArgs args) {                                           // second workgroup of a CU its registers
     const ChainParams &p = args.p;
     constexpr int PER = 4 * NCH;                 // DMA pieces (1 KiB each) per 4-row chunk
     extern __shared__ __align__(16) float smem[];

@@ -54,14 +54,15 @@ constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 //
 // Per tile: (1) ab[tok][s] = alpha * beta products from the two stashes into LDS; (2) scores[32][Kc] = ab . O^T on the
 // f32 matrix cores: v_mfma_f32_16x16x4_f32 accumulates its four products in k order, i.e. the same ascending-s fmaf
-// chain the r01 VALU loop ran (bit-identical, MI355X_MICROARCH.md / tests) -- every wavefront owns KCH of the 2 x Kc/16
-// output blocks, its A fragments come from the LDS tile, its B fragments straight from the matrix-core image of the
-// output matrix in L2 (OTm: one 16-byte load per lane covers four k-steps; nothing is staged, r01/r02a moved the whole
-// 54 KB matrix into every workgroup's LDS), the accumulators go to an LDS score tile; (3) per token one wavefront reads
-// its row, applies the priority matrix / threshold clamp and finds the first maximum with a ballot per 64 columns.
-// Measured (FARNN_DBG=16384, one tile of the config-1 / config-2 batches, cycles): r02a VALU GEMM 5.8 k / 7.8 k and the
-// keyed-DPP decode 5.4 k; now ...
-
+// chain the r01 VALU loop ran (MI355X_MICROARCH.md: bitwise the fmaf chain) -- a wavefront owns one token half and KCH
+// of the Kc/16 column blocks, its A fragments come from the LDS tile (shared by its blocks), its B fragments straight
+// from the matrix-core image of the output matrix in L2 (OTm: one 16-byte load per lane covers four k-steps; nothing is
+// staged -- r01/r02a moved the whole 54 KB matrix into every workgroup's LDS), the accumulators go to an LDS score tile;
+// (3) 16 lanes per token: priority matrix / threshold clamp / first index of the row maximum.
+// The f32 matrix cores run at the f32 VALU rate (256 flop/clk/CU): the gain over the VALU loop is the LDS operand
+// traffic and the issue slots, not the arithmetic.  Measured (FARNN_DBG=16384, one tile of the config-1 batch, two
+// workgroups per CU, cycles): r02a products 1.8 k, DMA wait 0.7 k, VALU GEMM 5.8 k, keyed-DPP decode 5.4 k; now products
+// 2.3 k, barrier 1.0 k, GEMM 4.3 k, decode 1.7 k.  score_tile_kernel for the config-1 batch: 14.4 -> 10.6 us.
 // foff_pre >= 0: the sequence's offset in the flat output is already known (the fused epilogue of chain_kernel computes
 // it during its hand-off)
 template <int KCH, bool SC1>
@@ -81,7 +82,6 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
                                                          // SPa/4 odd -- the 64 lanes of an A-fragment read hit 64 banks
     float *ab = smem;                                    // [TT][SPa] alpha*beta of the tile
     float *scl = ab + SCORE_TT * SPa;                    // [TT][Kc]  scores of the tile
-    float *scw = scl + SCORE_TT * Kc;                    // [waves][Kc] one score row per wave (P)
     // no prepared offsets: where this sequence starts in the flat output = sum of the lengths before it
     // (utils.py:153-164); B <= 1024 here, two loads per thread
     __shared__ int foff_w[SCORE_WAVES];
@@ -121,21 +121,20 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
             }
             continue;
         }
-        // B fragments of this wavefront's output blocks (block q: id = w*KCH + q; column block id >> 1, token half id & 1):
-        // a stream of 16-byte loads kept four groups ahead of the matrix cores; the first four fly while the
-        // products are formed.  All loops here are ROLLED: a tile runs this code once, and with the loops unrolled
-        // (r02a: 27-32 KB of straight-line code per tile) the tile's time was instruction fetch, not arithmetic.
+        // This wavefront's output blocks: token half w & 1, column blocks (w >> 1) * KCH + q -- KCH blocks that share their A
+        // fragments (one LDS read serves KCH matrix-core instructions) and accumulate independently (consecutive MFMAs never
+        // wait for each other).  B fragments: KCH 16-byte loads per state group, kept two groups ahead of the matrix cores;
+        // the first two groups fly while the products are formed.  All loops here are ROLLED: a tile runs this code once,
+        // and with the loops unrolled (r02a: 27-32 KB of straight-line code per tile) instruction fetch was a visible cost.
         typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const f32x4 *otm = reinterpret_cast<const f32x4 *>(p.OTm) + lane;
-        const int c16p = (c16 + 3) & ~3;                     // the stream carries whole fours of groups per block (re-reads)
-        int lq = 0, lg = 0;                                  // load cursor: block, group
-        auto next_b = [&]() {
-            const int blk = w * KCH + (lq < KCH ? lq : KCH - 1);
-            const f32x4 v = otm[((long long)(blk >> 1) * c16 + (lg < c16 ? lg : c16 - 1)) * 64];
-            if (++lg == c16p) { lg = 0; lq++; }
-            return v;
+        const f32x4 *otm = reinterpret_cast<const f32x4 *>(p.OTm) + ((long long)(w >> 1) * KCH * c16) * 64 + lane;
+        auto load_b = [&](int g, f32x4 (&dst)[KCH]) {            // group g (clamped) of the KCH column blocks
+            const int gc = g < c16 ? g : c16 - 1;
+#pragma unroll
+            for (int q = 0; q < KCH; q++) dst[q] = otm[((long long)q * c16 + gc) * 64];
         };
-        f32x4 b0 = next_b(), b1 = next_b(), b2 = next_b(), b3 = next_b();
+        f32x4 be[KCH], bo[KCH];                                  // even / odd groups
+        load_b(0, be); load_b(1, bo);
         // ---- phase 1: ab[tok][s] = a[i+1][s] * b~[i+1][s]; alpha = state after i+1 tokens, beta =
         // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
         const int G4 = 4 * c16;                               // float4 columns of a tile row (those past SP stay zero)
@@ -172,93 +171,135 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
 
         // ---- phase 2: the wavefront's KCH output blocks on the matrix cores -----------------------------------------
         if (!(p.dbg & 32)) {
+            const float *arow = ab + ((w & 1) * 16 + lr) * SPa + lk;           // this lane's k of k-step 4g + e: 16g + 4e + lk
+            f32x4 acc[KCH];
+#pragma unroll
+            for (int q = 0; q < KCH; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            auto a_group = [&](int g, float (&a)[4]) {                         // A fragments of group g (clamped: unused past c16)
+                const float *ap = arow + 16 * (g < c16 ? g : c16 - 1);
+                a[0] = ap[0]; a[1] = ap[4]; a[2] = ap[8]; a[3] = ap[12];
+            };
+            auto mfma_group = [&](const float (&a)[4], const f32x4 (&bb)[KCH]) {
+#pragma unroll
+                for (int q = 0; q < KCH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bb[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < KCH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bb[q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < KCH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bb[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < KCH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bb[q].w, acc[q], 0, 0, 0);
+            };
+            float ae[4], ao[4];
+            a_group(0, ae);
 #pragma unroll 1
+            for (int g = 0; g < c16; g += 2) {                // a register set is reloaded right after its use
+                a_group(g + 1, ao);
+                mfma_group(ae, be);
+                load_b(g + 2, be);
+                a_group(g + 2, ae);
+                if (g + 1 < c16) mfma_group(ao, bo);
+                load_b(g + 3, bo);
+            }
+            // rows lk*4 + r of the token half, column lr of each block
+#pragma unroll
             for (int q = 0; q < KCH; q++) {
-                const int blk = w * KCH + q;
-                const float *arow = ab + ((blk & 1) * 16 + lr) * SPa + lk;     // this lane's k of k-step 4g + e: 16g + 4e + lk
-                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-                auto a_group = [&](int g, float (&a)[4]) {                     // A fragments of group g (clamped: unused past c16)
-                    const float *ap = arow + 16 * (g < c16 ? g : c16 - 1);
-                    a[0] = ap[0]; a[1] = ap[4]; a[2] = ap[8]; a[3] = ap[12];
-                };
-                auto mfma4 = [&](const float (&a)[4], const f32x4 &bb) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bb.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bb.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bb.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bb.w, acc, 0, 0, 0);
-                };
-                float ae[4], ao[4];                           // even / odd groups
-                a_group(0, ae);
-#pragma unroll 1
-                for (int g = 0; g < c16; g += 4) {            // slot = group % 4: a register is reloaded right after its use;
-                    a_group(g + 1, ao);                       // the next group's A fragments are read under this group's MFMAs
-                    mfma4(ae, b0); b0 = next_b();
-#define FARNN_SCORE_GROUP(K_, ACUR, ANEXT, BREG)                                                        \
-                    a_group(g + K_ + 1, ANEXT);                                                          \
-                    if (g + K_ < c16) mfma4(ACUR, BREG);                                                 \
-                    BREG = next_b();
-                    FARNN_SCORE_GROUP(1, ao, ae, b1) FARNN_SCORE_GROUP(2, ae, ao, b2) FARNN_SCORE_GROUP(3, ao, ae, b3)
-#undef FARNN_SCORE_GROUP
-                }
-                // block done: rows lk*4 + r of the token half, column lr
-                float *dst = scl + ((blk & 1) * 16 + lk * 4) * Kc + (blk >> 1) * 16 + lr;
-                dst[0] = acc.x; dst[Kc] = acc.y; dst[2 * Kc] = acc.z; dst[3 * Kc] = acc.w;
+                float *dst = scl + ((w & 1) * 16 + lk * 4) * Kc + ((w >> 1) * KCH + q) * 16 + lr;
+                dst[0] = acc[q].x; dst[Kc] = acc[q].y; dst[2 * Kc] = acc[q].z; dst[3 * Kc] = acc[q].w;
             }
         }
         __syncthreads();
         long long q3 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        // ---- phase 3: 4 tokens per wavefront: priority, outputs, clamp, decode ------------------------------------------
+        // ---- phase 3: the wavefront's 4 tokens AT ONCE: 16 lanes per token, lane c of a token's row holds the columns
+        // 64m + 4c + e (one 16-byte LDS read per m).  Priority, outputs, threshold clamp, then the first index of the row
+        // maximum (torch.max's rule): lane maximum, 4 DPP steps over the 16 lanes, the lane's first column that equals the
+        // row maximum, 4 DPP steps of an unsigned minimum.  (r02a decoded token by token on all 64 lanes: ~100 issued
+        // instructions per token, 3.4 k cycles per tile with the CU's sixteen wavefronts all in this phase.)
         const int tg = w * 4;
+        if (p.P) {              // PriorityLayer: scores @ P (priority.py:20-30), row by row, back into the score tile
 #pragma unroll 1
-        for (int j = 0; j < 4; j++) {
-            const int i = t0 + tg + j;
-            if (tg + j < nt) {
+            for (int j = 0; j < 4; j++) {
+                if (tg + j >= nt) break;
+                float *sr = scl + (tg + j) * Kc;
                 float sc[KCH];
 #pragma unroll
-                for (int k = 0; k < KCH; k++) sc[k] = scl[(tg + j) * Kc + lane + 64 * k];
-                if (p.P) {      // PriorityLayer: scores @ P (priority.py:20-30)
-                    const float *sr = scl + (tg + j) * Kc;
+                for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
+                for (int cc = 0; cc < K; cc++) {
+                    const float sv = sr[cc];
+                    const float *prow = p.P + (long long)cc * Kc + lane;
 #pragma unroll
-                    for (int k = 0; k < KCH; k++) sc[k] = 0.0f;
-                    for (int cc = 0; cc < K; cc++) {
-                        const float sv = sr[cc];
-                        const float *prow = p.P + (long long)cc * Kc + lane;
+                    for (int k = 0; k < KCH; k++) sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                }
+                __builtin_amdgcn_wave_barrier();              // the row is this wavefront's alone: all reads before the writes
 #pragma unroll
-                        for (int k = 0; k < KCH; k++)
-                            sc[k] = fmaf(sv, prow[64 * k], sc[k]);
+                for (int k = 0; k < KCH; k++) sr[lane + 64 * k] = sc[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            const int j = lane >> 4, c = lane & 15;
+            const int tokl = tg + j, i = t0 + tokl;
+            const bool live = tokl < nt;                          // computed token; else a pad inside the tile (or nothing)
+            float v[KCH][4];
+#pragma unroll
+            for (int m = 0; m < KCH; m++) {
+                const float4 x4 = ld4(scl + (tokl < SCORE_TT ? tokl : 0) * Kc + 64 * m + 4 * c);
+                v[m][0] = x4.x; v[m][1] = x4.y; v[m][2] = x4.z; v[m][3] = x4.w;
+            }
+            if (p.scores && tokl < ntL) {                         // unclamped; zero rows at the pads of LOCAL mode
+                float *so = p.scores + ((long long)b * p.L + i) * K;
+#pragma unroll
+                for (int m = 0; m < KCH; m++)
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int col = 64 * m + 4 * c + e;
+                        if (col < K) so[col] = live ? v[m][e] : 0.0f;
                     }
-                }
-                if (p.scores) {
-                    float *so = p.scores + ((long long)b * p.L + i) * K;
+            }
+            float best = -INFINITY;
 #pragma unroll
-                    for (int k = 0; k < KCH; k++) {
-                        const int col = lane + 64 * k;
-                        if (col < K) so[col] = sc[k];
-                    }
-                }
-                // threshold clamp of the `oo` column, then decode: column k*64 + lane is candidate row k of
-                // wave_first_argmax (first index of the maximum, torch.max's rule; an all-NaN row gives 0 like torch)
-                float cand[KCH];
+            for (int m = 0; m < KCH; m++)
 #pragma unroll
-                for (int k = 0; k < KCH; k++) {
-                    const int col = lane + 64 * k;
-                    float v = sc[k] + 0.0f;                          // -0.0 -> +0.0 (torch: -0 == +0)
-                    if (col == clamp_col) v = fminf(v, p.threshold);
-                    if (p.use_crf && col < K) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = v;
-                    cand[k] = col < K ? v : -INFINITY;
+                for (int e = 0; e < 4; e++) {
+                    const int col = 64 * m + 4 * c + e;
+                    float x = v[m][e] + 0.0f;                     // -0.0 -> +0.0 (torch: -0 == +0)
+                    if (col == clamp_col) x = fminf(x, p.threshold);
+                    if (p.use_crf && live && col < K) p.crf_scores[((long long)b * p.L + i) * p.Kp + col] = x;
+                    x = col < K ? x : -INFINITY;
+                    v[m][e] = x;
+                    best = fmaxf(best, x);
                 }
-                if (!p.use_crf) {
-                    const int bi = (p.dbg & 64) ? 0 : wave_first_argmax<KCH>(cand);
-                    if (lane == 0) {
-                        const int tag = (bi == K - 1) ? p.o_idx : bi;
-                        if (p.tags) p.tags[(long long)b * p.L + i] = tag;
-                        if (p.flat && i < len) p.flat[foff + i] = tag;
-                    }
+            if (!p.use_crf) {
+                asm volatile("s_nop 1\n\t"
+                             "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1"
+                             : "+v"(best));
+                unsigned first = 0x7fffffffu;                     // this lane's first column that holds the row maximum
+#pragma unroll
+                for (int m = KCH - 1; m >= 0; m--)
+#pragma unroll
+                    for (int e = 3; e >= 0; e--) first = v[m][e] == best ? (unsigned)(64 * m + 4 * c + e) : first;
+                asm volatile("s_nop 1\n\t"
+                             "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1\n\t"
+                             "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+                             "s_nop 1"
+                             : "+v"(first));
+                if (c == 0 && tokl < ntL) {
+                    int bi = (first >= (unsigned)K || (p.dbg & 64)) ? 0 : (int)first;   // an all-NaN row gives 0 like torch
+                    const int tag = live ? ((bi == K - 1) ? p.o_idx : bi) : -1;
+                    if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                    if (p.flat && live && i < len) p.flat[foff + i] = tag;
                 }
-            } else if (tg + j < ntL) {      // pad position inside a partly valid tile (LOCAL mode)
-                if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
-                if (p.scores)
-                    for (int col = lane; col < K; col += WAVE) p.scores[((long long)b * p.L + i) * K + col] = 0.0f;
             }
         }
         if (probe) {
@@ -269,7 +310,6 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
         if (tile + tile_step < ntiles) __syncthreads();      // the next tile overwrites ab and the score tile
         if (probe) q0 = (long long)__builtin_amdgcn_s_memtime();
     }
-    (void)scw;
 }
 
 template <int KCH>
