@@ -680,6 +680,8 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         hh.reserve(B, L)
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in handles[1:]]
 
+    timed_by = ['HIP events on the dispatch packets of every N-th step (hipExtLaunchKernelGGL)']
+
     def timed_region(n_streams, steps, warmup, stride):
         counter = [0]
 
@@ -716,12 +718,23 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
                                    None, None, torch.cuda.current_stream(dev).cuda_stream)
             graph.replay()
             torch.cuda.synchronize(dev)
+        # One kernel per step (the fused chain + decode launch), auto stride: ONE pair of HIP events on the launch stream
+        # around the K launches of the timed region -- every launch is timed, none pays for an event pair of its own (a pair
+        # costs ~6 us of stream time; with the driver's --steps 20 that was 3.6 us on every step).  Average = region / K,
+        # launch gaps included (conservative).  Steps of several kernels keep per-launch events (every N-th step).
+        region = (stride != 0 and a.event_stride < 0 and world == 1 and n_streams == 1 and graph is None
+                  and 'fused' in handles[0].kernel_name(_lib.KERN_CHAIN))
+        ev = None
         for hh in handles[:n_streams]:
-            hh.set_profiling(stride)            # HIP events around the kernels of every N-th step
+            hh.set_profiling(0 if region else stride)   # HIP events around the kernels of every N-th step
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+        if region:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         t0 = time.perf_counter()
+        if region:
+            ev[0].record(streams[0])
         if graph is not None:
             assert steps % a.graph == 0, '--steps must be a multiple of --graph'
             for _ in range(steps // a.graph):
@@ -729,6 +742,8 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         else:
             for _ in range(steps):
                 step()
+        if region:
+            ev[1].record(streams[0])
         drain()                                 # every gather of the K steps is inside the timed region
         torch.cuda.synchronize(dev)
         if world > 1:
@@ -736,6 +751,9 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         sums = [0.0, 0, 0.0, 0]
+        if region:
+            sums[0], sums[1] = float(ev[0].elapsed_time(ev[1])), steps
+            timed_by[0] = 'one HIP event pair on the launch stream around the {} launches of the timed region'.format(steps)
         for hh in handles[:n_streams]:
             ms, n = hh.kernel_time(_lib.KERN_CHAIN); sums[0] += ms; sums[1] += n
             ms, n = hh.kernel_time(_lib.KERN_SCORE); sums[2] += ms; sums[3] += n
@@ -747,6 +765,7 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         return el, sums
 
     elapsed, (chain_ms, chain_n, score_ms, score_n) = timed_region(n_main, steps, warmup, event_stride)
+    timed_how = timed_by[0]
     pipelined = None
     if want_pipelined and n_main == 1:
         # same K steps with two batches in flight (two streams, two handles): the score/decode kernel
@@ -784,6 +803,7 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
                        ', {} batches in flight per GPU'.format(n_main) if n_main > 1 else '')},
         'roofline': roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, chain_n),
     }
+    out['roofline']['timed_by'] = timed_how
     if pipelined:
         out['pipelined'] = {'streams': pipelined[0], 'value': tok_total * steps / pipelined[1],
                             'unit': 'tokens/s', 'ms_per_step': pipelined[1] / steps * 1e3,
