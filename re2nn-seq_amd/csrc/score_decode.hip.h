@@ -450,9 +450,9 @@ viterbi_kernel(const ScoreParams p) {
 }
 
 // floats of the history area of viterbi_hist_kernel: [L][Kp] partitions; the fused form first stages the [SP][L]
-// alpha*beta products there
+// alpha*beta products there (row stride L + 16)
 __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, bool fused) {
-    const size_t a = (size_t)L * Kp, c = fused ? (size_t)SP * ((L + 3) & ~3) : 0;
+    const size_t a = (size_t)L * Kp, c = fused ? (size_t)SP * (((L + 3) & ~3) + 16) : 0;
     return a > c ? a : c;
 }
 
@@ -503,7 +503,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
     const bool probe = (p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
-    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0;
+    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0;
 
     // set-up without a register round trip: the scores and (behind them) the transition table stream
     // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
@@ -514,19 +514,21 @@ viterbi_hist_kernel(const ScoreParams p) {
         for (int k = wu; k < need; k += nwaves)
             lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(sc), lds0 + (unsigned)k * 1024u);
     } else {
-        const int S = p.S, SP = p.SP, SP4 = SP >> 2, Lq = (p.L + 3) & ~3;
-        // the transposed output matrix borrows the transition table's LDS area until the scores are done
-        const int ot_pieces = (S * p.Kc * 4 + 1023) / 1024;
-        const bool ot_lds = ot_pieces <= tr_pieces;
-        if (ot_lds) {
+        const int SP = p.SP, SP4 = SP >> 2, Lq = ((p.L + 3) & ~3) + 16;   // row stride of the products: the four state rows of an
+                                                                            // A-fragment read land in different banks (L = 64: 80)
+        // the matrix-core image of the output matrix (K2: one 1 KiB piece per (column block, state group)) borrows the
+        // transition table's LDS area until the scores are done, when it fits
+        const int otm_pieces = ((K + 15) >> 4) * p.c16;
+        const bool otm_lds = otm_pieces <= tr_pieces;
+        if (otm_lds) {
             const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
-            for (int k = wu; k < ot_pieces; k += nwaves)
-                lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.OT), lds0 + (unsigned)k * 1024u);
+            for (int k = wu; k < otm_pieces; k += nwaves)
+                lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.OTm), lds0 + (unsigned)k * 1024u);
         }
         float *abT = hist;                               // [SP][Lq] alpha*beta, token-contiguous (aliases hist)
         const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
         const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
-        for (int idx = tid; idx < Lq * SP4; idx += nthreads) {
+        for (int idx = tid; idx < (Lq - 16) * SP4; idx += nthreads) {
             const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
             float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
             if (tok < n) {       // alpha = state after tok+1 tokens; beta = backward state before token tok+1 (:415-420)
@@ -536,45 +538,80 @@ viterbi_hist_kernel(const ScoreParams p) {
             abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
             abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
         }
-        __syncthreads();                                 // (drains vmcnt too: the output matrix has landed)
-        const int ncg = (K + 3) >> 2, ntg = (n + 3) >> 2;
-        const int cg = tid % ncg, tg0 = tid / ncg, tgs = nthreads / ncg;
-        const int clamp_col = K - 3;                     // model_decompose.py:353
-        auto score_tiles = [&](auto op0, int ostride4) {   // op0: this lane's 4 tags in row 0 of the output matrix
-            for (int tg = tg0; tg < ntg && tgs > 0; tg += tgs) {
-                float acc[4][4];
+        __syncthreads();                                 // (drains vmcnt too: the image has landed)
+        if (probe) pa = (long long)__builtin_amdgcn_s_memtime();
+        // scores[n][K] = abT^T . O^T on the f32 matrix cores (v_mfma_f32_16x16x4_f32: the ascending-s fmaf chain of K2, same
+        // bits): units of one 16-token block x two 16-tag blocks (shared A fragments from the staged products, independent
+        // accumulators), B fragments from the matrix-core image of the output matrix (OTm, K2: staged in LDS by LDS-DMA when
+        // it fits the transition table's area, else from L2), two state groups ahead.  At most eight wavefronts take units
+        // -- two per SIMD (wavefront w sits on SIMD w % 4, HW_ID).  Measured: 12.9 k cycles for the config-3 sequence against
+        // 14 k for r02a's 4 x 4 VALU blocking (1 136 FMAs per lane on nine wavefronts, three of them on one SIMD); the
+        // matrix cores are not the bound (720 MFMAs = 5.8 k cycles over four SIMDs), the 4-way bank conflicts of the LDS waits are.
+        {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int lr = lane & 15, lk = lane >> 4;
+            const int c16 = p.c16, ntb = (n + 15) >> 4, ncb = (K + 15) >> 4, nblk = ntb * ncb;
+            const int ngw = nwaves < 8 ? nwaves : 8;
+            const int clamp_col = K - 3;                 // model_decompose.py:353
+            auto product = [&](auto otm) {               // otm: this lane's entry of the image, typed LDS or global pointer
+            const int ncp = (ncb + 1) >> 1;              // a unit = one token block x TWO column blocks: shared A fragments,
+#pragma unroll 1                                         // two independent accumulators
+            for (int unit = wu; unit < ntb * ncp && wu < ngw; unit += ngw) {
+                const int tb = unit / ncp, cb0 = 2 * (unit - tb * ncp), cb1 = cb0 + 1 < ncb ? cb0 + 1 : cb0;
+                auto bp0 = otm + cb0 * c16 * 64, bp1 = otm + cb1 * c16 * 64;
+                lds_cfloat *ap = (lds_cfloat *)abT + tb * 16 + lr;
+                auto a_group = [&](int g, float (&a)[4]) {
+                    const int gc = g < c16 ? g : c16 - 1;
 #pragma unroll
-                for (int u = 0; u < 4; u++)
-#pragma unroll
-                    for (int c = 0; c < 4; c++) acc[u][c] = 0.0f;
-                lds_cv4f *ap = (lds_cv4f *)((lds_cfloat *)abT + tg * 4);
-#pragma unroll 4
-                for (int s0 = 0; s0 < S; s0++) {
-                    const v4f a4 = ap[s0 * (Lq >> 2)];
-                    const v4f o4 = op0[(long long)s0 * ostride4];
-                    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, ov[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-#pragma unroll
-                        for (int c = 0; c < 4; c++) acc[u][c] = fmaf(av[u], ov[c], acc[u][c]);
-                }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int tok = tg * 4 + u;
-                    if (tok >= n) continue;
-                    float v[4];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        v[c] = acc[u][c] + 0.0f;                      // -0.0 -> +0.0 like score_tile_kernel
-                        if (cg * 4 + c == clamp_col) v[c] = fminf(v[c], p.threshold);
+                    for (int e = 0; e < 4; e++) {
+                        const int s = 16 * gc + 4 * e + lk;                   // this lane's k of k-step 4g + e
+                        a[e] = ap[(s < SP ? s : SP - 1) * Lq];                // (no product row there: B is zero, any finite A will do)
                     }
-                    st4(scl + (long long)tok * Kp + cg * 4, make_float4(v[0], v[1], v[2], v[3]));
+                };
+                auto b_group = [&](decltype(bp0) bp, int g) -> f32x4 { const v4f t = bp[(g < c16 ? g : c16 - 1) * 64]; return f32x4{t.x, t.y, t.z, t.w}; };
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                auto mfma8 = [&](const float (&a)[4], const f32x4 &b0, const f32x4 &b1) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1.w, acc1, 0, 0, 0);
+                };
+                f32x4 be0 = b_group(bp0, 0), be1 = b_group(bp1, 0), bo0 = b_group(bp0, 1), bo1 = b_group(bp1, 1);
+                float ae[4], ao[4];
+                a_group(0, ae);
+#pragma unroll 1
+                for (int g = 0; g < c16; g += 2) {
+                    a_group(g + 1, ao);
+                    mfma8(ae, be0, be1);
+                    be0 = b_group(bp0, g + 2); be1 = b_group(bp1, g + 2);
+                    a_group(g + 2, ae);
+                    if (g + 1 < c16) mfma8(ao, bo0, bo1);
+                    bo0 = b_group(bp0, g + 3); bo1 = b_group(bp1, g + 3);
                 }
+                auto store = [&](const f32x4 &acc, int cb) {                  // rows lk*4 + r of the token block, column lr
+                    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+                    const int col = cb * 16 + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int tok = tb * 16 + lk * 4 + r;
+                        float v = av[r] + 0.0f;                               // -0.0 -> +0.0 like score_tile_kernel
+                        if (col == clamp_col) v = fminf(v, p.threshold);
+                        if (tok < n && col < Kp) scl[(long long)tok * Kp + col] = v;
+                    }
+                };
+                store(acc0, cb0);
+                if (cb1 != cb0) store(acc1, cb1);
             }
-        };
-        if (ot_lds) score_tiles((lds_cv4f *)((lds_cfloat *)trl + cg * 4), p.Kc >> 2);
-        else score_tiles((glb_cv4f *)(p.OT + cg * 4), p.Kc >> 2);
+            };
+            if (otm_lds) product((lds_cv4f *)((lds_cfloat *)trl) + lane);
+            else product((glb_cv4f *)p.OTm + lane);
+        }
         __syncthreads();                                 // abT (aliasing hist) is free again
+        if (probe) pb = (long long)__builtin_amdgcn_s_memtime();
     }
     // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
     // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
@@ -754,8 +791,8 @@ viterbi_hist_kernel(const ScoreParams p) {
     }
     if (probe && tid == 0) {
         pc3 = (long long)__builtin_amdgcn_s_memtime();
-        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles, forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
-               b, n, nthreads, pc1 - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
+        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (products staged at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
+               b, n, nthreads, pc1 - pc0, pa - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
     }
     if (p.tags)
         for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
