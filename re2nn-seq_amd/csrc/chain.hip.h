@@ -66,6 +66,7 @@ struct ChainParams {
     int flat_in_kernel;     // 1: the epilogue writes the flat output and no prefix array exists: sum the lengths here
     int spin;               // polls the first-arrived direction spends waiting for the other one before it leaves
     int fence;              // 1: agent-scope release / acquire fences around the arrival (on top of the sc1 stores / loads)
+    int xcd_pair;           // 1: the two directions of a sequence run on the same XCD (B % 8 == 0)
 };
 
 constexpr int CHAIN_MAX_THREADS = 512;     // NW compute + NLD loader + 1 writer wavefronts <= 8
@@ -191,10 +192,15 @@ chain_kernel(const ChainKernelArgs args) {                                      
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int nthreads = blockDim.x;
+    // Workgroup -> (launch slot, direction).  Consecutive workgroup ids go to consecutive XCDs (id % 8): with p.xcd_pair the two
+    // directions of a slot are the ids 16q + x and 16q + 8 + x -- the same XCD, hence the same L2, so the stash rows one of
+    // them stores write-through and the other reads in the fused epilogue (and the arrival counter) meet in that L2
+    // instead of crossing the fabric.  Else: ids 2s and 2s + 1 (always two different XCDs).
     const int item = blockIdx.x;
-    const int dir = item & 1;
-    int b = p.order ? p.order[item >> 1] : (item >> 1);
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(item >> 1, p.B), reinterpret_cast<int *>(smem), tid, nthreads);
+    const int dir = p.xcd_pair ? ((item >> 3) & 1) : (item & 1);
+    const int slot = p.xcd_pair ? (((item >> 4) << 3) | (item & 7)) : (item >> 1);
+    int b = p.order ? p.order[slot] : slot;
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(slot, p.B), reinterpret_cast<int *>(smem), tid, nthreads);
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const int S = p.S, SP = p.SP, RPG = p.RPG, RPGp = p.RPGp, NQ = p.NQ, KS = p.KS;
@@ -531,6 +537,9 @@ chain_kernel(const ChainKernelArgs args) {                                      
     chain_body();
 
     if constexpr (FUSED) {
+        const bool eprobe = (p.dbg & 32768) && nsteps == p.L && tid == 0;      // diagnostic: the epilogue's timeline
+        const long long e0 = eprobe ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        long long e1 = 0, e2 = 0;
         // ---- hand-off: arrive at the sequence's counter; the second arrival scores the sequence -----------------
         __shared__ int arrive_s;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wavefront's stash stores have left (writer)
@@ -548,6 +557,7 @@ chain_kernel(const ChainKernelArgs args) {                                      
         const long long foff_pre = (p.flat_in_kernel && !(p.dbg & 2048)) ? (long long)*foff_lds : -1;
         __syncthreads();                                             // the adding wave joins; nobody loads before it
         const int arrived = arrive_s;
+        if (eprobe) e1 = (long long)__builtin_amdgcn_s_memtime();
         if (p.dbg & 128) return;                                     // ablation: no epilogue (wrong results)
         auto run_tiles = [&](int first) {                            // tiles first, first + 2, ... of this sequence
             switch (sp.kch) {
@@ -587,6 +597,7 @@ chain_kernel(const ChainKernelArgs args) {                                      
             if (!claim_s) return;
         }
         acquire();
+        if (eprobe) e2 = (long long)__builtin_amdgcn_s_memtime();
         // one call site for the tile code (four label-width variants of a large unrolled body)
         for (int first = (arrived & 1) ? 0 : 1;; first = 1) {
             run_tiles(first);
@@ -599,6 +610,9 @@ chain_kernel(const ChainKernelArgs args) {                                      
                 if (!claim_s) break;                                 // the other direction's workgroup took them
             }
         }
+        if (eprobe)
+            printf("epilogue of sequence %d dir %d (arrival %d): arrive %lld cycles, wait/claim %lld, tiles %lld\n", b, dir, arrived & 1,
+                   e1 - e0, e2 - e1, (long long)__builtin_amdgcn_s_memtime() - e2);
     }
 }
 

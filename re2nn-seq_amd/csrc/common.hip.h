@@ -80,6 +80,15 @@ __device__ __forceinline__ float4 ld4_agent(const float *p) {
                        __uint_as_float((unsigned)hi), __uint_as_float((unsigned)(hi >> 32)));
 }
 
+// 16-byte agent-scope load in ONE instruction (the atomic form above is two 8-byte loads).  The compiler does not count
+// inline-asm loads: the caller issues its loads and then passes every destination through wait_sc1_loads().
+__device__ __forceinline__ void ld4_agent_issue(v4f &dst, const float *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void wait_sc1_loads(v4f &a, v4f &b, v4f &c, v4f &d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
 // (value desc, index asc) combine for first-index argmax, matching torch.max tie-breaking.
 __device__ __forceinline__ void argmax_combine(float &v, int &i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }

@@ -139,26 +139,27 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
         // backward state before token i+1 is consumed (reversed_backward_score_x[:, i+1], :415-420)
         const int G4 = 4 * c16;                               // float4 columns of a tile row (those past SP stay zero)
         for (int idx0 = 0; idx0 < SCORE_TT * G4; idx0 += 2 * nthreads) {
-            float4 a4[2], b4[2];
+            v4f a4[2], b4[2];
             int tokv[2], s4v[2];
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 const int idx = idx0 + r * nthreads + tid;
                 const int tok = idx / G4;
                 tokv[r] = tok; s4v[r] = (idx - tok * G4) * 4;
-                a4[r] = make_float4(0.f, 0.f, 0.f, 0.f); b4[r] = a4[r];
+                a4[r] = v4f{0.f, 0.f, 0.f, 0.f}; b4[r] = a4[r];
                 if (tok < nt && s4v[r] < SP) {
                     const int i = t0 + tok;
                     const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
                     if (SC1) {
-                        a4[r] = ld4_agent(Ab + (long long)(i + 1) * SP + s4v[r]);
-                        b4[r] = ld4_agent(Bb + (long long)bidx * SP + s4v[r]);
+                        ld4_agent_issue(a4[r], Ab + (long long)(i + 1) * SP + s4v[r]);
+                        ld4_agent_issue(b4[r], Bb + (long long)bidx * SP + s4v[r]);
                     } else {
-                        a4[r] = ld4(Ab + (long long)(i + 1) * SP + s4v[r]);
-                        b4[r] = ld4(Bb + (long long)bidx * SP + s4v[r]);
+                        a4[r] = *reinterpret_cast<const v4f *>(Ab + (long long)(i + 1) * SP + s4v[r]);
+                        b4[r] = *reinterpret_cast<const v4f *>(Bb + (long long)bidx * SP + s4v[r]);
                     }
                 }
             }
+            if (SC1) wait_sc1_loads(a4[0], b4[0], a4[1], b4[1]);
 #pragma unroll
             for (int r = 0; r < 2; r++)
                 if (tokv[r] < SCORE_TT)
