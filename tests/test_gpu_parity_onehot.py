@@ -584,3 +584,40 @@ def test_fused_handoff_burst():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.run(rounds=int(os.environ.get('FARNN_SOAK_ROUNDS', '6')), verbose=True) == 0
+
+
+@pytest.mark.parametrize('C,use_p', [(129, False), (40, True), (200, False)])
+def test_local_scores_zero_rows_at_pads_and_mode_re_clamp(C, use_p):
+    """farnn_tag's three modes on one ragged batch (include/farnn.h): LOCAL with a score tensor -- rows of valid positions
+    equal the oracle's, rows at pad positions are zero, tags there -1; FARNN_MODE_RE == FARNN_MODE_FULL with the `oo`
+    column capped at the threshold (model_onehot.py:153-154), same tags."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(7 + C)
+    V, S, B, L = 200, 71, 24, 45
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=8.0)
+    P = (np.eye(C) + 0.25 * (rng.rand(C, C) < 0.05)).astype(np.float32) if use_p else None
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    lengths[0] = 1
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, P=P, o_idx=2, threshold=0.5)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+
+    def run(mode):
+        tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+        sc = torch.full((B, L, C), -7.0, dtype=torch.float32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(), None, sc.data_ptr())
+        torch.cuda.synchronize()
+        return tags.cpu().numpy(), sc.cpu().numpy()
+
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths, P=P)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    t_loc, s_loc = run(_lib.MODE_LOCAL)
+    assert_scores(s_loc[mask], ref[mask], exact=True)
+    assert (s_loc[~mask] == 0).all() and (t_loc[~mask] == -1).all()
+    t_full, s_full = run(_lib.MODE_FULL)
+    t_re, s_re = run(_lib.MODE_RE)
+    assert np.array_equal(t_full, t_re) and np.array_equal(t_full[mask], t_loc[mask])
+    want = s_full.copy()
+    want[:, :, C - 1] = np.minimum(want[:, :, C - 1], np.float32(0.5))
+    assert np.array_equal(s_re, want)
+    assert_scores(s_full[mask], ref[mask], exact=True)
+    h.close()
