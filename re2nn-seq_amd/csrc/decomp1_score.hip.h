@@ -525,120 +525,156 @@ struct Decomp0ScoreParams {
     float threshold;
 };
 
+// D0_TOK tokens per workgroup: a thread owns one factor column (then one label column) for four of them, so every factor
+// entry read from L2 feeds four FMAs (r02a: one workgroup per token re-read all four S x R factors -- 83 KB at the
+// config-2 size -- for every token: 730 MB of L2 traffic per launch, 88 us).
+constexpr int D0_TOK = 8;
+
 __global__ void __launch_bounds__(256)
 decomp0_score_kernel(const Decomp0ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, nt = blockDim.x;
-    const int i = blockIdx.x, b = blockIdx.y;
+    const int i0 = blockIdx.x * D0_TOK, b = blockIdx.y;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
-    const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, RW = p.RW, RWp = p.RWp, K = p.K;
-    if (i >= nsteps) {
-        if (p.tags && tid == 0) p.tags[(long long)b * p.L + i] = -1;
-        if (p.scores) for (int c = tid; c < K; c += nt) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
-        return;
+    const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, RW = p.RW, RWp = p.RWp, K = p.K, Kc = p.Kc;
+    const int ntok = min(D0_TOK, p.L - i0);              // positions of this workgroup that exist
+    const int nlive = max(0, min(D0_TOK, nsteps - i0));  // ... that were computed
+    for (int t = nlive + w; t < ntok; t += 4) {          // pads (LOCAL mode)
+        const int i = i0 + t;
+        if (p.tags && lane == 0) p.tags[(long long)b * p.L + i] = -1;
+        if (p.scores) for (int c = lane; c < K; c += WAVE) p.scores[((long long)b * p.L + i) * K + c] = 0.0f;
     }
-    float *alpha = smem;                 // [SP]
-    float *beta = alpha + SP;            // [SP]
-    float *ab = beta + SP;               // [Rp]
-    float *abw = ab + Rp;                // [RWp]
-    float *sc = abw + RWp;               // [Kc]
-    float *sc2 = sc + p.Kc;              // [Kc]
+    if (nlive <= 0) return;
+    float *alpha = smem;                                 // [D0_TOK][SP]
+    float *beta = alpha + D0_TOK * SP;                   // [D0_TOK][SP]
+    float *ab = beta + D0_TOK * SP;                      // [D0_TOK][Rp]
+    float *abw = ab + D0_TOK * Rp;                       // [D0_TOK][RWp]
+    float *sc = abw + D0_TOK * RWp;                      // [D0_TOK][Kc]
+    float *sc2 = sc + D0_TOK * Kc;                       // [D0_TOK][Kc]
+    __shared__ int tokid[D0_TOK];
 
-    const float *ar = p.A + ((long long)b * (p.L + 1) + i) * SP;
-    const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
-    const float *brow = p.Bk + ((long long)b * (p.L + 1) + bidx) * SP;
-    const float *vg = p.Vgen + (long long)clamp_tok(p.x[(long long)b * p.L + i], p.V) * Rp;
-    for (int s = tid; s < SP; s += nt) { alpha[s] = ar[s]; beta[s] = brow[s]; }
+    for (int idx = tid; idx < D0_TOK * SP; idx += nt) {
+        const int t = idx / SP, sidx = idx - t * SP;
+        float av = 0.0f, bv = 0.0f;
+        if (t < nlive) {
+            const int i = i0 + t;
+            const int bidx = (i + 1 <= len) ? len - (i + 1) : i + 1;
+            av = p.A[((long long)b * (p.L + 1) + i) * SP + sidx];                       // state BEFORE token i (:418)
+            bv = p.Bk[((long long)b * (p.L + 1) + bidx) * SP + sidx];
+        }
+        alpha[idx] = av; beta[idx] = bv;
+    }
+    if (tid < D0_TOK) tokid[tid] = tid < nlive ? clamp_tok(p.x[(long long)b * p.L + i0 + tid], p.V) : 0;
+    for (int idx = tid; idx < D0_TOK * (Rp + RWp); idx += nt) ab[idx] = 0.0f;          // (the pad columns are read, times zero)
     __syncthreads();
-    for (int r = tid; r < R + RW; r += nt) {
+    // ---- (a.S1)_r (b~.S2)_r per factor column, four tokens per thread ------------------------------------------
+    const int th = tid >> 7, cl = tid & 127;             // token half, column lane
+    for (int r = cl; r < R + RW; r += 128) {
         const bool lang = r < R;
         const int col = lang ? r : r - R, ld = lang ? Rp : RWp;
         const float *f1 = (lang ? p.S1 : p.S1w) + col, *f2 = (lang ? p.S2 : p.S2w) + col;
-        // two independent chains per product and the loads of eight steps in flight: a rolled single chain pays a
-        // memory round trip per element (scripts/probe/lds_rate.hip)
-        float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
-        int s = 0;
-        for (; s + 8 <= S; s += 8) {
-            float u1[8], u2[8];
+        const float *al = alpha + th * 4 * SP, *be = beta + th * 4 * SP;
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, bb[4] = {0.f, 0.f, 0.f, 0.f};
+        int sidx = 0;
+        for (; sidx + 4 <= S; sidx += 4) {               // eight factor loads in flight; the states come as 16-byte LDS reads
+            float u1[4], u2[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { u1[u] = f1[(long long)(s + u) * ld]; u2[u] = f2[(long long)(s + u) * ld]; }
+            for (int u = 0; u < 4; u++) { u1[u] = f1[(long long)(sidx + u) * ld]; u2[u] = f2[(long long)(sidx + u) * ld]; }
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
-                a0 = fmaf(alpha[s + u], u1[u], a0); a1 = fmaf(alpha[s + u + 1], u1[u + 1], a1);       // :314 / :318
-                b0 = fmaf(beta[s + u], u2[u], b0); b1 = fmaf(beta[s + u + 1], u2[u + 1], b1);         // :315 / :319
+            for (int t = 0; t < 4; t++) {
+                const float4 a4 = ld4(al + t * SP + sidx), b4 = ld4(be + t * SP + sidx);
+                a[t] = fmaf(a4.x, u1[0], a[t]); a[t] = fmaf(a4.y, u1[1], a[t]);                 // :314 / :318
+                a[t] = fmaf(a4.z, u1[2], a[t]); a[t] = fmaf(a4.w, u1[3], a[t]);
+                bb[t] = fmaf(b4.x, u2[0], bb[t]); bb[t] = fmaf(b4.y, u2[1], bb[t]);             // :315 / :319
+                bb[t] = fmaf(b4.z, u2[2], bb[t]); bb[t] = fmaf(b4.w, u2[3], bb[t]);
             }
         }
-        for (; s < S; s++) {
-            a0 = fmaf(alpha[s], f1[(long long)s * ld], a0);
-            b0 = fmaf(beta[s], f2[(long long)s * ld], b0);
+        for (; sidx < S; sidx++) {
+            const float u1 = f1[(long long)sidx * ld], u2 = f2[(long long)sidx * ld];
+#pragma unroll
+            for (int t = 0; t < 4; t++) { a[t] = fmaf(al[t * SP + sidx], u1, a[t]); bb[t] = fmaf(be[t * SP + sidx], u2, bb[t]); }
         }
-        const float a = a0 + a1, bb = b0 + b1;
-        if (lang) ab[col] = vg[col] * (a * bb);                                       // :313,:316
-        else abw[col] = a * bb;                                                       // :320
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int tk = th * 4 + t;
+            if (lang) ab[tk * Rp + col] = p.Vgen[(long long)tokid[tk] * Rp + col] * (a[t] * bb[t]);   // :313,:316
+            else abw[tk * RWp + col] = a[t] * bb[t];                                                  // :320
+        }
     }
     __syncthreads();
-    for (int c = tid; c < K; c += nt) {
-        float s0 = 0.0f, s1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
-        int r = 0;
-        for (; r + 8 <= R; r += 8) {
-            float cv[8];
+    // ---- label scores, four tokens per thread ---------------------------------------------------------------------
+    for (int c = cl; c < K; c += 128) {
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, w0[4] = {0.f, 0.f, 0.f, 0.f};
+        const float *abp = ab + th * 4 * Rp, *abq = abw + th * 4 * RWp;
+        for (int r = 0; r < R; r += 4) {                     // (the rows past R / RW are zero in CT / CwT's padded images? no: guarded)
+            float cv[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) cv[u] = p.CT[(long long)(r + u) * p.Kc + c];
+            for (int u = 0; u < 4; u++) cv[u] = r + u < R ? p.CT[(long long)(r + u) * Kc + c] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) { s0 = fmaf(ab[r + u], cv[u], s0); s1 = fmaf(ab[r + u + 1], cv[u + 1], s1); }   // :317
+            for (int t = 0; t < 4; t++) {
+                const float4 x4 = ld4(abp + t * Rp + r);                                      // Rp % 4 == 0; pads of ab are finite
+                s0[t] = fmaf(x4.x, cv[0], s0[t]); s0[t] = fmaf(x4.y, cv[1], s0[t]);           // :317
+                s0[t] = fmaf(x4.z, cv[2], s0[t]); s0[t] = fmaf(x4.w, cv[3], s0[t]);
+            }
         }
-        for (; r < R; r++) s0 = fmaf(ab[r], p.CT[(long long)r * p.Kc + c], s0);
-        int q = 0;
-        for (; q + 8 <= RW; q += 8) {
-            float cv[8];
+        for (int q = 0; q < RW; q += 4) {
+            float cv[4];
 #pragma unroll
-            for (int u = 0; u < 8; u++) cv[u] = p.CwT[(long long)(q + u) * p.Kc + c];
+            for (int u = 0; u < 4; u++) cv[u] = q + u < RW ? p.CwT[(long long)(q + u) * Kc + c] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) { w0 = fmaf(abw[q + u], cv[u], w0); w1 = fmaf(abw[q + u + 1], cv[u + 1], w1); } // :321
+            for (int t = 0; t < 4; t++) {
+                const float4 x4 = ld4(abq + t * RWp + q);
+                w0[t] = fmaf(x4.x, cv[0], w0[t]); w0[t] = fmaf(x4.y, cv[1], w0[t]);           // :321
+                w0[t] = fmaf(x4.z, cv[2], w0[t]); w0[t] = fmaf(x4.w, cv[3], w0[t]);
+            }
         }
-        for (; q < RW; q++) w0 = fmaf(abw[q], p.CwT[(long long)q * p.Kc + c], w0);
-        sc[c] = (s0 + s1) + (w0 + w1);                                                       // :322
+#pragma unroll
+        for (int t = 0; t < 4; t++) sc[(th * 4 + t) * Kc + c] = s0[t] + w0[t];                        // :322
     }
     __syncthreads();
-    const float *fin = sc;
-    if (p.P) {
-        for (int d = tid; d < K; d += nt) {
-            float s = 0.0f;
-            for (int c = 0; c < K; c++) s = fmaf(sc[c], p.P[(long long)c * p.Kc + d], s);
-            sc2[d] = s;
-        }
-        __syncthreads();
-        fin = sc2;
-    }
-    if (p.scores)
-        for (int c = tid; c < K; c += nt) p.scores[((long long)b * p.L + i) * K + c] = fin[c];
+    // ---- priority, outputs, decode: a wavefront per token ----------------------------------------------------------
     const int clamp_col = p.use_crf ? K - 3 : K - 1;
-    if (p.use_crf) {
-        for (int c = tid; c < K; c += nt) {
-            float vv = fin[c] + 0.0f;
-            if (c == clamp_col) vv = fminf(vv, p.threshold);
-            p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
+    for (int t = w; t < nlive; t += 4) {
+        const int i = i0 + t;
+        const float *fin = sc + t * Kc;
+        if (p.P) {
+            for (int d = lane; d < K; d += WAVE) {
+                float acc = 0.0f;
+                for (int c = 0; c < K; c++) acc = fmaf(fin[c], p.P[(long long)c * Kc + d], acc);
+                sc2[t * Kc + d] = acc;
+            }
+            __builtin_amdgcn_wave_barrier();
+            fin = sc2 + t * Kc;
         }
-    } else if (w == 0) {
-        float bv = -INFINITY; int bi = 0x7ffffffe;
-        for (int c = lane; c < K; c += WAVE) {
-            float vv = fin[c] + 0.0f;
-            if (c == clamp_col) vv = fminf(vv, p.threshold);
-            if (vv > bv) { bv = vv; bi = c; }
-        }
-        bi = wave_argmax_dpp(bv, bi);
-        if (lane == 0) {
-            if (bi >= K) bi = 0;
-            const int tag = (bi == K - 1) ? p.o_idx : bi;
-            if (p.tags) p.tags[(long long)b * p.L + i] = tag;
-            if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
+        if (p.scores)
+            for (int c = lane; c < K; c += WAVE) p.scores[((long long)b * p.L + i) * K + c] = fin[c];
+        if (p.use_crf) {
+            for (int c = lane; c < K; c += WAVE) {
+                float vv = fin[c] + 0.0f;
+                if (c == clamp_col) vv = fminf(vv, p.threshold);
+                p.crf_scores[((long long)b * p.L + i) * p.Kp + c] = vv;
+            }
+        } else {
+            float bv = -INFINITY; int bi = 0x7ffffffe;
+            for (int c = lane; c < K; c += WAVE) {
+                float vv = fin[c] + 0.0f;
+                if (c == clamp_col) vv = fminf(vv, p.threshold);
+                if (vv > bv) { bv = vv; bi = c; }
+            }
+            bi = wave_argmax_dpp(bv, bi);
+            if (lane == 0) {
+                if (bi >= K) bi = 0;
+                const int tag = (bi == K - 1) ? p.o_idx : bi;
+                if (p.tags) p.tags[(long long)b * p.L + i] = tag;
+                if (p.flat && i < len) p.flat[p.offs[b] + i] = tag;
+            }
         }
     }
 }
 
 inline size_t decomp0_score_lds_bytes(int SP, int Rp, int RWp, int Kc) {
-    return ((size_t)2 * SP + Rp + RWp + 2 * (size_t)Kc) * sizeof(float);
+    return (size_t)D0_TOK * ((size_t)2 * SP + Rp + RWp + 2 * (size_t)Kc) * sizeof(float);
 }
 
 // table[v][r] *= sum_c C[c][r]   (_R = V_vec * C_vec_sum, model_decompose.py:253,:393)

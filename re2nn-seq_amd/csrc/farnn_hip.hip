@@ -781,7 +781,7 @@ static int launch_decomp0_score(farnn_model *m, const int64_t *x, const int64_t 
     int rc;
     if ((rc = raise_lds_limit(decomp0_score_kernel, lds))) return rc;
     KernelTimer kt(m, KERN_SCORE, s);
-    decomp0_score_kernel<<<dim3(p.L, B), dim3(256), lds, s>>>(p);
+    decomp0_score_kernel<<<dim3((p.L + D0_TOK - 1) / D0_TOK, B), dim3(256), lds, s>>>(p);
     FARNN_HIP_TRY(hipGetLastError());
     if (m->use_crf) {
         ScoreParams v;
