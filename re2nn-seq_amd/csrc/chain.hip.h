@@ -561,10 +561,10 @@ chain_kernel(const ChainKernelArgs args) {                                      
         if (p.dbg & 128) return;                                     // ablation: no epilogue (wrong results)
         auto run_tiles = [&](int first) {                            // tiles first, first + 2, ... of this sequence
             switch (sp.kch) {
-                case 1: score_tiles<1, true>(sp, b, first, 2, esm, tid, foff_pre); break;
-                case 2: score_tiles<2, true>(sp, b, first, 2, esm, tid, foff_pre); break;
-                case 3: score_tiles<3, true>(sp, b, first, 2, esm, tid, foff_pre); break;
-                default: score_tiles<4, true>(sp, b, first, 2, esm, tid, foff_pre); break;
+                case 1: score_tiles<1, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
+                case 2: score_tiles<2, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
+                case 3: score_tiles<3, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
+                default: score_tiles<4, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
             }
         };
         auto acquire = [&]() {

@@ -63,15 +63,15 @@ constexpr int SCORE_TT = 32;       // tokens per tile (4 per wavefront)
 // traffic and the issue slots, not the arithmetic.  Measured (FARNN_DBG=16384, one tile of the config-1 batch, two
 // workgroups per CU, cycles): r02a products 1.8 k, DMA wait 0.7 k, VALU GEMM 5.8 k, keyed-DPP decode 5.4 k; now products
 // 2.3 k, barrier 1.0 k, GEMM 4.3 k, decode 1.7 k.  score_tile_kernel for the config-1 batch: 14.4 -> 10.6 us.
-// foff_pre >= 0: the sequence's offset in the flat output is already known (the fused epilogue of chain_kernel computes
-// it during its hand-off)
+// foff_pre >= 0 / len_pre >= 0: the sequence's offset in the flat output / its clamped length are already known (the fused
+// epilogue of chain_kernel has both)
 template <int KCH, bool SC1>
 __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, const int tile_first, const int tile_step,
-                                            float *smem, const int tid, const long long foff_pre = -1) {
+                                            float *smem, const int tid, const long long foff_pre = -1, const int len_pre = -1) {
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = SCORE_WAVES * 64;
-    const int len = clamp_len(p.len[b], p.L);
+    const int len = len_pre >= 0 ? len_pre : clamp_len(p.len[b], p.L);   // (the fused epilogue knows it: no L2 round trip)
     const int nsteps = p.full ? p.L : len;
     const int SP = p.SP, K = p.K, Kc = p.Kc;
     const int ntiles = (p.L + SCORE_TT - 1) / SCORE_TT;
