@@ -122,6 +122,56 @@ __device__ __forceinline__ void rowdots(const float *ml, const float *mg, int nr
     }
 }
 
+// The same row dot products with the rows held in REGISTERS for the whole sequence: pass i covers the rows i*128 + tid/4,
+// w[i][2c], w[i][2c+1] are this lane's two 16-byte pieces of chunk c.  The chunk of every x_s is read from LDS once and used
+// by all NP passes.
+template <int NSEQ, int NP, int NCH, typename Epi>
+__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, const float *X, int xs, int tid, Epi &&epi) {
+    const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+    lds_cfloat *xl = (lds_cfloat *)X + k * 4;
+    v2f tl[NP][NSEQ], th[NP][NSEQ];
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) { tl[i][s] = v2f{0.f, 0.f}; th[i][s] = v2f{0.f, 0.f}; }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) {
+            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * DR_CHUNK);
+            const v4f x0 = xp[0], x1 = xp[4];
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                const v4f a0 = w[i][2 * c], a1 = w[i][2 * c + 1];
+                tl[i][s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, th[i][s]);
+                tl[i][s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[i][s]);
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        float acc[NSEQ];
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) { const v2f t = tl[i][s] + th[i][s]; acc[s] = quad_sum(t.x + t.y); }
+        const int row = i * DR_RPP + rloc;
+        if (k == 0 && row < nrows) epi(row, acc);
+    }
+}
+
+// this lane's pieces of the rows of a packed matrix (rows past the last one: a copy of the last, never used)
+template <int NP, int NCH>
+__device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const float *M, int nrows, int ld, int tid) {
+    const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        const int row = i * DR_RPP + rloc;
+        glb_cv4f *src = (glb_cv4f *)(M + (long long)(row < nrows ? row : nrows - 1) * ld + k * 4);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { w[i][2 * c] = src[c * 8]; w[i][2 * c + 1] = src[c * 8 + 4]; }
+    }
+}
+
 __device__ __forceinline__ float gate_sigmoid(float x, float k) { return 1.0f / (1.0f + __expf(-(x * k))); }
 
 // update non-linearity on the hardware exponential: |error| ~1e-7 against the 1e-4 parity bar
@@ -138,7 +188,12 @@ __device__ __forceinline__ float dr_nl(float x, int nl) {
     }
 }
 
-template <int NSEQ>
+// NP1R / NP2R / NP3R > 0: the matrix lives in REGISTERS (that many 128-row passes of NCH2R / NCH3R chunks) instead of LDS /
+// L2: with the gates, or at rank 250, the packed rows exceed the 160 KiB of LDS and r02a streamed the rest from L2 on every
+// step (the shipped example configuration's shape, S = 104, rank 250, farnn = 2: 286 KB per workgroup per step, 5.1 us per
+// step).  Eight wavefronts have 512 KB of registers between them: P1 (gates) and P3 in registers + P2 in LDS hold that
+// model whole, and a step touches neither L2 nor HBM for weights.
+template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0>
 __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -204,6 +259,11 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int q = 0; q < 3; q++)
             for (long long i = (long long)tid * 4; i < cnt[q]; i += DR_THREADS * 4) st4(dst[q] + i, ld4(src[q] + i));
     }
+    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1)], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
+    v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3R > 0 ? NCH3R : 1)];
+    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R>(w1, p.P1, p.n1, ld2, tid);
+    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R>(w2, p.P2[dir], p.n2, ld2, tid);
+    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3R>(w3, p.P3[dir], p.n3, ld3, tid);
     __syncthreads();
     for (int j = tid; j < S; j += DR_THREADS) {
         const float hv = hinit[j];
@@ -284,7 +344,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     }
                 }
             };
-            if (!(p.dbg & 1)) rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
+            if (!(p.dbg & 1)) {
+                if constexpr (NP1R > 0) rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, H, c2p, tid, epi1);
+                else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
+            }
             wg_barrier_lds();
         }
         {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: z from the same h ------------
@@ -295,7 +358,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     else Z[s * SP + (row - R)] = gate_sigmoid(acc[s] + TVc[s * tvl + Rp + (row - R)], sig_k);
                 }
             };
-            if (!(p.dbg & 1)) rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+            if (!(p.dbg & 1)) {
+                if constexpr (NP2R > 0) rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, HBc, c2p, tid, epi2);
+                else rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+            }
         }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
@@ -327,7 +393,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
             };
-            if (!(p.dbg & 1)) rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
+            if (!(p.dbg & 1)) {
+                if constexpr (NP3R > 0) rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, X3c, c3p, tid, epi3);
+                else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
+            }
         }
         wg_barrier_lds();
     }
@@ -405,50 +474,92 @@ struct DecompRowsPack {
 // LDS access group touches (64 contiguous bytes each) start in different quarters of the 64 banks
 inline int rows_ld(int cols) { return (cols + DR_CHUNK - 1) / DR_CHUNK * DR_CHUNK + 16; }
 
-struct RowsPlan { int nseq, res1, res2, res3; size_t lds; };
+struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form: which matrices live in registers (0: none)
 
-inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, int L, RowsPlan &pl) {
+// register-resident forms that are instantiated (one sequence per workgroup): passes of P1 / P2, chunks of their rows,
+// passes / chunks of P3.  A: gated (farnn = 2) rank <= 252 at 96 < S <= 128 (the shipped shape); B: farnn = 1 with
+// R + S <= 256; C: farnn = 2 at rank ~100.
+#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 12) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 7)
+
+// one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
+inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
     const int Lr = (L + 3) & ~3;
     const int tvl = w.Rp + (w.farnn >= 1 ? w.SP : 0) + (w.farnn == 2 ? w.SP : 0);
-    int nseq = 1;
-    // measured (B=256, S=104): one sequence per workgroup in two rounds beats two per workgroup in one
-    // (145 vs 168 us at R=50, 374 vs 450 us gated R=250): the x reads and FMAs scale with NSEQ, only the
-    // weight reads are shared
-    while (nseq < 4 && 2 * ((B + nseq - 1) / nseq) > 512 * nseq) nseq *= 2;
-    if (const char *e = getenv("FARNN_ROWS_NSEQ")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) nseq = v; }
-    for (; nseq >= 1; nseq /= 2) {
-        if (nseq * tvl > DR_MAX_PF * DR_THREADS) continue;
-        const size_t fixed = 4 * ((size_t)nseq * Lr + w.SP + 3ull * nseq * k.nch2 * DR_CHUNK +
-                                  2ull * nseq * k.nch3 * DR_CHUNK + (size_t)nseq * w.SP + 2ull * nseq * tvl);
-        const size_t cap = 159 * 1024;
-        if (fixed + 16 * 1024 > cap) continue;               // leave room for at least some resident rows
-        size_t left = cap - fixed;
-        auto take = [&](int nrows, int ld) {
-            if (nrows == 0) return 0;
-            long long fit = (long long)(left / ((size_t)ld * 4));
-            int res = fit >= nrows ? nrows : (int)(fit / DR_RPP) * DR_RPP;
-            left -= (size_t)res * ld * 4;
-            return res;
-        };
+    if (nseq * tvl > DR_MAX_PF * DR_THREADS) return false;
+    const size_t fixed = 4 * ((size_t)nseq * Lr + w.SP + 3ull * nseq * k.nch2 * DR_CHUNK +
+                              2ull * nseq * k.nch3 * DR_CHUNK + (size_t)nseq * w.SP + 2ull * nseq * tvl);
+    const size_t cap = 159 * 1024;
+    if (fixed + 16 * 1024 > cap) return false;               // leave room for at least some resident rows
+    size_t left = cap - fixed;
+    auto take = [&](int nrows, int ld) {
+        if (nrows == 0) return 0;
+        long long fit = (long long)(left / ((size_t)ld * 4));
+        int res = fit >= nrows ? nrows : (int)(fit / DR_RPP) * DR_RPP;
+        left -= (size_t)res * ld * 4;
+        return res;
+    };
+    pl.form = 0;
+    if (forms && nseq == 1) {      // (two sequences per workgroup on these forms: measured slower, spills)
+        const int np1 = (k.n1 + DR_RPP - 1) / DR_RPP, np2 = (k.n2 + DR_RPP - 1) / DR_RPP, np3 = (k.n3 + DR_RPP - 1) / DR_RPP;
+#define FARNN_ROWS_MATCH(F_, A_, B_, C_, D_, E_)                                                                   \
+        if (!pl.form && (A_ == 0 || (k.n1 > 0 && np1 == A_ && k.nch2 == C_)) && (B_ == 0 || (np2 == B_ && k.nch2 == C_)) && \
+            (D_ == 0 || (np3 == D_ && k.nch3 == E_))) {                                                            \
+            /* the matrices left outside the registers must fit the LDS whole: nothing is streamed */           \
+            size_t need = 0;                                                                                       \
+            if (A_ == 0) need += (size_t)k.n1 * k.ld2 * 4;                                                         \
+            if (B_ == 0) need += (size_t)k.n2 * k.ld2 * 4;                                                         \
+            if (D_ == 0) need += (size_t)k.n3 * k.ld3 * 4;                                                         \
+            if (need <= left) {                                                                                    \
+                pl.form = F_;                                                                                      \
+                pl.res1 = A_ == 0 ? k.n1 : 0; pl.res2 = B_ == 0 ? k.n2 : 0; pl.res3 = D_ == 0 ? k.n3 : 0;          \
+                left -= need;                                                                                      \
+            }                                                                                                      \
+        }
+        FARNN_ROWS_FORMS(FARNN_ROWS_MATCH)
+#undef FARNN_ROWS_MATCH
+    }
+    if (!pl.form) {
         pl.res3 = take(k.n3, k.ld3);
         pl.res2 = take(k.n2, k.ld2);
         pl.res1 = take(k.n1, k.ld2);
-        pl.nseq = nseq;
-        pl.lds = cap - left;
-        return true;
     }
+    pl.nseq = nseq;
+    pl.lds = cap - left;
+    return true;
+}
+
+inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, int L, RowsPlan &pl) {
+    const bool forms = !getenv("FARNN_ROWS_NOREGS");
+    if (const char *e = getenv("FARNN_ROWS_NSEQ")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) {
+            for (int n = v; n >= 1; n /= 2)
+                if (rows_plan_try(k, w, L, n, forms, pl)) return true;
+            return false;
+        }
+    }
+    // a register-resident form (one sequence per workgroup, no weight leaves the CU after set-up) beats sharing streamed
+    // weights between sequences for any batch that is not huge: 210 vs 354 us at B = 256 for the gated rank-250 shape
+    if (forms && B <= 1024 && rows_plan_try(k, w, L, 1, true, pl) && pl.form) return true;
+    // measured (B=256, S=104): one sequence per workgroup in two rounds beats two per workgroup in one
+    // (145 vs 168 us at R=50, 374 vs 450 us gated R=250): the x reads and FMAs scale with NSEQ, only the
+    // weight reads are shared
+    int nseq = 1;
+    while (nseq < 4 && 2 * ((B + nseq - 1) / nseq) > 512 * nseq) nseq *= 2;
+    for (; nseq >= 1; nseq /= 2)
+        if (rows_plan_try(k, w, L, nseq, forms, pl)) return true;
     return false;
 }
 
-template <int NSEQ>
+template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0>
 inline int launch_rows_n(const DecompRowsParams &p, int groups, size_t lds, hipStream_t s) {
-    static int raised = -1;     // per process; the attribute is per (device, function) but monotone in lds
+    static int raised = -1;     // per process and instantiation; the attribute is per (device, function) but monotone in lds
     if ((int)lds > raised) {
-        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ>),
+        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = 160 * 1024;
     }
-    decomp_rows_kernel<NSEQ><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
+    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -466,6 +577,9 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     p.full = full; p.V = w.V; p.sig_k = w.sig_k;
     { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int groups = (B + pl.nseq - 1) / pl.nseq;
+#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_>(p, groups, pl.lds, s);
+    FARNN_ROWS_FORMS(FARNN_ROWS_LAUNCH)
+#undef FARNN_ROWS_LAUNCH
     if (pl.nseq == 4) return launch_rows_n<4>(p, groups, pl.lds, s);
     if (pl.nseq == 2) return launch_rows_n<2>(p, groups, pl.lds, s);
     return launch_rows_n<1>(p, groups, pl.lds, s);

@@ -1,9 +1,12 @@
 cd $GRAFT_REPO_ROOT
-run() { env "$@" python bench.py --workload decomp --rank 250 --farnn 2 --steps 60 --warmup 5 --no-cpu-baseline --no-other-configs --no-parity 2>/dev/null | python -c "
+python -m pytest tests/test_gpu_parity_bench_size.py tests/test_gpu_parity_decomposed.py -q 2>&1 | tail -3
+run() { env $1 python bench.py --workload decomp --rank $2 --farnn $3 --batch $4 --steps 60 --warmup 5 --no-cpu-baseline --no-other-configs 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('$*: step %.1f us  kernel %.1f + %.1f 2-stream %.1f' % (d['ms_per_step']*1e3, d['roofline']['chain_avg_us'], d['roofline']['score_decode_avg_us'], d['pipelined']['ms_per_step']*1e3))"; }
-run FARNN_ROWS_NSEQ=0
-run FARNN_ROWS_NSEQ=1
-run FARNN_ROWS_NSEQ=2
-run FARNN_ROWS_NSEQ=4
+print('$*: step %.1f us  kernel %.1f + %.1f 2-stream %.1f parity %s %.3e' % (d['ms_per_step']*1e3, d['roofline']['chain_avg_us'], d['roofline']['score_decode_avg_us'], d['pipelined']['ms_per_step']*1e3, d['parity']['tags_equal'], d['value']))"; }
+run X=0 250 2 256
+run X=0 250 2 304
+run FARNN_ROWS_NOREGS=1 250 2 304
+run X=0 250 2 512
+run FARNN_ROWS_NOREGS=1 250 2 512
+run X=0 50 0 256

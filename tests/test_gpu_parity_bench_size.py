@@ -49,7 +49,7 @@ def _snips_model(R, farnn, crf, seed=1234):
     return V, q, gates, tr
 
 
-@pytest.mark.parametrize('R,farnn,crf', [(50, 0, False), (250, 2, True), (100, 1, False)])
+@pytest.mark.parametrize('R,farnn,crf', [(50, 0, False), (250, 2, True), (100, 1, False), (100, 2, False), (150, 2, True)])
 def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf):
     from re2nn_seq_amd import _lib, synth
     B, L = 256, 64
