@@ -125,8 +125,11 @@ __device__ __forceinline__ void rowdots(const float *ml, const float *mg, int nr
 // The same row dot products with the rows held in REGISTERS for the whole sequence: pass i covers the rows i*128 + tid/4,
 // w[i][2c], w[i][2c+1] are this lane's two 16-byte pieces of chunk c.  The chunk of every x_s is read from LDS once and used
 // by all NP passes.
+// NP and NCH are upper bounds: passes past the last row are not written; chunks past the model's hold zero weights, and their
+// x reads run on into the LDS vectors behind x (state / gate / row floats, or past the allocation: zeros) -- finite times
+// zero.  (Clamping the chunk index instead turned the reads' immediate offsets into address arithmetic: +7 % per step.)
 template <int NSEQ, int NP, int NCH, typename Epi>
-__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, const float *X, int xs, int tid, Epi &&epi) {
+__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi) {
     const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
     lds_cfloat *xl = (lds_cfloat *)X + k * 4;
     v2f tl[NP][NSEQ], th[NP][NSEQ];
@@ -138,7 +141,7 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
     for (int c = 0; c < NCH; c++)
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) {
-            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * DR_CHUNK);
+            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * DR_CHUNK);   // compile-time offsets: the reads stay `ds_read ... offset:`
             const v4f x0 = xp[0], x1 = xp[4];
 #pragma unroll
             for (int i = 0; i < NP; i++) {
@@ -161,14 +164,18 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
 
 // this lane's pieces of the rows of a packed matrix (rows past the last one: a copy of the last, never used)
 template <int NP, int NCH>
-__device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const float *M, int nrows, int ld, int tid) {
+__device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const float *M, int nrows, int ld, int nch, int tid) {
     const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+    const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NP; i++) {
         const int row = i * DR_RPP + rloc;
         glb_cv4f *src = (glb_cv4f *)(M + (long long)(row < nrows ? row : nrows - 1) * ld + k * 4);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) { w[i][2 * c] = src[c * 8]; w[i][2 * c + 1] = src[c * 8 + 4]; }
+        for (int c = 0; c < NCH; c++) {
+            w[i][2 * c] = c < nch ? src[c * 8] : zero;
+            w[i][2 * c + 1] = c < nch ? src[c * 8 + 4] : zero;
+        }
     }
 }
 
@@ -261,9 +268,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
     }
     v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1)], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
     v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3R > 0 ? NCH3R : 1)];
-    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R>(w1, p.P1, p.n1, ld2, tid);
-    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R>(w2, p.P2[dir], p.n2, ld2, tid);
-    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3R>(w3, p.P3[dir], p.n3, ld3, tid);
+    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R>(w1, p.P1, p.n1, ld2, p.nch2, tid);
+    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
+    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3R>(w3, p.P3[dir], p.n3, ld3, p.nch3, tid);
     __syncthreads();
     for (int j = tid; j < S; j += DR_THREADS) {
         const float hv = hinit[j];
@@ -345,7 +352,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP1R > 0) rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, H, c2p, tid, epi1);
+                if constexpr (NP1R > 0) rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
                 else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             }
             wg_barrier_lds();
@@ -359,7 +366,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP2R > 0) rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, HBc, c2p, tid, epi2);
+                if constexpr (NP2R > 0) rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
                 else rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
             }
         }
@@ -394,7 +401,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP3R > 0) rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, X3c, c3p, tid, epi3);
+                if constexpr (NP3R > 0) rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3);
                 else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
             }
         }
@@ -476,10 +483,11 @@ inline int rows_ld(int cols) { return (cols + DR_CHUNK - 1) / DR_CHUNK * DR_CHUN
 
 struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form: which matrices live in registers (0: none)
 
-// register-resident forms that are instantiated (one sequence per workgroup): passes of P1 / P2, chunks of their rows,
-// passes / chunks of P3.  A: gated (farnn = 2) rank <= 252 at 96 < S <= 128 (the shipped shape); B: farnn = 1 with
-// R + S <= 256; C: farnn = 2 at rank ~100.
-#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 12) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 7)
+// register-resident forms that are instantiated (one sequence per workgroup): UPPER BOUNDS on the passes of P1 / P2, the
+// chunks of their rows and the passes / chunks of P3 (in order of cost; the first that holds the model is taken).
+// 1: farnn = 2, S <= 128, Rp + SP <= 224 (rank ~100-120); 2: farnn = 1 with R + S <= 256; 3: farnn = 2, S <= 128,
+// Rp + SP <= 384 (rank 150 / 250: the shipped example configurations).
+#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12)
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -502,8 +510,8 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
     if (forms && nseq == 1) {      // (two sequences per workgroup on these forms: measured slower, spills)
         const int np1 = (k.n1 + DR_RPP - 1) / DR_RPP, np2 = (k.n2 + DR_RPP - 1) / DR_RPP, np3 = (k.n3 + DR_RPP - 1) / DR_RPP;
 #define FARNN_ROWS_MATCH(F_, A_, B_, C_, D_, E_)                                                                   \
-        if (!pl.form && (A_ == 0 || (k.n1 > 0 && np1 == A_ && k.nch2 == C_)) && (B_ == 0 || (np2 == B_ && k.nch2 == C_)) && \
-            (D_ == 0 || (np3 == D_ && k.nch3 == E_))) {                                                            \
+        if (!pl.form && (A_ == 0 || (k.n1 > 0 && np1 <= A_ && k.nch2 <= C_)) && (B_ == 0 || (np2 <= B_ && k.nch2 <= C_)) && \
+            (D_ == 0 || (np3 <= D_ && k.nch3 <= E_)) && (A_ > 0 || k.n1 == 0)) {                                  \
             /* the matrices left outside the registers must fit the LDS whole: nothing is streamed */           \
             size_t need = 0;                                                                                       \
             if (A_ == 0) need += (size_t)k.n1 * k.ld2 * 4;                                                         \
