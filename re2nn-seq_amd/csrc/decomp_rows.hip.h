@@ -487,7 +487,9 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 // chunks of their rows and the passes / chunks of P3 (in order of cost; the first that holds the model is taken).
 // 1: farnn = 2, S <= 128, Rp + SP <= 224 (rank ~100-120); 2: farnn = 1 with R + S <= 256; 3: farnn = 2, S <= 128,
 // Rp + SP <= 384 (rank 150 / 250: the shipped example configurations).
-#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12)
+// 4: farnn = 2 at 128 < S <= 160 (the shipped configurations with --additional_states 30 at this automaton size): the gate
+// rows alone in registers, P2 / P3 in LDS as far as it goes, the rest streamed.
+#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(4, 3, 0, 5, 0, 0)
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -512,16 +514,12 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
 #define FARNN_ROWS_MATCH(F_, A_, B_, C_, D_, E_)                                                                   \
         if (!pl.form && (A_ == 0 || (k.n1 > 0 && np1 <= A_ && k.nch2 <= C_)) && (B_ == 0 || (np2 <= B_ && k.nch2 <= C_)) && \
             (D_ == 0 || (np3 <= D_ && k.nch3 <= E_)) && (A_ > 0 || k.n1 == 0)) {                                  \
-            /* the matrices left outside the registers must fit the LDS whole: nothing is streamed */           \
-            size_t need = 0;                                                                                       \
-            if (A_ == 0) need += (size_t)k.n1 * k.ld2 * 4;                                                         \
-            if (B_ == 0) need += (size_t)k.n2 * k.ld2 * 4;                                                         \
-            if (D_ == 0) need += (size_t)k.n3 * k.ld3 * 4;                                                         \
-            if (need <= left) {                                                                                    \
-                pl.form = F_;                                                                                      \
-                pl.res1 = A_ == 0 ? k.n1 : 0; pl.res2 = B_ == 0 ? k.n2 : 0; pl.res3 = D_ == 0 ? k.n3 : 0;          \
-                left -= need;                                                                                      \
-            }                                                                                                      \
+            /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
+               the sizes they were made for), the remainder is streamed as before */                               \
+            pl.form = F_;                                                                                          \
+            pl.res3 = D_ == 0 ? take(k.n3, k.ld3) : 0;                                                             \
+            pl.res2 = B_ == 0 ? take(k.n2, k.ld2) : 0;                                                             \
+            pl.res1 = A_ == 0 ? take(k.n1, k.ld2) : 0;                                                             \
         }
         FARNN_ROWS_FORMS(FARNN_ROWS_MATCH)
 #undef FARNN_ROWS_MATCH

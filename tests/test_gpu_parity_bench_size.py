@@ -24,10 +24,10 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
-def _snips_model(R, farnn, crf, seed=1234):
+def _snips_model(R, farnn, crf, seed=1234, S=104):
     """The generator bench.py uses for `--workload decomp` (same seed), plus gates / CRF rows on demand."""
     from re2nn_seq_amd import synth
-    V, S, C = 11000, 104, 73
+    V, C = 11000, 73
     wrng = np.random.RandomState(seed)
     p = synth.random_decomposed_params(V, S, C, R, 100, wrng, contractive=True)
     f = lambda a: np.asarray(a, np.float32)                       # noqa: E731
@@ -49,11 +49,14 @@ def _snips_model(R, farnn, crf, seed=1234):
     return V, q, gates, tr
 
 
-@pytest.mark.parametrize('R,farnn,crf', [(50, 0, False), (250, 2, True), (100, 1, False), (100, 2, False), (150, 2, True)])
-def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf):
+@pytest.mark.parametrize('R,farnn,crf,S', [(50, 0, False, 104), (250, 2, True, 104), (100, 1, False, 104), (100, 2, False, 104),
+                                            (150, 2, True, 104), (150, 2, False, 134), (150, 1, False, 134), (120, 0, False, 71)])
+def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf, S):
+    """(the S = 134 cases: `--additional_states 30` on top of the automaton, as two shipped example configurations have it;
+    the ungated rank-120 case: the rows kernel's P2-in-registers form)"""
     from re2nn_seq_amd import _lib, synth
     B, L = 256, 64
-    V, q, gates, tr = _snips_model(R, farnn, crf)
+    V, q, gates, tr = _snips_model(R, farnn, crf, S=S)
     x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4321))       # bench.py's rank-0 batch
     assert lengths.min() >= 5 and lengths.max() == L
     K = q['Cout'].shape[0]
