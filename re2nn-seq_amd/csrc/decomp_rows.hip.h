@@ -65,6 +65,7 @@ struct DecompRowsParams {
     int B, L, S, SP, R, Rp, farnn, nl, full, V;
     float sig_k;
     int dbg;                      // diagnostic ablation mask (FARNN_DBG); 0 in production
+    int lds_floats;               // the launch's dynamic LDS size (a whole KiB), in floats
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -251,7 +252,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
         return v; };
 
     // ---- set-up ------------------------------------------------------------------------------------
-    for (int i = tid; i < (int)(TV - Hinit); i += DR_THREADS) Hinit[i] = 0.0f;
+    // everything a vector read can touch is initialised: the register forms read whole (upper-bound) chunk counts and run on
+    // into the arrays behind the vector -- with zero weights, but LDS keeps what earlier workgroups left there (-inf pads of the
+    // Viterbi kernel: -inf x 0 = NaN).  Vectors and per-token buffers are zeroed here, the tail behind the resident rows below.
+    for (int i = tid; i < (int)(L1 - Hinit); i += DR_THREADS) Hinit[i] = 0.0f;
 #pragma unroll
     for (int s = 0; s < NSEQ; s++)
         for (int k = tid; k < nst[s]; k += DR_THREADS) {
@@ -265,6 +269,8 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
         for (int q = 0; q < 3; q++)
             for (long long i = (long long)tid * 4; i < cnt[q]; i += DR_THREADS * 4) st4(dst[q] + i, ld4(src[q] + i));
+        float *tail = L3 + cnt[2];
+        for (int i = tid; tail + i < smem + p.lds_floats; i += DR_THREADS) tail[i] = 0.0f;
     }
     v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1)], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
     v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3R > 0 ? NCH3R : 1)];
@@ -530,7 +536,7 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
         pl.res1 = take(k.n1, k.ld2);
     }
     pl.nseq = nseq;
-    pl.lds = cap - left;
+    pl.lds = (cap - left + 1023) / 1024 * 1024;              // whole KiB: the kernel zeroes the tail (no allocation-granule slack)
     return true;
 }
 
@@ -582,6 +588,7 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;
     p.full = full; p.V = w.V; p.sig_k = w.sig_k;
     { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.lds_floats = (int)(pl.lds / 4);
     const int groups = (B + pl.nseq - 1) / pl.nseq;
 #define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_>(p, groups, pl.lds, s);
     FARNN_ROWS_FORMS(FARNN_ROWS_LAUNCH)

@@ -136,3 +136,37 @@ def test_onehot_ifst_crf_at_bench_size_vs_oracle():
     assert np.array_equal(fo.flatten(want, lengths), flat.cpu().numpy())
     assert (tags.cpu().numpy()[~mask] == -1).all()
     h.close()
+
+
+def test_register_forms_do_not_see_what_earlier_kernels_left_in_lds():
+    """The rows kernel's register forms read whole (upper-bound) chunk counts of their input vectors and run on into the LDS
+    behind them with zero weights; LDS keeps what earlier workgroups wrote there -- the Viterbi kernel's -inf pads would
+    turn 0 x garbage into NaN.  A Viterbi launch that covers every CU, then a gated decomposed model: scores finite and
+    equal to the oracle's."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(3)
+    Vc, Sc, Cc = 300, 71, 128
+    T, W, O, h0, hT = synth.random_ifst_tensors(Vc, Sc, Cc, rng, edges_per_word=8.0)
+    trc = fo.crf_default_transitions(Cc) + rng.randn(Cc + 2, Cc + 2).astype(np.float32)
+    hc = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0, use_crf=True, crf_trans=trc)
+    xc, lc = synth.random_batch(Vc, 512, 64, rng, min_len=40)
+    xcd, lcd = _t(xc).cuda(), _t(lc).cuda()
+    tc = torch.empty((512, 64), dtype=torch.int32, device='cuda')
+    B, L = 256, 64
+    V, q, gates, tr = _snips_model(100, 2, False)
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4321))
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=2, gates=gates,
+                                sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    K = q['Cout'].shape[0]
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    for _ in range(3):
+        hc.tag(xcd.data_ptr(), lcd.data_ptr(), 512, 64, _lib.MODE_LOCAL, tc.data_ptr(), None, None)
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, None, scores.data_ptr())
+        torch.cuda.synchronize()
+        got = scores.cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    h.close(); hc.close()
