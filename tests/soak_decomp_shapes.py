@@ -1,0 +1,76 @@
+"""Random geometries of the decomposed i-FST (states, rank, gates, CRF, batch, length) through farnn_tag, scores against the
+oracle (1e-4): covers the register kernel, the rows kernel's register forms (upper bounds on passes / chunks), the LDS +
+L2 path, the score tiles and the Viterbi layouts at shapes no fixed test names.    python tests/soak_decomp_shapes.py [n]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import farnn_oracle as fo                    # noqa: E402
+from re2nn_seq_amd import _lib, synth                    # noqa: E402
+
+
+def run(n=60, seed=0, verbose=True):
+    rng = np.random.RandomState(seed)
+    f = lambda a: np.asarray(a, np.float32)              # noqa: E731
+    bad = 0
+    for it in range(n):
+        S = int(rng.choice([5, 17, 40, 64, 71, 96, 104, 128, 134, 150]))
+        R = int(rng.choice([3, 20, 50, 64, 65, 100, 150, 250]))
+        farnn = int(rng.randint(0, 3))
+        crf = bool(rng.rand() < 0.3)
+        C = int(rng.choice([5, 30, 73, 126]))
+        V, B, L = 150, int(rng.choice([1, 7, 24, 40])), int(rng.choice([3, 17, 33, 64]))
+        p = synth.random_decomposed_params(V, S, C, R, 20, rng, contractive=True)
+        Cout = f(p['C_output_mat'])
+        tr = None
+        if crf:
+            Cout = np.concatenate([Cout, (rng.rand(2, S) * 0.01).astype(np.float32)], 0)
+            tr = fo.crf_default_transitions(C) + (rng.randn(C + 2, C + 2) * 1.0).astype(np.float32)
+        q = {'Vgen': f(p['V_embed']), 'S1': f(p['S1']), 'S2': f(p['S2']), 'W': f(p['wildcard_mat']), 'Cout': Cout,
+             'h0': f(p['start_vector']), 'hT': f(p['final_vector']), 'farnn': farnn, 'nl': fo.NL_TANH,
+             'semiring': fo.SEMIRING_SUM, 'sig_k': 5}
+        gates = None
+        if farnn:
+            gates = {'Wss1': f(rng.randn(S, S) * 0.03), 'Wrs1': f(rng.randn(R, S) * 0.03), 'bs1': f(np.full(S, 1.0))}
+            if farnn == 2:
+                gates.update(Wss2=f(rng.randn(S, S) * 0.03), Wrs2=f(rng.randn(R, S) * 0.03), bs2=f(np.full(S, 1.0)))
+            q.update(gates)
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn, gates=gates,
+                                    sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0, use_crf=crf, crf_trans=tr)
+        K = Cout.shape[0]
+        xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+        scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        tags2 = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, scores.data_ptr())
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags2.data_ptr(), None, None)
+        torch.cuda.synchronize()
+        ref = fo.decomp_ifst_scores(q, x, lengths)
+        mask = np.arange(L)[None, :] < lengths[:, None]
+        got = scores.cpu().numpy()
+        err = np.abs(got[mask] - ref[mask]).max() if mask.any() else 0.0
+        ok = np.isfinite(got).all() and err <= 1e-4 + 1e-4 * np.abs(ref[mask]).max()
+        if crf:     # Viterbi on the GPU's own scores, fused and unfused launches
+            own = fo.decode_crf(got, lengths, tr, 0.5, 0)
+            ok = ok and np.array_equal(own[mask], tags.cpu().numpy()[mask]) and np.array_equal(own[mask], tags2.cpu().numpy()[mask])
+        else:
+            ok = ok and np.array_equal(tags.cpu().numpy()[mask], tags2.cpu().numpy()[mask])
+        if not ok:
+            bad += 1
+        if verbose and (not ok or it % 10 == 0):
+            print('{} S={} R={} farnn={} crf={} C={} B={} L={} kernel={} err={:.2e} {}'.format(
+                it, S, R, farnn, crf, C, B, L, h.kernel_name(_lib.KERN_CHAIN), err, 'ok' if ok else 'MISMATCH'), flush=True)
+        h.close()
+    return bad
+
+
+if __name__ == '__main__':
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    bad = run(n)
+    print('soak: {} random decomposed geometries, {} mismatches'.format(n, bad))
+    sys.exit(1 if bad else 0)

@@ -575,3 +575,14 @@ def test_word_table_and_normalisation_folded_on_the_device(add_nl, normalize):
             _lib.create_decomp_ifst_folded(f(Vemb), f(E), f(G), f(beta), f(S1), f(S2), W, Cout, h0, hT, normalize='l2')
         finally:
             del _lib.NORM['l2']
+
+
+def test_decomposed_random_geometries_vs_oracle():
+    """Short form of tests/soak_decomp_shapes.py (150 random geometries ran clean): states x rank x gates x CRF x
+    batch x length drawn at random -- register kernel, the rows kernel's register forms, the LDS + L2 path, score tiles and
+    Viterbi layouts at shapes no fixed test names; scores within 1e-4 of the oracle, Viterbi bit-exact on the GPU's scores."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('soak_decomp_shapes', os.path.join(os.path.dirname(__file__), 'soak_decomp_shapes.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.run(n=int(os.environ.get('FARNN_SOAK_SHAPES', '30')), seed=7, verbose=True) == 0
