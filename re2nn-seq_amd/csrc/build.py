@@ -1,41 +1,101 @@
 """Build libfarnn_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
 
-    python re2nn-seq_amd/csrc/build.py [--force]
+    python re2nn-seq_amd/csrc/build.py [--force] [--probes]
+
+Every `*.hip` file of this directory is one translation unit: they compile in parallel to
+`build/<name>.o` and link into `libfarnn_hip.so`.  A unit is recompiled when the sha256 of its
+source, of the headers it included last time (hipcc -MD) or of the flags changed -- content, not
+mtimes, so a prebuilt library newer than edited sources is never mistaken for current.
+`--probes` (or FARNN_PROBES=1) builds the profiling variant: -DFARNN_PROBES compiles the kernels'
+s_memtime phase probes and their printf in; the production object has none of them.
 """
+import hashlib
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, 'farnn_hip.hip')
 OUT = os.path.join(HERE, 'libfarnn_hip.so')
+OBJ = os.path.join(HERE, 'build')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 
-def _sources():
-    root = os.path.dirname(os.path.dirname(HERE))
-    srcs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(('.hip', '.h'))]
-    srcs.append(os.path.join(root, 'include', 'farnn.h'))
-    return srcs
+def _units():
+    return sorted(os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith('.hip'))
 
 
-def up_to_date():
-    if not os.path.exists(OUT):
-        return False
-    t = os.path.getmtime(OUT)
-    return all(os.path.getmtime(s) <= t for s in _sources())
+def _flags(probes):
+    extra = os.environ.get('FARNN_EXTRA_FLAGS', '').split()
+    return FLAGS + (['-DFARNN_PROBES=1'] if probes else []) + extra
 
 
-def build_hip(force=False, verbose=True):
-    if not force and up_to_date():
-        return OUT
-    cmd = [HIPCC] + FLAGS + os.environ.get('FARNN_EXTRA_FLAGS', '').split() + ['-o', OUT, SRC]
+def _deps(depfile):
+    """the prerequisites a make-style depfile lists (system headers under /opt/rocm are skipped)"""
+    try:
+        text = open(depfile).read()
+    except OSError:
+        return None
+    text = text.replace('\\\n', ' ')
+    deps = []
+    for line in text.split('\n'):
+        if ':' not in line:
+            continue
+        for tok in line.split(':', 1)[1].split():
+            if not tok.startswith(('/opt/', '/usr/')):
+                deps.append(tok if os.path.isabs(tok) else os.path.join(HERE, tok))
+    return deps
+
+
+def _digest(files, flags):
+    h = hashlib.sha256(' '.join(flags).encode())
+    for f in sorted(set(files)):
+        try:
+            h.update(open(f, 'rb').read())
+        except OSError:
+            return None
+    return h.hexdigest()
+
+
+def _compile(src, flags, force, verbose):
+    name = os.path.splitext(os.path.basename(src))[0]
+    obj, dep, stamp = (os.path.join(OBJ, name + ext) for ext in ('.o', '.d', '.sha'))
+    if not force and os.path.exists(obj):
+        deps = _deps(dep)
+        if deps is not None:
+            want = _digest([src] + deps, flags)
+            try:
+                if want and open(stamp).read().strip() == want:
+                    return obj, False
+            except OSError:
+                pass
+    cmd = [HIPCC] + flags + ['-c', '-MD', '-MF', dep, '-o', obj, src]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)
+    digest = _digest([src] + (_deps(dep) or []), flags)
+    with open(stamp, 'w') as f:
+        f.write(digest or '')
+    return obj, True
+
+
+def build_hip(force=False, verbose=True, probes=None):
+    if probes is None:
+        probes = os.environ.get('FARNN_PROBES', '') not in ('', '0')
+    os.makedirs(OBJ, exist_ok=True)
+    flags = _flags(probes)
+    units = _units()
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
+        done = list(pool.map(lambda s: _compile(s, flags, force, verbose), units))
+    objs = [o for o, _ in done]
+    if any(changed for _, changed in done) or not os.path.exists(OUT):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
     return OUT
 
 
 if __name__ == '__main__':
-    build_hip(force='--force' in sys.argv)
+    build_hip(force='--force' in sys.argv, probes=True if '--probes' in sys.argv else None)
