@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libfarnn_hip.so')
+# FARNN_LIB: a diagnostic build of the same library (csrc/build.py --probes); never a different implementation
+LIB_PATH = os.environ.get('FARNN_LIB') or os.path.join(_HERE, 'csrc', 'libfarnn_hip.so')
 
 OK = 0
 NL = {'none': 0, 'relu': 1, 'tanh': 2, 'relutanh': 3, 'sigmoid': 4}

@@ -6,8 +6,9 @@ Every `*.hip` file of this directory is one translation unit: they compile in pa
 `build/<name>.o` and link into `libfarnn_hip.so`.  A unit is recompiled when the sha256 of its
 source, of the headers it included last time (hipcc -MD) or of the flags changed -- content, not
 mtimes, so a prebuilt library newer than edited sources is never mistaken for current.
-`--probes` (or FARNN_PROBES=1) builds the profiling variant: -DFARNN_PROBES compiles the kernels'
-s_memtime phase probes and their printf in; the production object has none of them.
+`--probes` (or FARNN_PROBES=1) builds the profiling variant libfarnn_hip_probes.so beside it (objects
+under build_probes/): -DFARNN_PROBES compiles the kernels' s_memtime phase probes and their printf
+in; the production library has none of them.  FARNN_LIB=<path> makes the package load that variant.
 """
 import hashlib
 import os
@@ -58,9 +59,9 @@ def _digest(files, flags):
     return h.hexdigest()
 
 
-def _compile(src, flags, force, verbose):
+def _compile(src, flags, force, verbose, objdir):
     name = os.path.splitext(os.path.basename(src))[0]
-    obj, dep, stamp = (os.path.join(OBJ, name + ext) for ext in ('.o', '.d', '.sha'))
+    obj, dep, stamp = (os.path.join(objdir, name + ext) for ext in ('.o', '.d', '.sha'))
     if not force and os.path.exists(obj):
         deps = _deps(dep)
         if deps is not None:
@@ -83,18 +84,20 @@ def _compile(src, flags, force, verbose):
 def build_hip(force=False, verbose=True, probes=None):
     if probes is None:
         probes = os.environ.get('FARNN_PROBES', '') not in ('', '0')
-    os.makedirs(OBJ, exist_ok=True)
+    objdir = OBJ + '_probes' if probes else OBJ
+    out = OUT.replace('.so', '_probes.so') if probes else OUT
+    os.makedirs(objdir, exist_ok=True)
     flags = _flags(probes)
     units = _units()
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
-        done = list(pool.map(lambda s: _compile(s, flags, force, verbose), units))
+        done = list(pool.map(lambda s: _compile(s, flags, force, verbose, objdir), units))
     objs = [o for o, _ in done]
-    if any(changed for _, changed in done) or not os.path.exists(OUT):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+    if any(changed for _, changed in done) or not os.path.exists(out):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.run(cmd, check=True, cwd=HERE)
-    return OUT
+    return out
 
 
 if __name__ == '__main__':

@@ -1,0 +1,31 @@
+// libfarnn_hip.so -- K1r, the register-fed recurrence with the score + decode stage beside it (chain_regs.hip.h), and its launcher.
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include "common.hip.h"
+#include "host_util.hip.h"
+#include "chain_regs.hip.h"
+
+namespace farnn {
+
+int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int NP = RG_NWC * p.G;
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, NP, p.sp.c16, p.sp.Kc, score).total * sizeof(float);
+    const dim3 grid(2 * p.B), block(RG_WAVES * 64);
+    int rc;
+#define FARNN_LAUNCH_REGS(MX, SC)                                                              \
+    do {                                                                                       \
+        if ((rc = raise_lds_limit(chain_regs_kernel<MX, SC>, lds))) return rc;                 \
+        if (e0 && e1)                                                                          \
+            hipExtLaunchKernelGGL((chain_regs_kernel<MX, SC>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
+        else                                                                                   \
+            chain_regs_kernel<MX, SC><<<grid, block, lds, s>>>(p);                            \
+    } while (0)
+    if (maxsr) { if (score) FARNN_LAUNCH_REGS(true, true); else FARNN_LAUNCH_REGS(true, false); }
+    else       { if (score) FARNN_LAUNCH_REGS(false, true); else FARNN_LAUNCH_REGS(false, false); }
+#undef FARNN_LAUNCH_REGS
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+}  // namespace farnn

@@ -1,0 +1,79 @@
+// Host-visible half of K1r (chain_regs.hip.h): parameters, geometry, LDS carve and the launcher that chain_regs.hip exports to
+// the library's other translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.hip.h"
+#include "score_params.hip.h"
+
+namespace farnn {
+
+constexpr int RG_NWC = 6;        // compute wavefronts
+constexpr int RG_WAVES = 8;      // + writer + scorer
+constexpr int RG_D = 4;          // steps of block pieces in flight per lane
+constexpr int RG_RQ = 4;         // rows per lane per step (one float4 of the state)
+constexpr int RG_TT = 16;        // tokens per score tile
+constexpr int RG_MAXG = 4;       // row groups per compute wavefront
+
+struct RegsParams {
+    const float *Mf, *Mb;        // [V][SR][SP] blocks and their transposes (layout.hip.h)
+    long long blk;               // floats per block
+    const float *o, *h0, *hT;
+    const int64_t *x, *len;
+    const int *order;            // launch order or nullptr
+    int sort;                    // 1: every workgroup selects its sequence by length rank (launch_order.hip.h)
+    float *A, *Bk;               // stash [B][L+1][SP]
+    int B, L, S, SP, CPR, V;
+    int G, RPG;                  // row groups per compute wavefront, rows per group
+    int nl, full;
+    unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
+    unsigned long long *arr;     // [B]    {epoch, 1 << 31 | tiles scored} of the workgroup that finished first
+    unsigned *claim;             // [B][NT] epoch of the launch that claimed the tile
+    unsigned epoch;
+    int NT;                      // claim words per sequence (>= ceil(L / 16))
+    int spin;                    // polls a finished workgroup spends on a tile of its own half before it leaves it to the other
+    int solo_margin;             // the scorer starts a tile alone only if the chain has at least this many steps left after it
+    ScoreParams sp;
+};
+
+struct RegsGeom {
+    int G, RPG, NP, CPR, SP, rows;
+    bool ok;
+};
+
+inline RegsGeom regs_geometry(int S) {
+    RegsGeom g;
+    g.SP = round_up(S, 4);
+    g.CPR = g.SP / 4;
+    g.ok = g.CPR <= 64 && S >= 1;
+    g.G = g.ok ? 64 / g.CPR : 1;
+    if (g.G > RG_MAXG) g.G = RG_MAXG;
+    g.NP = RG_NWC * g.G;
+    g.RPG = (S + g.NP - 1) / g.NP;
+    if (g.RPG > RG_RQ) g.ok = false;
+    g.rows = (g.NP - 1) * g.RPG + RG_RQ;      // every row index a lane's four loads can form
+    return g;
+}
+
+// LDS carve, in floats (host and device agree through this one function)
+struct RegsLds {
+    int tok, hp, part, ol, hist, ab, scl, misc, total;
+};
+__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score) {
+    RegsLds l;
+    int at = 0;
+    l.tok = at;  at += 2 * ((L + 1) & ~1);             // a 64-bit block offset per step
+    l.hp = at;   at += NP * 4;
+    l.part = at; at += 2 * NP * SP;
+    l.ol = at;   at += SP;
+    l.hist = at; at += (L + 1) * SP + 16;          // + the launch-order scratch's tail
+    l.ab = at;   at += score ? RG_TT * (16 * c16 + 4) : 0;
+    l.scl = at;  at += score ? RG_TT * Kc : 0;
+    l.misc = at; at += 32;
+    l.total = at;
+    return l;
+}
+
+// launches chain_regs_kernel<maxsr, score> on 2 * p.B workgroups; e0 / e1: optional events on the dispatch packet
+int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+
+}  // namespace farnn

@@ -19,6 +19,7 @@
 #include "decomp_regs.hip.h"
 #include "compact.hip.h"
 #include "host_util.hip.h"
+#include "chain_regs_params.hip.h"
 
 namespace farnn {
 thread_local char g_err[512] = "";
@@ -76,6 +77,12 @@ struct farnn_model {
     int wsB = 0, wsL = 0;                   // workspace CAPACITY: sequences, positions
     int curL = 0;                           // the current call's L: every stride of the workspace arrays
     ChainGeom geom;
+    RegsGeom rgeom;                         // geometry of the register-fed recurrence kernel (chain_regs.hip.h); rgeom.ok: usable
+    unsigned long long *hs = nullptr;       // hand-off words of that kernel: progress [2][B], arrival [B] (64-bit), claims [B][hsNT]
+    int hsNT = 0;                           // claim words per sequence
+    size_t hs_bytes = 0;
+    unsigned epoch_u = 0;                   // launches of that kernel in its scoring form so far (0 is never a launch's epoch)
+    bool last_regs = false;                 // the last recurrence ran on chain_regs_kernel
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
     bool dense_decomp = false;              // decomposed model served by dense per-word blocks + chain_kernel
@@ -162,6 +169,15 @@ static int upload_transposed(farnn_model *m, float **dst, const float *src, int 
     return FARNN_OK;
 }
 
+
+// the dense-block recurrence's geometries: the ring kernel's (chain.hip.h) and the register-fed kernel's (chain_regs.hip.h);
+// the blocks get enough zero rows for either
+static void pick_chain_geometry(farnn_model *m) {
+    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    m->rgeom = regs_geometry(m->S);
+    if (m->rgeom.SP != m->geom.SP) m->rgeom.ok = false;
+    if (m->rgeom.ok && m->rgeom.rows > m->geom.SR) m->geom.SR = m->rgeom.rows;
+}
 
 static int default_crf_transitions(std::vector<float> &tr, int K) {
     // CRF.__init__ (crf.py:39-46): zeros, [:,START]=-1e4, [STOP,:]=-1e4
@@ -251,7 +267,7 @@ static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_m
     m->K = d->C + (m->use_crf ? 2 : 0);
     m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    pick_chain_geometry(m);
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -341,11 +357,13 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
         FARNN_HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); (void)hipFree(m->order);
         if (m->pair_cnt) (void)hipFree(m->pair_cnt);
+        if (m->hs) (void)hipFree(m->hs);
         if (m->crf_scores) (void)hipFree(m->crf_scores);
         if (m->d1_br) (void)hipFree(m->d1_br);
     }
     m->d1_br = nullptr;
     m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->pair_cnt = nullptr; m->wsB = m->wsL = 0;
+    m->hs = nullptr;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
@@ -353,6 +371,10 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->pair_cnt, (size_t)2 * nB * sizeof(int)));
     FARNN_HIP_TRY(hipMemset(m->pair_cnt, 0, (size_t)2 * nB * sizeof(int)));
+    m->hsNT = (nL + RG_TT - 1) / RG_TT;
+    m->hs_bytes = round_up_sz((size_t)3 * nB * sizeof(unsigned long long) + (size_t)nB * m->hsNT * sizeof(unsigned), 16);
+    FARNN_HIP_TRY(hipMalloc((void **)&m->hs, m->hs_bytes));
+    FARNN_HIP_TRY(hipMemset(m->hs, 0, m->hs_bytes));
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     if (m->d1_BSSp)
@@ -429,6 +451,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     switch (which) {
         case KERN_CHAIN:
             if (m->compact_on) return "compact_chain_kernel";
+            if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
             if (m->last_fused) return "chain_kernel<fused score+decode epilogue>";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
@@ -452,6 +475,52 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
                         hipStream_t s, const ScoreParams *fuse_sp = nullptr, bool *fused = nullptr) {
     const ChainGeom &g = m->geom;
     if (fused) *fused = false;
+    m->last_regs = false;
+    // ---- the register-fed kernel (chain_regs.hip.h) where its geometry applies: S <= 72, two workgroups per compute unit.
+    // With fuse_sp (threshold/argmax decode, K <= 256) the scores and the decode run beside the recurrence: ONE launch.
+    if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0)) {
+        const RegsGeom &rg = m->rgeom;
+        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= 5 && m->Kc <= 256 && m->curL <= 1023 &&
+                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
+        if (score) {
+            // the hand-off words carry the launch's epoch, a kernel argument: a captured launch would replay with a frozen one.
+            // Under stream capture the step is two launches (recurrence, score kernel) with no state between replays.
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) score = false;
+        }
+        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score).total * sizeof(float);
+        if (score && lds > 80 * 1024) {             // the score tiles do not fit beside a second workgroup: recurrence only
+            score = false;
+            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false).total * sizeof(float);
+        }
+        if (lds <= 80 * 1024) {
+            RegsParams rp;
+            memset(&rp, 0, sizeof(rp));
+            rp.Mf = m->Mf; rp.Mb = m->Mb; rp.blk = (long long)m->geom.SR * m->SP;
+            rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
+            rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
+            rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
+            rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full;
+            if (score) {
+                if (++m->epoch_u == 0) {            // the epoch wrapped: no word of an earlier launch may look current
+                    FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
+                    m->epoch_u = 1;
+                }
+                rp.prog = m->hs; rp.arr = m->hs + (size_t)2 * m->wsB;
+                rp.claim = reinterpret_cast<unsigned *>(m->hs + (size_t)3 * m->wsB);
+                rp.epoch = m->epoch_u; rp.NT = m->hsNT;
+                rp.spin = env_int("FARNN_FUSE_SPIN", 64);
+                rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 6);
+                rp.sp = *fuse_sp;
+                if (fused) *fused = true;
+            }
+            KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
+            const int rc = launch_chain_regs(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1);
+            if (rc) return rc;
+            m->last_regs = true;
+            return FARNN_OK;
+        }
+    }
     ChainParams p;
     p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
@@ -538,7 +607,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 static int build_dense_blocks(farnn_model *m) {
     const DecompWeights &w = m->dw;
     if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask) || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    pick_chain_geometry(m);
     m->chain_ks = env_int("FARNN_KS", 3);
     if (m->geom.NCH > 4 || m->geom.SP != m->SP) return FARNN_OK;
     const size_t nM = (size_t)m->V * m->geom.SR * m->SP;
@@ -1121,7 +1190,7 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
     m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    pick_chain_geometry(m);
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -1162,7 +1231,7 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     m->mask_by_output = d->mask_by_output;
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    pick_chain_geometry(m);
     m->chain_ks = env_int("FARNN_KS", 3);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
@@ -1653,6 +1722,7 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->pair_cnt) (void)hipFree(m->pair_cnt);
     if (m->crf_scores) (void)hipFree(m->crf_scores);
     if (m->d1_br) (void)hipFree(m->d1_br);
+    if (m->hs) (void)hipFree(m->hs);
     delete m;
 }
 

@@ -18,28 +18,9 @@
 // left in the workspace (B*L*K floats, ~1% of the chain kernel's traffic).
 #pragma once
 #include "common.hip.h"
+#include "score_params.hip.h"
 
 namespace farnn {
-
-struct ScoreParams {
-    const float *A, *Bk;    // stash [B][L+1][SP]
-    const float *OT;        // [S][Kc] transposed output matrix, columns >= K zero (alloc padded to 1 KiB)
-    const float *P;         // [K][Kc] priority matrix or nullptr
-    const float *trT;       // [K][Kp] TRANSPOSED CRF transitions trT[j][i] = tr[i][j], or nullptr
-    const int64_t *len;     // [B]
-    const int64_t *offs;    // [B+1] exclusive prefix of lengths (flat output) or nullptr: with `flat` set the
-                            //        kernel then sums the lengths before its sequence itself (B <= 1024)
-    int32_t *tags;          // [B][L] or nullptr
-    int64_t *flat;          // [sum len] or nullptr
-    float *scores;          // [B][L][K] or nullptr (unclamped, what forward_score returns)
-    float *crf_scores;      // [B][L][Kp] workspace: clamped scores for the Viterbi kernel
-    const float *OTm;       // matrix-core image of OT (ot_to_mfma_kernel), c16 = ceil(S/16) state groups
-    int c16;
-    int B, L, S, SP, K, Kp, Kc, kch;
-    int full, use_crf, o_idx;
-    float threshold;
-    int dbg;                // diagnostic ablation mask (FARNN_DBG bits 16/32/64); 0 in production
-};
 
 constexpr int SCORE_KCH = 4;       // label columns per lane: K <= 256
 constexpr int SCORE_WAVES = 8;
