@@ -59,7 +59,17 @@ def _digest(files, flags):
     return h.hexdigest()
 
 
+def _unit_flags(src):
+    """extra flags a unit asks for itself: a line `// build-flags: <flags>` in its first lines"""
+    with open(src) as f:
+        for _, line in zip(range(12), f):
+            if line.startswith('// build-flags:'):
+                return line.split(':', 1)[1].split()
+    return []
+
+
 def _compile(src, flags, force, verbose, objdir):
+    flags = flags + _unit_flags(src)
     name = os.path.splitext(os.path.basename(src))[0]
     obj, dep, stamp = (os.path.join(objdir, name + ext) for ext in ('.o', '.d', '.sha'))
     if not force and os.path.exists(obj):

@@ -34,16 +34,21 @@
 //   consumer: ONE lane polls that word (relaxed, sc1), then ONE agent-scope acquire fence (buffer_inv sc1), then the loads
 //             (the acquiring wavefront's own; other wavefronts behind s_waitcnt vmcnt(0) + a workgroup barrier); the loads of
 //             handed-off rows are sc1 loads on top of that.
-// Nobody waits for a workgroup that may not be resident: every wait on the other direction is bounded, tiles are claimed
-// by an atomic exchange of the launch's epoch (exactly once), and each workgroup ends with an exchange on the sequence's
-// arrival word: the one that finds the other's entry there sweeps up every tile nobody claimed -- by then both stashes are
-// complete and published.  All words carry the launch's epoch: nothing is reset between launches and an aborted launch
-// leaves nothing behind that a later one could mistake for its own.
+// Nobody waits for a workgroup that may not be resident: every wait on the other direction is bounded.  Until its arrival
+// a workgroup scores tiles of its OWN half only (the halves are disjoint), then it exchanges the sequence's arrival word
+// for {epoch, the mask of its tiles}: the workgroup that finds the other's word there scores every tile in neither mask --
+// by then both stashes are complete and published -- so every tile is scored exactly once.  All words carry the launch's
+// epoch: nothing is reset between launches and an aborted launch leaves nothing behind that a later one could mistake
+// for its own.
 #pragma once
 #include "common.hip.h"
 #include "score_params.hip.h"
 #include "launch_order.hip.h"
 #include "chain_regs_params.hip.h"
+
+#ifndef FARNN_ABLATE
+#define FARNN_ABLATE 0       /* timing-only ablation builds set bits; the shipped library is built with 0 */
+#endif
 
 namespace farnn {
 
@@ -75,15 +80,17 @@ __device__ __forceinline__ int lds_flag_get(const int *f) {
     return v;
 }
 // steps every compute wavefront has finished, as the polling wavefront sees them (lane i reads wavefront i's flag)
-__device__ __forceinline__ bool regs_flags_reached(const int *flags, int lane, int target) {
-    const int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0));
-    return __ballot(v < target) == 0ull;
+// (a compute wavefront's flag: the steps whose partial sums it has written; the state row of step t -- row t + 1 of `hist` -- is
+// complete once every flag reads t + 2, or nsteps + 1 after the last step)
+__device__ __forceinline__ bool regs_rows_reached(const int *flags, int lane, int rows) {
+    const int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0) * 64);
+    return __ballot(v < rows + 1) == 0ull;
 }
-__device__ __forceinline__ int regs_flags_min(const int *flags, int lane) {
-    int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0));
+__device__ __forceinline__ int regs_rows_done(const int *flags, int lane) {
+    int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0) * 64);
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) v = min(v, __shfl_xor(v, off, WAVE));
-    return __builtin_amdgcn_readfirstlane(v);
+    return __builtin_amdgcn_readfirstlane(v) - 1;
 }
 
 __device__ __forceinline__ float quad_sum(float x) {
@@ -103,10 +110,14 @@ __device__ __forceinline__ float quad_max(float x) {
 template <bool COOP>
 __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b, const int dir, const int len, const int nsteps,
                                                 const int k, const float *hist, float *ab, float *scl, const long long foff,
-                                                const int wv, const int lane) {
+                                                const int wv, const int lane_in) {
+    // Everything per-lane below is derived from this opaque copy: left to itself the compiler hoists the tile's index and
+    // address arithmetic out of the callers' tile loops and then spills it (56-448 bytes of scratch per lane, measured)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
     const ScoreParams &sp = p.sp;
     constexpr int NWV = COOP ? RG_WAVES : 1;
-    constexpr int CH = COOP ? 1 : 4;                     // column blocks a wavefront runs side by side (shared A fragments)
+    constexpr int CH = COOP ? 1 : 2;                     // column blocks a wavefront runs side by side (shared A fragments)
     constexpr int NIT = COOP ? 1 : 5;                    // product items per lane: 16 tokens x 4 c16 float4 columns, c16 <= 5
     const int c16 = sp.c16, SPa = 16 * c16 + 4, SP = p.SP, K = sp.K, Kc = sp.Kc, ncb = Kc / 16;
     const int t0 = k * RG_TT;
@@ -114,6 +125,26 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
     const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
     const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
     const int G4 = 4 * c16;
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NG = 5;                                // state groups of 16 (c16 <= 5: the launcher checks)
+    const int lr = lane & 15, lk = lane >> 4;
+    const f32x4 *otm = reinterpret_cast<const f32x4 *>(sp.OTm);      // uniform base; the lane is the load's vector offset
+    asm volatile("" : "+s"(otm));                        // (its address arithmetic stays inside the tile: hoisted out of the tile loops, the
+                                                         //  dozens of 64-bit addresses cost more registers than the kernel has)
+    // B fragments of a run of CH column blocks: ALL state groups at once (one round trip to L2, not one per group -- beside
+    // twelve wavefronts that keep sixteen block loads in flight each, a dependent load of this wavefront takes microseconds)
+    f32x4 bf[NG][CH];
+    auto load_b = [&](int cb0) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            const int gc = g < c16 ? g : c16 - 1;
+#pragma unroll
+            for (int q = 0; q < CH; q++) {
+                const int cb = cb0 + q < ncb ? cb0 + q : ncb - 1;
+                bf[g][q] = (otm + ((long long)cb * c16 + gc) * 64)[lane];
+            }
+        }
+    };
     // ---- phase 1: ab[tok][s] = a[i+1][s] * bt[i+1][s]; the own direction's rows from LDS, the other's from the stash
     {
         float4 oth[NIT];
@@ -131,6 +162,7 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
             const float *src = (dir == 0 ? Bb + (long long)bi * SP : Ab + (long long)ai * SP) + (s4 < SP ? s4 : 0);
             oth[it] = ld4_agent(src);
         }
+        if (wv * CH < ncb) load_b(wv * CH);              // in flight while the products are formed
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
             if (tokv[it] < RG_TT) {
@@ -144,40 +176,28 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
         }
     }
     if (COOP) __syncthreads(); else asm volatile("" ::: "memory");
-    // ---- phase 2: scl[16][Kc] = ab . O^T on the f32 matrix cores; B fragments from the matrix-core image of O^T in L2
+    // ---- phase 2: scl[16][Kc] = ab . O^T on the f32 matrix cores
     {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int lr = lane & 15, lk = lane >> 4;
         const float *arow = ab + lr * SPa + lk;
-        const f32x4 *otm = reinterpret_cast<const f32x4 *>(sp.OTm) + lane;
         for (int cb0 = wv * CH; cb0 < ncb; cb0 += NWV * CH) {
-            f32x4 acc[CH], bc[CH], bn[CH];
+            if (cb0 != wv * CH) load_b(cb0);
+            f32x4 acc[CH];
 #pragma unroll
             for (int q = 0; q < CH; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            auto load_b = [&](int g, f32x4 (&dst)[CH]) {
-                const int gc = g < c16 ? g : c16 - 1;
 #pragma unroll
-                for (int q = 0; q < CH; q++) {
-                    const int cb = cb0 + q < ncb ? cb0 + q : ncb - 1;
-                    dst[q] = otm[((long long)cb * c16 + gc) * 64];
+            for (int g = 0; g < NG; g++) {
+                if (g < c16) {
+                    const float *ap = arow + 16 * g;
+                    const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
+#pragma unroll
+                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[g][q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[g][q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[g][q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[g][q].w, acc[q], 0, 0, 0);
                 }
-            };
-            load_b(0, bc);
-#pragma unroll 1
-            for (int g = 0; g < c16; g++) {
-                load_b(g + 1, bn);
-                const float *ap = arow + 16 * g;
-                const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-#pragma unroll
-                for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bc[q].x, acc[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bc[q].y, acc[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bc[q].z, acc[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bc[q].w, acc[q], 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < CH; q++) bc[q] = bn[q];
             }
 #pragma unroll
             for (int q = 0; q < CH; q++) {
@@ -284,11 +304,12 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
 }
 
 // misc words in LDS
-enum { RGM_SFLAG = 0,        // [6] partial sums of step t written: t + 1
-       RGM_DFLAG = 8,        // [6] state row t + 1 written:        t + 1
+enum { RGM_SFLAG = 32,       // [6][64] a compute wavefront's step flag, one word per lane (lane 0's is polled)
        RGM_FOFF = 16,        // where the sequence starts in the flat output
-       RGM_MINE_LO = 17, RGM_MINE_HI = 18,     // tiles this workgroup's scorer took while the chain ran
-       RGM_COOP_K = 19 };    // the tile the workgroup scores next, or -1
+       RGM_MINE = 17,        // tiles this workgroup's scorer did while the chain ran (bit k = tile k)
+       RGM_ACQ = 18,         // the other direction's progress covered by this workgroup's latest acquire
+       RGM_TODO = 19,
+       RGM_IDENT = 20 };     // the partial-sum reduction's identity (0.0f / -inf): what a masked read returns      // tiles the eight wavefronts score together next
 
 // FARNN_PROBES (profiling build only): s_memtime stamps of the workgroups of full-length sequences, printed at their end
 #if defined(FARNN_PROBES)
@@ -297,7 +318,7 @@ enum { RGM_SFLAG = 0,        // [6] partial sums of step t written: t + 1
 #define FARNN_RG_STAMP(i) do { } while (0)
 #endif
 
-template <bool MAXSR, bool SCORE>
+template <bool MAXSR, bool SCORE, bool NLX>
 __global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD = 128 VGPRs: two workgroups per compute unit
 chain_regs_kernel(const RegsParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -310,7 +331,7 @@ chain_regs_kernel(const RegsParams p) {
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
     const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
-    float *hp = smem + lds.hp, *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
+    float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
     float *ab = smem + lds.ab, *scl = smem + lds.scl;
     int *misc = reinterpret_cast<int *>(smem + lds.misc);
 
@@ -330,22 +351,16 @@ chain_regs_kernel(const RegsParams p) {
         const int idx = (dir == 0) ? k : (k < len ? len - 1 - k : k);
         tokoff[k] = (long long)clamp_tok(p.x[(long long)b * p.L + idx], p.V) * p.blk * 4;
     }
-    for (int idx = tid; idx < NP * 4; idx += nthreads) {
-        const int gi = idx >> 2, ii = idx & 3, row = gi * RPG + ii;
-        float v = 0.0f;
-        if (ii < RPG && row < S) {
-            v = hinit[row];
-            if (dir == 1 && p.o) v *= p.o[row];                       // the backward chain's input is pre-scaled (:393)
-        }
-        hp[idx] = v;
-    }
     for (int j = tid; j < SP; j += nthreads) ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
     for (int j = tid; j < (nsteps + 1) * SP; j += nthreads) hist[j] = (j < S) ? hinit[j] : 0.0f;     // row 0; pad columns zero
-    if (tid < 32) misc[tid] = tid == RGM_COOP_K ? -1 : 0;
+    if (tid < 32 + RG_NWC * 64) misc[tid] = tid == RGM_ACQ ? -1 : (tid == RGM_IDENT && MAXSR ? (int)0xff800000u : 0);
     __syncthreads();
     if (w == 0) FARNN_RG_STAMP(1);
+#if FARNN_ABLATE & 256                               /* 256 = set-up only */
+    return;
+#endif
 
-    int *sflag = misc + RGM_SFLAG, *dflag = misc + RGM_DFLAG;
+    int *sflag = misc + RGM_SFLAG;
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
     int kmid = 0;                                    // tiles kmid.. belong to the forward workgroup's half, the rest to the backward one's
@@ -372,24 +387,46 @@ chain_regs_kernel(const RegsParams p) {
 #pragma unroll
             for (int u = 0; u < RG_RQ; u++) voff[u] = ((unsigned)(row0 + u) * (unsigned)SP + (unsigned)c * 4u) * 4u;
             const char *Mbase = reinterpret_cast<const char *>(dir == 0 ? p.Mf : p.Mb);
-            const float *myhp = hp + gid * 4;
             const int rows_w = G * RPG;
             const int rj = lane >> 2, rs = lane & 3;              // reduce: four lanes per row
             const int my_row = w * rows_w + rj;
             const bool my_valid = rj < rows_w && my_row < S;
             const bool my_writer = my_valid && rs == 0;
-            const int my_hp = my_valid ? (w * G + rj / RPG) * 4 + rj % RPG : 0;
-            const int rowc = my_valid ? my_row : 0;
             const float my_o = my_valid ? ol[my_row] : 1.0f;
-            const int nl_mode = p.nl;
             const float ninf = -INFINITY;
             bool okrow[RG_RQ];
 #pragma unroll
             for (int u = 0; u < RG_RQ; u++) okrow[u] = u < RPG && row0 + u < S;
+            // Everything a step addresses in LDS is a per-lane pointer computed ONCE, and every lane always has somewhere to
+            // read or write: the two partial-sum buffers sit RG_PART_STRIDE floats apart (a compile-time immediate on the
+            // ds_ instructions: the unrolled step knows its buffer), idle lanes store to a dump slot, masked reads point at a
+            // word that holds the sum's identity.  No EXEC juggling, no address arithmetic, no select in the step.
             constexpr int NQI = (RG_NWC * RG_MAXG + 3) / 4;      // partial vectors per reducing lane, at most
-            int qoff[NQI];                                       // this lane's partial vectors (clamped: the mask below drops the repeats)
+            float *ident = reinterpret_cast<float *>(misc + RGM_IDENT);     // 0.0f (sum) or -inf (max)
+            float *dump = part + 2 * RG_PART_STRIDE;             // [64][4]
+            const float *qptr[NQI];                              // this lane's partial-vector entries in buffer 0
 #pragma unroll
-            for (int i = 0; i < NQI; i++) qoff[i] = ((rs + 4 * i < NP) ? rs + 4 * i : rs) * SP + rowc;
+            for (int i = 0; i < NQI; i++)
+                qptr[i] = (my_valid && rs + 4 * i < NP) ? part + (rs + 4 * i) * SP + my_row : ident;
+            float *wptr = active ? part + gid * SP + c * 4 : dump + lane * 4;                  // this lane's partial sums, buffer 0
+            float *hptr = my_writer ? hist + SP + my_row : dump + lane * 4;                      // where this lane's new state goes
+            const int hstep = my_writer ? SP : 0;
+            // The state entries a lane multiplies with -- rows g * RPG + u of this wavefront's share -- come straight from the
+            // lanes that finish them (row j sits in lanes 4j .. 4j + 3 after the quad reduce): one ds_bpermute each, no
+            // LDS store + load round trip.  hs[u] holds them from step to step (pre-scaled for the backward chain, :393).
+            int bsrc[RG_RQ];
+            float hs[RG_RQ];
+#pragma unroll
+            for (int u = 0; u < RG_RQ; u++) {
+                bsrc[u] = 16 * (g * RPG + (u < RPG ? u : 0));     // byte address of lane 4 * (g * RPG + u)
+                // (from LDS -- row 0 of `hist`, `ol` -- not from global memory: a compiler-counted global load feeding this
+                //  loop-carried value makes hipcc put s_waitcnt vmcnt(0) into the loop, which drains the ring every step)
+                hs[u] = okrow[u] ? hist[row0 + u] * (dir == 1 ? ol[row0 + u] : 1.0f) : 0.0f;
+            }
+            const int nl_mode = p.nl;
+            const bool nl_relu = nl_mode == FARNN_NL_RELU;
+            int *myflag = sflag + w * 64 + lane;                  // every lane stores its own word: no EXEC juggling for one lane
+            const int *pflag = sflag + (lane < RG_NWC ? lane : 0) * 64;
 
             // The ring: RG_D steps x RG_RQ rows of 16 bytes per lane, loaded by inline asm so that NO compiler wait ever
             // drains it (hipcc's own bookkeeping merges the loop's back edge into vmcnt(0): measured, the ring then has no depth).
@@ -397,12 +434,15 @@ chain_regs_kernel(const RegsParams p) {
             // that names the four registers "+v" (cdna_hip_programming.md 5.7, form ii).  Loads retire in issue order, so
             // step t's four pieces have landed once at most the pieces of the steps issued after it are outstanding.
             v4f r[RG_D][RG_RQ];
-#define FARNN_RG_ISSUE(d, t_)                                                                  \
+#define FARNN_RG_BASE(t_, lo_, hi_)                                                            \
             do {                                                                               \
                 const long long off_ = tokoff[t_];                                             \
-                const unsigned lo_ = __builtin_amdgcn_readfirstlane((unsigned)off_);           \
-                const unsigned hi_ = __builtin_amdgcn_readfirstlane((unsigned)(off_ >> 32));  \
-                const char *bp_ = Mbase + (((long long)hi_ << 32) | lo_);                      \
+                lo_ = __builtin_amdgcn_readfirstlane((unsigned)off_);                          \
+                hi_ = __builtin_amdgcn_readfirstlane((unsigned)(off_ >> 32));                 \
+            } while (0)
+#define FARNN_RG_ISSUE(d, lo_, hi_)                                                            \
+            do {                                                                               \
+                const char *bp_ = Mbase + (((long long)(hi_) << 32) | (lo_));                  \
                 asm volatile("s_nop 4\n\t"                                                     \
                              "global_load_dwordx4 %0, %4, %8\n\t"                              \
                              "global_load_dwordx4 %1, %5, %8\n\t"                              \
@@ -423,68 +463,131 @@ chain_regs_kernel(const RegsParams p) {
                          "s_waitcnt vmcnt(12)\n"                                               \
                          "2:"                                                                  \
                          : "+v"(r[d][0]), "+v"(r[d][1]), "+v"(r[d][2]), "+v"(r[d][3]) : "s"(rem_) : "scc")
+            unsigned nlo = 0, nhi = 0;                           // where step t + RG_D's block is (read one step ahead)
 #pragma unroll
             for (int d = 0; d < RG_D; d++) {
 #pragma unroll
                 for (int u = 0; u < RG_RQ; u++) r[d][u] = v4f{0.f, 0.f, 0.f, 0.f};
-                if (d < nsteps) FARNN_RG_ISSUE(d, d);
+                if (d < nsteps) {
+                    FARNN_RG_BASE(d, nlo, nhi);
+                    FARNN_RG_ISSUE(d, nlo, nhi);
+                }
             }
-            int pb = 0;
+            FARNN_RG_BASE(RG_D < nsteps ? RG_D : 0, nlo, nhi);
+#if defined(FARNN_PROBES)
+            long long ph[5] = {0, 0, 0, 0, 0}, pt = 0;
+#define FARNN_RG_PHASE(i) do { if (probe && w == 0 && (p.dbg & 256)) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph[i] += n_ - pt; pt = n_; } } while (0)
+            if (probe && w == 0) pt = (long long)__builtin_amdgcn_s_memtime();
+#else
+#define FARNN_RG_PHASE(i) do { } while (0)
+#endif
+#if FARNN_ABLATE & 512                               /* 512 = no steps at all */
+            for (int t0 = 0; t0 < 0; t0 += RG_D) {
+#else
             for (int t0 = 0; t0 < nsteps; t0 += RG_D) {
+#endif
 #pragma unroll
                 for (int d = 0; d < RG_D; d++) {
                     const int t = t0 + d;
                     if (t >= nsteps) break;
-                    const float4 h4 = ld4(myhp);
-                    const float hv[4] = {h4.x, h4.y, h4.z, h4.w};
                     static_assert(RG_D == 4 && RG_RQ == 4, "FARNN_RG_WAIT is written out for a 4 x 4 ring");
                     FARNN_RG_WAIT(d, nsteps - 1 - t);            // steps issued after this one: min(RG_D - 1, nsteps - 1 - t)
+                    FARNN_RG_PHASE(0);                           // wait for this step's block pieces
                     v4f acc = MAXSR ? v4f{ninf, ninf, ninf, ninf} : v4f{0.f, 0.f, 0.f, 0.f};
+#if FARNN_ABLATE & 8                                 /* 8 = no FMAs */
+                    acc = r[d][0] + r[d][1] * hs[0] + r[d][2] + r[d][3];
+#else
 #pragma unroll
                     for (int u = 0; u < RG_RQ; u++) {
                         if (MAXSR) {
-                            acc.x = fmaxf(acc.x, okrow[u] ? hv[u] * r[d][u].x : ninf);
-                            acc.y = fmaxf(acc.y, okrow[u] ? hv[u] * r[d][u].y : ninf);
-                            acc.z = fmaxf(acc.z, okrow[u] ? hv[u] * r[d][u].z : ninf);
-                            acc.w = fmaxf(acc.w, okrow[u] ? hv[u] * r[d][u].w : ninf);
+                            acc.x = fmaxf(acc.x, okrow[u] ? hs[u] * r[d][u].x : ninf);
+                            acc.y = fmaxf(acc.y, okrow[u] ? hs[u] * r[d][u].y : ninf);
+                            acc.z = fmaxf(acc.z, okrow[u] ? hs[u] * r[d][u].z : ninf);
+                            acc.w = fmaxf(acc.w, okrow[u] ? hs[u] * r[d][u].w : ninf);
                         } else {
-                            acc.x = fmaf(hv[u], r[d][u].x, acc.x);
-                            acc.y = fmaf(hv[u], r[d][u].y, acc.y);
-                            acc.z = fmaf(hv[u], r[d][u].z, acc.z);
-                            acc.w = fmaf(hv[u], r[d][u].w, acc.w);
+                            acc.x = fmaf(hs[u], r[d][u].x, acc.x);
+                            acc.y = fmaf(hs[u], r[d][u].y, acc.y);
+                            acc.z = fmaf(hs[u], r[d][u].z, acc.z);
+                            acc.w = fmaf(hs[u], r[d][u].w, acc.w);
                         }
                     }
-                    float *pp = part + pb * NP * SP;
-                    if (active) *reinterpret_cast<v4f *>(pp + gid * SP + c * 4) = acc;
-                    if (lane == 0) lds_flag_set(sflag + w, t + 1);
+#endif
+                    const int boff = (d & 1) * RG_PART_STRIDE;           // this step's partial-sum buffer (t and d have the same parity)
+#if !(FARNN_ABLATE & 32)                             /* 32 = no partial-sum / flag stores */
+                    *reinterpret_cast<v4f *>(wptr + boff) = acc;
+                    lds_flag_set(myflag, t + 1);                 // behind the partial sums in this wavefront's LDS order
+#endif
                     asm volatile("" : "+v"(acc));                // the slot's registers are dead from here: reload them
-                    if (t + RG_D < nsteps) FARNN_RG_ISSUE(d, t + RG_D);
-                    while (!regs_flags_reached(sflag, lane, t + 1)) {}
-                    // reduce the rows this wavefront consumes next: four lanes per row, each a quarter of the partial vectors
+#if !(FARNN_ABLATE & 1)                              /* ablation builds (scripts/build_ablate.sh): 1 = no block loads */
+                    if (t + RG_D < nsteps) FARNN_RG_ISSUE(d, nlo, nhi);
+#endif
+                    FARNN_RG_PHASE(1);                           // FMAs, partial store, flag, next loads issued
+                    // the other wavefronts' flags FIRST, then this lane's share of the partial sums and the next block address in the
+                    // same batch: the LDS serves a wavefront in order, so partial sums read behind flags that say "written" are the
+                    // written ones -- one round trip when the partners are on time, the whole batch again when they are not
                     float pv[NQI];
+                    long long noff;
+#if FARNN_ABLATE & 16                                /* 16 = no LDS reads at all in the step */
 #pragma unroll
-                    for (int i = 0; i < NQI; i++) pv[i] = pp[qoff[i]];
-                    float s = MAXSR ? ninf : 0.0f;
+                    for (int i = 0; i < NQI; i++) pv[i] = acc.x;
+                    noff = 0;
+#else
+                    for (;;) {
+                        const int fl = lds_flag_get(pflag);
 #pragma unroll
-                    for (int i = 0; i < NQI; i++) {
-                        const float v = (i == 0 || rs + 4 * i < NP) ? pv[i] : (MAXSR ? ninf : 0.0f);
-                        s = MAXSR ? fmaxf(s, v) : s + v;
+                        for (int i = 0; i < NQI; i++) pv[i] = qptr[i][boff];
+                        noff = tokoff[t + RG_D + 1 < nsteps ? t + RG_D + 1 : 0];
+                        asm volatile("" ::: "memory");
+                        if (__ballot(fl < t + 1) == 0ull) break;
+#if FARNN_ABLATE & 2                                 /* 2 = nobody waits for the partners (wrong results) */
+                        break;
+#endif
                     }
+#endif
+                    nlo = __builtin_amdgcn_readfirstlane((unsigned)noff);
+                    nhi = __builtin_amdgcn_readfirstlane((unsigned)(noff >> 32));
+                    FARNN_RG_PHASE(2);                           // the partners' partial sums
+                    static_assert(NQI == 6, "the reduction tree below is written out for six partial sums per lane");
+                    float s;
+                    if (MAXSR) s = fmaxf(fmaxf(fmaxf(pv[0], pv[1]), fmaxf(pv[2], pv[3])), fmaxf(pv[4], pv[5]));
+                    else       s = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + (pv[4] + pv[5]);
                     s = MAXSR ? quad_max(s) : quad_sum(s);
-                    if (my_writer) {
-                        const float pre = dir == 0 ? s * my_o : s;                         // (:377-386) / (:393-402)
-                        const float hn = nl_mode == FARNN_NL_NONE ? pre : (nl_mode == FARNN_NL_RELU ? fmaxf(pre, 0.0f) : apply_nl(pre, nl_mode));
-                        hist[(t + 1) * SP + my_row] = hn;
-                        hp[my_hp] = dir == 0 ? hn : hn * my_o;
+                    const float pre = dir == 0 ? s * my_o : s;                             // (:377-386) / (:393-402)
+                    float hn;
+                    if (NLX) hn = apply_nl(pre, nl_mode);                                  // tanh, relu-tanh, sigmoid
+                    else     hn = nl_relu ? fmaxf(pre, 0.0f) : pre;                        // none / relu: no branch in the step
+                    const float hx = my_valid ? (dir == 0 ? hn : hn * my_o) : 0.0f;        // what the next step multiplies with
+#if !(FARNN_ABLATE & 64)                             /* 64 = no state store */
+                    *hptr = hn;                                                            // row t + 1 of `hist` (or the dump slot)
+                    hptr += hstep;
+#endif
+#if !(FARNN_ABLATE & 4)                              /* 4 = no state exchange (wrong results) */
+#pragma unroll
+                    for (int u = 0; u < RG_RQ; u++) {
+                        const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc[u], __float_as_int(hx)));
+                        hs[u] = u < RPG ? v : 0.0f;
                     }
-                    if (lane == 0) lds_flag_set(dflag + w, t + 1);
-                    pb ^= 1;
+#endif
+                    FARNN_RG_PHASE(3);                           // row reduce, nonlinearity, state exchange
                 }
             }
+            lds_flag_set(myflag, nsteps + 1);                    // (the last state row is in `hist`: writer / scorer count rows by these flags)
+#if defined(FARNN_PROBES)
+            if (probe && w == 0 && lane == 0 && (p.dbg & 256))
+                printf("seq %d dir %d chain phases, cycles per step: block wait %lld, fma + store + issue %lld, partner wait + partial reads %lld, reduce + exchange %lld\n",
+                       b, dir, ph[0] / nsteps, ph[1] / nsteps, ph[2] / nsteps, ph[3] / nsteps);
+#endif
+#undef FARNN_RG_PHASE
 #undef FARNN_RG_ISSUE
+#undef FARNN_RG_BASE
 #undef FARNN_RG_WAIT
             __builtin_amdgcn_s_setprio(0);
             if (w == 0) FARNN_RG_STAMP(2);
+#if defined(FARNN_PROBES)
+            if (!SCORE && probe && w == 0 && lane == 0)
+                printf("seq %d dir %d: setup %lld, chain %lld (%lld per step)\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
+                       (stamps[2] - stamps[1]) / nsteps);
+#endif
         }
     } else if (w == RG_NWC) {
         // =================================================================================================================
@@ -499,7 +602,7 @@ chain_regs_kernel(const RegsParams p) {
         }
         int next = 0;                                             // rows 0 .. next - 1 are stored
         while (next <= nsteps) {
-            const int avail = nsteps > 0 ? regs_flags_min(dflag, lane) : 0;      // rows 0 .. avail are complete in hist
+            const int avail = nsteps > 0 ? max(regs_rows_done(sflag, lane), 0) : 0;   // rows 0 .. avail are complete in hist
             if (avail < next) { __builtin_amdgcn_s_sleep(2); continue; }
             for (int rr = next; rr <= avail; rr++) {
                 const float *src = hist + rr * SP;
@@ -534,7 +637,8 @@ chain_regs_kernel(const RegsParams p) {
             if (lane == 0) misc[RGM_FOFF] = partsum;
         }
         const long long foff = misc[RGM_FOFF];
-        unsigned long long mine = 0ull;
+        unsigned mine = 0u;
+        int acq = -1;                 // the other direction's progress as polled before this workgroup's latest acquire
         const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
         const int kfirst = dir == 0 ? kmid : kmid - 1, kstep = dir == 0 ? 1 : -1, klast = dir == 0 ? ntl : -1;
         for (int k = kfirst; k != klast; k += kstep) {
@@ -542,118 +646,105 @@ chain_regs_kernel(const RegsParams p) {
             regs_tile_need(k, len, nsteps, na, nb);
             const int need_own = dir == 0 ? na : nb, need_oth = dir == 0 ? nb : na;
             if (nsteps - need_own < p.solo_margin) break;             // the chain ends soon: all eight wavefronts will do it
-            while (!regs_flags_reached(dflag, lane, need_own)) __builtin_amdgcn_s_sleep(4);
-            bool ready = false;
-            for (;;) {
-                int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
-                pr = __builtin_amdgcn_readfirstlane(pr);
-                if (pr >= need_oth) { ready = true; break; }
-                if (regs_flags_reached(dflag, lane, nsteps)) break;   // our chain is done: no open-ended wait beyond it
-                __builtin_amdgcn_s_sleep(8);
+            while (!regs_rows_reached(sflag, lane, need_own)) __builtin_amdgcn_s_sleep(4);
+            if (need_oth > acq) {
+                int pr = -1;
+                for (;;) {
+                    pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+                    pr = __builtin_amdgcn_readfirstlane(pr);
+                    if (pr >= need_oth) break;
+                    if (regs_rows_reached(sflag, lane, nsteps)) break;    // our chain is done: no open-ended wait beyond it
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (pr < need_oth) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // after the poll matched, before the loads
+                acq = pr;
             }
-            if (!ready) break;
-            unsigned old = 0;
-            if (lane == 0) old = __hip_atomic_exchange(p.claim + (long long)b * p.NT + k, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (old == p.epoch) continue;                             // the other workgroup took it
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // after the poll matched, before the loads
             regs_score_tile<false>(p, b, dir, len, nsteps, k, hist, ab, scl, foff, 0, lane);
-            mine |= 1ull << k;
+            mine |= 1u << k;
         }
-        if (lane == 0) { misc[RGM_MINE_LO] = (int)(unsigned)mine; misc[RGM_MINE_HI] = (int)(unsigned)(mine >> 32); }
+        if (lane == 0) { misc[RGM_MINE] = (int)mine; misc[RGM_ACQ] = acq; }
         FARNN_RG_STAMP(3);
     }
     if constexpr (!SCORE) return;
 
     // =====================================================================================================================
-    // the chain is done: all eight wavefronts score what is left, then the arrival
+    // the chain is done.  Before the arrival a workgroup touches only the tiles of its own half: those the other direction's
+    // progress (as covered by an acquire) allows are scored now by all eight wavefronts; the arrival word carries the
+    // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
     __syncthreads();
     if (w == 0) FARNN_RG_STAMP(4);
     const long long foff = misc[RGM_FOFF];
-    unsigned long long mine = ((unsigned long long)(unsigned)misc[RGM_MINE_HI] << 32) | (unsigned)misc[RGM_MINE_LO];
-    const unsigned long long all_tiles = ntl >= 64 ? ~0ull : ((1ull << ntl) - 1ull);
-    const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
-    unsigned *claims = p.claim + (long long)b * p.NT;
-    int other_tiles = -1;                                            // >= 0 once this workgroup is the second arrival
-    // the scorer wavefront decides (polls, claims, acquires); the decision reaches the others through LDS + barrier
-    for (int pass = 0; pass < 2; pass++) {                           // 0: before the arrival; 1: the second arrival's sweep
-        unsigned long long taken = 0ull;                             // tiles somebody has claimed, as of the snapshot
-        if (w == RG_WAVES - 1) {
-            unsigned cv = 0;
-            if (lane < ntl) cv = __hip_atomic_load(claims + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            taken = __ballot(lane < ntl && cv == p.epoch);
+    const unsigned all_tiles = ntl >= 32 ? ~0u : ((1u << ntl) - 1u);
+    unsigned long long arrived = 0ull;                                // (scorer wavefront, lane 0) what the arrival exchange returned
+    unsigned promised = 0u;
+    if (w == RG_WAVES - 1) {
+        const unsigned mine = (unsigned)misc[RGM_MINE];
+        int acq = misc[RGM_ACQ];
+        const unsigned own_half = dir == 0 ? (all_tiles & ~((1u << kmid) - 1u)) : (all_tiles & ((1u << kmid) - 1u));
+        const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
+        unsigned todo = 0u;
+        for (int it = 0;; it++) {
+            int miss = 0;
+            todo = 0u;
+            for (int k = 0; k < ntl; k++) {
+                if (!((own_half & ~mine) >> k & 1u)) continue;
+                int na, nb;
+                regs_tile_need(k, len, nsteps, na, nb);
+                if ((dir == 0 ? nb : na) <= acq) todo |= 1u << k; else miss++;
+            }
+            if (!miss || it >= p.spin) break;                         // bounded: what stays open goes to the second arrival
+            int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+            pr = __builtin_amdgcn_readfirstlane(pr);
+            if (pr > acq) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before the barrier below
+                acq = pr;
+            } else __builtin_amdgcn_s_sleep(8);
         }
-        for (int ord = 0; ord < ntl; ord++) {
-            if (w == RG_WAVES - 1) {
-                // this workgroup's half first (forward: kmid upwards, backward: kmid - 1 downwards), then the other half
-                int k;
-                if (dir == 0) k = ord < ntl - kmid ? kmid + ord : ntl - 1 - ord;
-                else          k = ord < kmid ? kmid - 1 - ord : ord;
-                int go = -1;
-                if (!((taken >> k) & 1ull)) {
-                    bool ready = pass == 1;                          // the sweep: both stashes are complete and published
-                    if (!ready) {
-                        int na, nb;
-                        regs_tile_need(k, len, nsteps, na, nb);
-                        const int need_oth = dir == 0 ? nb : na;
-                        const bool own_half = dir == 0 ? k >= kmid : k < kmid;
-                        const int polls = own_half ? p.spin : 1;
-                        for (int it = 0; it < polls && !ready; it++) {
-                            int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
-                            pr = __builtin_amdgcn_readfirstlane(pr);
-                            ready = pr >= need_oth;
-                            if (!ready && it + 1 < polls) __builtin_amdgcn_s_sleep(8);
-                        }
-                    }
-                    if (ready) {
-                        unsigned old = 0;
-                        if (lane == 0) old = __hip_atomic_exchange(claims + k, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        old = __builtin_amdgcn_readfirstlane(old);
-                        if (old != p.epoch) {
-                            go = k;
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before the barrier
-                        }
-                    }
-                }
-                if (lane == 0) misc[RGM_COOP_K] = go;
-            }
-            __syncthreads();
-            const int k = misc[RGM_COOP_K];
-            if (k >= 0) {
-                regs_score_tile<true>(p, b, dir, len, nsteps, k, hist, ab, scl, foff, w, lane);
-                mine |= 1ull << k;
-            }
-            __syncthreads();                                         // the tile's LDS and the decision word are free again
+        promised = mine | todo;
+        // arrival: this workgroup's stash rows are stored and drained (the writer, before the barrier above); the exchange
+        // is in flight while the promised tiles are scored
+        if (lane == 0)
+            arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)p.epoch << 32) | 0x80000000ull | promised,
+                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) misc[RGM_TODO] = (int)todo;
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 2; pass++) {
+        const unsigned todo = (unsigned)misc[RGM_TODO];
+        for (int k = 0; k < ntl; k++) {
+            if (!((todo >> k) & 1u)) continue;
+            regs_score_tile<true>(p, b, dir, len, nsteps, k, hist, ab, scl, foff, w, lane);
+            __syncthreads();                                         // the tile's LDS is free again
         }
         if (pass == 1) break;
         if (w == 0) FARNN_RG_STAMP(5);
-        // ---- arrival: this workgroup's stash rows are stored and drained (the writer), its tiles are done
+        __syncthreads();                                             // every wavefront has read this pass's mask
         if (w == RG_WAVES - 1) {
-            unsigned long long old = 0ull;
-            const unsigned long long me = ((unsigned long long)p.epoch << 32) | 0x80000000ull | (unsigned)__popcll(mine);
-            if (lane == 0) old = __hip_atomic_exchange(p.arr + b, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(old >> 32));
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)old);
-            int ot = -1;
-            if (hi == p.epoch && (lo & 0x80000000u)) ot = (int)(lo & 0x7fffffffu);
-            if (lane == 0) misc[RGM_COOP_K] = ot;
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(arrived >> 32));
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)arrived);
+            unsigned rest = 0u;
+            if (hi == p.epoch && (lo & 0x80000000u)) {               // second of the two: the other's rows are all published
+                rest = all_tiles & ~(promised | (lo & 0x7fffffffu));
+                if (rest) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            if (lane == 0) misc[RGM_TODO] = (int)rest;
         }
         __syncthreads();
-        other_tiles = misc[RGM_COOP_K];
-        __syncthreads();
-        if (other_tiles < 0) break;                                  // first of the two: the other one sweeps
-        if (other_tiles + __popcll(mine) >= ntl) break;              // everything was scored
-        (void)all_tiles;
+        if (misc[RGM_TODO] == 0) break;
     }
 #if defined(FARNN_PROBES)
     if (probe && tid == 0) {
         const long long e = (long long)__builtin_amdgcn_s_memtime();
         printf("seq %d dir %d: setup %lld, chain %lld (%lld per step), scorer alone until +%lld, all waves meet +%lld, tiles together %lld, "
-               "arrival + sweep %lld; tiles alone %d of %d, second arrival %d\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
+               "arrival + sweep %lld; tiles alone %d of %d\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
                (stamps[2] - stamps[1]) / nsteps, stamps[3] - stamps[2], stamps[4] - stamps[2], stamps[5] - stamps[4], e - stamps[5],
-               __popcll(((unsigned long long)(unsigned)misc[RGM_MINE_HI] << 32) | (unsigned)misc[RGM_MINE_LO]), ntl, other_tiles >= 0);
+               __popc((unsigned)misc[RGM_MINE]), ntl);
     }
 #endif
 }

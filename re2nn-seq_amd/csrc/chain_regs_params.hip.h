@@ -13,6 +13,8 @@ constexpr int RG_D = 4;          // steps of block pieces in flight per lane
 constexpr int RG_RQ = 4;         // rows per lane per step (one float4 of the state)
 constexpr int RG_TT = 16;        // tokens per score tile
 constexpr int RG_MAXG = 4;       // row groups per compute wavefront
+constexpr int RG_MAXSP = 72;     // padded state count the geometry reaches (RPG <= 4 rows x 6 * G groups)
+constexpr int RG_PART_STRIDE = RG_NWC * RG_MAXG * RG_MAXSP;    // floats between the two partial-sum buffers
 
 struct RegsParams {
     const float *Mf, *Mb;        // [V][SR][SP] blocks and their transposes (layout.hip.h)
@@ -26,11 +28,10 @@ struct RegsParams {
     int G, RPG;                  // row groups per compute wavefront, rows per group
     int nl, full;
     unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
-    unsigned long long *arr;     // [B]    {epoch, 1 << 31 | tiles scored} of the workgroup that finished first
-    unsigned *claim;             // [B][NT] epoch of the launch that claimed the tile
+    unsigned long long *arr;     // [B]    {epoch, 1 << 31 | mask of the tiles it scores} of the workgroup that arrived last
     unsigned epoch;
-    int NT;                      // claim words per sequence (>= ceil(L / 16))
-    int spin;                    // polls a finished workgroup spends on a tile of its own half before it leaves it to the other
+    int spin;                    // polls a finished workgroup spends on the tiles of its own half before it leaves them to the other
+    int dbg;                     // FARNN_DBG ablation / probe mask: read by the profiling build (-DFARNN_PROBES) only
     int solo_margin;             // the scorer starts a tile alone only if the chain has at least this many steps left after it
     ScoreParams sp;
 };
@@ -62,13 +63,13 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
     RegsLds l;
     int at = 0;
     l.tok = at;  at += 2 * ((L + 1) & ~1);             // a 64-bit block offset per step
-    l.hp = at;   at += NP * 4;
-    l.part = at; at += 2 * NP * SP;
+    l.hp = at;
+    l.part = at; at += 2 * RG_PART_STRIDE + 64 * 4;     // two partial-sum buffers + the idle lanes' dump slots
     l.ol = at;   at += SP;
     l.hist = at; at += (L + 1) * SP + 16;          // + the launch-order scratch's tail
     l.ab = at;   at += score ? RG_TT * (16 * c16 + 4) : 0;
     l.scl = at;  at += score ? RG_TT * Kc : 0;
-    l.misc = at; at += 32;
+    l.misc = at; at += 32 + RG_NWC * 64;           // words + the compute wavefronts' step flags
     l.total = at;
     return l;
 }

@@ -78,8 +78,7 @@ struct farnn_model {
     int curL = 0;                           // the current call's L: every stride of the workspace arrays
     ChainGeom geom;
     RegsGeom rgeom;                         // geometry of the register-fed recurrence kernel (chain_regs.hip.h); rgeom.ok: usable
-    unsigned long long *hs = nullptr;       // hand-off words of that kernel: progress [2][B], arrival [B] (64-bit), claims [B][hsNT]
-    int hsNT = 0;                           // claim words per sequence
+    unsigned long long *hs = nullptr;       // hand-off words of that kernel: progress [2][B], arrival [B] (64-bit each)
     size_t hs_bytes = 0;
     unsigned epoch_u = 0;                   // launches of that kernel in its scoring form so far (0 is never a launch's epoch)
     bool last_regs = false;                 // the last recurrence ran on chain_regs_kernel
@@ -371,8 +370,7 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->pair_cnt, (size_t)2 * nB * sizeof(int)));
     FARNN_HIP_TRY(hipMemset(m->pair_cnt, 0, (size_t)2 * nB * sizeof(int)));
-    m->hsNT = (nL + RG_TT - 1) / RG_TT;
-    m->hs_bytes = round_up_sz((size_t)3 * nB * sizeof(unsigned long long) + (size_t)nB * m->hsNT * sizeof(unsigned), 16);
+    m->hs_bytes = round_up_sz((size_t)3 * nB * sizeof(unsigned long long), 16);
     FARNN_HIP_TRY(hipMalloc((void **)&m->hs, m->hs_bytes));
     FARNN_HIP_TRY(hipMemset(m->hs, 0, m->hs_bytes));
     if (m->use_crf)
@@ -480,7 +478,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     // With fuse_sp (threshold/argmax decode, K <= 256) the scores and the decode run beside the recurrence: ONE launch.
     if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0)) {
         const RegsGeom &rg = m->rgeom;
-        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= 5 && m->Kc <= 256 && m->curL <= 1023 &&
+        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= 5 && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
         if (score) {
             // the hand-off words carry the launch's epoch, a kernel argument: a captured launch would replay with a frozen one.
@@ -500,16 +498,15 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
             rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
             rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
             rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
-            rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full;
+            rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
             if (score) {
                 if (++m->epoch_u == 0) {            // the epoch wrapped: no word of an earlier launch may look current
                     FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
                     m->epoch_u = 1;
                 }
                 rp.prog = m->hs; rp.arr = m->hs + (size_t)2 * m->wsB;
-                rp.claim = reinterpret_cast<unsigned *>(m->hs + (size_t)3 * m->wsB);
-                rp.epoch = m->epoch_u; rp.NT = m->hsNT;
-                rp.spin = env_int("FARNN_FUSE_SPIN", 64);
+                rp.epoch = m->epoch_u;
+                rp.spin = env_int("FARNN_FUSE_SPIN", 4);
                 rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 6);
                 rp.sp = *fuse_sp;
                 if (fused) *fused = true;
