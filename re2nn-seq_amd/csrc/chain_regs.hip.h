@@ -79,15 +79,20 @@ __device__ __forceinline__ int lds_flag_get(const int *f) {
     asm volatile("" ::: "memory");
     return v;
 }
-// steps every compute wavefront has finished, as the polling wavefront sees them (lane i reads wavefront i's flag)
-// (a compute wavefront's flag: the steps whose partial sums it has written; the state row of step t -- row t + 1 of `hist` -- is
-// complete once every flag reads t + 2, or nsteps + 1 after the last step)
-__device__ __forceinline__ bool regs_rows_reached(const int *flags, int lane, int rows) {
-    const int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0) * 64);
-    return __ballot(v < rows + 1) == 0ull;
+// A compute wavefront's step flag = the number of steps whose partial sums it has written.  It lives in the partial-sum
+// buffer the step wrote (wavefront i: float 4 i of the buffer's flag area, `fbase` in buffer 0), stored by the same
+// ds_write_b128 as the partial sums.  Writer / scorer count state rows by them: row t + 1 of `hist` is complete once every
+// wavefront's newer flag reads t + 2, or nsteps + 1 after the last step.
+__device__ __forceinline__ int regs_flag_newest(const float *fbase, int lane) {
+    const int *f = reinterpret_cast<const int *>(fbase) + 4 * (lane < RG_NWC ? lane : 0);
+    const int v0 = lds_flag_get(f), v1 = lds_flag_get(f + RG_PART_STRIDE);
+    return max(v0, v1);
 }
-__device__ __forceinline__ int regs_rows_done(const int *flags, int lane) {
-    int v = lds_flag_get(flags + (lane < RG_NWC ? lane : 0) * 64);
+__device__ __forceinline__ bool regs_rows_reached(const float *fbase, int lane, int rows) {
+    return __ballot(regs_flag_newest(fbase, lane) < rows + 1) == 0ull;
+}
+__device__ __forceinline__ int regs_rows_done(const float *fbase, int lane) {
+    int v = regs_flag_newest(fbase, lane);
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) v = min(v, __shfl_xor(v, off, WAVE));
     return __builtin_amdgcn_readfirstlane(v) - 1;
@@ -104,122 +109,183 @@ __device__ __forceinline__ float quad_max(float x) {
     return x;
 }
 
-// ---- one 16-token tile: products, matrix-core product, decode ------------------------------------------------------------
-// COOP: all eight wavefronts of the workgroup call it together (workgroup barriers between the phases); else one wavefront
-// alone.  Same arithmetic either way: per output the k-steps run in ascending state order.
+typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int RG_NG = 5;             // state groups of 16 (c16 <= 5: the launcher checks)
+constexpr int RG_NOB = 2;            // tiles whose rows of the other direction the scorer parks in LDS ahead of the chain's end
+
+// B fragments (matrix-core image of O^T, score_decode.hip.h) of column block cb, all state groups: one round trip to L2
+__device__ __forceinline__ void regs_load_b(const ScoreParams &sp, int cb, int lane, rg_f32x4 (&bf)[RG_NG]) {
+    const rg_f32x4 *otm = reinterpret_cast<const rg_f32x4 *>(sp.OTm);
+    const int c16 = sp.c16;
+#pragma unroll
+    for (int g = 0; g < RG_NG; g++) bf[g] = (otm + ((long long)cb * c16 + (g < c16 ? g : c16 - 1)) * 64)[lane];
+}
+
+// the other direction's row that token i of sequence b multiplies with (the stash row index and its base)
+__device__ __forceinline__ const float *regs_other_row(const RegsParams &p, int b, int dir, int len, int i) {
+    const int ai = i + 1, bi = (i + 1 <= len) ? len - (i + 1) : i + 1;
+    const long long base = (long long)b * (p.L + 1) * p.SP;
+    return dir == 0 ? p.Bk + base + (long long)bi * p.SP : p.A + base + (long long)ai * p.SP;
+}
+
+// park the other direction's rows of tile k in LDS (obuf[16][SP]); one wavefront, after the acquire that covers them
+__device__ __forceinline__ void regs_park_rows(const RegsParams &p, int b, int dir, int len, int nsteps, int k, float *obuf, int lane_in) {
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    const int SP = p.SP, CPR = p.CPR, t0 = k * RG_TT, nt = min(RG_TT, nsteps - t0);
+    constexpr int NIT = 5;                               // 16 tokens x CPR <= 18 chunks of 16 bytes over 64 lanes
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int idx = it * 64 + lane;
+        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
+        v[it] = ld4_agent(regs_other_row(p, b, dir, len, t0 + (tok < nt ? tok : 0)) + c4);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+        const int idx = it * 64 + lane;
+        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
+        if (tok < nt) st4(obuf + tok * SP + c4, v[it]);
+    }
+}
+
+// ---- 16-token tiles: products, matrix-core product, decode ---------------------------------------------------------------
+// COOP: all eight wavefronts of the workgroup call it together (workgroup barriers between the phases) and score up to TWO
+// tiles (k0, k1; k1 < 0: one) in one pass -- the two tiles share the B fragments and run as independent accumulator chains on
+// the matrix cores, and each half of the workgroup decodes one of them.  Else one wavefront alone scores tile k0.
+// Same arithmetic either way: per output the k-steps run in ascending state order.
+// par0 / par1: the other direction's rows of the tile parked in LDS ([16][SP]) or nullptr (then they come from the stash);
+// bpre: COOP only -- the B fragments of column block `wv`, loaded by the caller ahead of time.
+// ab: [NTL][16][SPa], scl: [NTL][16][Kc] with NTL = 2 (COOP) / 1.
 template <bool COOP>
-__device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b, const int dir, const int len, const int nsteps,
-                                                const int k, const float *hist, float *ab, float *scl, const long long foff,
-                                                const int wv, const int lane_in) {
+__device__ __forceinline__ void regs_score_tiles(const RegsParams &p, const int b, const int dir, const int len, const int nsteps,
+                                                 const int k0, const int k1, const float *hist, const float *par0, const float *par1,
+                                                 float *ab, float *scl, const long long foff, const int wv, const int lane_in,
+                                                 const rg_f32x4 (&bpre)[RG_NG]) {
     // Everything per-lane below is derived from this opaque copy: left to itself the compiler hoists the tile's index and
     // address arithmetic out of the callers' tile loops and then spills it (56-448 bytes of scratch per lane, measured)
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const ScoreParams &sp = p.sp;
     constexpr int NWV = COOP ? RG_WAVES : 1;
-    constexpr int CH = COOP ? 1 : 2;                     // column blocks a wavefront runs side by side (shared A fragments)
-    constexpr int NIT = COOP ? 1 : 5;                    // product items per lane: 16 tokens x 4 c16 float4 columns, c16 <= 5
+    constexpr int NWV1 = COOP ? RG_WAVES - 1 : 1;        // wavefronts that form the products: the writer wavefront (it copies its last
+                                                         // state rows to the stash meanwhile: the caller) takes none
+    constexpr int NTL = COOP ? 2 : 1;
+    constexpr int NIT = COOP ? 2 : 5;                    // product items per lane: NTL x 16 tokens x 4 c16 float4 columns, c16 <= 5
     const int c16 = sp.c16, SPa = 16 * c16 + 4, SP = p.SP, K = sp.K, Kc = sp.Kc, ncb = Kc / 16;
-    const int t0 = k * RG_TT;
-    const int nt = min(RG_TT, nsteps - t0);
-    const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
-    const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
-    const int G4 = 4 * c16;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    constexpr int NG = 5;                                // state groups of 16 (c16 <= 5: the launcher checks)
+    const int G4 = 4 * c16, TI = RG_TT * G4;             // items per tile
     const int lr = lane & 15, lk = lane >> 4;
-    const f32x4 *otm = reinterpret_cast<const f32x4 *>(sp.OTm);      // uniform base; the lane is the load's vector offset
-    asm volatile("" : "+s"(otm));                        // (its address arithmetic stays inside the tile: hoisted out of the tile loops, the
-                                                         //  dozens of 64-bit addresses cost more registers than the kernel has)
-    // B fragments of a run of CH column blocks: ALL state groups at once (one round trip to L2, not one per group -- beside
-    // twelve wavefronts that keep sixteen block loads in flight each, a dependent load of this wavefront takes microseconds)
-    f32x4 bf[NG][CH];
-    auto load_b = [&](int cb0) {
-#pragma unroll
-        for (int g = 0; g < NG; g++) {
-            const int gc = g < c16 ? g : c16 - 1;
-#pragma unroll
-            for (int q = 0; q < CH; q++) {
-                const int cb = cb0 + q < ncb ? cb0 + q : ncb - 1;
-                bf[g][q] = (otm + ((long long)cb * c16 + gc) * 64)[lane];
-            }
-        }
-    };
-    // ---- phase 1: ab[tok][s] = a[i+1][s] * bt[i+1][s]; the own direction's rows from LDS, the other's from the stash
+    const bool two = COOP && k1 >= 0;
+#if defined(FARNN_PROBES)
+    const bool tprobe = COOP && nsteps == p.L && p.L >= 32 && wv == 0 && lane_in == 0 && (p.dbg & 512);
+    long long tq0 = tprobe ? (long long)__builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq2 = 0;
+#endif
+    // ---- phase 1: ab[tok][s] = a[i+1][s] * bt[i+1][s]; the own direction's rows from LDS (`hist`), the other's from LDS
+    // (parked) or the stash.  Stored in the order the matrix cores' A fragments are read: a lane's four k-steps of a state
+    // group -- states 16g + 4e + lk, e = 0..3 -- are four consecutive floats (one ds_read_b128 per group instead of four reads)
     {
         float4 oth[NIT];
-        int tokv[NIT], s4v[NIT], ownrow[NIT];
-        bool livev[NIT];
+        int dstv[NIT], ownoff[NIT];
+        bool livev[NIT], wrv[NIT];
+        const int pw = COOP ? (wv < RG_NWC ? wv : wv - 1) : 0;       // this wavefront among the NWV1
+        const bool p1 = !COOP || wv != RG_NWC;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int idx = it * NWV * 64 + wv * 64 + lane;
-            const int tok = idx / G4, s4 = (idx - tok * G4) * 4;
-            tokv[it] = tok; s4v[it] = s4;
-            livev[it] = tok < nt && s4 < SP;
-            const int i = t0 + (tok < nt ? tok : 0);
+            const int idx = p1 ? it * NWV1 * 64 + pw * 64 + lane : NTL * TI;
+            const int ti = (NTL == 2 && idx >= TI) ? 1 : 0;
+            const int rem = idx - ti * TI;
+            const int tok = rem / G4, s4 = (rem - tok * G4) * 4;
+            const int kk = ti ? k1 : k0;
+            const int t0 = kk * RG_TT, nt = min(RG_TT, nsteps - t0);
+            wrv[it] = tok < RG_TT && kk >= 0;
+            livev[it] = wrv[it] && tok < nt && s4 < SP;
+            const int tokc = livev[it] ? tok : 0, i = (kk >= 0 ? t0 : 0) + tokc;
             const int ai = i + 1, bi = (i + 1 <= len) ? len - (i + 1) : i + 1;
-            ownrow[it] = dir == 0 ? ai : bi;
-            const float *src = (dir == 0 ? Bb + (long long)bi * SP : Ab + (long long)ai * SP) + (s4 < SP ? s4 : 0);
-            oth[it] = ld4_agent(src);
+            ownoff[it] = (dir == 0 ? ai : bi) * SP + (s4 < SP ? s4 : 0);
+            // states s4 + lk' of group g = s4 / 16, k-step e = (s4 % 16) / 4: position 16 g + 4 lk' + e
+            dstv[it] = (ti * RG_TT + (tok < RG_TT ? tok : 0)) * SPa + (s4 & ~15) + ((s4 >> 2) & 3);
+            const float *par = ti ? par1 : par0;
+            if (par) oth[it] = ld4(par + tokc * SP + (s4 < SP ? s4 : 0));
+            else     oth[it] = ld4_agent(regs_other_row(p, b, dir, len, i) + (s4 < SP ? s4 : 0));
         }
-        if (wv * CH < ncb) load_b(wv * CH);              // in flight while the products are formed
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            if (tokv[it] < RG_TT) {
+            if (wrv[it]) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (livev[it]) {
-                    const float4 own = ld4(hist + ownrow[it] * SP + s4v[it]);
+                    const float4 own = ld4(hist + ownoff[it]);
                     v = make_float4(own.x * oth[it].x, own.y * oth[it].y, own.z * oth[it].z, own.w * oth[it].w);
                 }
-                st4(ab + tokv[it] * SPa + s4v[it], v);
+                float *dst = ab + dstv[it];
+                dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
             }
         }
     }
     if (COOP) __syncthreads(); else asm volatile("" ::: "memory");
-    // ---- phase 2: scl[16][Kc] = ab . O^T on the f32 matrix cores
+#if defined(FARNN_PROBES)
+    if (tprobe) tq1 = (long long)__builtin_amdgcn_s_memtime();
+#endif
+    // ---- phase 2: scl[tile][16][Kc] = ab[tile] . O^T on the f32 matrix cores
     {
-        const float *arow = ab + lr * SPa + lk;
-        for (int cb0 = wv * CH; cb0 < ncb; cb0 += NWV * CH) {
-            if (cb0 != wv * CH) load_b(cb0);
-            f32x4 acc[CH];
+        const float *arow = ab + lr * SPa + 4 * lk;
+        rg_f32x4 bn[RG_NG];                                  // the next column block's fragments, in flight behind the MFMAs
+        if (!COOP) regs_load_b(sp, 0, lane, bn);
+        for (int cb = wv; cb < ncb; cb += NWV) {
+            rg_f32x4 bf[RG_NG];
+            if (COOP) {
+                if (cb == wv) {
 #pragma unroll
-            for (int q = 0; q < CH; q++) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int g = 0; g < RG_NG; g++) bf[g] = bpre[g];
+                } else regs_load_b(sp, cb, lane, bf);
+            } else {
 #pragma unroll
-            for (int g = 0; g < NG; g++) {
+                for (int g = 0; g < RG_NG; g++) bf[g] = bn[g];
+                regs_load_b(sp, cb + 1 < ncb ? cb + 1 : cb, lane, bn);
+            }
+            rg_f32x4 acc0 = rg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll
+            for (int g = 0; g < RG_NG; g++) {
                 if (g < c16) {
-                    const float *ap = arow + 16 * g;
-                    const float a0 = ap[0], a1 = ap[4], a2 = ap[8], a3 = ap[12];
-#pragma unroll
-                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[g][q].x, acc[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[g][q].y, acc[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[g][q].z, acc[q], 0, 0, 0);
-#pragma unroll
-                    for (int q = 0; q < CH; q++) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[g][q].w, acc[q], 0, 0, 0);
+                    const float4 a4 = ld4(arow + 16 * g);
+                    float4 c4 = a4;
+                    if (two) c4 = ld4(arow + RG_TT * SPa + 16 * g);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[g].x, acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.x, bf[g].x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[g].y, acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.y, bf[g].y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[g].z, acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.z, bf[g].z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bf[g].w, acc0, 0, 0, 0);
+                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.w, bf[g].w, acc1, 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int q = 0; q < CH; q++) {
-                if (cb0 + q < ncb) {
-                    float *dst = scl + (lk * 4) * Kc + (cb0 + q) * 16 + lr;       // rows lk*4 + r, column lr of the block
-                    dst[0] = acc[q].x; dst[Kc] = acc[q].y; dst[2 * Kc] = acc[q].z; dst[3 * Kc] = acc[q].w;
-                }
+            float *dst = scl + (lk * 4) * Kc + cb * 16 + lr;                 // rows lk*4 + r, column lr of the block
+            dst[0] = acc0.x; dst[Kc] = acc0.y; dst[2 * Kc] = acc0.z; dst[3 * Kc] = acc0.w;
+            if (two) {
+                dst += RG_TT * Kc;
+                dst[0] = acc1.x; dst[Kc] = acc1.y; dst[2 * Kc] = acc1.z; dst[3 * Kc] = acc1.w;
             }
         }
     }
     if (COOP) __syncthreads(); else asm volatile("" ::: "memory");
+#if defined(FARNN_PROBES)
+    if (tprobe) tq2 = (long long)__builtin_amdgcn_s_memtime();
+#endif
     // ---- phase 3: four tokens per pass, 16 lanes per token (score_decode.hip.h's decode): priority matrix, `scores`
-    // output, threshold clamp, first index of the row maximum, oo -> o_idx
+    // output, threshold clamp, first index of the row maximum, oo -> o_idx.  COOP: wavefronts 0-3 decode tile k0, 4-7 tile k1.
     const int kch = Kc / 64;
     const int clamp_col = K - 1;                         // model_decompose.py:365 / model_onehot.py:166-167
-    for (int tg = COOP ? 4 * wv : 0; tg < RG_TT; tg += COOP ? RG_TT : 4) {
+    const int ti3 = COOP ? (wv >> 2) : 0;
+    const int kk3 = ti3 ? k1 : k0;
+    const int t0 = kk3 * RG_TT, nt = kk3 >= 0 ? min(RG_TT, nsteps - t0) : 0;
+    float *sclt = scl + ti3 * RG_TT * Kc;
+    for (int tg = COOP ? 4 * (wv & 3) : 0; tg < RG_TT; tg += COOP ? RG_TT : 4) {
         if (tg >= nt) break;
         if (sp.P) {                                      // PriorityLayer: scores @ P (priority.py:20-30), row by row
 #pragma unroll 1
             for (int j = 0; j < 4; j++) {
                 if (tg + j >= nt) break;
-                float *sr = scl + (tg + j) * Kc;
+                float *sr = sclt + (tg + j) * Kc;
                 float sc[4] = {0.f, 0.f, 0.f, 0.f};
                 for (int cc = 0; cc < K; cc++) {
                     const float sv = sr[cc];
@@ -244,7 +310,7 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < kch) x4 = ld4(scl + (live ? tokl : 0) * Kc + 64 * m + 4 * c);
+            if (m < kch) x4 = ld4(sclt + (live ? tokl : 0) * Kc + 64 * m + 4 * c);
             v[m][0] = x4.x; v[m][1] = x4.y; v[m][2] = x4.z; v[m][3] = x4.w;
         }
         if (sp.scores && live) {
@@ -301,15 +367,19 @@ __device__ __forceinline__ void regs_score_tile(const RegsParams &p, const int b
             if (sp.flat && i < len) sp.flat[foff + i] = tag;
         }
     }
+#if defined(FARNN_PROBES)
+    if (tprobe)
+        printf("seq %d dir %d tiles %d %d (all wavefronts): products + barrier %lld, matrix cores + barrier %lld, decode %lld\n", b, dir, k0, k1,
+               tq1 - tq0, tq2 - tq1, (long long)__builtin_amdgcn_s_memtime() - tq2);
+#endif
 }
 
 // misc words in LDS
-enum { RGM_SFLAG = 32,       // [6][64] a compute wavefront's step flag, one word per lane (lane 0's is polled)
-       RGM_FOFF = 16,        // where the sequence starts in the flat output
+enum { RGM_FOFF = 16,        // where the sequence starts in the flat output
        RGM_MINE = 17,        // tiles this workgroup's scorer did while the chain ran (bit k = tile k)
        RGM_ACQ = 18,         // the other direction's progress covered by this workgroup's latest acquire
        RGM_TODO = 19,
-       RGM_IDENT = 20 };     // the partial-sum reduction's identity (0.0f / -inf): what a masked read returns      // tiles the eight wavefronts score together next
+       RGM_PARK = 21 };      // [RG_NOB] tile + 1 whose rows of the other direction are parked in obuf[slot]     // the partial-sum reduction's identity (0.0f / -inf): what a masked read returns      // tiles the eight wavefronts score together next
 
 // FARNN_PROBES (profiling build only): s_memtime stamps of the workgroups of full-length sequences, printed at their end
 #if defined(FARNN_PROBES)
@@ -332,7 +402,7 @@ chain_regs_kernel(const RegsParams p) {
     const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
     float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
-    float *ab = smem + lds.ab, *scl = smem + lds.scl;
+    float *ab = smem + lds.ab, *scl = smem + lds.scl, *obuf = smem + lds.obuf;
     int *misc = reinterpret_cast<int *>(smem + lds.misc);
 
     int b = p.order ? p.order[slot] : slot;
@@ -353,25 +423,35 @@ chain_regs_kernel(const RegsParams p) {
     }
     for (int j = tid; j < SP; j += nthreads) ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
     for (int j = tid; j < (nsteps + 1) * SP; j += nthreads) hist[j] = (j < S) ? hinit[j] : 0.0f;     // row 0; pad columns zero
-    if (tid < 32 + RG_NWC * 64) misc[tid] = tid == RGM_ACQ ? -1 : (tid == RGM_IDENT && MAXSR ? (int)0xff800000u : 0);
+    if (tid < 32) misc[tid] = tid == RGM_ACQ ? -1 : 0;
+    if (tid < 2) part[tid * RG_PART_STRIDE + RG_PART_STRIDE - 1] = MAXSR ? -INFINITY : 0.0f;     // the reduction's identity (masked reads)
+    if (tid < 2 * 4 * RG_NWC) part[(tid / (4 * RG_NWC)) * RG_PART_STRIDE + NP * SP + tid % (4 * RG_NWC)] = 0.0f;   // the step flags
     __syncthreads();
     if (w == 0) FARNN_RG_STAMP(1);
 #if FARNN_ABLATE & 256                               /* 256 = set-up only */
     return;
 #endif
 
-    int *sflag = misc + RGM_SFLAG;
+    const float *sflag = part + NP * SP;            // the step flags (buffer 0; buffer 1 is RG_PART_STRIDE floats on)
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
     int kmid = 0;                                    // tiles kmid.. belong to the forward workgroup's half, the rest to the backward one's
+    int pubmax = 0;                                  // the last row of THIS direction that a tile of the OTHER workgroup's half needs
     if (SCORE) {
         for (; kmid < ntl; kmid++) {
             int na, nb;
             regs_tile_need(kmid, len, nsteps, na, nb);
             if (na >= nb) break;
         }
+        for (int k = 0; k < ntl; k++) {
+            int na, nb;
+            regs_tile_need(k, len, nsteps, na, nb);
+            const bool others = dir == 0 ? k < kmid : k >= kmid;
+            if (others) pubmax = max(pubmax, dir == 0 ? na : nb);
+        }
     }
 
+    int wr_next = 0;                                 // (writer wavefront) the next state row to copy to the stash
     if (w < RG_NWC) {
         // =================================================================================================================
         // compute wavefronts
@@ -402,13 +482,22 @@ chain_regs_kernel(const RegsParams p) {
             // ds_ instructions: the unrolled step knows its buffer), idle lanes store to a dump slot, masked reads point at a
             // word that holds the sum's identity.  No EXEC juggling, no address arithmetic, no select in the step.
             constexpr int NQI = (RG_NWC * RG_MAXG + 3) / 4;      // partial vectors per reducing lane, at most
-            float *ident = reinterpret_cast<float *>(misc + RGM_IDENT);     // 0.0f (sum) or -inf (max)
+            const float *ident = part + RG_PART_STRIDE - 1;      // the last word of a buffer (never a partial sum: NP * SP < RG_PART_STRIDE)
+                                                                 // holds 0.0f (sum) or -inf (max), in BOTH buffers: the reads add the buffer's offset
             float *dump = part + 2 * RG_PART_STRIDE;             // [64][4]
             const float *qptr[NQI];                              // this lane's partial-vector entries in buffer 0
 #pragma unroll
             for (int i = 0; i < NQI; i++)
                 qptr[i] = (my_valid && rs + 4 * i < NP) ? part + (rs + 4 * i) * SP + my_row : ident;
-            float *wptr = active ? part + gid * SP + c * 4 : dump + lane * 4;                  // this lane's partial sums, buffer 0
+            // (an idle lane's slot lies in the buffer's unused tail, behind the NP partial vectors and the six flag slots: the step
+            //  adds the buffer's offset to every partial-sum pointer, so the slot must exist in both buffers.)  The FIRST idle
+            //  lane stores the wavefront's step flag with the same instruction: its slot is the flag slot, its "partial sum" the
+            //  step count.  (No idle lane -- 64 = G * CPR: one more ds_write_b32.)
+            const int nact = G * p.CPR;                           // lanes that own a piece of the block
+            const bool has_flane = nact < 64;
+            const bool is_flane = lane == nact;
+            float *fslot = part + NP * SP + 4 * w;                // this wavefront's flag (buffer 0)
+            float *wptr = active ? part + gid * SP + c * 4 : (is_flane ? fslot : part + NP * SP + 4 * RG_NWC + (lane - nact) * 4);
             float *hptr = my_writer ? hist + SP + my_row : dump + lane * 4;                      // where this lane's new state goes
             const int hstep = my_writer ? SP : 0;
             // The state entries a lane multiplies with -- rows g * RPG + u of this wavefront's share -- come straight from the
@@ -425,8 +514,7 @@ chain_regs_kernel(const RegsParams p) {
             }
             const int nl_mode = p.nl;
             const bool nl_relu = nl_mode == FARNN_NL_RELU;
-            int *myflag = sflag + w * 64 + lane;                  // every lane stores its own word: no EXEC juggling for one lane
-            const int *pflag = sflag + (lane < RG_NWC ? lane : 0) * 64;
+            const int *pflag = reinterpret_cast<const int *>(part + NP * SP) + 4 * (lane < RG_NWC ? lane : 0);   // the partners' flags (buffer 0)
 
             // The ring: RG_D steps x RG_RQ rows of 16 bytes per lane, loaded by inline asm so that NO compiler wait ever
             // drains it (hipcc's own bookkeeping merges the loop's back edge into vmcnt(0): measured, the ring then has no depth).
@@ -434,11 +522,19 @@ chain_regs_kernel(const RegsParams p) {
             // that names the four registers "+v" (cdna_hip_programming.md 5.7, form ii).  Loads retire in issue order, so
             // step t's four pieces have landed once at most the pieces of the steps issued after it are outstanding.
             v4f r[RG_D][RG_RQ];
+            // Block addresses: the byte offsets of 64 steps' blocks sit in a register pair (lane l: step window + l), a step's
+            // offset is two v_readlane -- no LDS read in the step; the window is reloaded from LDS once per 64 steps.
+#define FARNN_RG_WINDOW(t_)                                                                    \
+            do {                                                                               \
+                const int ti_ = (t_) + lane;                                                   \
+                const long long o_ = tokoff[ti_ < nsteps ? ti_ : nsteps - 1];                  \
+                tkw_lo = (int)(unsigned)o_; tkw_hi = (int)(unsigned)(o_ >> 32);                \
+            } while (0)
 #define FARNN_RG_BASE(t_, lo_, hi_)                                                            \
             do {                                                                               \
-                const long long off_ = tokoff[t_];                                             \
-                lo_ = __builtin_amdgcn_readfirstlane((unsigned)off_);                          \
-                hi_ = __builtin_amdgcn_readfirstlane((unsigned)(off_ >> 32));                 \
+                const int li_ = (t_) & 63;                                                     \
+                lo_ = (unsigned)__builtin_amdgcn_readlane(tkw_lo, li_);                        \
+                hi_ = (unsigned)__builtin_amdgcn_readlane(tkw_hi, li_);                        \
             } while (0)
 #define FARNN_RG_ISSUE(d, lo_, hi_)                                                            \
             do {                                                                               \
@@ -463,7 +559,9 @@ chain_regs_kernel(const RegsParams p) {
                          "s_waitcnt vmcnt(12)\n"                                               \
                          "2:"                                                                  \
                          : "+v"(r[d][0]), "+v"(r[d][1]), "+v"(r[d][2]), "+v"(r[d][3]) : "s"(rem_) : "scc")
-            unsigned nlo = 0, nhi = 0;                           // where step t + RG_D's block is (read one step ahead)
+            unsigned nlo = 0, nhi = 0;
+            int tkw_lo, tkw_hi;
+            FARNN_RG_WINDOW(0);
 #pragma unroll
             for (int d = 0; d < RG_D; d++) {
 #pragma unroll
@@ -473,7 +571,6 @@ chain_regs_kernel(const RegsParams p) {
                     FARNN_RG_ISSUE(d, nlo, nhi);
                 }
             }
-            FARNN_RG_BASE(RG_D < nsteps ? RG_D : 0, nlo, nhi);
 #if defined(FARNN_PROBES)
             long long ph[5] = {0, 0, 0, 0, 0}, pt = 0;
 #define FARNN_RG_PHASE(i) do { if (probe && w == 0 && (p.dbg & 256)) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph[i] += n_ - pt; pt = n_; } } while (0)
@@ -514,29 +611,34 @@ chain_regs_kernel(const RegsParams p) {
 #endif
                     const int boff = (d & 1) * RG_PART_STRIDE;           // this step's partial-sum buffer (t and d have the same parity)
 #if !(FARNN_ABLATE & 32)                             /* 32 = no partial-sum / flag stores */
+                    if (has_flane) acc.x = is_flane ? __int_as_float(t + 1) : acc.x;      // the flag rides in the idle lane's slot
+                    asm volatile("" ::: "memory");
                     *reinterpret_cast<v4f *>(wptr + boff) = acc;
-                    lds_flag_set(myflag, t + 1);                 // behind the partial sums in this wavefront's LDS order
+                    if (!has_flane && lane == 0) lds_flag_set(reinterpret_cast<int *>(fslot + boff), t + 1);   // behind the partial sums in LDS order
 #endif
                     asm volatile("" : "+v"(acc));                // the slot's registers are dead from here: reload them
 #if !(FARNN_ABLATE & 1)                              /* ablation builds (scripts/build_ablate.sh): 1 = no block loads */
-                    if (t + RG_D < nsteps) FARNN_RG_ISSUE(d, nlo, nhi);
+                    if (t + RG_D < nsteps) {
+                        if (((t + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + RG_D);
+                        FARNN_RG_BASE(t + RG_D, nlo, nhi);
+                        FARNN_RG_ISSUE(d, nlo, nhi);
+                    }
 #endif
                     FARNN_RG_PHASE(1);                           // FMAs, partial store, flag, next loads issued
                     // the other wavefronts' flags FIRST, then this lane's share of the partial sums and the next block address in the
                     // same batch: the LDS serves a wavefront in order, so partial sums read behind flags that say "written" are the
                     // written ones -- one round trip when the partners are on time, the whole batch again when they are not
                     float pv[NQI];
-                    long long noff;
 #if FARNN_ABLATE & 16                                /* 16 = no LDS reads at all in the step */
 #pragma unroll
                     for (int i = 0; i < NQI; i++) pv[i] = acc.x;
-                    noff = 0;
 #else
                     for (;;) {
-                        const int fl = lds_flag_get(pflag);
+                        const int fl = lds_flag_get(pflag + boff);
 #pragma unroll
-                        for (int i = 0; i < NQI; i++) pv[i] = qptr[i][boff];
-                        noff = tokoff[t + RG_D + 1 < nsteps ? t + RG_D + 1 : 0];
+                        for (int i = 0; i < NQI - 1; i++) pv[i] = qptr[i][boff];
+                        pv[NQI - 1] = MAXSR ? ninf : 0.0f;
+                        if (NP > 4 * (NQI - 1)) pv[NQI - 1] = qptr[NQI - 1][boff];     // (G = 4 only: more than 20 partial vectors)
                         asm volatile("" ::: "memory");
                         if (__ballot(fl < t + 1) == 0ull) break;
 #if FARNN_ABLATE & 2                                 /* 2 = nobody waits for the partners (wrong results) */
@@ -544,8 +646,6 @@ chain_regs_kernel(const RegsParams p) {
 #endif
                     }
 #endif
-                    nlo = __builtin_amdgcn_readfirstlane((unsigned)noff);
-                    nhi = __builtin_amdgcn_readfirstlane((unsigned)(noff >> 32));
                     FARNN_RG_PHASE(2);                           // the partners' partial sums
                     static_assert(NQI == 6, "the reduction tree below is written out for six partial sums per lane");
                     float s;
@@ -571,7 +671,7 @@ chain_regs_kernel(const RegsParams p) {
                     FARNN_RG_PHASE(3);                           // row reduce, nonlinearity, state exchange
                 }
             }
-            lds_flag_set(myflag, nsteps + 1);                    // (the last state row is in `hist`: writer / scorer count rows by these flags)
+            if (lane == 0) lds_flag_set(reinterpret_cast<int *>(fslot), nsteps + 1);   // (the last state row is in `hist`: writer / scorer count rows by these flags)
 #if defined(FARNN_PROBES)
             if (probe && w == 0 && lane == 0 && (p.dbg & 256))
                 printf("seq %d dir %d chain phases, cycles per step: block wait %lld, fma + store + issue %lld, partner wait + partial reads %lld, reduce + exchange %lld\n",
@@ -580,6 +680,7 @@ chain_regs_kernel(const RegsParams p) {
 #undef FARNN_RG_PHASE
 #undef FARNN_RG_ISSUE
 #undef FARNN_RG_BASE
+#undef FARNN_RG_WINDOW
 #undef FARNN_RG_WAIT
             __builtin_amdgcn_s_setprio(0);
             if (w == 0) FARNN_RG_STAMP(2);
@@ -600,28 +701,34 @@ chain_regs_kernel(const RegsParams p) {
                 for (long long e = (long long)nsteps * p.sp.K + lane; e < (long long)p.L * p.sp.K; e += WAVE)
                     p.sp.scores[(long long)b * p.L * p.sp.K + e] = 0.0f;
         }
-        int next = 0;                                             // rows 0 .. next - 1 are stored
-        while (next <= nsteps) {
-            const int avail = nsteps > 0 ? max(regs_rows_done(sflag, lane), 0) : 0;   // rows 0 .. avail are complete in hist
-            if (avail < next) { __builtin_amdgcn_s_sleep(2); continue; }
-            for (int rr = next; rr <= avail; rr++) {
-                const float *src = hist + rr * SP;
-                float *dst = stash + (long long)rr * SP;
-                if (SCORE) {
-                    for (int j = 2 * lane; j < SP; j += 2 * WAVE) st2_agent(dst + j, src[j], src[j + 1]);
-                } else {
-                    for (int j = lane; j < SP; j += WAVE) dst[j] = src[j];
-                }
-            }
-            next = avail + 1;
+        // rows 0 .. wr_next - 1 are stored.  One row per pass; when the chain is done the wavefront goes to the workgroup's
+        // meeting point at once: what it has not copied yet it copies after the tiles, before the final publish.
+        int published = -1;
+        auto copy_row = [&](int rr) {
+            const float *src = hist + rr * SP;
+            float *dst = stash + (long long)rr * SP;
             if (SCORE) {
+                for (int j = 2 * lane; j < SP; j += 2 * WAVE) st2_agent(dst + j, src[j], src[j + 1]);
+            } else {
+                for (int j = lane; j < SP; j += WAVE) dst[j] = src[j];
+            }
+        };
+        while (wr_next <= nsteps) {
+            if (nsteps > 0 && !regs_rows_reached(sflag, lane, wr_next)) { __builtin_amdgcn_s_sleep(1); continue; }
+            if (SCORE && nsteps > 0 && wr_next > pubmax && regs_rows_reached(sflag, lane, nsteps)) break;   // the chain is done
+            copy_row(wr_next);
+            wr_next++;
+            // The progress word feeds the other workgroup's tiles: once it covers the last row they need (pubmax), the
+            // rest is drained and published once, at the end -- no write-through round trip per row after that.
+            if (SCORE && wr_next - 1 < nsteps && published < pubmax &&
+                (wr_next - 1 >= pubmax || !regs_rows_reached(sflag, lane, wr_next))) {   // caught up with the chain, or pubmax reached
+                published = wr_next - 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this (the only storing) wavefront has left
                 if (lane == 0)
-                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)avail,
+                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)published,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if (SCORE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (SCORE) {
         // =================================================================================================================
         // scorer wavefront: tiles of this workgroup's half, while the chain runs
@@ -660,8 +767,38 @@ chain_regs_kernel(const RegsParams p) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");    // after the poll matched, before the loads
                 acq = pr;
             }
-            regs_score_tile<false>(p, b, dir, len, nsteps, k, hist, ab, scl, foff, 0, lane);
+            {
+                const rg_f32x4 none[RG_NG] = {};
+                regs_score_tiles<false>(p, b, dir, len, nsteps, k, -1, hist, nullptr, nullptr, ab, scl, foff, 0, lane, none);
+            }
             mine |= 1u << k;
+        }
+        // What is left of this half goes to all eight wavefronts when the chain ends.  Until then this wavefront parks the
+        // other direction's rows of (up to RG_NOB of) those tiles in LDS, so that the tiles start from LDS and registers.
+        {
+            int slot = 0;
+            for (int k = kfirst; k != klast && slot < RG_NOB; k += kstep) {
+                if ((mine >> k) & 1u) continue;
+                int na, nb;
+                regs_tile_need(k, len, nsteps, na, nb);
+                const int need_oth = dir == 0 ? nb : na;
+                if (need_oth > acq) {
+                    int pr = -1;
+                    for (;;) {
+                        pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+                        pr = __builtin_amdgcn_readfirstlane(pr);
+                        if (pr >= need_oth) break;
+                        if (regs_rows_reached(sflag, lane, nsteps)) break;
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    if (pr < need_oth) break;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    acq = pr;
+                }
+                regs_park_rows(p, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
+                if (lane == 0) misc[RGM_PARK + slot] = k + 1;
+                slot++;
+            }
         }
         if (lane == 0) { misc[RGM_MINE] = (int)mine; misc[RGM_ACQ] = acq; }
         FARNN_RG_STAMP(3);
@@ -673,13 +810,12 @@ chain_regs_kernel(const RegsParams p) {
     // progress (as covered by an acquire) allows are scored now by all eight wavefronts; the arrival word carries the
     // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
-    __syncthreads();
-    if (w == 0) FARNN_RG_STAMP(4);
-    const long long foff = misc[RGM_FOFF];
+    rg_f32x4 bpre[RG_NG];                                            // this wavefront's column block of O^T: in flight across the barrier
+    regs_load_b(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
     const unsigned all_tiles = ntl >= 32 ? ~0u : ((1u << ntl) - 1u);
-    unsigned long long arrived = 0ull;                                // (scorer wavefront, lane 0) what the arrival exchange returned
     unsigned promised = 0u;
     if (w == RG_WAVES - 1) {
+        // which tiles of this half can be scored now: those the other direction's progress, as covered by an acquire, allows
         const unsigned mine = (unsigned)misc[RGM_MINE];
         int acq = misc[RGM_ACQ];
         const unsigned own_half = dir == 0 ? (all_tiles & ~((1u << kmid) - 1u)) : (all_tiles & ((1u << kmid) - 1u));
@@ -704,31 +840,65 @@ chain_regs_kernel(const RegsParams p) {
             } else __builtin_amdgcn_s_sleep(8);
         }
         promised = mine | todo;
-        // arrival: this workgroup's stash rows are stored and drained (the writer, before the barrier above); the exchange
-        // is in flight while the promised tiles are scored
-        if (lane == 0)
-            arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)p.epoch << 32) | 0x80000000ull | promised,
-                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) misc[RGM_TODO] = (int)todo;
     }
-    __syncthreads();
+    wg_barrier_lds();                                                // the chain is done, the mask is there (LDS only: this wavefront's
+                                                                     // O^T loads and the writer's last stores stay in flight)
+    if (w == 0) FARNN_RG_STAMP(4);
+    if (w == RG_NWC)                                                 // the state rows the writer had not copied yet: issued now, landed by the
+        for (; wr_next <= nsteps; wr_next++)                         // time the tiles are done (this wavefront forms no products meanwhile)
+            for (int j = 2 * lane; j < SP; j += 2 * WAVE)
+                st2_agent(stash + (long long)wr_next * SP + j, hist[wr_next * SP + j], hist[wr_next * SP + j + 1]);
+    // ---- arrival: ONE lane exchanges the sequence's arrival word for {epoch, the tiles this workgroup scores}; the
+    // exchange is in flight while those tiles are scored.  (The word says nothing about this workgroup's stash rows: they
+    // are published through the progress word, below; the workgroup that has to read them waits for that.)
+    unsigned long long arrived = 0ull;
+    if (w == RG_WAVES - 1 && lane == 0)
+        arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)p.epoch << 32) | 0x80000000ull | promised,
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long foff = misc[RGM_FOFF];
     for (int pass = 0; pass < 2; pass++) {
-        const unsigned todo = (unsigned)misc[RGM_TODO];
-        for (int k = 0; k < ntl; k++) {
-            if (!((todo >> k) & 1u)) continue;
-            regs_score_tile<true>(p, b, dir, len, nsteps, k, hist, ab, scl, foff, w, lane);
-            __syncthreads();                                         // the tile's LDS is free again
+        unsigned todo = (unsigned)misc[RGM_TODO];
+        while (todo) {                                               // two tiles per pass
+            const int k0 = __builtin_ctz(todo);
+            todo &= todo - 1u;
+            const int k1 = todo ? __builtin_ctz(todo) : -1;
+            if (todo) todo &= todo - 1u;
+            const float *par0 = nullptr, *par1 = nullptr;
+#pragma unroll
+            for (int sl = 0; sl < RG_NOB; sl++) {
+                if (misc[RGM_PARK + sl] == k0 + 1) par0 = obuf + sl * RG_TT * SP;
+                if (misc[RGM_PARK + sl] == k1 + 1) par1 = obuf + sl * RG_TT * SP;
+            }
+            regs_score_tiles<true>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1, ab, scl, foff, w, lane, bpre);
+            __syncthreads();                                         // the tiles' LDS is free again
         }
         if (pass == 1) break;
         if (w == 0) FARNN_RG_STAMP(5);
-        __syncthreads();                                             // every wavefront has read this pass's mask
+        // every stash row of this direction has been stored by the writer wavefront: it drains them (they had the tiles'
+        // time to land) and publishes the full count
+        if (w == RG_NWC) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)nsteps,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (w == RG_WAVES - 1) {
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(arrived >> 32));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)arrived);
             unsigned rest = 0u;
-            if (hi == p.epoch && (lo & 0x80000000u)) {               // second of the two: the other's rows are all published
+            if (hi == p.epoch && (lo & 0x80000000u)) {               // second of the two
                 rest = all_tiles & ~(promised | (lo & 0x7fffffffu));
                 if (rest) {
+                    // The other workgroup has arrived: it is resident, past its chain, and publishes its full row count
+                    // after a bounded amount of work of its own (it waits for nobody) -- so this wait ends.
+                    const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
+                    for (;;) {
+                        int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+                        pr = __builtin_amdgcn_readfirstlane(pr);
+                        if (pr >= nsteps) break;
+                        __builtin_amdgcn_s_sleep(8);
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }

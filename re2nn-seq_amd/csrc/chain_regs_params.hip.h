@@ -52,12 +52,14 @@ inline RegsGeom regs_geometry(int S) {
     g.RPG = (S + g.NP - 1) / g.NP;
     if (g.RPG > RG_RQ) g.ok = false;
     g.rows = (g.NP - 1) * g.RPG + RG_RQ;      // every row index a lane's four loads can form
+    // a partial-sum buffer: NP vectors, a 16-byte slot per idle lane, and its last word = the reduction's identity
+    if (g.NP * g.SP + 4 * RG_NWC + 4 * (64 - g.G * g.CPR) >= RG_PART_STRIDE) g.ok = false;      // (+ the six step flags)
     return g;
 }
 
 // LDS carve, in floats (host and device agree through this one function)
 struct RegsLds {
-    int tok, hp, part, ol, hist, ab, scl, misc, total;
+    int tok, hp, part, ol, hist, ab, scl, obuf, misc, total;
 };
 __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score) {
     RegsLds l;
@@ -67,9 +69,10 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
     l.part = at; at += 2 * RG_PART_STRIDE + 64 * 4;     // two partial-sum buffers + the idle lanes' dump slots
     l.ol = at;   at += SP;
     l.hist = at; at += (L + 1) * SP + 16;          // + the launch-order scratch's tail
-    l.ab = at;   at += score ? RG_TT * (16 * c16 + 4) : 0;
-    l.scl = at;  at += score ? RG_TT * Kc : 0;
-    l.misc = at; at += 32 + RG_NWC * 64;           // words + the compute wavefronts' step flags
+    l.ab = at;   at += score ? 2 * RG_TT * (16 * c16 + 4) : 0;    // two tiles' products
+    l.scl = at;  at += score ? 2 * RG_TT * Kc : 0;               // two tiles' scores
+    l.obuf = at; at += score ? 2 * RG_TT * SP : 0;    // RG_NOB tiles of the other direction's rows
+    l.misc = at; at += 32;
     l.total = at;
     return l;
 }

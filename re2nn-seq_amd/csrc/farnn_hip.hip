@@ -507,7 +507,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
                 rp.prog = m->hs; rp.arr = m->hs + (size_t)2 * m->wsB;
                 rp.epoch = m->epoch_u;
                 rp.spin = env_int("FARNN_FUSE_SPIN", 4);
-                rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 6);
+                rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 24);
                 rp.sp = *fuse_sp;
                 if (fused) *fused = true;
             }
