@@ -451,7 +451,7 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
         rf.update(bound='hbm', achieved=0.0, peak=HBM_PEAK_GBS, unit='GB/s', frac=0.0)
         return rf
     L = a.seqlen
-    byte_bound = ('chain_kernel' in kname and dom == _lib.KERN_CHAIN) or 'fst4' in kname
+    byte_bound = (('chain_kernel' in kname or 'chain_regs_kernel' in kname) and dom == _lib.KERN_CHAIN) or 'fst4' in kname
     if byte_bound:
         alg = h.kernel_algorithmic_bytes(dom, tok_local)
         achieved = alg / dom_s / 1e9

@@ -59,15 +59,6 @@ struct ChainParams {
     int NQP, PPS;           // chunks per phase per compute wave; phases per step (ring/barrier unit)
     int nl, full;
     int dbg;                // diagnostic ablation mask (FARNN_DBG); 0 in production
-    // fused epilogue (chain_kernel<..., FUSED = true>): per-sequence arrival counters [B] (monotonic: two arrivals per
-    // launch, the workgroup whose add returns an odd value arrived second and scores the sequence) and the hand-off form
-    int *pair_cnt;
-    int *claim;             // [B] which launch (epoch) last claimed the sequence's odd tiles
-    int epoch;              // this launch's number (unique per handle)
-    int flat_in_kernel;     // 1: the epilogue writes the flat output and no prefix array exists: sum the lengths here
-    int spin;               // polls the first-arrived direction spends waiting for the other one before it leaves
-    int fence;              // 1: agent-scope release / acquire fences around the arrival (on top of the sc1 stores / loads)
-    int xcd_pair;           // 1: the two directions of a sequence run on the same XCD (B % 8 == 0)
 };
 
 constexpr int CHAIN_MAX_THREADS = 512;     // NW compute + NLD loader + 1 writer wavefronts <= 8
@@ -80,57 +71,21 @@ constexpr int CHAIN_MAX_G = 4;
 // FQ > 3 (one compute wavefront owning up to 24 rows per lane group) needs the register file of a
 // <= 6-wavefront workgroup for the prefetched block share.
 //
-// FUSED: the label scores and the threshold/argmax decode (K2, score_decode.hip.h) run as the EPILOGUE of this
-// kernel -- one launch per tagging step (north_star; reference loop model_onehot.py:411-426).  The two directions of
-// a sequence stay separate workgroups (a workgroup that owned both would carry 2 x len block loads on one CU: the
-// kernel is bound by the per-CU L2->LDS fill rate and the folded launch order pairs a long with a short chain per CU).
-// Hand-off, deadlock-free (nobody waits): every workgroup stores its stash rows write-through (`sc1`, 8 bytes per
-// lane), drains them (writer wavefront: s_waitcnt vmcnt(0)), meets at a workgroup barrier, then one lane adds 1 to the
-// sequence's arrival counter (agent scope).  The workgroup whose add came SECOND owns the sequence's epilogue: it
-// reads both stashes with `sc1` loads (L2-served, never this CU's L1), stages the transposed output matrix in the
-// now idle DMA ring and scores every 32-token tile of the sequence with all eight wavefronts
-// (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility": valid forms, row 1;
-// p.fence adds the agent-scope release / acquire fences on both sides).
-struct ChainKernelArgs {      // ONE kernel argument, so that the epilogue can address its half of the kernarg segment
-    ChainParams p;
-    ScoreParams sp;
-};
-
-static_assert(sizeof(ScoreParams) % 4 == 0, "ScoreParams is copied word by word");
-template <class KARGS>
-__device__ __forceinline__ ScoreParams load_epilogue_params() {
-    union { ScoreParams sp; unsigned w[sizeof(ScoreParams) / 4]; } u;
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef __attribute__((address_space(4))) const char kchar_t;
-    typedef __attribute__((address_space(4))) const unsigned kword_t;
-    kchar_t *ka = (kchar_t *)__builtin_amdgcn_kernarg_segment_ptr();
-    kword_t *src = (kword_t *)(ka + offsetof(KARGS, sp));
-    asm volatile("" : "+s"(src));                    // the scalar loads below cannot move above this point
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(ScoreParams) / 4; i++) u.w[i] = src[i];
-#else
-    memset(&u, 0, sizeof(u));
-#endif
-    return u.sp;
-}
-
-template <int NCH, bool MAXSR, int FQ, bool FUSED>
-__global__ void __launch_bounds__(FQ > 3 ? 384 : CHAIN_MAX_THREADS, FUSED ? 4 : 1)   // fused (4 waves per SIMD = 128 VGPRs): the epilogue must not cost the
-chain_kernel(const ChainKernelArgs args) {                                           // second workgroup of a CU its registers
-    const ChainParams &p = args.p;
+// One launch per tagging step (scores + decode beside the recurrence) is chain_regs.hip.h's kernel for the geometries it covers
+// (S <= 72); this kernel serves the rest, followed by the score / Viterbi kernels of score_decode.hip.h.
+template <int NCH, bool MAXSR, int FQ>
+__global__ void __launch_bounds__(FQ > 3 ? 384 : CHAIN_MAX_THREADS)
+chain_kernel(const ChainParams p) {
     constexpr int PER = 4 * NCH;                 // DMA pieces (1 KiB each) per 4-row chunk
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int nthreads = blockDim.x;
-    // Workgroup -> (launch slot, direction).  Consecutive workgroup ids go to consecutive XCDs (id % 8).  Default: ids 2s and
-    // 2s + 1 -- every forward chain on an even XCD, every backward chain on an odd one, so an XCD's L2 caches one direction's
-    // blocks only.  With p.xcd_pair the two directions of a slot are the ids 16q + x and 16q + 8 + x -- the same XCD: the stash
-    // rows one stores write-through and the other reads in the fused epilogue meet in that L2, at the price of both
-    // directions' blocks competing for it (0.4 us faster per step, 50 % more fabric traffic: not the default).
+    // Workgroup -> (launch slot, direction).  Consecutive workgroup ids go to consecutive XCDs (id % 8): ids 2s and 2s + 1 put
+    // every forward chain on an even XCD and every backward chain on an odd one, so an XCD's L2 caches one direction's blocks only.
     const int item = blockIdx.x;
-    const int dir = p.xcd_pair ? ((item >> 3) & 1) : (item & 1);
-    const int slot = p.xcd_pair ? (((item >> 4) << 3) | (item & 7)) : (item >> 1);
+    const int dir = item & 1;
+    const int slot = item >> 1;
     int b = p.order ? p.order[slot] : slot;
     if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(slot, p.B), reinterpret_cast<int *>(smem), tid, nthreads);
     const int len = clamp_len(p.len[b], p.L);
@@ -170,10 +125,8 @@ chain_kernel(const ChainKernelArgs args) {                                      
     }
     for (int j = tid; j < SP; j += nthreads) ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
     for (int j = tid; j < 2 * SP; j += nthreads) hfull[j] = 0.0f;      // pad columns of every stash row stay zero
-    __shared__ int foff_word;
-    int *foff_lds = &foff_word;
-    // the recurrence proper; a wavefront leaves it with `return` when its role is done (FUSED: the epilogue follows)
-    auto chain_body = [&]() {
+    // the recurrence proper; a wavefront leaves it with `return` when its role is done
+    {
     if (nsteps == 0) {
         for (int j = tid; j < SP; j += nthreads) stash[j] = (j < S) ? hinit[j] : 0.0f;
         return;
@@ -202,19 +155,7 @@ chain_kernel(const ChainKernelArgs args) {                                      
     // writer wavefront
     // =========================================================================================
     if (w == NW + NLD) {
-        if (FUSED && p.flat_in_kernel && !(p.dbg & 2048)) {        // where sequence b starts in the flat output (utils.py:153-164): sum of the
-            int part = 0;                       // lengths in front of it, by this otherwise idle wavefront (B <= 1024)
-            for (int j = lane; j < b; j += WAVE) part += clamp_len(p.len[j], p.L);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
-            if (lane == 0) *foff_lds = part;
-        }
-        if (FUSED) {                                                 // write-through (sc1) 8-byte stores: see the hand-off above
-            for (int j = 2 * lane; j < SP; j += 2 * WAVE)
-                st2_agent(stash + j, j < S ? hinit[j] : 0.0f, j + 1 < S ? hinit[j + 1] : 0.0f);
-        } else {
-            for (int j = lane; j < SP; j += WAVE) stash[j] = (j < S) ? hinit[j] : 0.0f;   // state 0
-        }
+        for (int j = lane; j < SP; j += WAVE) stash[j] = (j < S) ? hinit[j] : 0.0f;   // state 0
         wg_barrier_lds();                                            // B_{-1}
         for (int f = (p.dbg & 4) ? NF : 0; f <= NF; f++) {
             wg_barrier_lds();                                        // B_f (f == NF: the final one)
@@ -222,16 +163,12 @@ chain_kernel(const ChainKernelArgs args) {                                      
                 const int t = f / PPS - 1;
                 const float *src = hfull + (t & 1) * SP;
                 float *srow = stash + (long long)(t + 1) * SP;
-                if (FUSED && !(p.dbg & 256)) {
-                    for (int j = 2 * lane; j < SP; j += 2 * WAVE) st2_agent(srow + j, src[j], src[j + 1]);
-                } else {
-                    for (int j = lane; j < SP; j += WAVE) srow[j] = src[j];     // pad columns: hfull's stay zero
-                }
+                for (int j = lane; j < SP; j += WAVE) srow[j] = src[j];         // pad columns: hfull's stay zero
             }
         }
         return;
     }
-    if (w > NW + NLD) {                                              // helper wavefronts (FUSED: eight for the epilogue)
+    if (w > NW + NLD) {                                              // helper wavefront (FARNN_CHAIN_HELPER experiment)
         wg_barrier_lds();                                            // B_{-1}
         for (int f = (p.dbg & 4) ? NF : 0; f <= NF; f++) wg_barrier_lds();
         return;
@@ -465,86 +402,6 @@ chain_kernel(const ChainKernelArgs args) {                                      
         }
     }
     wg_barrier_lds();                                                // final: last state -> writer
-    };   // chain_body
-    chain_body();
-
-    if constexpr (FUSED) {
-        const bool eprobe = (p.dbg & 32768) && nsteps == p.L && tid == 0;      // diagnostic: the epilogue's timeline
-        const long long e0 = eprobe ? (long long)__builtin_amdgcn_s_memtime() : 0;
-        long long e1 = 0, e2 = 0;
-        // ---- hand-off: arrive at the sequence's counter; the second arrival scores the sequence -----------------
-        __shared__ int arrive_s;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // this wavefront's stash stores have left (writer)
-        __syncthreads();
-        if (tid == 0) {
-            if (p.fence) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the compiler may drop the fence's own wait)
-            }
-            arrive_s = __hip_atomic_fetch_add(p.pair_cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const ScoreParams sp = load_epilogue_params<ChainKernelArgs>();
-        float *esm = reinterpret_cast<float *>(ring);                // products tile + score tile
-        const int ntv = (nsteps + SCORE_TT - 1) / SCORE_TT;          // tiles that hold computed tokens
-        const long long foff_pre = (p.flat_in_kernel && !(p.dbg & 2048)) ? (long long)*foff_lds : -1;
-        __syncthreads();                                             // the adding wave joins; nobody loads before it
-        const int arrived = arrive_s;
-        if (eprobe) e1 = (long long)__builtin_amdgcn_s_memtime();
-        if (p.dbg & 128) return;                                     // ablation: no epilogue (wrong results)
-        auto run_tiles = [&](int first) {                            // tiles first, first + 2, ... of this sequence
-            switch (sp.kch) {
-                case 1: score_tiles<1, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
-                case 2: score_tiles<2, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
-                case 3: score_tiles<3, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
-                default: score_tiles<4, true>(sp, b, first, 2, esm, tid, foff_pre, len); break;
-            }
-        };
-        auto acquire = [&]() {
-            if (p.fence) {
-                if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-            }
-        };
-        // Work split between the two workgroups of a sequence: the SECOND arrival owns the even tiles (and every
-        // pad-only tile); the odd tiles go to whoever claims them first -- the first arrival if it sees the other
-        // direction finish within a bounded wait (the two chains have the same length and end within microseconds
-        // of each other), else the second arrival after its own tiles.  Nobody waits for a workgroup that may not be
-        // resident longer than the bound, so the launch cannot deadlock; the claim (an exchange of the launch's epoch)
-        // makes every tile scored exactly once.
-        __shared__ int claim_s;
-        if (!(arrived & 1)) {                                        // first of the two directions
-            if (ntv < 2 || p.spin <= 0) return;
-            if (tid == 0) {
-                int seen = 0;
-                for (int it = 0; it < p.spin && !seen; it++) {
-                    seen = __hip_atomic_load(p.pair_cnt + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrived + 2;
-                    if (!seen) __builtin_amdgcn_s_sleep(4);
-                }
-                int won = 0;
-                if (seen) won = __hip_atomic_exchange(p.claim + b, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch;
-                claim_s = won;
-            }
-            __syncthreads();                                         // the polling wave joins; loads only behind it
-            if (!claim_s) return;
-        }
-        acquire();
-        if (eprobe) e2 = (long long)__builtin_amdgcn_s_memtime();
-        // one call site for the tile code (four label-width variants of a large unrolled body)
-        for (int first = (arrived & 1) ? 0 : 1;; first = 1) {
-            run_tiles(first);
-            if (first == 1) break;
-            if (ntv >= 2) {                                          // the odd tiles: still unclaimed?
-                __syncthreads();
-                if (tid == 0)
-                    claim_s = __hip_atomic_exchange(p.claim + b, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != p.epoch;
-                __syncthreads();
-                if (!claim_s) break;                                 // the other direction's workgroup took them
-            }
-        }
-        if (eprobe)
-            printf("epilogue of sequence %d dir %d (arrival %d): arrive %lld cycles, wait/claim %lld, tiles %lld\n", b, dir, arrived & 1,
-                   e1 - e0, e2 - e1, (long long)__builtin_amdgcn_s_memtime() - e2);
     }
 }
 

@@ -588,6 +588,13 @@ chain_regs_kernel(const RegsParams p) {
                     const int t = t0 + d;
                     if (t >= nsteps) break;
                     static_assert(RG_D == 4 && RG_RQ == 4, "FARNN_RG_WAIT is written out for a 4 x 4 ring");
+                    // where the block of step t + RG_D is: fixed at the step's start, where the wavefront waits for its state exchange
+                    // anyway (the once-per-64-steps window reload is an LDS read: its wait must not sit between the partial-sum
+                    // store and the loads' issue)
+                    if (t + RG_D < nsteps) {
+                        if (((t + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + RG_D);
+                        FARNN_RG_BASE(t + RG_D, nlo, nhi);
+                    }
                     FARNN_RG_WAIT(d, nsteps - 1 - t);            // steps issued after this one: min(RG_D - 1, nsteps - 1 - t)
                     FARNN_RG_PHASE(0);                           // wait for this step's block pieces
                     v4f acc = MAXSR ? v4f{ninf, ninf, ninf, ninf} : v4f{0.f, 0.f, 0.f, 0.f};
@@ -618,11 +625,7 @@ chain_regs_kernel(const RegsParams p) {
 #endif
                     asm volatile("" : "+v"(acc));                // the slot's registers are dead from here: reload them
 #if !(FARNN_ABLATE & 1)                              /* ablation builds (scripts/build_ablate.sh): 1 = no block loads */
-                    if (t + RG_D < nsteps) {
-                        if (((t + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + RG_D);
-                        FARNN_RG_BASE(t + RG_D, nlo, nhi);
-                        FARNN_RG_ISSUE(d, nlo, nhi);
-                    }
+                    if (t + RG_D < nsteps) FARNN_RG_ISSUE(d, nlo, nhi);
 #endif
                     FARNN_RG_PHASE(1);                           // FMAs, partial store, flag, next loads issued
                     // the other wavefronts' flags FIRST, then this lane's share of the partial sums and the next block address in the
@@ -875,6 +878,7 @@ chain_regs_kernel(const RegsParams p) {
         }
         if (pass == 1) break;
         if (w == 0) FARNN_RG_STAMP(5);
+        wg_barrier_lds();                                            // every wavefront has read this pass's mask (it is rewritten below)
         // every stash row of this direction has been stored by the writer wavefront: it drains them (they had the tiles'
         // time to land) and publishes the full count
         if (w == RG_NWC) {

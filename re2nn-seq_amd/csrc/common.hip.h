@@ -34,6 +34,14 @@ inline int fail(int code, const char *fmt, const char *a = "", const char *b = "
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// In-kernel phase probes (s_memtime stamps, device printf) exist in the profiling build only (build.py --probes: -DFARNN_PROBES);
+// in the production library the predicate is a compile-time false and the probe code is gone.
+#if defined(FARNN_PROBES)
+#define FARNN_PROBE_ON(expr) (expr)
+#else
+#define FARNN_PROBE_ON(expr) false
+#endif
+
 // ---- device helpers ---------------------------------------------------------------------------
 // update_nonlinear dispatch (reference model_onehot.py:379-386).  `nl` is wave-uniform.
 __device__ __forceinline__ float apply_nl(float v, int nl) {

@@ -161,7 +161,7 @@ compact_chain_kernel(const CompactParams p) {
             a[k] = hnext;
         }
     };
-    const long long tb0 = __builtin_amdgcn_s_memtime();
+    const long long tb0 = FARNN_PROBE_ON(p.dbg & 4096) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     // main part: whole groups of PF steps with NO branch around a fetch (a conditional fetch makes the compiler merge the
     // loaded registers with moves right behind the load, i.e. wait for it at once); the look-ahead index is clamped instead
     int t0 = 0;
@@ -178,7 +178,7 @@ compact_chain_kernel(const CompactParams p) {
 #pragma unroll
     for (int u = 0; u < PF; u++)
         if (t0 + u < nsteps) step(t0 + u, ring[u]);
-    if ((p.dbg & 4096) && item < 2 && lane == 0)
+    if (FARNN_PROBE_ON(p.dbg & 4096) && item < 2 && lane == 0)
         printf("compact chain %d (dir %d): %d steps, %lld cycles per step\n", item, dir, nsteps,
                (long long)(__builtin_amdgcn_s_memtime() - tb0) / nsteps);
 }

@@ -135,7 +135,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
     static_assert(CS >= 1 && CS <= NCH3, "rr chunks");
     long long cyc[4] = {0, 0, 0, 0};
     for (int t = 0; t < nsteps; t++) {
-        long long c0 = (p.dbg & 4096) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+        long long c0 = FARNN_PROBE_ON(p.dbg & 4096) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const int cur = t & 1, nxt = cur ^ 1;
         const float v2 = *v_addr(tk2);                        // step t+2's entry: in flight for two steps
         tk2 = tok[t + 3 < nsteps ? t + 3 : nsteps - 1];      // (consumed at the next step's start)
@@ -173,9 +173,9 @@ decomp_regs_kernel(const DecompRegsParams p) {
                 }
             }
         }
-        if (p.dbg & 4096) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c1 = __builtin_amdgcn_s_memtime(); cyc[0] += c1 - c0; c0 = c1; }
+        if (FARNN_PROBE_ON(p.dbg & 4096)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c1 = __builtin_amdgcn_s_memtime(); cyc[0] += c1 - c0; c0 = c1; }
         wg_barrier_lds();
-        if (p.dbg & 4096) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[1] += c1 - c0; c0 = c1; }
+        if (FARNN_PROBE_ON(p.dbg & 4096)) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[1] += c1 - c0; c0 = c1; }
         // ---- phase B: the rr chunks of P3, h'[j] = nl(<[Sb[j, :] | Wd[:, j]], [rr | h]>), into the other buffers and the stash
         {
             lds_cfloat *xq = (lds_cfloat *)X3c + k * 4;
@@ -212,11 +212,11 @@ decomp_regs_kernel(const DecompRegsParams p) {
             }
         }
         v0 = v1; v1 = v2;
-        if (p.dbg & 4096) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c1 = __builtin_amdgcn_s_memtime(); cyc[2] += c1 - c0; c0 = c1; }
+        if (FARNN_PROBE_ON(p.dbg & 4096)) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long c1 = __builtin_amdgcn_s_memtime(); cyc[2] += c1 - c0; c0 = c1; }
         wg_barrier_lds();
-        if (p.dbg & 4096) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[3] += c1 - c0; }
+        if (FARNN_PROBE_ON(p.dbg & 4096)) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[3] += c1 - c0; }
     }
-    if ((p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)
+    if (FARNN_PROBE_ON(p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)
         printf("regs kernel wg %d wave %d: %d steps, cycles per step: A %lld  barrier %lld  B %lld  barrier %lld\n", (int)blockIdx.x, wtid >> 6,
                nsteps, cyc[0] / nsteps, cyc[1] / nsteps, cyc[2] / nsteps, cyc[3] / nsteps);
 }

@@ -72,8 +72,6 @@ struct farnn_model {
     float *d1_br = nullptr;                 // [B*L][MT][NT*16] per-row-tile partial output-rank vectors (decomposed independent=1)
     int64_t *offs = nullptr;
     int *order = nullptr;
-    int *pair_cnt = nullptr;                // [2][B] arrival counters of the fused chain+score launch (monotonic) and tile claims
-    int epoch = 0;                          // launches of the fused kernel so far
     int wsB = 0, wsL = 0;                   // workspace CAPACITY: sequences, positions
     int curL = 0;                           // the current call's L: every stride of the workspace arrays
     ChainGeom geom;
@@ -104,6 +102,11 @@ struct farnn_model {
     } hslot[FARNN_HOST_SLOTS];
     hipStream_t hs_run = nullptr;
     int hnext = 0;
+    // stream ordering of the handle's ONE workspace (stash, hand-off words, launch order): a call on another stream than the
+    // previous call's waits for that call's work first
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    hipEvent_t ev_order = nullptr;
 };
 
 // ---- small helpers ---------------------------------------------------------------------------
@@ -355,21 +358,18 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     if (m->A) {
         FARNN_HIP_TRY(hipDeviceSynchronize());
         (void)hipFree(m->A); (void)hipFree(m->Bk); (void)hipFree(m->offs); (void)hipFree(m->order);
-        if (m->pair_cnt) (void)hipFree(m->pair_cnt);
         if (m->hs) (void)hipFree(m->hs);
         if (m->crf_scores) (void)hipFree(m->crf_scores);
         if (m->d1_br) (void)hipFree(m->d1_br);
     }
     m->d1_br = nullptr;
-    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->pair_cnt = nullptr; m->wsB = m->wsL = 0;
+    m->A = m->Bk = m->crf_scores = nullptr; m->offs = nullptr; m->order = nullptr; m->wsB = m->wsL = 0;
     m->hs = nullptr;
     size_t stash = (size_t)nB * (nL + 1) * m->SP * sizeof(float);
     FARNN_HIP_TRY(hipMalloc((void **)&m->A, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
-    FARNN_HIP_TRY(hipMalloc((void **)&m->pair_cnt, (size_t)2 * nB * sizeof(int)));
-    FARNN_HIP_TRY(hipMemset(m->pair_cnt, 0, (size_t)2 * nB * sizeof(int)));
     m->hs_bytes = round_up_sz((size_t)3 * nB * sizeof(unsigned long long), 16);
     FARNN_HIP_TRY(hipMalloc((void **)&m->hs, m->hs_bytes));
     FARNN_HIP_TRY(hipMemset(m->hs, 0, m->hs_bytes));
@@ -450,7 +450,6 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
         case KERN_CHAIN:
             if (m->compact_on) return "compact_chain_kernel";
             if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
-            if (m->last_fused) return "chain_kernel<fused score+decode epilogue>";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
                 return m->rows.ok ? ((m->last_wave || (m->calls == 0 && m->dw.farnn == 0 && m->dw.R <= DG_ROWS && !getenv("FARNN_DECOMP_NOREGS"))) ? "decomp_regs_kernel" : "decomp_rows_kernel") : "decomp_chain_kernel";
@@ -518,6 +517,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
             return FARNN_OK;
         }
     }
+    (void)fuse_sp;
     ChainParams p;
     p.Mf = m->Mf; p.Mb = m->Mb; p.blk = (long long)m->geom.SR * m->SP;
     p.o = m->o; p.h0 = m->h0; p.hT = m->hT; p.x = x; p.len = len; p.A = m->A; p.Bk = m->Bk;
@@ -526,10 +526,6 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR; p.V = m->V;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
     p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
-    // default: ids 2s / 2s + 1 -- forward chains on the even XCDs, backward chains on the odd ones, so every L2 caches ONE
-    // direction's blocks (19 MB of the 39 MB working set).  FARNN_XCD_PAIR=1 puts both directions of a sequence on one XCD
-    // (hand-off through one L2): 0.4 us faster per step but 103-119 -> 159-166 MB of fabric traffic per launch (measured).
-    p.xcd_pair = (B % 8 == 0 && env_int("FARNN_XCD_PAIR", 0)) ? 1 : 0;
     // ring shape: a whole step per phase when it fits, KS phases deep
     int ks = 2, nqp = g.NQ;
     if (!g.pick_ring(m->curL, m->chain_ks, ks, nqp))
@@ -539,46 +535,17 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);         // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
-    ScoreParams sp;
-    memset(&sp, 0, sizeof(sp));
-    // the fused form needs eight wavefronts for the epilogue, the one-chunk-per-lane geometries (S <= 256), the
-    // sequence's score tile + output matrix inside the (then idle) DMA ring, and the arrival counters
-    const bool six_wave_fast = block.x <= 384 && g.NCH == 1 && p.PPS == 1 && g.NQ > 3;   // keeps its own fast path
-    const bool do_fuse = fuse_sp && m->pair_cnt && g.NCH == 1 && g.NW + g.NLD + 1 <= SCORE_WAVES && !six_wave_fast &&
-                         score_lds_bytes(m->S, m->Kc) <= (size_t)ks * g.phase_bytes(nqp) &&
-                         !env_int("FARNN_NOFUSE", 0);
-    if (do_fuse) {
-        sp = *fuse_sp;
-        block = dim3(SCORE_WAVES * 64);
-        p.pair_cnt = m->pair_cnt;
-        p.claim = m->pair_cnt + m->wsB;
-        p.epoch = ++m->epoch;
-        p.spin = env_int("FARNN_FUSE_SPIN", 160);
-        p.flat_in_kernel = (sp.flat && !sp.offs) ? 1 : 0;
-        p.fence = env_int("FARNN_FUSE_FENCE", 0);
-        if (fused) *fused = true;
-    } else {
-        p.pair_cnt = nullptr; p.claim = nullptr; p.epoch = 0; p.spin = 0; p.fence = 0; p.flat_in_kernel = 0;
-        if (env_int("FARNN_CHAIN_HELPER", 0) && block.x < 512) block = dim3(block.x + 64);     // experiment: an idle eighth wavefront
-    }
-#define FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, FU)                                                 \
-    do {                                                                                      \
-        if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ, FU>, lds))) return rc;            \
-        if (kt.e0 && kt.e1)                                                                   \
-            hipExtLaunchKernelGGL((chain_kernel<NCH, MX, FQ, FU>), grid, block, (uint32_t)lds, s, kt.e0, kt.e1, 0, ka); \
-        else                                                                                  \
-            chain_kernel<NCH, MX, FQ, FU><<<grid, block, lds, s>>>(ka);                    \
-    } while (0)
+    if (env_int("FARNN_CHAIN_HELPER", 0) && block.x < 512) block = dim3(block.x + 64);     // experiment: an idle eighth wavefront
 #define FARNN_LAUNCH_CHAIN(NCH, MX, FQ)                                                       \
     do {                                                                                      \
-        if constexpr (NCH == 1 && FQ <= 3) {                                                  \
-            if (do_fuse) FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, true); else FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, false); \
-        } else FARNN_LAUNCH_CHAIN_F(NCH, MX, FQ, false);                                      \
+        if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ>, lds))) return rc;                \
+        if (kt.e0 && kt.e1)                                                                   \
+            hipExtLaunchKernelGGL((chain_kernel<NCH, MX, FQ>), grid, block, (uint32_t)lds, s, kt.e0, kt.e1, 0, p); \
+        else                                                                                  \
+            chain_kernel<NCH, MX, FQ><<<grid, block, lds, s>>>(p);                            \
     } while (0)
 #define FARNN_LAUNCH_CHAIN_MX(NCH, FQ)                                                        \
     do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true, FQ); else FARNN_LAUNCH_CHAIN(NCH, false, FQ); } while (0)
-    ChainKernelArgs ka;
-    ka.p = p; ka.sp = sp;
     KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
     const int fq_max = block.x <= 384 ? 6 : 3;
     const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= fq_max && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
@@ -595,7 +562,6 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     else return fail(FARNN_ERANGE, "unsupported state count%s%s");
 #undef FARNN_LAUNCH_CHAIN_MX
 #undef FARNN_LAUNCH_CHAIN
-#undef FARNN_LAUNCH_CHAIN_F
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -925,6 +891,16 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
     FARNN_HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
+    // One workspace per handle: two calls on different streams (a forward_score on torch's stream while batches submitted
+    // through farnn_tag_host_submit are in flight on the handle's own stream, ...) would race on the stash and on the
+    // hand-off words.  A stream switch costs one event: recorded NOW on the previous call's stream (i.e. behind all its work),
+    // awaited by this call's stream.  Calls that stay on one stream pay nothing.
+    if (m->have_last && m->last_stream != s) {
+        if (!m->ev_order) FARNN_HIP_TRY(hipEventCreateWithFlags(&m->ev_order, hipEventDisableTiming));
+        FARNN_HIP_TRY(hipEventRecord(m->ev_order, m->last_stream));
+        FARNN_HIP_TRY(hipStreamWaitEvent(s, m->ev_order, 0));
+    }
+    m->last_stream = s; m->have_last = true;
     // the workspace arrays are strided with the CALL's L (every kernel writes whatever it later reads, pad columns
     // included), so (B, L) only have to fit the capacity: a loop whose batches vary in size or length allocates once
     if (B > m->wsB || L > m->wsL)
@@ -1635,6 +1611,8 @@ extern "C" int farnn_tag_host_submit(farnn_model *m, const int64_t *x_host, cons
     if (!m->hs_run) FARNN_HIP_TRY(hipStreamCreateWithFlags(&m->hs_run, hipStreamNonBlocking));
     const int slot = m->hnext;
     farnn_model::HostSlot &h = m->hslot[slot];
+    // a ticket nobody waited for (the caller dropped it): the slot is free again once its batch has completed
+    if (h.busy && h.ev_out && hipEventQuery(h.ev_out) == hipSuccess) h.busy = false;
     if (h.busy) return fail(FARNN_EINVAL, "tag_host_submit: FARNN_HOST_SLOTS batches already in flight (wait for the oldest ticket first)%s%s");
     const size_t N = (size_t)B * L;
     if (N > h.capN || (size_t)B > h.capB) {
@@ -1716,10 +1694,10 @@ extern "C" void farnn_destroy(farnn_model *m) {
     if (m->Bk) (void)hipFree(m->Bk);
     if (m->offs) (void)hipFree(m->offs);
     if (m->order) (void)hipFree(m->order);
-    if (m->pair_cnt) (void)hipFree(m->pair_cnt);
     if (m->crf_scores) (void)hipFree(m->crf_scores);
     if (m->d1_br) (void)hipFree(m->d1_br);
     if (m->hs) (void)hipFree(m->hs);
+    if (m->ev_order) (void)hipEventDestroy(m->ev_order);
     delete m;
 }
 

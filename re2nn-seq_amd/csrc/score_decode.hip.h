@@ -88,7 +88,7 @@ __device__ __forceinline__ void score_tiles(const ScoreParams &p, const int b, c
     const int SP4 = SP >> 2;
     const int clamp_col = p.use_crf ? K - 3 : K - 1;      // model_decompose.py:353 / :365
     const int lr = lane & 15, lk = lane >> 4;            // MFMA fragment coordinates
-    const bool probe = (p.dbg & 16384) && nsteps == p.L && tid == 0;     // diagnostic: cycles of the phases
+    const bool probe = FARNN_PROBE_ON(p.dbg & 16384) && nsteps == p.L && tid == 0;     // diagnostic: cycles of the phases
     long long q0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (int tile = tile_first; tile < ntiles; tile += tile_step) {
         const int t0 = tile * SCORE_TT;
@@ -484,7 +484,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
-    const bool probe = (p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
+    const bool probe = FARNN_PROBE_ON(p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
     long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0;
 
     // set-up without a register round trip: the scores and (behind them) the transition table stream

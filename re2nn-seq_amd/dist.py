@@ -1,8 +1,8 @@
 """Batch sharding over the GPUs of one node: the only parallel axis of the tagging path.
 
 Sequences are independent, so each rank (one process per GPU, torch.distributed over RCCL/xGMI;
-"nccl" IS RCCL on ROCm) tags a contiguous slice of the batch with its own replica of the
-weights, and ONE collective returns the tag ids: an all-gather of int32 [B/N, L] -- 512 KiB per
+"nccl" IS RCCL on ROCm) tags its share of the batch -- length-balanced by default (balanced_assignment),
+contiguous slices on request -- with its own replica of the weights, and ONE collective returns the tag ids: an all-gather of int32 [B/N, L] -- 512 KiB per
 GPU at the largest BASELINE config, latency- not bandwidth-bound on the 7 point-to-point xGMI
 links.  The reference has no multi-GPU facility at all; this is the MI355X-native
 addition of section 8e.  Works unchanged on CPU tensors with the gloo backend (tests).
@@ -23,6 +23,52 @@ def shard_bounds(n, rank, world_size):
     base, extra = divmod(n, world_size)
     lo = rank * base + min(rank, extra)
     return lo, lo + base + (1 if rank < extra else 0)
+
+
+def balanced_assignment(lengths, world_size):
+    """Length-balanced sharding ("length-sorted or length-bucketed sharding so ranks finish together"): the
+    sequences, longest first (ties by index), are dealt to the ranks in serpentine order -- 0..W-1, W-1..0, ... -- so every
+    rank gets the same count (+-1), a long sequence of every length class and nearly the same number of valid tokens (a
+    rank's time is its longest chain, then its token count).  Deterministic: every rank derives the same assignment from
+    the replicated `lengths`.  Returns a list of W int64 index tensors (rank r tags x[idx[r]])."""
+    n = int(lengths.shape[0])
+    lens = lengths.detach().to('cpu', torch.int64)
+    order = sorted(range(n), key=lambda i: (-int(lens[i]), i))
+    per = [[] for _ in range(world_size)]
+    for i, idx in enumerate(order):
+        rnd, pos = divmod(i, world_size)
+        per[pos if rnd % 2 == 0 else world_size - 1 - pos].append(idx)
+    return [torch.tensor(sorted(p), dtype=torch.int64) for p in per]
+
+
+def shard_batch_balanced(x, lengths, rank=None, world_size=None):
+    """This rank's share of a replicated batch under balanced_assignment: (x_r, lengths_r, assignment)."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    assign = balanced_assignment(lengths, world_size)
+    idx = assign[rank].to(x.device)
+    return x.index_select(0, idx), lengths.index_select(0, idx), assign
+
+
+def gather_tags_balanced(local_tags, assign, n_total, group=None):
+    """All-gather the per-rank blocks of a balanced assignment and undo the permutation: [n_total, L], rows in batch order."""
+    w = len(assign)
+    if w == 1:
+        return local_tags
+    L = local_tags.shape[1]
+    biggest = max(int(a.shape[0]) for a in assign)
+    buf = local_tags
+    if buf.shape[0] < biggest:
+        pad = torch.full((biggest - buf.shape[0], L), -1, dtype=buf.dtype, device=buf.device)
+        buf = torch.cat([buf, pad], dim=0)
+    out = torch.empty((w * biggest, L), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    res = torch.empty((n_total, L), dtype=buf.dtype, device=buf.device)
+    for r, a in enumerate(assign):
+        if a.shape[0]:
+            res.index_copy_(0, a.to(buf.device), out[r * biggest: r * biggest + int(a.shape[0])])
+    return res
 
 
 def shard_batch(x, lengths, rank=None, world_size=None):
@@ -53,9 +99,13 @@ def gather_tags(local_tags, n_total, group=None):
     return torch.cat([out[r * biggest: r * biggest + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
-def tag_sharded(tag_fn, x, lengths, group=None):
+def tag_sharded(tag_fn, x, lengths, group=None, balance=True):
     """Tag a replicated batch: every rank runs `tag_fn(x_shard, lengths_shard) -> int32 [n_r, L]`
-    on its slice; returns the gathered [B, L] tags on every rank."""
+    on its share; returns the gathered [B, L] tags (batch order) on every rank.  balance=True: length-balanced shares
+    (balanced_assignment); False: contiguous slices."""
+    if balance:
+        xs, ls, assign = shard_batch_balanced(x, lengths)
+        return gather_tags_balanced(tag_fn(xs, ls), assign, x.shape[0], group=group)
     xs, ls, _ = shard_batch(x, lengths)
     return gather_tags(tag_fn(xs, ls), x.shape[0], group=group)
 

@@ -41,6 +41,16 @@ class PendingLocal:
                 self._pred = pred
         return None, self._pred, self._true
 
+    def __del__(self):
+        # a ticket dropped without result() (an exception in the caller's loop): wait for its batch so that the library's
+        # slot and this model's in-flight count are released (the library also reclaims a completed slot by itself)
+        if self._pred is None and self._dev_result is None and self._ticket >= 0:
+            try:
+                self._owner.handle.tag_host_wait(self._ticket, None)
+                self._owner._in_flight -= 1
+            except Exception:
+                pass
+
 
 class NativeTagger:
     """Base of the FARNN_* mirrors.  Subclasses implement ``_build_handle()``."""

@@ -43,9 +43,11 @@ def _worker(rank, world, port, B, out_dir):
     xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
     lo, hi = fdist.shard_bounds(B, rank, world)
     assert fdist.shard_batch(xt, lt)[2] == (lo, hi)
-    tags = fdist.tag_sharded(tag_fn, xt, lt)
+    tags = fdist.tag_sharded(tag_fn, xt, lt)                         # length-balanced shares (the default)
+    tags_c = fdist.tag_sharded(tag_fn, xt, lt, balance=False)        # contiguous slices
     full = fo.decode_argmax(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths), 0.5, 0)
     ok = tags.shape == (B, L) and np.array_equal(tags.numpy().astype(np.int64), full)
+    ok = ok and np.array_equal(tags_c.numpy().astype(np.int64), full)
     with open(os.path.join(out_dir, 'rank{}.txt'.format(rank)), 'w') as f:
         f.write('ok' if ok else 'mismatch')
     dist.barrier()
@@ -58,6 +60,34 @@ def test_sharded_tagging_two_ranks_gloo(tmp_path, B):
     mp.spawn(_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / 'rank{}.txt'.format(r)).read_text() == 'ok'
+
+
+@pytest.mark.parametrize('B', [10, 2])
+def test_sharded_tagging_three_ranks_gloo(tmp_path, B):
+    """world size 3: ragged shares, and a batch smaller than the world (one rank tags nothing)"""
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), B, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / 'rank{}.txt'.format(r)).read_text() == 'ok'
+
+
+def test_balanced_assignment_evens_out_tokens_and_long_chains():
+    """ranks should finish together -- a rank's time is its longest chain, then its token count."""
+    from re2nn_seq_amd.dist import balanced_assignment, shard_bounds
+    rng = np.random.RandomState(5)
+    for n, w in ((256, 8), (1024, 8), (257, 3), (5, 8), (0, 2)):
+        lengths = torch.from_numpy(np.sort(rng.randint(1, 65, size=n))[::-1].copy())     # sorted: the worst case for slices
+        assign = balanced_assignment(lengths, w)
+        assert sorted(int(i) for a in assign for i in a) == list(range(n))                # a partition of the batch
+        sizes = [int(a.shape[0]) for a in assign]
+        assert max(sizes) - min(sizes) <= 1
+        if n >= 4 * w:
+            tok = [int(lengths[a].sum()) for a in assign]
+            longest = [int(lengths[a].max()) for a in assign]
+            assert max(tok) - min(tok) <= 64 + 0.02 * max(tok)                            # within one sequence + 2 %
+            assert max(longest) - min(longest) <= 1 + (64 * w) // n
+            contiguous = [int(lengths[slice(*shard_bounds(n, r, w))].sum()) for r in range(w)]
+            assert max(contiguous) - min(contiguous) > 4 * (max(tok) - min(tok))          # what the slices would have given
 
 
 def test_shard_bounds_cover_the_batch():
