@@ -78,6 +78,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='ifst', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
+    ap.add_argument('--vocab', type=int, default=0,
+                    help='dry runs only: override the workload\'s vocabulary size (the line then says so; never a headline number)')
     ap.add_argument('--seqlen', type=int, default=64)
     ap.add_argument('--rank', type=int, default=50, help='decomp: CP rank')
     ap.add_argument('--farnn', type=int, default=0, help='decomp: gate mode 0/1/2 (reference --farnn)')
@@ -99,7 +101,11 @@ def parse():
     ap.add_argument('--event-stride', type=int, default=-1,
                     help='time the kernels of every N-th step with HIP events (0 = never; default: chosen from '
                          '--steps so that at least 8 launches are timed, at most every 16th step)')
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.vocab > 0:
+        d_, _, s_, c_ = WORKLOADS[a.workload]
+        WORKLOADS[a.workload] = (d_ + ' [DRY RUN: vocabulary reduced to {}]'.format(a.vocab), a.vocab, s_, c_)
+    return a
 
 
 def auto_event_stride(steps):
@@ -268,7 +274,7 @@ def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
 
     def float_compare(ref, n, crf_tr=None):
         """ref [n, Lmax, K] oracle scores: scores to 1e-4, tags equal wherever the oracle's decision margin
-        exceeds 1e-3 (argmax paths) / everywhere (the check the tests apply at this size)."""
+        exceeds 2e-4, twice the score bar (argmax paths) / everywhere (the check the tests apply at this size)."""
         sc, tg = gpu_scores(n)
         Lmax = ref.shape[1]
         m = mask[:n, :Lmax]
@@ -278,7 +284,7 @@ def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
         rt = fo.decode_argmax(ref, 0.5, 0)
         refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
         top2 = np.sort(refc[m], axis=1)[:, -2:]
-        safe = (top2[:, 1] - top2[:, 0]) > 1e-3
+        safe = (top2[:, 1] - top2[:, 0]) > 2e-4
         same_fresh = np.array_equal(tg[:, :Lmax][m][safe], rt[m][safe])
         same_timed = np.array_equal(gpu_tags[:n, :Lmax][m][safe], rt[m][safe])
         out['tags_equal'] = bool(same_fresh and same_timed and err <= 1e-4 * max(1.0, float(np.abs(ref[m]).max())))
@@ -291,24 +297,28 @@ def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
                                                  want_scores=(name == 'ifst_crf'), nthreads=min(os.cpu_count() or 1, 16))
         if name == 'ifst':
             out['tags_equal'] = bool(np.array_equal(tags, gpu_tags))
+            out['tags_compared'] = int(tags.size)
+            out['tags_within_margin_skipped'] = 0
             out['oracle'] = 'C port of the oracle, every position of every sequence, bit-exact'
         else:
             ext = fo.onehot_crf_extension_scores(scores)
             ref = fo.decode_crf(ext, lengths, extras['tr'], 0.5, 0)
             out['tags_equal'] = bool(np.array_equal(ref[mask], gpu_tags.astype(np.int64)[mask]))
+            out['tags_compared'] = int(mask.sum())
+            out['tags_within_margin_skipped'] = 0
             out['oracle'] = 'C-port scores + numpy Viterbi (crf.py:102-195), every valid position, bit-exact'
     elif name == 'decomp':
         ref = fo.decomp_ifst_scores(extras['q'], x, lengths)
         float_compare(ref, B)
-        out['oracle'] = 'numpy oracle decomp_ifst_scores, whole batch: scores <= 1e-4, tags outside 1e-3 margins'
+        out['oracle'] = 'numpy oracle decomp_ifst_scores, whole batch: scores <= 1e-4, tags outside 2e-4 margins'
     elif name in ('decomp1', 'decomp0'):
         n = min(B, 8)
         fn = fo.decomp_ind1_scores if name == 'decomp1' else fo.decomp_fst_scores
         ref = fn(extras['q'], x[:n], lengths[:n])
         float_compare(ref, n)
-        out['oracle'] = 'numpy oracle, first {} sequences: scores <= 1e-4, tags outside 1e-3 margins'.format(n)
+        out['oracle'] = 'numpy oracle, first {} sequences: scores <= 1e-4, tags outside 2e-4 margins'.format(n)
     elif name == 'fst4':
-        n = min(B, 6)
+        n = min(B, 32)
         ref = fo.onehot_fst4_scores(extras['T4'], extras['W4'], extras['h0'], extras['hT'], x[:n], lengths[:n])
         rt = fo.decode_argmax(ref, 0.5, 0)
         out['tags_equal'] = bool(np.array_equal(rt[mask[:n]], gpu_tags[:n].astype(np.int64)[mask[:n]]))
@@ -429,6 +439,16 @@ def load_traffic(name, a):
         return json.load(f).get(name, {}).get('hbm_bytes_per_launch')
 
 
+def traffic_head():
+    """which commit's kernels profiles/traffic.json was measured on"""
+    tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        with open(tpath) as f:
+            return json.load(f).get('_measured_at', {}).get('head')
+    except (OSError, ValueError):
+        return None
+
+
 def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_timed):
     """The dominant kernel (by measured time) against the ceiling that bounds it.
       dense-block recurrence / 4-D scoring stream : bytes.  Working set above the 256 MiB Infinity Cache ->
@@ -459,7 +479,7 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
         SP = (S + 3) // 4 * 4
         ws = (2.0 * V * S * SP * 4) if 'chain' in kname else (1.0 * V * C * S * SP * 4)
         rf.update(achieved=achieved, unit='GB/s', traffic=traffic, algorithmic_bytes_per_launch=alg,
-                  working_set_bytes=ws)
+                  working_set_bytes=ws, traffic_head=traffic_head() if traffic is not None else None)
         if ws > INFINITY_CACHE_BYTES:
             peak = HBM_PEAK_GBS
             if traffic is not None and 0 < traffic < alg:

@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-#define FARNN_ABI_VERSION 1
+/* 2: FARNN_MODE_RE, farnn_tag_host_submit/_wait, farnn_flatten_host, the compact / folded creators, farnn_set_compact
+ * (round 2); calls on different streams of one handle are ordered by the library (round 3).  1: round 1. */
+#define FARNN_ABI_VERSION 2
 
 /* ---- return codes ------------------------------------------------------------------- */
 #define FARNN_OK         0

@@ -185,11 +185,12 @@ compact_chain_kernel(const CompactParams p) {
 
 // ---- building the bitmaps (create time) -----------------------------------------------------------------------------
 // from the dense tensors the reference's loader writes: T [V][S][S], W [S][S] (device).  Every entry must be 0 or 1;
-// `bad` counts the others (the handle then has no compact form).  grid = (ceil(S*S/256), V + 1): block row V is W.
+// `bad` counts the others (the handle then has no compact form).  grid = (V + 1, ceil(S*S/256)): block column V is W
+// (the vocabulary rides on grid.x: grid.y stops at 65 535).
 __global__ void dense_to_bits_kernel(const float *T, const float *W, u64 *bitsF, u64 *bitsB, u64 *wF, u64 *wB,
                                      int V, int S, int NS, int *bad) {
-    const long long v = blockIdx.y;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const long long v = blockIdx.x;
+    const int idx = blockIdx.y * blockDim.x + threadIdx.x;
     if (idx >= S * S) return;
     const int i = idx / S, j = idx - i * S;
     const float val = v < V ? T[v * S * S + idx] : W[idx];

@@ -536,7 +536,12 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
         pl.res1 = take(k.n1, k.ld2);
     }
     pl.nseq = nseq;
-    pl.lds = (cap - left + 1023) / 1024 * 1024;              // whole KiB: the kernel zeroes the tail (no allocation-granule slack)
+    // Register forms read whole vector chunks, up to a chunk past the model's width: everything up to the end of the ALLOCATION
+    // must be initialised.  The kernel zeroes its tail up to lds_floats; round that up to a multiple of both 1 KiB (LDS-DMA
+    // pieces) and the LDS allocation granule (1280 B on gfx950: what the hardware hands out beyond the request), capped by
+    // the 160 KiB of the CU, so that no allocated-but-unzeroed slack can sit behind it
+    pl.lds = (cap - left + 5119) / 5120 * 5120;
+    if (pl.lds > 160 * 1024) pl.lds = 160 * 1024;
     return true;
 }
 

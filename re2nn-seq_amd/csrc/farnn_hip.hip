@@ -242,7 +242,7 @@ static int build_bitmaps_from_dense(farnn_model *m, const float *T, const float 
     int *bad = nullptr;
     FARNN_HIP_TRY(hipMalloc((void **)&bad, sizeof(int)));
     FARNN_HIP_TRY(hipMemset(bad, 0, sizeof(int)));
-    dense_to_bits_kernel<<<dim3((m->S * m->S + 255) / 256, m->V + 1), 256>>>(T, W, m->bmF, m->bmB, m->bmWF, m->bmWB, m->V, m->S,
+    dense_to_bits_kernel<<<dim3(m->V + 1, (m->S * m->S + 255) / 256), 256>>>(T, W, m->bmF, m->bmB, m->bmWF, m->bmWB, m->V, m->S,
                                                                           m->bmNS, bad);
     return finish_bitmaps(m, bad);
 }
@@ -862,7 +862,10 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
 // forward_RE's view of the scores (model_onehot.py:153-154): the `oo` column (the last one) capped at the threshold
 __global__ void clamp_oo_column_kernel(float *scores, long long rows, int K, int col, float threshold) {
     const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < rows) scores[r * K + col] = fminf(scores[r * K + col], threshold);
+    if (r < rows) {                                  // torch.min: a NaN score stays a NaN (fminf would turn it into the threshold)
+        const float x = scores[r * K + col];
+        scores[r * K + col] = (x < threshold || x != x) ? x : threshold;
+    }
 }
 
 static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,

@@ -67,7 +67,7 @@ note = ('(2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch from separate rocprofv3
         '(MI355X_MICROARCH.md, HBM section)')
 f_, w_ = pick('ifst ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
-    traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_kernel', 'source': note}
+    traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel', 'source': note}
 f_ = pick('synth512 B1024 L128', 'chain', 'FETCH_SIZE')
 if f_ is not None:
     traffic['synth512'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'chain_kernel', 'source': note + ' (reads only)'}
@@ -85,7 +85,7 @@ for d in sorted(glob.glob(os.path.join(src, 'sq*_*'))):
         continue
     for row in csv.DictReader(open(files[-1])):
         kn = row['Kernel_Name'].split('(')[0].replace('void ', '')
-        if 'farnn::' in kn and any(t in kn for t in ('chain_kernel', 'score_tile', 'viterbi', 'decomp_regs', 'decomp_rows')):
+        if 'farnn::' in kn and any(t in kn for t in ('chain_kernel', 'chain_regs', 'score_tile', 'viterbi', 'decomp_regs', 'decomp_rows')):
             key = (wl, kn, row['Counter_Name'])
             sq[key][0] += float(row['Counter_Value']); sq[key][1] += 1
 with open(os.path.join(dst, tag + '_pmc_sq.csv'), 'w') as f:
@@ -93,6 +93,14 @@ with open(os.path.join(dst, tag + '_pmc_sq.csv'), 'w') as f:
     w.writerow(['workload', 'kernel', 'counter', 'mean_per_dispatch', 'dispatches'])
     for (wl, kn, c), (s_, n) in sorted(sq.items()):
         w.writerow([wl, kn, c, '%.1f' % (s_ / n), n])
+# the split is valid for the kernels of the commit it was measured at: stamp it (bench.py prints it as traffic_head)
+import subprocess
+try:
+    head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(['git', 'status', '--porcelain', '--', 're2nn-seq_amd/csrc'], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+except Exception:
+    head, dirty = 'unknown', False
+traffic['_measured_at'] = {'head': head + ('+dirty' if dirty else ''), 'profile': tag}
 with open(os.path.join(dst, 'traffic.json'), 'w') as f:
     json.dump(traffic, f, indent=1)
 for r in rows:

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in _declared_symbols():
         assert hasattr(lib, name), name
     lib.farnn_abi_version.restype = ctypes.c_int
-    assert lib.farnn_abi_version() == 1
+    assert lib.farnn_abi_version() == 2
 
 
 def test_no_torch_types_in_the_abi():

@@ -80,3 +80,21 @@ def test_bench_default_line_carries_every_single_gpu_config():
         assert 'error' not in o, o
         assert o['value'] > 0 and o['parity']['tags_equal'] is True, o
         assert 0 < o['roofline']['frac'] <= 1.0
+
+
+def test_bench_config5_path_two_ranks_dry_run():
+    """BASELINE configs[4]'s code path (`--workload synth512`: device-side tensor generation, the S = 512 geometry of the
+    ring kernel, per-rank shards, the overlapped gather) on two ranks over gloo, at a reduced vocabulary so that it fits
+    beside a second rank on one device.  The first real 8-GPU run must not be this path's first execution."""
+    env = dict(os.environ, FARNN_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'synth512', '--vocab', '400',
+           '--batch', '64', '--seqlen', '128', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['value'] > 0 and 'DRY RUN' in d['config']['workload']
+    assert d['config']['padded_tokens_per_step'] == 2 * 64 * 128

@@ -9,7 +9,7 @@ tiles -- so the small-geometry tests do not stand in for these.
     config 3   ATIS-BIO-sized onehot i-FST + fused Viterbi: V=950, S=71, C=128 (+2), B=256, L=64
 
 Oracle: oracle/farnn_oracle.py (pinned to the reference by tests/test_oracle_golden.py).  Bar: scores within
-1e-4 (north_star), tags equal wherever the oracle's decision margin exceeds 1e-3; bit-exact for the onehot path.
+1e-4 (north_star), tags equal wherever the oracle's decision margin exceeds 2e-4 (twice the score bar); bit-exact for the onehot path.
 Reference: model_decompose_single.py:207-304, model_decompose.py:339-371, crf.py:102-195."""
 import numpy as np
 import pytest
@@ -85,7 +85,7 @@ def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf, S):
         rt = fo.decode_argmax(ref, 0.5, 0)
         refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
         top2 = np.sort(refc[mask], axis=1)[:, -2:]
-        safe = (top2[:, 1] - top2[:, 0]) > 1e-3
+        safe = (top2[:, 1] - top2[:, 0]) > 2e-4                    # twice the 1e-4 score bar: what that bar justifies
         assert safe.mean() > 0.9                                   # the comparison is not vacuous
         assert np.array_equal(tg[mask][safe], rt[mask][safe])
         assert np.array_equal(tg2[mask][safe], rt[mask][safe])
@@ -98,9 +98,39 @@ def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf, S):
         assert np.array_equal(own[mask], tg[mask].astype(np.int64))
         assert np.array_equal(own[mask], tg2[mask].astype(np.int64))       # fused kernel == score kernel + Viterbi
         assert np.array_equal(fo.flatten(own, lengths), flat.cpu().numpy())
-        want = fo.decode_crf(ref, lengths, tr, 0.5, 0)
-        seq_equal = np.array([np.array_equal(want[b, :lengths[b]], tg[b, :lengths[b]]) for b in range(B)])
-        assert seq_equal.mean() >= 0.97, seq_equal.mean()
+        # ... and EVERY sequence whose path differs from the oracle's path must be as good a path as the oracle's under the
+        # ORACLE's scores: |path score - best path score| <= 1e-3 * |score| (a tie within the float noise of 1e-4 scores
+        # summed over <= 64 positions), not "97 % of the sequences equal"
+        sref = np.array(ref, dtype=np.float32, copy=True)
+        sref[..., K - 3] = np.minimum(sref[..., K - 3], np.float32(0.5))
+        want_raw = fo.viterbi_paths(sref, lengths, tr)
+        START, STOP = K - 2, K - 1
+
+        def path_score(sc, path):
+            t = float(sc[0, path[0]] + tr[START, path[0]])
+            for i in range(1, len(path)):
+                t += float(sc[i, path[i]] + tr[path[i - 1], path[i]])
+            return t + float(tr[path[-1], STOP])
+
+        n_diff = 0
+        for b in range(B):
+            n = int(lengths[b])
+            got_b, want_b = tg[b, :n].astype(np.int64), want_raw[b, :n].astype(np.int64)
+            want_mapped = np.where(want_b == K - 3, 0, want_b)
+            if np.array_equal(got_b, want_mapped):
+                continue
+            n_diff += 1
+            # undo the K-3 -> o_idx mapping of the GPU's tags: where the oracle's raw tag maps to the same id, take it
+            raw = got_b.copy()
+            amb = (got_b == 0)
+            raw[amb & (want_b == K - 3)] = K - 3
+            best = path_score(sref[b], want_b)
+            mine = path_score(sref[b], raw)
+            for i in np.nonzero(amb & (want_b != K - 3) & (want_b != 0))[0]:      # ambiguous inside a differing stretch: the better reading
+                alt = raw.copy(); alt[i] = K - 3
+                mine = max(mine, path_score(sref[b], alt))
+            assert mine <= best + 1e-3 * abs(best) and mine >= best - 1e-3 * abs(best), (b, mine, best)
+        assert n_diff <= B // 8, n_diff                            # (near-ties are rare; a flood of them is a bug)
     h.close()
 
 
