@@ -498,7 +498,8 @@ chain_regs_kernel(const RegsParams p) {
             const bool is_flane = lane == nact;
             float *fslot = part + NP * SP + 4 * w;                // this wavefront's flag (buffer 0)
             float *wptr = active ? part + gid * SP + c * 4 : (is_flane ? fslot : part + NP * SP + 4 * RG_NWC + (lane - nact) * 4);
-            float *hptr = my_writer ? hist + SP + my_row : dump + lane * 4;                      // where this lane's new state goes
+            float *hptr = my_writer ? hist + SP + my_row : dump + lane;     // where this lane's new state goes (dump: consecutive words --
+                                                                            // at a stride of four they met four to a bank: 25 % of the LDS cycles were conflicts)
             const int hstep = my_writer ? SP : 0;
             // The state entries a lane multiplies with -- rows g * RPG + u of this wavefront's share -- come straight from the
             // lanes that finish them (row j sits in lanes 4j .. 4j + 3 after the quad reduce): one ds_bpermute each, no
