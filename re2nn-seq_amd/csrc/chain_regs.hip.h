@@ -45,28 +45,13 @@
 #include "score_params.hip.h"
 #include "launch_order.hip.h"
 #include "chain_regs_params.hip.h"
+#include "beside.hip.h"
 
 #ifndef FARNN_ABLATE
 #define FARNN_ABLATE 0       /* timing-only ablation builds set bits; the shipped library is built with 0 */
 #endif
 
 namespace farnn {
-
-// what tile k needs: forward rows 0..needA and backward rows 0..needB stored (a row = one state, row 0 the initial one)
-__device__ __forceinline__ void regs_tile_need(int k, int len, int nsteps, int &needA, int &needB) {
-    const int lo = k * RG_TT;
-    const int hi = min(lo + RG_TT, nsteps) - 1;
-    needA = hi + 1;                                   // alpha of token i is row i + 1
-    int nb = 0;                                       // beta of token i is row len - (i + 1); pads of FULL mode: row i + 1
-    if (lo < len) nb = len - lo - 1;
-    if (hi >= len) nb = max(nb, hi + 1);
-    needB = nb;
-}
-
-__device__ __forceinline__ int regs_read_prog(const unsigned long long *w, unsigned epoch) {
-    const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return (unsigned)(v >> 32) == epoch ? (int)(unsigned)v : -1;
-}
 
 // workgroup-visible words in LDS: relaxed atomics (never cached in a register, never reordered by the hardware: the LDS
 // executes a wavefront's operations in order); the compiler barriers keep the plain LDS accesses on their side
@@ -108,278 +93,6 @@ __device__ __forceinline__ float quad_max(float x) {
     x = fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true)));
     return x;
 }
-
-typedef float rg_f32x4 __attribute__((ext_vector_type(4)));
-constexpr int RG_NG = 5;             // state groups of 16 (c16 <= 5: the launcher checks)
-constexpr int RG_NOB = 2;            // tiles whose rows of the other direction the scorer parks in LDS ahead of the chain's end
-
-// B fragments (matrix-core image of O^T, score_decode.hip.h) of column block cb, all state groups: one round trip to L2
-__device__ __forceinline__ void regs_load_b(const ScoreParams &sp, int cb, int lane, rg_f32x4 (&bf)[RG_NG]) {
-    const rg_f32x4 *otm = reinterpret_cast<const rg_f32x4 *>(sp.OTm);
-    const int c16 = sp.c16;
-#pragma unroll
-    for (int g = 0; g < RG_NG; g++) bf[g] = (otm + ((long long)cb * c16 + (g < c16 ? g : c16 - 1)) * 64)[lane];
-}
-
-// the other direction's row that token i of sequence b multiplies with (the stash row index and its base)
-__device__ __forceinline__ const float *regs_other_row(const RegsParams &p, int b, int dir, int len, int i) {
-    const int ai = i + 1, bi = (i + 1 <= len) ? len - (i + 1) : i + 1;
-    const long long base = (long long)b * (p.L + 1) * p.SP;
-    return dir == 0 ? p.Bk + base + (long long)bi * p.SP : p.A + base + (long long)ai * p.SP;
-}
-
-// park the other direction's rows of tile k in LDS (obuf[16][SP]); one wavefront, after the acquire that covers them
-__device__ __forceinline__ void regs_park_rows(const RegsParams &p, int b, int dir, int len, int nsteps, int k, float *obuf, int lane_in) {
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));
-    const int SP = p.SP, CPR = p.CPR, t0 = k * RG_TT, nt = min(RG_TT, nsteps - t0);
-    constexpr int NIT = 5;                               // 16 tokens x CPR <= 18 chunks of 16 bytes over 64 lanes
-    float4 v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
-        v[it] = ld4_agent(regs_other_row(p, b, dir, len, t0 + (tok < nt ? tok : 0)) + c4);
-    }
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
-        if (tok < nt) st4(obuf + tok * SP + c4, v[it]);
-    }
-}
-
-// ---- 16-token tiles: products, matrix-core product, decode ---------------------------------------------------------------
-// COOP: all eight wavefronts of the workgroup call it together (workgroup barriers between the phases) and score up to TWO
-// tiles (k0, k1; k1 < 0: one) in one pass -- the two tiles share the B fragments and run as independent accumulator chains on
-// the matrix cores, and each half of the workgroup decodes one of them.  Else one wavefront alone scores tile k0.
-// Same arithmetic either way: per output the k-steps run in ascending state order.
-// par0 / par1: the other direction's rows of the tile parked in LDS ([16][SP]) or nullptr (then they come from the stash);
-// bpre: COOP only -- the B fragments of column block `wv`, loaded by the caller ahead of time.
-// ab: [NTL][16][SPa], scl: [NTL][16][Kc] with NTL = 2 (COOP) / 1.
-template <bool COOP>
-__device__ __forceinline__ void regs_score_tiles(const RegsParams &p, const int b, const int dir, const int len, const int nsteps,
-                                                 const int k0, const int k1, const float *hist, const float *par0, const float *par1,
-                                                 float *ab, float *scl, const long long foff, const int wv, const int lane_in,
-                                                 const rg_f32x4 (&bpre)[RG_NG]) {
-    // Everything per-lane below is derived from this opaque copy: left to itself the compiler hoists the tile's index and
-    // address arithmetic out of the callers' tile loops and then spills it (56-448 bytes of scratch per lane, measured)
-    int lane = lane_in;
-    asm volatile("" : "+v"(lane));
-    const ScoreParams &sp = p.sp;
-    constexpr int NWV = COOP ? RG_WAVES : 1;
-    constexpr int NWV1 = COOP ? RG_WAVES - 1 : 1;        // wavefronts that form the products: the writer wavefront (it copies its last
-                                                         // state rows to the stash meanwhile: the caller) takes none
-    constexpr int NTL = COOP ? 2 : 1;
-    constexpr int NIT = COOP ? 2 : 5;                    // product items per lane: NTL x 16 tokens x 4 c16 float4 columns, c16 <= 5
-    const int c16 = sp.c16, SPa = 16 * c16 + 4, SP = p.SP, K = sp.K, Kc = sp.Kc, ncb = Kc / 16;
-    const int G4 = 4 * c16, TI = RG_TT * G4;             // items per tile
-    const int lr = lane & 15, lk = lane >> 4;
-    const bool two = COOP && k1 >= 0;
-#if defined(FARNN_PROBES)
-    const bool tprobe = COOP && nsteps == p.L && p.L >= 32 && wv == 0 && lane_in == 0 && (p.dbg & 512);
-    long long tq0 = tprobe ? (long long)__builtin_amdgcn_s_memtime() : 0, tq1 = 0, tq2 = 0;
-#endif
-    // ---- phase 1: ab[tok][s] = a[i+1][s] * bt[i+1][s]; the own direction's rows from LDS (`hist`), the other's from LDS
-    // (parked) or the stash.  Stored in the order the matrix cores' A fragments are read: a lane's four k-steps of a state
-    // group -- states 16g + 4e + lk, e = 0..3 -- are four consecutive floats (one ds_read_b128 per group instead of four reads)
-    {
-        float4 oth[NIT];
-        int dstv[NIT], ownoff[NIT];
-        bool livev[NIT], wrv[NIT];
-        const int pw = COOP ? (wv < RG_NWC ? wv : wv - 1) : 0;       // this wavefront among the NWV1
-        const bool p1 = !COOP || wv != RG_NWC;
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int idx = p1 ? it * NWV1 * 64 + pw * 64 + lane : NTL * TI;
-            const int ti = (NTL == 2 && idx >= TI) ? 1 : 0;
-            const int rem = idx - ti * TI;
-            const int tok = rem / G4, s4 = (rem - tok * G4) * 4;
-            const int kk = ti ? k1 : k0;
-            const int t0 = kk * RG_TT, nt = min(RG_TT, nsteps - t0);
-            wrv[it] = tok < RG_TT && kk >= 0;
-            livev[it] = wrv[it] && tok < nt && s4 < SP;
-            const int tokc = livev[it] ? tok : 0, i = (kk >= 0 ? t0 : 0) + tokc;
-            const int ai = i + 1, bi = (i + 1 <= len) ? len - (i + 1) : i + 1;
-            ownoff[it] = (dir == 0 ? ai : bi) * SP + (s4 < SP ? s4 : 0);
-            // states s4 + lk' of group g = s4 / 16, k-step e = (s4 % 16) / 4: position 16 g + 4 lk' + e
-            dstv[it] = (ti * RG_TT + (tok < RG_TT ? tok : 0)) * SPa + (s4 & ~15) + ((s4 >> 2) & 3);
-            const float *par = ti ? par1 : par0;
-            if (par) oth[it] = ld4(par + tokc * SP + (s4 < SP ? s4 : 0));
-            else     oth[it] = ld4_agent(regs_other_row(p, b, dir, len, i) + (s4 < SP ? s4 : 0));
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            if (wrv[it]) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (livev[it]) {
-                    const float4 own = ld4(hist + ownoff[it]);
-                    v = make_float4(own.x * oth[it].x, own.y * oth[it].y, own.z * oth[it].z, own.w * oth[it].w);
-                }
-                float *dst = ab + dstv[it];
-                dst[0] = v.x; dst[4] = v.y; dst[8] = v.z; dst[12] = v.w;
-            }
-        }
-    }
-    if (COOP) __syncthreads(); else asm volatile("" ::: "memory");
-#if defined(FARNN_PROBES)
-    if (tprobe) tq1 = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    // ---- phase 2: scl[tile][16][Kc] = ab[tile] . O^T on the f32 matrix cores
-    {
-        const float *arow = ab + lr * SPa + 4 * lk;
-        rg_f32x4 bn[RG_NG];                                  // the next column block's fragments, in flight behind the MFMAs
-        if (!COOP) regs_load_b(sp, 0, lane, bn);
-        for (int cb = wv; cb < ncb; cb += NWV) {
-            rg_f32x4 bf[RG_NG];
-            if (COOP) {
-                if (cb == wv) {
-#pragma unroll
-                    for (int g = 0; g < RG_NG; g++) bf[g] = bpre[g];
-                } else regs_load_b(sp, cb, lane, bf);
-            } else {
-#pragma unroll
-                for (int g = 0; g < RG_NG; g++) bf[g] = bn[g];
-                regs_load_b(sp, cb + 1 < ncb ? cb + 1 : cb, lane, bn);
-            }
-            rg_f32x4 acc0 = rg_f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll
-            for (int g = 0; g < RG_NG; g++) {
-                if (g < c16) {
-                    const float4 a4 = ld4(arow + 16 * g);
-                    float4 c4 = a4;
-                    if (two) c4 = ld4(arow + RG_TT * SPa + 16 * g);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, bf[g].x, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.x, bf[g].x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, bf[g].y, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.y, bf[g].y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, bf[g].z, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.z, bf[g].z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, bf[g].w, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c4.w, bf[g].w, acc1, 0, 0, 0);
-                }
-            }
-            float *dst = scl + (lk * 4) * Kc + cb * 16 + lr;                 // rows lk*4 + r, column lr of the block
-            dst[0] = acc0.x; dst[Kc] = acc0.y; dst[2 * Kc] = acc0.z; dst[3 * Kc] = acc0.w;
-            if (two) {
-                dst += RG_TT * Kc;
-                dst[0] = acc1.x; dst[Kc] = acc1.y; dst[2 * Kc] = acc1.z; dst[3 * Kc] = acc1.w;
-            }
-        }
-    }
-    if (COOP) __syncthreads(); else asm volatile("" ::: "memory");
-#if defined(FARNN_PROBES)
-    if (tprobe) tq2 = (long long)__builtin_amdgcn_s_memtime();
-#endif
-    // ---- phase 3: four tokens per pass, 16 lanes per token (score_decode.hip.h's decode): priority matrix, `scores`
-    // output, threshold clamp, first index of the row maximum, oo -> o_idx.  COOP: wavefronts 0-3 decode tile k0, 4-7 tile k1.
-    const int kch = Kc / 64;
-    const int clamp_col = K - 1;                         // model_decompose.py:365 / model_onehot.py:166-167
-    const int ti3 = COOP ? (wv >> 2) : 0;
-    const int kk3 = ti3 ? k1 : k0;
-    const int t0 = kk3 * RG_TT, nt = kk3 >= 0 ? min(RG_TT, nsteps - t0) : 0;
-    float *sclt = scl + ti3 * RG_TT * Kc;
-    for (int tg = COOP ? 4 * (wv & 3) : 0; tg < RG_TT; tg += COOP ? RG_TT : 4) {
-        if (tg >= nt) break;
-        if (sp.P) {                                      // PriorityLayer: scores @ P (priority.py:20-30), row by row
-#pragma unroll 1
-            for (int j = 0; j < 4; j++) {
-                if (tg + j >= nt) break;
-                float *sr = sclt + (tg + j) * Kc;
-                float sc[4] = {0.f, 0.f, 0.f, 0.f};
-                for (int cc = 0; cc < K; cc++) {
-                    const float sv = sr[cc];
-                    const float *prow = sp.P + (long long)cc * Kc + lane;
-#pragma unroll
-                    for (int m = 0; m < 4; m++)
-                        if (m < kch) sc[m] = fmaf(sv, prow[64 * m], sc[m]);
-                }
-                __builtin_amdgcn_wave_barrier();
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int m = 0; m < 4; m++)
-                    if (m < kch) sr[lane + 64 * m] = sc[m];
-            }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("" ::: "memory");
-        }
-        const int j = lane >> 4, c = lane & 15;
-        const int tokl = tg + j, i = t0 + tokl;
-        const bool live = tokl < nt;
-        float v[4][4];
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            float4 x4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < kch) x4 = ld4(sclt + (live ? tokl : 0) * Kc + 64 * m + 4 * c);
-            v[m][0] = x4.x; v[m][1] = x4.y; v[m][2] = x4.z; v[m][3] = x4.w;
-        }
-        if (sp.scores && live) {
-            float *so = sp.scores + ((long long)b * p.L + i) * K;
-#pragma unroll
-            for (int m = 0; m < 4; m++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int col = 64 * m + 4 * c + e;
-                    if (m < kch && col < K) so[col] = v[m][e];
-                }
-        }
-        float best = -INFINITY;
-#pragma unroll
-        for (int m = 0; m < 4; m++)
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                const int col = 64 * m + 4 * c + e;
-                float x = v[m][e] + 0.0f;                // -0.0 -> +0.0 (torch: -0 == +0)
-                if (col == clamp_col) x = fminf(x, sp.threshold);
-                x = (m < kch && col < K) ? x : -INFINITY;
-                v[m][e] = x;
-                best = fmaxf(best, x);
-            }
-        asm volatile("s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1"
-                     : "+v"(best));
-        unsigned first = 0x7fffffffu;                    // this lane's first column that holds the row maximum
-#pragma unroll
-        for (int m = 3; m >= 0; m--)
-#pragma unroll
-            for (int e = 3; e >= 0; e--) first = v[m][e] == best ? (unsigned)(64 * m + 4 * c + e) : first;
-        asm volatile("s_nop 1\n\t"
-                     "v_min_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_u32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1\n\t"
-                     "v_min_u32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
-                     "s_nop 1"
-                     : "+v"(first));
-        if (c == 0 && live) {
-            const int bi = first >= (unsigned)K ? 0 : (int)first;             // an all-NaN row gives 0 like torch
-            const int tag = (bi == K - 1) ? sp.o_idx : bi;
-            if (sp.tags) sp.tags[(long long)b * p.L + i] = tag;
-            if (sp.flat && i < len) sp.flat[foff + i] = tag;
-        }
-    }
-#if defined(FARNN_PROBES)
-    if (tprobe)
-        printf("seq %d dir %d tiles %d %d (all wavefronts): products + barrier %lld, matrix cores + barrier %lld, decode %lld\n", b, dir, k0, k1,
-               tq1 - tq0, tq2 - tq1, (long long)__builtin_amdgcn_s_memtime() - tq2);
-#endif
-}
-
-// misc words in LDS
-enum { RGM_FOFF = 16,        // where the sequence starts in the flat output
-       RGM_MINE = 17,        // tiles this workgroup's scorer did while the chain ran (bit k = tile k)
-       RGM_ACQ = 18,         // the other direction's progress covered by this workgroup's latest acquire
-       RGM_TODO = 19,
-       RGM_PARK = 21 };      // [RG_NOB] tile + 1 whose rows of the other direction are parked in obuf[slot]     // the partial-sum reduction's identity (0.0f / -inf): what a masked read returns      // tiles the eight wavefronts score together next
 
 // FARNN_PROBES (profiling build only): s_memtime stamps of the workgroups of full-length sequences, printed at their end
 #if defined(FARNN_PROBES)
@@ -435,22 +148,11 @@ chain_regs_kernel(const RegsParams p) {
     const float *sflag = part + NP * SP;            // the step flags (buffer 0; buffer 1 is RG_PART_STRIDE floats on)
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
-    int kmid = 0;                                    // tiles kmid.. belong to the forward workgroup's half, the rest to the backward one's
-    int pubmax = 0;                                  // the last row of THIS direction that a tile of the OTHER workgroup's half needs
-    if (SCORE) {
-        for (; kmid < ntl; kmid++) {
-            int na, nb;
-            regs_tile_need(kmid, len, nsteps, na, nb);
-            if (na >= nb) break;
-        }
-        for (int k = 0; k < ntl; k++) {
-            int na, nb;
-            regs_tile_need(k, len, nsteps, na, nb);
-            const bool others = dir == 0 ? k < kmid : k >= kmid;
-            if (others) pubmax = max(pubmax, dir == 0 ? na : nb);
-        }
-    }
-
+    int kmid = 0, pubmax = 0;                        // this workgroup's half of the tiles; the last row the other half needs of it
+    if (SCORE) bs_halves(dir, len, nsteps, kmid, pubmax);
+    BesideParams bs;                                 // the scoring stage's view of the parameters (beside.hip.h)
+    bs.A = p.A; bs.Bk = p.Bk; bs.B = p.B; bs.L = p.L; bs.SP = p.SP; bs.CPR = p.CPR; bs.prog = p.prog; bs.arr = p.arr;
+    bs.epoch = p.epoch; bs.spin = p.spin; bs.dbg = p.dbg; bs.sp = p.sp;
     int wr_next = 0;                                 // (writer wavefront) the next state row to copy to the stash
     if (w < RG_NWC) {
         // =================================================================================================================
@@ -737,15 +439,9 @@ chain_regs_kernel(const RegsParams p) {
         // =================================================================================================================
         // scorer wavefront: tiles of this workgroup's half, while the chain runs
         // =================================================================================================================
-        {                                                             // where sequence b starts in the flat output (utils.py:153-164)
-            int partsum = 0;
-            if (p.sp.flat) {
-                if (p.sp.offs) partsum = lane == 0 ? (int)p.sp.offs[b] : 0;
-                else for (int j = lane; j < b; j += WAVE) partsum += clamp_len(p.len[j], p.L);
-            }
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) partsum += __shfl_xor(partsum, off, WAVE);
-            if (lane == 0) misc[RGM_FOFF] = partsum;
+        {
+            const int fo = bs_flat_offset(bs, b, lane);               // where sequence b starts in the flat output (utils.py:153-164)
+            if (lane == 0) misc[RGM_FOFF] = fo;
         }
         const long long foff = misc[RGM_FOFF];
         unsigned mine = 0u;
@@ -754,14 +450,14 @@ chain_regs_kernel(const RegsParams p) {
         const int kfirst = dir == 0 ? kmid : kmid - 1, kstep = dir == 0 ? 1 : -1, klast = dir == 0 ? ntl : -1;
         for (int k = kfirst; k != klast; k += kstep) {
             int na, nb;
-            regs_tile_need(k, len, nsteps, na, nb);
+            bs_tile_need(k, len, nsteps, na, nb);
             const int need_own = dir == 0 ? na : nb, need_oth = dir == 0 ? nb : na;
             if (nsteps - need_own < p.solo_margin) break;             // the chain ends soon: all eight wavefronts will do it
             while (!regs_rows_reached(sflag, lane, need_own)) __builtin_amdgcn_s_sleep(4);
             if (need_oth > acq) {
                 int pr = -1;
                 for (;;) {
-                    pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+                    pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
                     pr = __builtin_amdgcn_readfirstlane(pr);
                     if (pr >= need_oth) break;
                     if (regs_rows_reached(sflag, lane, nsteps)) break;    // our chain is done: no open-ended wait beyond it
@@ -773,7 +469,7 @@ chain_regs_kernel(const RegsParams p) {
             }
             {
                 const rg_f32x4 none[RG_NG] = {};
-                regs_score_tiles<false>(p, b, dir, len, nsteps, k, -1, hist, nullptr, nullptr, ab, scl, foff, 0, lane, none);
+                bs_score_tiles<false, RG_WAVES, RG_NG, RG_NWC>(bs, b, dir, len, nsteps, k, -1, hist, nullptr, nullptr, ab, scl, foff, 0, lane, none);
             }
             mine |= 1u << k;
         }
@@ -784,12 +480,12 @@ chain_regs_kernel(const RegsParams p) {
             for (int k = kfirst; k != klast && slot < RG_NOB; k += kstep) {
                 if ((mine >> k) & 1u) continue;
                 int na, nb;
-                regs_tile_need(k, len, nsteps, na, nb);
+                bs_tile_need(k, len, nsteps, na, nb);
                 const int need_oth = dir == 0 ? nb : na;
                 if (need_oth > acq) {
                     int pr = -1;
                     for (;;) {
-                        pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
+                        pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
                         pr = __builtin_amdgcn_readfirstlane(pr);
                         if (pr >= need_oth) break;
                         if (regs_rows_reached(sflag, lane, nsteps)) break;
@@ -799,7 +495,7 @@ chain_regs_kernel(const RegsParams p) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     acq = pr;
                 }
-                regs_park_rows(p, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
+                bs_park_rows<RG_NG>(bs, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
                 if (lane == 0) misc[RGM_PARK + slot] = k + 1;
                 slot++;
             }
@@ -814,111 +510,28 @@ chain_regs_kernel(const RegsParams p) {
     // progress (as covered by an acquire) allows are scored now by all eight wavefronts; the arrival word carries the
     // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
-    rg_f32x4 bpre[RG_NG];                                            // this wavefront's column block of O^T: in flight across the barrier
-    regs_load_b(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
-    const unsigned all_tiles = ntl >= 32 ? ~0u : ((1u << ntl) - 1u);
-    unsigned promised = 0u;
-    if (w == RG_WAVES - 1) {
-        // which tiles of this half can be scored now: those the other direction's progress, as covered by an acquire, allows
-        const unsigned mine = (unsigned)misc[RGM_MINE];
-        int acq = misc[RGM_ACQ];
-        const unsigned own_half = dir == 0 ? (all_tiles & ~((1u << kmid) - 1u)) : (all_tiles & ((1u << kmid) - 1u));
-        const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
-        unsigned todo = 0u;
-        for (int it = 0;; it++) {
-            int miss = 0;
-            todo = 0u;
-            for (int k = 0; k < ntl; k++) {
-                if (!((own_half & ~mine) >> k & 1u)) continue;
-                int na, nb;
-                regs_tile_need(k, len, nsteps, na, nb);
-                if ((dir == 0 ? nb : na) <= acq) todo |= 1u << k; else miss++;
-            }
-            if (!miss || it >= p.spin) break;                         // bounded: what stays open goes to the second arrival
-            int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
-            pr = __builtin_amdgcn_readfirstlane(pr);
-            if (pr > acq) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the invalidate has completed before the barrier below
-                acq = pr;
-            } else __builtin_amdgcn_s_sleep(8);
-        }
-        promised = mine | todo;
-        if (lane == 0) misc[RGM_TODO] = (int)todo;
-    }
-    wg_barrier_lds();                                                // the chain is done, the mask is there (LDS only: this wavefront's
-                                                                     // O^T loads and the writer's last stores stay in flight)
     if (w == 0) FARNN_RG_STAMP(4);
-    if (w == RG_NWC)                                                 // the state rows the writer had not copied yet: issued now, landed by the
-        for (; wr_next <= nsteps; wr_next++)                         // time the tiles are done (this wavefront forms no products meanwhile)
-            for (int j = 2 * lane; j < SP; j += 2 * WAVE)
-                st2_agent(stash + (long long)wr_next * SP + j, hist[wr_next * SP + j], hist[wr_next * SP + j + 1]);
-    // ---- arrival: ONE lane exchanges the sequence's arrival word for {epoch, the tiles this workgroup scores}; the
-    // exchange is in flight while those tiles are scored.  (The word says nothing about this workgroup's stash rows: they
-    // are published through the progress word, below; the workgroup that has to read them waits for that.)
-    unsigned long long arrived = 0ull;
-    if (w == RG_WAVES - 1 && lane == 0)
-        arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)p.epoch << 32) | 0x80000000ull | promised,
-                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long foff = misc[RGM_FOFF];
-    for (int pass = 0; pass < 2; pass++) {
-        unsigned todo = (unsigned)misc[RGM_TODO];
-        while (todo) {                                               // two tiles per pass
-            const int k0 = __builtin_ctz(todo);
-            todo &= todo - 1u;
-            const int k1 = todo ? __builtin_ctz(todo) : -1;
-            if (todo) todo &= todo - 1u;
-            const float *par0 = nullptr, *par1 = nullptr;
-#pragma unroll
-            for (int sl = 0; sl < RG_NOB; sl++) {
-                if (misc[RGM_PARK + sl] == k0 + 1) par0 = obuf + sl * RG_TT * SP;
-                if (misc[RGM_PARK + sl] == k1 + 1) par1 = obuf + sl * RG_TT * SP;
+    bs_finish<RG_WAVES, RG_NG, RG_WAVES - 1, RG_NWC>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane,
+        [&]() {                                                      // the state rows the writer had not copied yet: issued now, landed by
+            if (w == RG_NWC)                                         // the time the tiles are done (it forms no products meanwhile)
+                for (; wr_next <= nsteps; wr_next++)
+                    for (int j = 2 * lane; j < SP; j += 2 * WAVE)
+                        st2_agent(stash + (long long)wr_next * SP + j, hist[wr_next * SP + j], hist[wr_next * SP + j + 1]);
+        },
+        [&]() {                                                      // every stash row has been stored by the writer: drained (they had the
+            if (w == RG_NWC) {                                       // tiles' time to land), then the full count in the progress word
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0)
+                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)nsteps,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            regs_score_tiles<true>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1, ab, scl, foff, w, lane, bpre);
-            __syncthreads();                                         // the tiles' LDS is free again
-        }
-        if (pass == 1) break;
-        if (w == 0) FARNN_RG_STAMP(5);
-        wg_barrier_lds();                                            // every wavefront has read this pass's mask (it is rewritten below)
-        // every stash row of this direction has been stored by the writer wavefront: it drains them (they had the tiles'
-        // time to land) and publishes the full count
-        if (w == RG_NWC) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)nsteps,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (w == RG_WAVES - 1) {
-            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(arrived >> 32));
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)arrived);
-            unsigned rest = 0u;
-            if (hi == p.epoch && (lo & 0x80000000u)) {               // second of the two
-                rest = all_tiles & ~(promised | (lo & 0x7fffffffu));
-                if (rest) {
-                    // The other workgroup has arrived: it is resident, past its chain, and publishes its full row count
-                    // after a bounded amount of work of its own (it waits for nobody) -- so this wait ends.
-                    const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
-                    for (;;) {
-                        int pr = lane == 0 ? regs_read_prog(oprog, p.epoch) : 0;
-                        pr = __builtin_amdgcn_readfirstlane(pr);
-                        if (pr >= nsteps) break;
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-            }
-            if (lane == 0) misc[RGM_TODO] = (int)rest;
-        }
-        __syncthreads();
-        if (misc[RGM_TODO] == 0) break;
-    }
+        });
 #if defined(FARNN_PROBES)
     if (probe && tid == 0) {
         const long long e = (long long)__builtin_amdgcn_s_memtime();
-        printf("seq %d dir %d: setup %lld, chain %lld (%lld per step), scorer alone until +%lld, all waves meet +%lld, tiles together %lld, "
-               "arrival + sweep %lld; tiles alone %d of %d\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
-               (stamps[2] - stamps[1]) / nsteps, stamps[3] - stamps[2], stamps[4] - stamps[2], stamps[5] - stamps[4], e - stamps[5],
+        printf("seq %d dir %d: setup %lld, chain %lld (%lld per step), scorer alone until +%lld, all waves at the meeting point +%lld, "
+               "tiles + arrival %lld; tiles alone %d of %d\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
+               (stamps[2] - stamps[1]) / nsteps, stamps[3] - stamps[2], stamps[4] - stamps[2], e - stamps[4],
                __popc((unsigned)misc[RGM_MINE]), ntl);
     }
 #endif

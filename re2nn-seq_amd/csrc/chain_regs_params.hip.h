@@ -11,7 +11,6 @@ constexpr int RG_NWC = 6;        // compute wavefronts
 constexpr int RG_WAVES = 8;      // + writer + scorer
 constexpr int RG_D = 4;          // steps of block pieces in flight per lane
 constexpr int RG_RQ = 4;         // rows per lane per step (one float4 of the state)
-constexpr int RG_TT = 16;        // tokens per score tile
 constexpr int RG_MAXG = 4;       // row groups per compute wavefront
 constexpr int RG_MAXSP = 72;     // padded state count the geometry reaches (RPG <= 4 rows x 6 * G groups)
 constexpr int RG_PART_STRIDE = RG_NWC * RG_MAXG * RG_MAXSP;    // floats between the two partial-sum buffers
@@ -35,6 +34,7 @@ struct RegsParams {
     int solo_margin;             // the scorer starts a tile alone only if the chain has at least this many steps left after it
     ScoreParams sp;
 };
+constexpr int RG_NG = 5;         // state groups of 16 the scoring stage of this kernel reaches (S <= 72 -> c16 <= 5)
 
 struct RegsGeom {
     int G, RPG, NP, CPR, SP, rows;

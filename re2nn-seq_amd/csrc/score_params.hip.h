@@ -25,4 +25,20 @@ struct ScoreParams {
     int dbg;                // diagnostic ablation mask (FARNN_DBG bits 16/32/64); 0 in production
 };
 
+constexpr int RG_TT = 16;            // tokens per score tile of the stage when it runs beside a recurrence (beside.hip.h)
+constexpr int RG_NOB = 2;            // tiles whose rows of the other direction are parked in LDS ahead of the chain's end
+
+// What the score + decode stage needs when it runs BESIDE a recurrence kernel (beside.hip.h): the stashes, the hand-off words of
+// the two workgroups of a sequence, and the stage's own parameters.
+struct BesideParams {
+    const float *A, *Bk;         // stash [B][L+1][SP]
+    int B, L, SP, CPR;           // CPR = SP / 4
+    unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
+    unsigned long long *arr;     // [B]    {epoch, 1 << 31 | mask of the tiles it scores} of the workgroup that arrived last
+    unsigned epoch;
+    int spin;                    // polls a finished workgroup spends on the tiles of its own half before it leaves them to the other
+    int dbg;                     // FARNN_DBG probe mask: read by the profiling build (-DFARNN_PROBES) only
+    ScoreParams sp;
+};
+
 }  // namespace farnn
