@@ -451,6 +451,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
             if (m->compact_on) return "compact_chain_kernel";
             if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
             if (m->dense_decomp) return "chain_kernel";
+            if (m->kind == KIND_DECOMP && m->last_fused && m->last_wave) return "decomp_regs_kernel<fused: scores + decode beside the recurrence>";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
                 return m->rows.ok ? ((m->last_wave || (m->calls == 0 && m->dw.farnn == 0 && m->dw.R <= DG_ROWS && !getenv("FARNN_DECOMP_NOREGS"))) ? "decomp_regs_kernel" : "decomp_rows_kernel") : "decomp_chain_kernel";
             return "chain_kernel";
@@ -631,8 +632,11 @@ static int build_rows_pack(farnn_model *m) {
 }
 
 // the recurrence of the three decomposed kinds: rows kernel when packed, else the older kernels
+// fuse_sp != nullptr: ask for the one-launch form (scores + argmax decode beside the recurrence); *fused tells whether the
+// model's kernel and geometry allowed it (else the caller launches the score kernel itself)
 static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int64_t *lengths, int B, int full,
-                                    hipStream_t s) {
+                                    hipStream_t s, const ScoreParams *fuse_sp = nullptr, bool *fused = nullptr) {
+    if (fused) *fused = false;
     const int *order = m->order_valid ? m->order : nullptr;
     if (m->n_cu <= 0) {
         int dev = 0, ncu = 0;
@@ -642,9 +646,32 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
     }
     RegsPlan rp;
     m->last_wave = m->rows.ok && regs_plan(m->rows, m->dw, m->curL, rp);
-    if (m->last_wave)        // farnn = 0, rank <= 64: four wavefronts per chain, the packed rows in registers
+    if (m->last_wave) {      // farnn = 0, rank <= 64: four wavefronts per chain, the packed rows in registers
+        BesideParams bs;
+        const BesideParams *use = nullptr;
+        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= DG_NG && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
+                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
+        if (score) {
+            rp.lds_score = regs_score_lds(rp, m->curL, m->SP, m->c16, m->Kc);
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // (a captured launch would replay with a frozen epoch)
+            if (rp.lds_score > 80 * 1024 || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
+                score = false;
+        }
+        if (score) {
+            if (++m->epoch_u == 0) {
+                FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
+                m->epoch_u = 1;
+            }
+            memset(&bs, 0, sizeof(bs));
+            bs.A = m->A; bs.Bk = m->Bk; bs.B = B; bs.L = m->curL; bs.SP = m->SP; bs.CPR = m->SP / 4;
+            bs.prog = m->hs; bs.arr = m->hs + (size_t)2 * m->wsB; bs.epoch = m->epoch_u;
+            bs.spin = env_int("FARNN_FUSE_SPIN", 4); bs.dbg = env_int("FARNN_DBG", 0); bs.sp = *fuse_sp;
+            use = &bs;
+            if (fused) *fused = true;
+        }
         return launch_decomp_regs(m->rows, m->dw, rp, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B, m->curL,
-                                  full, s);
+                                  full, s, use);
+    }
     RowsPlan pl;
     if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->curL, pl))
         return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B,
@@ -969,10 +996,16 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
             }
         case KIND_DECOMP: {
             if (m->dense_decomp) return launch_chain_and_decode(m, x, lengths, B, L, full, tags, flat_tags, scores, s);
+            bool fused = false;
             {
                 KernelTimer kt(m, KERN_CHAIN, s);
-                if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
+                if (!m->use_crf) {
+                    const ScoreParams sp = make_score_params(m, lengths, B, full, tags, flat_tags, scores);
+                    if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s, &sp, &fused))) return rc;
+                } else if ((rc = launch_decomp_recurrence(m, x, lengths, B, full, s))) return rc;
             }
+            m->last_fused = fused;
+            if (fused) return FARNN_OK;
             return launch_score_decode(m, lengths, B, full, tags, flat_tags, scores, s);
         }
         case KIND_DECOMP0: {
