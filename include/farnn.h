@@ -17,7 +17,8 @@
  *   - x / lengths / tags / scores of farnn_tag() are DEVICE pointers (e.g. tensor.data_ptr()
  *     of PyTorch-ROCm tensors used purely as containers); the library never retains them
  *     after the call's work has been enqueued on `stream`;
- *   - one caller thread per handle (the reference is single-threaded Python).
+ *   - one caller thread per handle (the reference is single-threaded Python); one workspace per handle: a call on another
+ *     stream than the previous call's is ordered behind that call's work by the library.
  */
 #ifndef FARNN_H
 #define FARNN_H
