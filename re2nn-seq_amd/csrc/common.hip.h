@@ -248,4 +248,17 @@ __device__ __forceinline__ int wave_first_argmax(const float (&v)[NR]) {
     return idx;
 }
 
+// the same answer when the maximum m is already known (bit-identical to one of the candidates): no reduction at all
+template <int NR>
+__device__ __forceinline__ int wave_first_equal(const float (&v)[NR], const float m) {
+    int idx = 0;
+    bool found = false;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const unsigned long long hit = __ballot(v[r] == m);
+        if (!found && hit) { idx = r * 64 + __builtin_ctzll(hit); found = true; }
+    }
+    return idx;
+}
+
 }  // namespace farnn

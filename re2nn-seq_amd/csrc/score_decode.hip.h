@@ -17,6 +17,7 @@
 // table, the partitions and the back-pointers in LDS; it reads the clamped scores the tile kernel
 // left in the workspace (B*L*K floats, ~1% of the chain kernel's traffic).
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 #include "score_params.hip.h"
 
@@ -438,6 +439,14 @@ __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, boo
     return a > c ? a : c;
 }
 
+// LDS reads / counted waits as explicit instructions (the forward step of viterbi_hist_kernel issues ALL of a step's reads up
+// front; left to the compiler they were issued piecemeal through a recycled register quad -- three exposed LDS round trips per
+// step).  The registers a wait releases are its "+v" operands, so no use of them can move in front of it.
+template <int OFF> __device__ __forceinline__ void lds_read16_at(v4f &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void lds_wait_for(v4f &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+
 // History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
 // VALUES of every step; the back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE
 // path the backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
@@ -611,6 +620,7 @@ viterbi_hist_kernel(const ScoreParams p) {
     const int nst = (K + GT - 1) / GT;                   // tail wavefront: source slots per lane (<= IB + 4)
     constexpr int NSL = IB + 4;
     v2f trs[NSL];                                        // tr[i][j0], tr[i][j0+1] of this lane's sources
+#define FARNN_TRS_SET(SL, X, Y) do { trs[SL] = v2f{(X), (Y)}; } while (0)
     int ixs[4];                                          // full: leftover sources (clamped into the row; their tr is -inf)
     {
         const float *row0 = p.trT + (long long)(own0 ? j0 : 0) * Kp, *row1 = p.trT + (long long)(own1 ? j0 + 1 : 0) * Kp;
@@ -626,14 +636,14 @@ viterbi_hist_kernel(const ScoreParams p) {
                 const int i = 8 * IB + 8 * xk + g;
                 const bool ok = i < K;
                 ixs[xk] = ok ? i : K - 1;
-                trs[IB + xk] = v2f{(ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf};
+                FARNN_TRS_SET(IB + xk, (ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf);
             }
         } else {
 #pragma unroll
             for (int sl = 0; sl < NSL; sl++) {
                 const int i = g + GT * sl;
                 const bool ok = i < K;
-                trs[sl] = v2f{(ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf};
+                FARNN_TRS_SET(sl, (ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf);
             }
 #pragma unroll
             for (int xk = 0; xk < 4; xk++) ixs[xk] = 0;
@@ -673,30 +683,61 @@ viterbi_hist_kernel(const ScoreParams p) {
     // hoisting the partition-independent add (f + tr) behind the step's LDS write was measured and bought nothing (the
     // idle time around the write and the barrier is ~100 cycles, not the ~350 the first probe suggested), and
     // v_pk_add_f32 issues at half rate on gfx950, so the packed form saves registers and LDS reads, not issue slots.
-    for (int t = 1; t < n; t++) {
-        const float *pin = hist + (size_t)(t - 1) * PW;
-        const v2f f = scores_at(t);
-        auto f_tr = [&](int sl) { return f + trs[sl]; };
-        v2f best = v2f{ninf, ninf};
-        if (!tail) {
-            float4 p4[IB4 > 0 ? IB4 : 1];
-            float px[4];                                 // leftover sources: read up front, no LDS wait inside a branch
+    // Two loops, the full wavefronts' specialised on its number of leftover slots: with the tail / leftover / ablation tests
+    // inside one loop a step spent ~250 cycles on a dozen scalar branches (a taken branch refills the instruction buffer).
+    const unsigned pin_lane = (unsigned)(size_t)(hist + g * 4);               // this lane's 16 bytes of a 32-source block
+    const unsigned f_lane = (unsigned)(size_t)fcol;
+    unsigned px_lane[4];
 #pragma unroll
-            for (int xk = 0; xk < 4; xk++) px[xk] = pin[ixs[xk]];
+    for (int xk = 0; xk < 4; xk++) px_lane[xk] = (unsigned)(size_t)(hist + ixs[xk]);
+    auto publish = [&](int t, const v2f &best) {
+        if (writer) *reinterpret_cast<v2f *>(hist + (size_t)t * PW + j0) = best;   // (j0 + 1 == K: -inf into the pad)
+        wg_barrier_lds();
+    };
+    auto full_steps = [&](auto xs_c) {
+        constexpr int XSC = decltype(xs_c)::value;       // leftover source slots per lane (0..4)
+        v2f fnext = n > 1 ? scores_at(1) : v2f{0.f, 0.f};
+        for (int t = 1; t < n; t++) {
+            const v2f f = fnext;
+            auto f_tr = [&](int sl) { return f + trs[sl]; };
+            v2f best = v2f{ninf, ninf};
+            // every LDS read of the step up front, oldest first: the scores of the NEXT step, the IB4 blocks, the leftovers
+            // (left to the compiler they went through one recycled register quad: three exposed LDS round trips per step)
+            const unsigned row = (unsigned)((t - 1) * PW) * 4u;
+            const unsigned frow = (unsigned)((t + 1 < n ? t + 1 : t) * Kp) * 4u;
+            v4f p4[IB4 > 0 ? IB4 : 1];
+            float px[XSC > 0 ? XSC : 1];
+            asm volatile("ds_read_b64 %0, %1" : "=v"(fnext) : "v"(f_lane + frow));
+            if constexpr (IB4 > 0) lds_read16_at<0>(p4[0], pin_lane + row);
+            if constexpr (IB4 > 1) lds_read16_at<128>(p4[1], pin_lane + row);
+            if constexpr (IB4 > 2) lds_read16_at<256>(p4[2], pin_lane + row);
+            if constexpr (IB4 > 3) lds_read16_at<384>(p4[3], pin_lane + row);
+            if constexpr (IB4 > 4) lds_read16_at<512>(p4[4], pin_lane + row);
+            if constexpr (IB4 > 5) lds_read16_at<640>(p4[5], pin_lane + row);
+            if constexpr (IB4 > 6) lds_read16_at<768>(p4[6], pin_lane + row);
 #pragma unroll
-            for (int k4 = 0; k4 < IB4; k4++) {
-                p4[k4] = ld4(pin + k4 * 32 + g * 4);     // (the compiler pipelines these reads as the registers allow)
+            for (int xk = 0; xk < XSC; xk++) asm volatile("ds_read_b32 %0, %1" : "=v"(px[xk]) : "v"(px_lane[xk] + row));
+            auto block = [&](int k4) {
                 const v2f v0 = f_tr(k4 * 4 + 0) + v2f{p4[k4].x, p4[k4].x}, v1 = f_tr(k4 * 4 + 1) + v2f{p4[k4].y, p4[k4].y};
                 const v2f v2 = f_tr(k4 * 4 + 2) + v2f{p4[k4].z, p4[k4].z}, v3 = f_tr(k4 * 4 + 3) + v2f{p4[k4].w, p4[k4].w};
                 best.x = fmaxf(fmaxf(best.x, v0.x), v1.x); best.y = fmaxf(fmaxf(best.y, v0.y), v1.y);
                 best.x = fmaxf(fmaxf(best.x, v2.x), v3.x); best.y = fmaxf(fmaxf(best.y, v2.y), v3.y);
-            }
+            };
+            if constexpr (IB4 > 0) { lds_wait_for<IB4 + XSC - 1>(p4[0]); block(0); }
+            if constexpr (IB4 > 1) { lds_wait_for<IB4 + XSC - 2>(p4[1]); block(1); }
+            if constexpr (IB4 > 2) { lds_wait_for<IB4 + XSC - 3>(p4[2]); block(2); }
+            if constexpr (IB4 > 3) { lds_wait_for<IB4 + XSC - 4>(p4[3]); block(3); }
+            if constexpr (IB4 > 4) { lds_wait_for<IB4 + XSC - 5>(p4[4]); block(4); }
+            if constexpr (IB4 > 5) { lds_wait_for<IB4 + XSC - 6>(p4[5]); block(5); }
+            if constexpr (IB4 > 6) { lds_wait_for<IB4 + XSC - 7>(p4[6]); block(6); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fnext));
 #pragma unroll
-            for (int xk = 0; xk < 4; xk++)
-                if (xk < XS) {
-                    const v2f v = f_tr(IB + xk) + v2f{px[xk], px[xk]};
-                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
-                }
+            for (int xk = 0; xk < XSC; xk++) {
+                asm volatile("" : "+v"(px[xk]));         // (behind the wait)
+                const v2f v = f_tr(IB + xk) + v2f{px[xk], px[xk]};
+                best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+            }
+            fnext.y = own1 ? fnext.y : 0.0f;             // (scores_at's rule: nothing is read into a half without a tag)
             // the eight lanes of the group: xor 1, xor 2 inside the quad, then the mirrored quad of the half row
             asm volatile("s_nop 1\n\t"
                          "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -709,7 +750,15 @@ viterbi_hist_kernel(const ScoreParams p) {
                          "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
                          "s_nop 1"
                          : "+v"(best.x), "+v"(best.y));
-        } else {
+            publish(t, best);
+        }
+    };
+    auto tail_steps = [&]() {
+        for (int t = 1; t < n; t++) {
+            const float *pin = hist + (size_t)(t - 1) * PW;
+            const v2f f = scores_at(t);
+            auto f_tr = [&](int sl) { return f + trs[sl]; };
+            v2f best = v2f{ninf, ninf};
 #pragma unroll
             for (int s4 = 0; s4 < NSL; s4 += 4) {        // four slots at a time (slots beyond nst: -inf transitions)
                 if (s4 >= nst) continue;
@@ -731,44 +780,78 @@ viterbi_hist_kernel(const ScoreParams p) {
             if (GT >= 32) FARNN_SCAN2("row_bcast:15 row_mask:0xa bank_mask:0xf");
             if (GT >= 64) FARNN_SCAN2("row_bcast:31 row_mask:0xc bank_mask:0xf");
 #undef FARNN_SCAN2
+            publish(t, best);
         }
-        if (writer) *reinterpret_cast<v2f *>(hist + (size_t)t * PW + j0) = best;   // (j0 + 1 == K: -inf into the pad)
-        wg_barrier_lds();
+    };
+    if (tail) tail_steps();
+    else switch (XS) {
+        case 0: full_steps(std::integral_constant<int, 0>{}); break;
+        case 1: full_steps(std::integral_constant<int, 1>{}); break;
+        case 2: full_steps(std::integral_constant<int, 2>{}); break;
+        case 3: full_steps(std::integral_constant<int, 3>{}); break;
+        default: full_steps(std::integral_constant<int, 4>{}); break;
     }
     if (tail) __builtin_amdgcn_s_setprio(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transition table is in LDS
     __syncthreads();
     if (probe) pc2 = (long long)__builtin_amdgcn_s_memtime();
     if (w == 0 && n > 0) {
-        // One wavefront walks the path.  Candidate i of a step sits in lane i % 64, row i / 64 (NRB rows cover PW >= K);
-        // per step: one LDS round trip (the row of the table and the score the pointer selects), two adds per candidate,
-        // six v_max on the DPP network and a ballot per row (r01/r02 used the keyed argmax: 1 140 cycles per step, as much
-        // as the whole forward pass -- FARNN_DBG=8192 prints the phases).
-        constexpr int NRB = (32 * IB4 + 32 + 63) / 64;         // PW <= 32*IB4 + 32
-        int itr[NRB], ipp[NRB];                          // no guards in the loop: candidates >= K read a pad of the
-#pragma unroll                                           // partitions (-inf) and, harmlessly, the table's last valid entry
-        for (int r = 0; r < NRB; r++) {
-            const int i = r * 64 + lane;
-            itr[r] = i < K ? i : K - 1;
-            ipp[r] = i < PW ? i : PW - 1;
-        }
-        auto first_argmax = [&](float f, const float *tr, const float *pp) {
-            float c[NRB];
-#pragma unroll
-            for (int r = 0; r < NRB; r++) c[r] = (f + tr[itr[r]]) + pp[ipp[r]];
-            return wave_first_argmax<NRB>(c);
+        // One wavefront walks the path, and a lone wavefront issues one instruction every ~4-5 cycles: the step is bound by its
+        // instruction COUNT plus one LDS round trip (r02: eight 4-byte reads, a six-level DPP max, three ballots -- 590 cycles).
+        // Lane q holds FOUR consecutive candidates (4q .. 4q+3; PW / 4 <= 64 lanes cover a row): the table's row and the
+        // partitions' row are one 16-byte read each, the latter fetched a step ahead.  There is NO reduction: the maximum of a
+        // step's candidates IS part_t[ptr], which the forward pass took over exactly these values (a max returns one of its
+        // operands' bits) -- two broadcast reads fetch it and the score f_t[ptr] beside the table's row.
+        const int nq = PW >> 2, q = lane < nq ? lane : nq - 1;
+        const unsigned long long valid = nq >= 64 ? ~0ull : ((1ull << nq) - 1ull);
+        const float *hq = hist + 4 * q, *tq = trl + 4 * q;
+        auto first_equal = [&](const float4 &c, float m) {                    // first index (torch.max's rule); 0 if none (NaN)
+            const bool h0 = c.x == m, h1 = c.y == m, h2 = c.z == m, h3 = c.w == m;
+            const int e = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;                       // this lane's first hit, if it has one
+            const unsigned long long any = (__ballot(h0) | __ballot(h1) | __ballot(h2) | __ballot(h3)) & valid;
+            const int l = __builtin_ctzll(any | (1ull << 63));
+            return any ? 4 * l + __builtin_amdgcn_readlane(e, l) : 0;
         };
-        int ptr = first_argmax(0.0f, trl + (long long)STOP * Kp, hist + (size_t)(n - 1) * PW);   // crf.py:168-169 (0 + x = x)
+        auto candidates = [&](float f, const float4 &tr, const float4 &pp) {  // (feat + trans) + partition: crf.py:123,145
+            return make_float4((f + tr.x) + pp.x, (f + tr.y) + pp.y, (f + tr.z) + pp.z, (f + tr.w) + pp.w);
+        };
+        float4 prv = *reinterpret_cast<const float4 *>(hq + (n - 1) * PW);
+        float4 c = candidates(0.0f, *reinterpret_cast<const float4 *>(tq + STOP * Kp), prv);      // crf.py:168-169 (0 + x = x)
+        // (candidates in [K, PW) are -inf through the partitions' pads; lanes beyond the row repeat its last four)
+        int ptr = first_equal(c, wave_max_dpp(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w))));
+        prv = *reinterpret_cast<const float4 *>(hq + (n > 1 ? n - 2 : 0) * PW);                    // part_{t-1} of the first step
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const unsigned hq0 = (unsigned)(size_t)hq, tq0 = (unsigned)(size_t)tq, h0 = (unsigned)(size_t)hist;
+        const unsigned sc_off = (unsigned)(size_t)scl - h0;
         int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
         for (int t = n - 1; t >= 0; t--) {
-            const int tag = (ptr == K - 3) ? p.o_idx : ptr;                   // model_decompose.py:356
-            mytag = lane == (t & 63) ? tag : mytag;
-            if ((t & 63) == 0 && t + lane < n) {         // 64 positions at a time, coalesced
-                if (p.tags) p.tags[(long long)b * p.L + t + lane] = mytag;
-                if (p.flat) p.flat[foff + t + lane] = mytag;
+            {
+                const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
+                const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
+                asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(mytag) : "s"(tg), "s"(tl) : "m0");   // (one SGPR per instruction)
+            }
+            if ((t & 63) == 0) {                         // 64 positions at a time, coalesced
+                if (t + lane < n) {
+                    if (p.tags) p.tags[(long long)b * p.L + t + lane] = mytag;
+                    if (p.flat) p.flat[foff + t + lane] = mytag;
+                }
             }
             // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values
-            if (t > 0) ptr = first_argmax(scl[(long long)t * Kp + ptr], trl + (long long)ptr * Kp, hist + (size_t)(t - 1) * PW);
+            if (t > 0) {
+                const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
+                const unsigned a_pre = hq0 + 4u * (unsigned)(tp * PW), a_tr = tq0 + 4u * (unsigned)(ptr * Kp);
+                const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;     // (PW == Kp)
+                f32x4 pre, tr;
+                float m, f;
+                // one statement, so that the order is this one: the row fetched ahead first (its latency hides behind the others'
+                // -- LDS reads return in order), then the three the step waits for
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(pre), "=&v"(tr), "=&v"(m), "=&v"(f) : "v"(a_pre), "v"(a_tr), "v"(a_m), "v"(a_f) : "memory");
+                c = candidates(f, make_float4(tr.x, tr.y, tr.z, tr.w), prv);
+                ptr = first_equal(c, m);
+                prv = make_float4(pre.x, pre.y, pre.z, pre.w);
+            }
         }
     }
     if (probe && tid == 0) {
