@@ -516,7 +516,12 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
         return rf
     # latency-bound kernels: VALU flops of the dominant kernel per valid token
     R, K = a.rank, h.num_columns()
-    if dom == _lib.KERN_CHAIN:            # decomposed recurrence, both directions
+    if 'chain_viterbi' in kname:          # ONE launch: dense-block recurrence (both directions) + score GEMM + Viterbi DP
+        fl_tok = 2.0 * (2 * S * S) + 2.0 * K * S + 3.0 * K * K
+        per_step_us = dom_s * 1e6 / max(1, L)
+        note = ('recurrence, scores and CRF decode of a sequence in one workgroup: three serial passes over its {} positions '
+                '(chain step, Viterbi forward step, back-trace step); the blocks are L2-resident, scores and partitions stay in LDS'.format(L))
+    elif dom == _lib.KERN_CHAIN:          # decomposed recurrence, both directions
         fl_tok = 2.0 * (4 * S * R + 2 * S * S)
         if a.farnn >= 1:
             fl_tok += (2.0 if a.farnn == 2 else 1.0) * (2 * S * S + 2 * S * R) * 2

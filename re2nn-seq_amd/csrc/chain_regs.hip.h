@@ -101,15 +101,16 @@ __device__ __forceinline__ float quad_max(float x) {
 #define FARNN_RG_STAMP(i) do { } while (0)
 #endif
 
+// The kernel's body as a function of (LDS base, thread index 0..511, item = 2 * launch slot + direction): chain_regs_kernel runs
+// it on one workgroup per item; chain_viterbi_kernel (chain_viterbi.hip) runs the two directions of a sequence as the two
+// halves of ONE sixteen-wavefront workgroup and hangs the CRF decode behind them.  Workgroup barriers in here are reached by
+// both halves alike (the same sequence, the same length).  *b_out: the sequence the slot maps to.
 template <bool MAXSR, bool SCORE, bool NLX>
-__global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD = 128 VGPRs: two workgroups per compute unit
-chain_regs_kernel(const RegsParams p) {
-    extern __shared__ __align__(16) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem, const int tid, const int item, int *b_out) {
+    const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = RG_WAVES * 64;
     // ids 2s / 2s + 1: forward chains on the even XCDs, backward chains on the odd ones -- an L2 caches one direction's blocks
-    const int item = blockIdx.x;
     const int dir = item & 1, slot = item >> 1;
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
     const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE);
@@ -120,6 +121,7 @@ chain_regs_kernel(const RegsParams p) {
 
     int b = p.order ? p.order[slot] : slot;
     if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(slot, p.B), reinterpret_cast<int *>(hist), tid, nthreads);
+    if (b_out) *b_out = b;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
     const float *hinit = dir == 0 ? p.h0 : p.hT;
@@ -419,6 +421,7 @@ chain_regs_kernel(const RegsParams p) {
                 for (int j = lane; j < SP; j += WAVE) dst[j] = src[j];
             }
         };
+        if (!SCORE && !p.A) wr_next = nsteps + 1;                // (chain_viterbi_kernel: the rows are consumed where they lie, in LDS)
         while (wr_next <= nsteps) {
             if (nsteps > 0 && !regs_rows_reached(sflag, lane, wr_next)) { __builtin_amdgcn_s_sleep(1); continue; }
             if (SCORE && nsteps > 0 && wr_next > pubmax && regs_rows_reached(sflag, lane, nsteps)) break;   // the chain is done
@@ -535,6 +538,13 @@ chain_regs_kernel(const RegsParams p) {
                __popc((unsigned)misc[RGM_MINE]), ntl);
     }
 #endif
+}
+
+template <bool MAXSR, bool SCORE, bool NLX>
+__global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD = 128 VGPRs: two workgroups per compute unit
+chain_regs_kernel(const RegsParams p) {
+    extern __shared__ __align__(16) float smem[];
+    chain_regs_body<MAXSR, SCORE, NLX>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
 }
 
 }  // namespace farnn

@@ -80,4 +80,9 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
 // launches chain_regs_kernel<maxsr, score> on 2 * p.B workgroups; e0 / e1: optional events on the dispatch packet
 int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 
+// chain_viterbi.hip: the two chains of a sequence and its scores + CRF decode in ONE workgroup, one launch per tagging step
+// (p.prog / p.arr / p.epoch unused).  chain_viterbi_fits: tag sets of 32..159 labels whose decode fits the LDS.
+bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp);
+int launch_chain_viterbi(const RegsParams &p, const ScoreParams &sp, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+
 }  // namespace farnn

@@ -449,6 +449,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     switch (which) {
         case KERN_CHAIN:
             if (m->compact_on) return "compact_chain_kernel";
+            if (m->last_regs && m->last_fused && m->use_crf) return "chain_viterbi_kernel<fused: recurrence + scores + CRF decode>";
             if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP && m->last_fused && m->last_wave) return "decomp_regs_kernel<fused: scores + decode beside the recurrence>";
@@ -466,6 +467,19 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
 }
 
 // ---- the hot path ----------------------------------------------------------------------------
+
+// the register-fed recurrence's view of a call (chain_regs_params.hip.h); the hand-off words are filled in by the callers that use them
+static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64_t *len, int B, int full) {
+    const RegsGeom &rg = m->rgeom;
+    RegsParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.Mf = m->Mf; rp.Mb = m->Mb; rp.blk = (long long)m->geom.SR * m->SP;
+    rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
+    rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
+    rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
+    rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
+    return rp;
+}
 
 // fuse_sp != nullptr: ask for the fused launch (scores + argmax decode as the chain kernel's epilogue); *fused tells
 // whether the geometry allowed it (else the caller launches the score kernel itself)
@@ -492,13 +506,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
             lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false).total * sizeof(float);
         }
         if (lds <= 80 * 1024) {
-            RegsParams rp;
-            memset(&rp, 0, sizeof(rp));
-            rp.Mf = m->Mf; rp.Mb = m->Mb; rp.blk = (long long)m->geom.SR * m->SP;
-            rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
-            rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
-            rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
-            rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
+            RegsParams rp = make_regs_params(m, x, len, B, full);
             if (score) {
                 if (++m->epoch_u == 0) {            // the epoch wrapped: no word of an earlier launch may look current
                     FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
@@ -882,7 +890,21 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         if ((rc = launch_chain(m, x, len, B, L, full, s, &sp, &fused))) return rc;
         m->last_fused = fused;
         if (fused) return FARNN_OK;
-    } else if ((rc = launch_chain(m, x, len, B, L, full, s))) return rc;
+    } else {
+        // CRF decode: recurrence + scores + Viterbi in ONE launch (chain_viterbi.hip) where the register-fed recurrence applies and
+        // the decode's LDS fits; else the recurrence kernel followed by the (fused score +) Viterbi kernel
+        m->last_fused = false;
+        const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
+        if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0) && !env_int("FARNN_NOFUSE", 0) && viterbi_can_fuse(m, sp) &&
+            (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp)) {
+            const RegsParams rp = make_regs_params(m, x, len, B, full);
+            KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
+            if ((rc = launch_chain_viterbi(rp, sp, m->semiring == FARNN_SEMIRING_MAX, s, kt.e0, kt.e1))) return rc;
+            m->last_regs = true; m->last_fused = true;
+            return FARNN_OK;
+        }
+        if ((rc = launch_chain(m, x, len, B, L, full, s))) return rc;
+    }
     return launch_score_decode(m, len, B, full, tags, flat, scores, s);
 }
 

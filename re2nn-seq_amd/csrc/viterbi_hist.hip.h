@@ -1,0 +1,497 @@
+// The CRF decode with the partitions' history in LDS (K2b): viterbi_hist_body / viterbi_hist_kernel, its LDS sizes, and the
+// flat-offset helper the decode kernels share.  A header of its own because two translation units hold it: farnn_hip.hip (the
+// stand-alone kernel behind a recurrence kernel) and chain_viterbi.hip (the same body as the epilogue of the recurrence: ONE
+// launch per tagging step of a CRF model).
+#pragma once
+#include <type_traits>
+#include <hip/hip_runtime.h>
+#include "common.hip.h"
+#include "score_params.hip.h"
+
+namespace farnn {
+
+// flat-output offset of sequence b without a prepared prefix array: the sum of the (clamped) lengths in
+// front of it (utils.py:153-164).  Called by every thread of the workgroup; B <= 1024.
+__device__ __forceinline__ long long flat_offset_in_kernel(const int64_t *len, int b, int L, int tid, int nthreads) {
+    __shared__ int fo_w[16];
+    int part = 0;
+    for (int j = tid; j < b; j += nthreads) {
+        const int v = (int)len[j];
+        part += v < 0 ? 0 : (v > L ? L : v);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, WAVE);
+    if ((tid & 63) == 0) fo_w[tid >> 6] = part;
+    __syncthreads();
+    int tot = 0;
+    for (int ww = 0; ww < (nthreads >> 6); ww++) tot += fo_w[ww];
+    __syncthreads();
+    return (long long)tot;
+}
+
+
+// floats of the history area of viterbi_hist_kernel: [L][Kp] partitions; the fused form first stages the [SP][L]
+// alpha*beta products there (row stride L + 16)
+__host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, bool fused) {
+    const size_t a = (size_t)L * Kp, c = fused ? (size_t)SP * (((L + 3) & ~3) + 16) : 0;
+    return a > c ? a : c;
+}
+
+// LDS reads / counted waits as explicit instructions (the forward step of viterbi_hist_kernel issues ALL of a step's reads up
+// front; left to the compiler they were issued piecemeal through a recycled register quad -- three exposed LDS round trips per
+// step).  The registers a wait releases are its "+v" operands, so no use of them can move in front of it.
+template <int OFF> __device__ __forceinline__ void lds_read16_at(v4f &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void lds_wait_for(v4f &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+
+// History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
+// VALUES of every step; the back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE
+// path the backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
+// expression on the same values, so the path is bit-identical.  The transposed transition table stays in LDS for
+// that second pass.
+// Forward pass layout (r02; FARNN_DBG=8192 prints the phase cycle counts).  The step is VALU-issue bound on the one CU
+// that owns the sequence: two adds (crf.py:123,145) and half a v_max3 per (source, tag), K*K pairs -- 660 cycles per step
+// at K = 130 if the four SIMDs were perfectly balanced, plus ~300 of LDS latency and barrier.  EIGHT lanes share a PAIR of
+// destination tags (j0, j0+1); lane g of the group owns the sources 32*k + 4*g .. +3 of every 32-source block k < IB4 (a
+// 16-byte LDS read per block, the eight lanes cover a contiguous 128 bytes: no bank conflicts) plus up to four leftover
+// sources 32*IB4 + g + 8x (K - 32*IB4 < 32): at most one wasted source slot per lane for any K (r01: four lanes per tag,
+// block sizes 8/16/36/52/64 -- K = 75 ran 36 slots per lane for 19 useful ones).  The two tags ride in the halves of
+// packed-f32 registers (v_pk_add_f32 issues at half rate on gfx950, so this saves registers and LDS reads, not issue
+// slots); the group is combined by three v_max with DPP operands per tag.  Tag pairs that do not fill a wavefront (K = 130:
+// the START/STOP pair) go to a TAIL wavefront that spreads them over all its lanes and runs at raised priority -- its
+// step is a short latency chain that otherwise runs behind the SIMD's older, issue-bound wavefronts.
+// Measured on the config-3 batch (K = 130, 64 positions; cycles at ~2.3 GHz): set-up + scores 25.6 k, forward pass
+// 1 190 per step (K = 128: 910), backtrace 590 per step (r01: 1 140 -- the keyed 64-bit DPP argmax).  Tried and dropped:
+// hoisting (f + tr) of the coming step behind the LDS write (no gain: the idle time there is ~100 cycles), conditional
+// leftover reads (waits inside branches: +130 per step).
+// FUSED: the workgroup also computes the clamped scores of its sequence (what score_tile_kernel would
+// have written to crf_scores) straight into LDS -- one kernel from stash to tags, no score round trip
+// through HBM: alpha*beta products staged transposed in the (not yet used) history area, then a
+// register-blocked [tokens x S].[S x K] product, 4 tokens x 4 tags per lane, against the L2-resident
+// transposed output matrix.  Same fmaf chain in s order as score_tile_kernel: identical bits.
+// The kernel's body as a function of (LDS base, thread index, thread count, sequence): viterbi_hist_kernel runs it on one
+// workgroup per sequence; chain_viterbi_kernel runs it behind the two chains of the sequence, on the first `nthreads` threads
+// of their workgroup (the others have left: a workgroup barrier counts the wavefronts that are still there).
+// ldsF / ldsB (FUSED only): the sequence's forward / backward state rows [L + 1][SP] where they still lie in LDS (they must not
+// overlap the products' area, the first SP * (L + 16) floats), else nullptr: the rows are read from the stash.  image_staged:
+// the output matrix's matrix-core image is already in the transition table's LDS area.
+template <int IB4, bool FUSED>
+__device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *smem, const int tid, const int nthreads, const int b,
+                                                  const float *ldsF = nullptr, const float *ldsB = nullptr, const bool image_staged = false) {
+    constexpr int IB = IB4 * 4;
+    const int lane = tid & 63, w = tid >> 6;
+    const int n = clamp_len(p.len[b], p.L);
+    (void)p.full;
+    const int K = p.K, Kp = p.Kp;
+    const int PW = Kp;                                   // partition row stride (K rounded up to 4), pads -inf
+    float *hist = smem;                                  // [L][PW] partitions of every step (FUSED: first the products)
+    const int sc_pieces = (p.L * Kp * 4 + 1023) / 1024, tr_pieces = (K * Kp * 4 + 1023) / 1024;
+    float *scl = hist + viterbi_hist_floats(Kp, p.SP, p.L, FUSED);   // [L][Kp] clamped scores of this sequence (whole KiB)
+    float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
+    const float *sc = p.crf_scores + (long long)b * p.L * Kp;
+    const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
+    const int START = K - 2, STOP = K - 1;
+    const float ninf = -INFINITY;
+    const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
+    const bool probe = FARNN_PROBE_ON(p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
+    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0;
+
+    // set-up without a register round trip: the scores and (behind them) the transition table stream
+    // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
+    // during the forward pass (counted vmcnt: this wavefront's table pieces are its youngest operations)
+    if (!FUSED) {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)scl);
+        const int need = (n * Kp * 4 + 1023) / 1024;
+        for (int k = wu; k < need; k += nwaves)
+            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(sc), lds0 + (unsigned)k * 1024u);
+    } else {
+        const int SP = p.SP, SP4 = SP >> 2, Lq = ((p.L + 3) & ~3) + 16;   // row stride of the products: the four state rows of an
+                                                                            // A-fragment read land in different banks (L = 64: 80)
+        // the matrix-core image of the output matrix (K2: one 1 KiB piece per (column block, state group)) borrows the
+        // transition table's LDS area until the scores are done, when it fits
+        const int otm_pieces = ((K + 15) >> 4) * p.c16;
+        const bool otm_lds = otm_pieces <= tr_pieces;
+        if (otm_lds && !image_staged) {
+            const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
+            for (int k = wu; k < otm_pieces; k += nwaves)
+                lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.OTm), lds0 + (unsigned)k * 1024u);
+        }
+        float *abT = hist;                               // [SP][Lq] alpha*beta, token-contiguous (aliases hist)
+        const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
+        const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
+        if (ldsF) {                                      // the chains ran in this workgroup: their rows never left the LDS
+            lds_cfloat *lf = (lds_cfloat *)ldsF, *lb = (lds_cfloat *)ldsB;
+            for (int idx = tid; idx < (Lq - 16) * SP4; idx += nthreads) {
+                const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
+                v4f a4 = v4f{0.f, 0.f, 0.f, 0.f}, b4 = a4;
+                if (tok < n) {
+                    a4 = *(lds_cv4f *)(lf + (tok + 1) * SP + s4);
+                    b4 = *(lds_cv4f *)(lb + (n - (tok + 1)) * SP + s4);
+                }
+                abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
+                abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
+            }
+        } else
+        for (int idx = tid; idx < (Lq - 16) * SP4; idx += nthreads) {
+            const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
+            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
+            if (tok < n) {       // alpha = state after tok+1 tokens; beta = backward state before token tok+1 (:415-420)
+                a4 = ld4(Ab + (long long)(tok + 1) * SP + s4);
+                b4 = ld4(Bb + (long long)(n - (tok + 1)) * SP + s4);
+            }
+            abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
+            abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
+        }
+        __syncthreads();                                 // (drains vmcnt too: the image has landed)
+        if (probe) pa = (long long)__builtin_amdgcn_s_memtime();
+        // scores[n][K] = abT^T . O^T on the f32 matrix cores (v_mfma_f32_16x16x4_f32: the ascending-s fmaf chain of K2, same
+        // bits): units of one 16-token block x two 16-tag blocks (shared A fragments from the staged products, independent
+        // accumulators), B fragments from the matrix-core image of the output matrix (OTm, K2: staged in LDS by LDS-DMA when
+        // it fits the transition table's area, else from L2), two state groups ahead.  At most eight wavefronts take units
+        // -- two per SIMD (wavefront w sits on SIMD w % 4, HW_ID).  Measured: 12.9 k cycles for the config-3 sequence against
+        // 14 k for r02a's 4 x 4 VALU blocking (1 136 FMAs per lane on nine wavefronts, three of them on one SIMD); the
+        // matrix cores are not the bound (720 MFMAs = 5.8 k cycles over four SIMDs), the 4-way bank conflicts of the LDS waits are.
+        {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int lr = lane & 15, lk = lane >> 4;
+            const int c16 = p.c16, ntb = (n + 15) >> 4, ncb = (K + 15) >> 4, nblk = ntb * ncb;
+            const int ngw = nwaves < 8 ? nwaves : 8;
+            const int clamp_col = K - 3;                 // model_decompose.py:353
+            auto product = [&](auto otm) {               // otm: this lane's entry of the image, typed LDS or global pointer
+            const int ncp = (ncb + 1) >> 1;              // a unit = one token block x TWO column blocks: shared A fragments,
+#pragma unroll 1                                         // two independent accumulators
+            for (int unit = wu; unit < ntb * ncp && wu < ngw; unit += ngw) {
+                const int tb = unit / ncp, cb0 = 2 * (unit - tb * ncp), cb1 = cb0 + 1 < ncb ? cb0 + 1 : cb0;
+                auto bp0 = otm + cb0 * c16 * 64, bp1 = otm + cb1 * c16 * 64;
+                lds_cfloat *ap = (lds_cfloat *)abT + tb * 16 + lr;
+                auto a_group = [&](int g, float (&a)[4]) {
+                    const int gc = g < c16 ? g : c16 - 1;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int s = 16 * gc + 4 * e + lk;                   // this lane's k of k-step 4g + e
+                        a[e] = ap[(s < SP ? s : SP - 1) * Lq];                // (no product row there: B is zero, any finite A will do)
+                    }
+                };
+                auto b_group = [&](decltype(bp0) bp, int g) -> f32x4 { const v4f t = bp[(g < c16 ? g : c16 - 1) * 64]; return f32x4{t.x, t.y, t.z, t.w}; };
+                f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+                auto mfma8 = [&](const float (&a)[4], const f32x4 &b0, const f32x4 &b1) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b0.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b1.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b0.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b1.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b0.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b1.z, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b0.w, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b1.w, acc1, 0, 0, 0);
+                };
+                f32x4 be0 = b_group(bp0, 0), be1 = b_group(bp1, 0), bo0 = b_group(bp0, 1), bo1 = b_group(bp1, 1);
+                float ae[4], ao[4];
+                a_group(0, ae);
+#pragma unroll 1
+                for (int g = 0; g < c16; g += 2) {
+                    a_group(g + 1, ao);
+                    mfma8(ae, be0, be1);
+                    be0 = b_group(bp0, g + 2); be1 = b_group(bp1, g + 2);
+                    a_group(g + 2, ae);
+                    if (g + 1 < c16) mfma8(ao, bo0, bo1);
+                    bo0 = b_group(bp0, g + 3); bo1 = b_group(bp1, g + 3);
+                }
+                auto store = [&](const f32x4 &acc, int cb) {                  // rows lk*4 + r of the token block, column lr
+                    const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+                    const int col = cb * 16 + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int tok = tb * 16 + lk * 4 + r;
+                        float v = av[r] + 0.0f;                               // -0.0 -> +0.0 like score_tile_kernel
+                        if (col == clamp_col) v = fminf(v, p.threshold);
+                        if (tok < n && col < Kp) scl[(long long)tok * Kp + col] = v;
+                    }
+                };
+                store(acc0, cb0);
+                if (cb1 != cb0) store(acc1, cb1);
+            }
+            };
+            if (otm_lds) product((lds_cv4f *)((lds_cfloat *)trl) + lane);
+            else product((glb_cv4f *)p.OTm + lane);
+        }
+        __syncthreads();                                 // abT (aliasing hist) is free again
+        if (probe) pb = (long long)__builtin_amdgcn_s_memtime();
+    }
+    // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
+    // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
+    // that e.g. K = 130 (64 pairs + START/STOP) costs the ninth wavefront 3 source slots per lane instead of 17
+    const int npairs = (K + 1) >> 1, nfull = npairs >> 3, rem = npairs & 7;
+    const bool tail = wu >= nfull;                       // wave-uniform
+    const int GT = rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8;
+    const int g = tail ? (lane & (GT - 1)) : (tid & 7);  // lane of its group
+    const int grp = tail ? lane / GT : 0;
+    const int pair = tail ? nfull * 8 + grp : (tid >> 3);
+    const int j0 = 2 * pair;
+    const bool own0 = j0 < K && (!tail || grp < rem), own1 = own0 && j0 + 1 < K;
+    const bool writer = own0 && (tail ? g == GT - 1 : g == 0);
+    const int XS = (K - 8 * IB + 7) >> 3;                // full wavefronts: leftover source slots per lane (0..4)
+    const int nst = (K + GT - 1) / GT;                   // tail wavefront: source slots per lane (<= IB + 4)
+    constexpr int NSL = IB + 4;
+    v2f trs[NSL];                                        // tr[i][j0], tr[i][j0+1] of this lane's sources
+#define FARNN_TRS_SET(SL, X, Y) do { trs[SL] = v2f{(X), (Y)}; } while (0)
+    int ixs[4];                                          // full: leftover sources (clamped into the row; their tr is -inf)
+    {
+        const float *row0 = p.trT + (long long)(own0 ? j0 : 0) * Kp, *row1 = p.trT + (long long)(own1 ? j0 + 1 : 0) * Kp;
+        if (!tail) {
+#pragma unroll
+            for (int k4 = 0; k4 < IB4; k4++) {           // sources 32*k4 + 4*g + u: a 128-byte span per read, no bank conflicts
+                const float4 a = ld4(row0 + k4 * 32 + g * 4), c = ld4(row1 + k4 * 32 + g * 4);
+                trs[k4 * 4 + 0] = v2f{own0 ? a.x : ninf, own1 ? c.x : ninf}; trs[k4 * 4 + 1] = v2f{own0 ? a.y : ninf, own1 ? c.y : ninf};
+                trs[k4 * 4 + 2] = v2f{own0 ? a.z : ninf, own1 ? c.z : ninf}; trs[k4 * 4 + 3] = v2f{own0 ? a.w : ninf, own1 ? c.w : ninf};
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) {
+                const int i = 8 * IB + 8 * xk + g;
+                const bool ok = i < K;
+                ixs[xk] = ok ? i : K - 1;
+                FARNN_TRS_SET(IB + xk, (ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf);
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NSL; sl++) {
+                const int i = g + GT * sl;
+                const bool ok = i < K;
+                FARNN_TRS_SET(sl, (ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf);
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) ixs[xk] = 0;
+        }
+    }
+    const v2f t_start = writer ? v2f{p.trT[(long long)j0 * Kp + START], own1 ? p.trT[(long long)(j0 + 1) * Kp + START] : 0.0f}
+                               : v2f{0.f, 0.f};                                                  // before the table DMA
+    int my_tr = 0;
+    {
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
+        for (int k = wu; k < tr_pieces; k += nwaves, my_tr++)
+            lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.trT), lds0 + (unsigned)k * 1024u);
+    }
+    if (PW > K)
+        for (int i = tid; i < n * (PW - K); i += nthreads) hist[(i / (PW - K)) * PW + K + i % (PW - K)] = ninf;
+    wait_vmcnt(my_tr);                                   // scores + this lane's transition entries landed
+    wg_barrier_lds();                                    // (a __syncthreads would drain the table DMA)
+    // scores of this lane's two tags (a tag beyond K reads a finite pad column and its transitions are -inf)
+    const float *fcol = scl + (own0 ? j0 : 0);
+    auto scores_at = [&](int t) {                        // f_t[j0], f_t[j0+1]; nothing is read into a half without a tag
+        v2f f = *reinterpret_cast<const v2f *>(fcol + (size_t)t * Kp);
+        f.y = own1 ? f.y : 0.0f;
+        return f;
+    };
+    if (writer) {                                                             // crf.py:135
+        const v2f f0 = scores_at(0);
+        hist[j0] = f0.x + t_start.x;
+        if (own1) hist[j0 + 1] = f0.y + t_start.y;
+    }
+    wg_barrier_lds();
+    if (probe) pc1 = (long long)__builtin_amdgcn_s_memtime();
+    // the tail wavefront's step is a short latency chain (LDS read, a few adds, six DPP levels, LDS write): at the default
+    // priority the SIMD's older wavefronts starve it until their own issue-bound step is over and the chain then runs
+    // behind them (K = 130: +330 cycles per step); first in line, it hides inside their step
+    if (tail) __builtin_amdgcn_s_setprio(3);
+    // One step: two adds (crf.py:123,145) and half a v_max3 per (source, tag).  The step is VALU-issue bound on the CU:
+    // hoisting the partition-independent add (f + tr) behind the step's LDS write was measured and bought nothing (the
+    // idle time around the write and the barrier is ~100 cycles, not the ~350 the first probe suggested), and
+    // v_pk_add_f32 issues at half rate on gfx950, so the packed form saves registers and LDS reads, not issue slots.
+    // Two loops, the full wavefronts' specialised on its number of leftover slots: with the tail / leftover / ablation tests
+    // inside one loop a step spent ~250 cycles on a dozen scalar branches (a taken branch refills the instruction buffer).
+    const unsigned pin_lane = (unsigned)(size_t)(hist + g * 4);               // this lane's 16 bytes of a 32-source block
+    const unsigned f_lane = (unsigned)(size_t)fcol;
+    unsigned px_lane[4];
+#pragma unroll
+    for (int xk = 0; xk < 4; xk++) px_lane[xk] = (unsigned)(size_t)(hist + ixs[xk]);
+    auto publish = [&](int t, const v2f &best) {
+        if (writer) *reinterpret_cast<v2f *>(hist + (size_t)t * PW + j0) = best;   // (j0 + 1 == K: -inf into the pad)
+        wg_barrier_lds();
+    };
+    auto full_steps = [&](auto xs_c) {
+        constexpr int XSC = decltype(xs_c)::value;       // leftover source slots per lane (0..4)
+        v2f fnext = n > 1 ? scores_at(1) : v2f{0.f, 0.f};
+        for (int t = 1; t < n; t++) {
+            const v2f f = fnext;
+            auto f_tr = [&](int sl) { return f + trs[sl]; };
+            v2f best = v2f{ninf, ninf};
+            // every LDS read of the step up front, oldest first: the scores of the NEXT step, the IB4 blocks, the leftovers
+            // (left to the compiler they went through one recycled register quad: three exposed LDS round trips per step)
+            const unsigned row = (unsigned)((t - 1) * PW) * 4u;
+            const unsigned frow = (unsigned)((t + 1 < n ? t + 1 : t) * Kp) * 4u;
+            v4f p4[IB4 > 0 ? IB4 : 1];
+            float px[XSC > 0 ? XSC : 1];
+            asm volatile("ds_read_b64 %0, %1" : "=v"(fnext) : "v"(f_lane + frow));
+            if constexpr (IB4 > 0) lds_read16_at<0>(p4[0], pin_lane + row);
+            if constexpr (IB4 > 1) lds_read16_at<128>(p4[1], pin_lane + row);
+            if constexpr (IB4 > 2) lds_read16_at<256>(p4[2], pin_lane + row);
+            if constexpr (IB4 > 3) lds_read16_at<384>(p4[3], pin_lane + row);
+            if constexpr (IB4 > 4) lds_read16_at<512>(p4[4], pin_lane + row);
+            if constexpr (IB4 > 5) lds_read16_at<640>(p4[5], pin_lane + row);
+            if constexpr (IB4 > 6) lds_read16_at<768>(p4[6], pin_lane + row);
+#pragma unroll
+            for (int xk = 0; xk < XSC; xk++) asm volatile("ds_read_b32 %0, %1" : "=v"(px[xk]) : "v"(px_lane[xk] + row));
+            auto block = [&](int k4) {
+                const v2f v0 = f_tr(k4 * 4 + 0) + v2f{p4[k4].x, p4[k4].x}, v1 = f_tr(k4 * 4 + 1) + v2f{p4[k4].y, p4[k4].y};
+                const v2f v2 = f_tr(k4 * 4 + 2) + v2f{p4[k4].z, p4[k4].z}, v3 = f_tr(k4 * 4 + 3) + v2f{p4[k4].w, p4[k4].w};
+                best.x = fmaxf(fmaxf(best.x, v0.x), v1.x); best.y = fmaxf(fmaxf(best.y, v0.y), v1.y);
+                best.x = fmaxf(fmaxf(best.x, v2.x), v3.x); best.y = fmaxf(fmaxf(best.y, v2.y), v3.y);
+            };
+            if constexpr (IB4 > 0) { lds_wait_for<IB4 + XSC - 1>(p4[0]); block(0); }
+            if constexpr (IB4 > 1) { lds_wait_for<IB4 + XSC - 2>(p4[1]); block(1); }
+            if constexpr (IB4 > 2) { lds_wait_for<IB4 + XSC - 3>(p4[2]); block(2); }
+            if constexpr (IB4 > 3) { lds_wait_for<IB4 + XSC - 4>(p4[3]); block(3); }
+            if constexpr (IB4 > 4) { lds_wait_for<IB4 + XSC - 5>(p4[4]); block(4); }
+            if constexpr (IB4 > 5) { lds_wait_for<IB4 + XSC - 6>(p4[5]); block(5); }
+            if constexpr (IB4 > 6) { lds_wait_for<IB4 + XSC - 7>(p4[6]); block(6); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fnext));
+#pragma unroll
+            for (int xk = 0; xk < XSC; xk++) {
+                asm volatile("" : "+v"(px[xk]));         // (behind the wait)
+                const v2f v = f_tr(IB + xk) + v2f{px[xk], px[xk]};
+                best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+            }
+            fnext.y = own1 ? fnext.y : 0.0f;             // (scores_at's rule: nothing is read into a half without a tag)
+            // the eight lanes of the group: xor 1, xor 2 inside the quad, then the mirrored quad of the half row
+            asm volatile("s_nop 1\n\t"
+                         "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                         "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1"
+                         : "+v"(best.x), "+v"(best.y));
+            publish(t, best);
+        }
+    };
+    auto tail_steps = [&]() {
+        for (int t = 1; t < n; t++) {
+            const float *pin = hist + (size_t)(t - 1) * PW;
+            const v2f f = scores_at(t);
+            auto f_tr = [&](int sl) { return f + trs[sl]; };
+            v2f best = v2f{ninf, ninf};
+#pragma unroll
+            for (int s4 = 0; s4 < NSL; s4 += 4) {        // four slots at a time (slots beyond nst: -inf transitions)
+                if (s4 >= nst) continue;
+                float ps[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int i = g + GT * (s4 + u); ps[u] = pin[i < PW ? i : PW - 1]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const v2f v = f_tr(s4 + u) + v2f{ps[u], ps[u]};
+                    best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y);
+                }
+            }
+            // max scan over the GT lanes of the group: its last lane ends up with the group's maximum
+#define FARNN_SCAN2(CTRL) asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 1" : "+v"(best.x), "+v"(best.y))
+            FARNN_SCAN2("row_shr:1 row_mask:0xf bank_mask:0xf");
+            FARNN_SCAN2("row_shr:2 row_mask:0xf bank_mask:0xf");
+            FARNN_SCAN2("row_shr:4 row_mask:0xf bank_mask:0xf");
+            if (GT >= 16) FARNN_SCAN2("row_shr:8 row_mask:0xf bank_mask:0xf");
+            if (GT >= 32) FARNN_SCAN2("row_bcast:15 row_mask:0xa bank_mask:0xf");
+            if (GT >= 64) FARNN_SCAN2("row_bcast:31 row_mask:0xc bank_mask:0xf");
+#undef FARNN_SCAN2
+            publish(t, best);
+        }
+    };
+    if (tail) tail_steps();
+    else switch (XS) {
+        case 0: full_steps(std::integral_constant<int, 0>{}); break;
+        case 1: full_steps(std::integral_constant<int, 1>{}); break;
+        case 2: full_steps(std::integral_constant<int, 2>{}); break;
+        case 3: full_steps(std::integral_constant<int, 3>{}); break;
+        default: full_steps(std::integral_constant<int, 4>{}); break;
+    }
+    if (tail) __builtin_amdgcn_s_setprio(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the transition table is in LDS
+    __syncthreads();
+    if (probe) pc2 = (long long)__builtin_amdgcn_s_memtime();
+    if (w == 0 && n > 0) {
+        // One wavefront walks the path, and a lone wavefront issues one instruction every ~4-5 cycles: the step is bound by its
+        // instruction COUNT plus one LDS round trip (r02: eight 4-byte reads, a six-level DPP max, three ballots -- 590 cycles).
+        // Lane q holds FOUR consecutive candidates (4q .. 4q+3; PW / 4 <= 64 lanes cover a row): the table's row and the
+        // partitions' row are one 16-byte read each, the latter fetched a step ahead.  There is NO reduction: the maximum of a
+        // step's candidates IS part_t[ptr], which the forward pass took over exactly these values (a max returns one of its
+        // operands' bits) -- two broadcast reads fetch it and the score f_t[ptr] beside the table's row.
+        const int nq = PW >> 2, q = lane < nq ? lane : nq - 1;
+        const unsigned long long valid = nq >= 64 ? ~0ull : ((1ull << nq) - 1ull);
+        const float *hq = hist + 4 * q, *tq = trl + 4 * q;
+        auto first_equal = [&](const float4 &c, float m) {                    // first index (torch.max's rule); 0 if none (NaN)
+            const bool h0 = c.x == m, h1 = c.y == m, h2 = c.z == m, h3 = c.w == m;
+            const int e = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;                       // this lane's first hit, if it has one
+            const unsigned long long any = (__ballot(h0) | __ballot(h1) | __ballot(h2) | __ballot(h3)) & valid;
+            const int l = __builtin_ctzll(any | (1ull << 63));
+            return any ? 4 * l + __builtin_amdgcn_readlane(e, l) : 0;
+        };
+        auto candidates = [&](float f, const float4 &tr, const float4 &pp) {  // (feat + trans) + partition: crf.py:123,145
+            return make_float4((f + tr.x) + pp.x, (f + tr.y) + pp.y, (f + tr.z) + pp.z, (f + tr.w) + pp.w);
+        };
+        float4 prv = *reinterpret_cast<const float4 *>(hq + (n - 1) * PW);
+        float4 c = candidates(0.0f, *reinterpret_cast<const float4 *>(tq + STOP * Kp), prv);      // crf.py:168-169 (0 + x = x)
+        // (candidates in [K, PW) are -inf through the partitions' pads; lanes beyond the row repeat its last four)
+        int ptr = first_equal(c, wave_max_dpp(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w))));
+        prv = *reinterpret_cast<const float4 *>(hq + (n > 1 ? n - 2 : 0) * PW);                    // part_{t-1} of the first step
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const unsigned hq0 = (unsigned)(size_t)hq, tq0 = (unsigned)(size_t)tq, h0 = (unsigned)(size_t)hist;
+        const unsigned sc_off = (unsigned)(size_t)scl - h0;
+        int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
+        for (int t = n - 1; t >= 0; t--) {
+            {
+                const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
+                const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
+                unsigned keep;                                        // (one SGPR per instruction: the lane select rides in M0)
+                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                             : "+v"(mytag), "=&s"(keep) : "s"(tg), "s"(tl));
+            }
+            if ((t & 63) == 0) {                         // 64 positions at a time, coalesced
+                if (t + lane < n) {
+                    if (p.tags) p.tags[(long long)b * p.L + t + lane] = mytag;
+                    if (p.flat) p.flat[foff + t + lane] = mytag;
+                }
+            }
+            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values
+            if (t > 0) {
+                const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
+                const unsigned a_pre = hq0 + 4u * (unsigned)(tp * PW), a_tr = tq0 + 4u * (unsigned)(ptr * Kp);
+                const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;     // (PW == Kp)
+                f32x4 pre, tr;
+                float m, f;
+                // one statement, so that the order is this one: the row fetched ahead first (its latency hides behind the others'
+                // -- LDS reads return in order), then the three the step waits for
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(pre), "=&v"(tr), "=&v"(m), "=&v"(f) : "v"(a_pre), "v"(a_tr), "v"(a_m), "v"(a_f) : "memory");
+                c = candidates(f, make_float4(tr.x, tr.y, tr.z, tr.w), prv);
+                ptr = first_equal(c, m);
+                prv = make_float4(pre.x, pre.y, pre.z, pre.w);
+            }
+        }
+    }
+    if (probe && tid == 0) {
+        pc3 = (long long)__builtin_amdgcn_s_memtime();
+        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (products staged at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
+               b, n, nthreads, pc1 - pc0, pa - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
+    }
+    if (p.tags)
+        for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
+}
+
+template <int IB4, bool FUSED>
+__global__ void __launch_bounds__(IB4 < 7 ? 128 * IB4 + 128 : 1024)        // K < 32*IB4 + 32: 8 lanes per tag pair
+viterbi_hist_kernel(const ScoreParams p) {
+    extern __shared__ __align__(16) float smem[];
+    viterbi_hist_body<IB4, FUSED>(p, smem, (int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x);
+}
+
+// viterbi_hist_kernel: contiguous float4 blocks per lane (K = 32*IB4 + leftovers) and its thread count
+inline int viterbi_hist_ib4(int K) { return K / 32; }
+inline int viterbi_hist_threads(int K) { return round_up(((K + 1) / 2) * 8, 64); }
+inline size_t viterbi_hist_lds_bytes(int K, int Kp, int SP, int L, bool fused) {
+    return viterbi_hist_floats(Kp, SP, L, fused) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +
+           ((size_t)K * Kp * 4 + 1023) / 1024 * 1024;
+}
+
+}  // namespace farnn

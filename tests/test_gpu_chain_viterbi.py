@@ -1,0 +1,131 @@
+"""The one-launch CRF tagging step (csrc/chain_viterbi.hip: both chains of a sequence, its scores and its Viterbi decode in one
+sixteen-wavefront workgroup) against the oracle over random geometries: state counts 1..72, tag sets of 32..159 labels (the
+form's range; others must take the two-launch path and still be right), sequence lengths 1..120 (rows consumed in LDS, and the
+stash fall-back where the LDS plan does not fit), LOCAL / FULL mode, none / relu non-linearities (integer path counts: the decoded
+paths are bit-identical to the numpy Viterbi on the oracle's scores), both semirings, ragged and full-length batches.  Every
+draw is also run in the two-launch form (FARNN_NOFUSE=1) and through the stash (FARNN_CV_STASH=1): identical tags.
+
+    FARNN_SHAPE_SOAK=<n> raises the number of random configurations (default 30 in the suite), FARNN_SHAPE_SEED=<s> draws others.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import farnn_oracle as fo                    # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _tag(h, x, lengths, B, L, mode):
+    from re2nn_seq_amd import _lib
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+    tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+    flat = torch.full((int(lengths.sum()),), -7, dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(), flat.data_ptr(), None)
+    torch.cuda.synchronize()
+    return tags.cpu().numpy(), flat.cpu().numpy(), h.kernel_name(_lib.KERN_CHAIN)
+
+
+def _one(rng):
+    from re2nn_seq_amd import _lib, synth
+    S = int(rng.choice([1, 2, 7, 16, 31, 48, 63, 64, 65, 71, 72]))
+    C = int(rng.choice([9, 30, 31, 62, 63, 64, 100, 126, 127, 128, 129, 157, 158, 200]))
+    L = int(rng.choice([1, 2, 16, 17, 33, 64, 65, 100, 120]))
+    B = int(rng.choice([1, 2, 7, 33]))
+    nl = str(rng.choice(['none', 'relu']))
+    semiring = str(rng.choice(['sum', 'sum', 'max']))
+    full = bool(rng.rand() < 0.3)
+    V, K = 41, C + 2
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=max(2.0, S / 5), n_final=min(2, S))
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    if rng.rand() < 0.3:
+        lengths[:] = L
+    sem = fo.SEMIRING_MAX if semiring == 'max' else fo.SEMIRING_SUM
+    nlc = fo.NL_NONE if nl == 'none' else fo.NL_RELU
+    with np.errstate(all='ignore'):
+        sc = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths, nl=nlc, semiring=sem, P=None)
+    if not np.isfinite(sc).all() or float(np.abs(sc).max()) >= 2.0 ** 22:
+        return None                                      # path counts beyond fp32's exact range: not a parity case
+    tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    ext = fo.onehot_crf_extension_scores(sc)
+    want = fo.decode_crf(ext, lengths, tr, 0.5, 0)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
+    what = 'S={} C={} L={} B={} nl={} {} full={}'.format(S, C, L, B, nl, semiring, full)
+    names = {}
+    for env in ({}, {'FARNN_CV_STASH': '1'}, {'FARNN_NOFUSE': '1'}):
+        os.environ.update(env)
+        try:
+            h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, semiring=semiring, use_crf=True, crf_trans=tr)
+            tg, fl, name = _tag(h, x, lengths, B, L, mode)
+            h.close()
+        finally:
+            for k in env:
+                del os.environ[k]
+        key = next(iter(env), 'default')
+        names[key] = name
+        assert np.array_equal(tg[mask].astype(np.int64), want[mask]), (what, key, name)
+        assert (tg[~mask] == -1).all(), (what, key, name)
+        assert np.array_equal(fl, fo.flatten(want, lengths)), (what, key, name)
+    one_launch = 32 <= K <= 131 and L <= 64            # (larger tag sets: as far as history + scores + table fit the LDS)
+    if one_launch:
+        assert 'chain_viterbi_kernel' in names['default'], (what, names)
+    assert 'chain_viterbi' not in names['FARNN_NOFUSE'], (what, names)
+    return what + ' [' + names['default'] + ']'
+
+
+def test_chain_viterbi_random_shapes_vs_oracle():
+    n = int(os.environ.get('FARNN_SHAPE_SOAK', '30'))
+    rng = np.random.RandomState(int(os.environ.get('FARNN_SHAPE_SEED', '20261004')))
+    done, fused = 0, 0
+    while done < n:
+        what = _one(rng)
+        if what is None:
+            continue
+        done += 1
+        fused += 'chain_viterbi' in what
+    assert fused * 3 >= n                                  # a good share of the draws really took the one-launch form
+
+
+def test_chain_viterbi_under_graph_capture():
+    """No epoch, no progress words: the one-launch CRF step replays from a HIP graph (the arg-max form is two launches there)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(5)
+    V, S, C, B, L = 200, 71, 128, 64, 48
+    K = C + 2
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng)
+    tr = (rng.randn(K, K) * 0.1).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=True, crf_trans=tr)
+    h.reserve(B, L)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+    tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # one eager call first (lazy attribute set-up)
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None, side.cuda_stream)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None,
+              torch.cuda.current_stream().cuda_stream)
+    assert 'chain_viterbi_kernel' in h.kernel_name(_lib.KERN_CHAIN)
+    x2, l2 = synth.random_batch(V, B, L, rng, min_len=1)
+    xd.copy_(torch.from_numpy(x2)); ld.copy_(torch.from_numpy(l2))
+    tags.fill_(-7)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    sc = fo.onehot_ifst_scores(T, W, O, h0, hT, x2, l2, nl=fo.NL_NONE, semiring=fo.SEMIRING_SUM, P=None)
+    want = fo.decode_crf(fo.onehot_crf_extension_scores(sc), l2, tr, 0.5, 0)
+    mask = np.arange(L)[None, :] < l2[:, None]
+    assert np.array_equal(tags.cpu().numpy()[mask].astype(np.int64), want[mask])
+    h.close()
