@@ -63,7 +63,11 @@ chain_viterbi_kernel(const RegsParams p, const ScoreParams sp, const ChainViterb
     }
     int b = 0;
     float *mine = smem + (half ? pl.off1 : pl.off0);
-    chain_regs_body<MAXSR, false, NLX>(p, mine, tid & (RG_WAVES * 64 - 1), 2 * (int)blockIdx.x + half, &b);
+    // wavefront w of a workgroup sits on SIMD w % 4: the forward chain's six compute wavefronts (roles 0-5) are wavefronts 0-5,
+    // on SIMDs 0 1 2 3 0 1; the backward chain's roles are rotated by two -- wavefronts 10-15, on SIMDs 2 3 0 1 2 3 -- so that
+    // every SIMD carries three compute wavefronts (unrotated: four on SIMDs 0 and 1, two on 2 and 3)
+    const int role_tid = half ? ((tid + 6 * 64) & (RG_WAVES * 64 - 1)) : tid;
+    chain_regs_body<MAXSR, false, NLX>(p, mine, role_tid, 2 * (int)blockIdx.x + half, &b);
     __syncthreads();                                 // (s_waitcnt vmcnt(0) in front of it: the image / every stash row has landed)
     if (tid >= vthreads) return;
     const int hist_off = regs_lds(p.L, p.SP, RG_NWC * p.G, 0, 0, false).hist;
