@@ -13,6 +13,7 @@ FARNN_NOFUSE=1 python bench.py $Q 2>/dev/null > $O/bench_ifst_two_kernels.json
 FARNN_NOREGS=1 FARNN_NOFUSE=1 python bench.py $Q 2>/dev/null > $O/bench_ifst_ring_kernel_r02.json
 python bench.py --full-length $Q 2>/dev/null > $O/bench_ifst_full.json
 python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf.json
+FARNN_NOFUSE=1 python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf_two_kernels.json
 python bench.py --workload decomp $Q --steps 300 2>/dev/null > $O/bench_decomp.json
 FARNN_DECOMP_NOREGS=1 python bench.py --workload decomp $Q --steps 300 2>/dev/null > $O/bench_decomp_rows_kernel.json
 python bench.py --workload decomp --rank 100 --farnn 1 $Q --steps 100 2>/dev/null > $O/bench_decomp_r100_farnn1.json
