@@ -78,6 +78,8 @@ def parse():
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--workload', default='ifst', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
+    ap.add_argument('--states', type=int, default=0,
+                    help='decomp workloads: automaton states S (default 104; 134 = the shipped configurations with --additional_states 30)')
     ap.add_argument('--vocab', type=int, default=0,
                     help='dry runs only: override the workload\'s vocabulary size (the line then says so; never a headline number)')
     ap.add_argument('--seqlen', type=int, default=64)
@@ -102,6 +104,9 @@ def parse():
                     help='time the kernels of every N-th step with HIP events (0 = never; default: chosen from '
                          '--steps so that at least 8 launches are timed, at most every 16th step)')
     a = ap.parse_args()
+    if a.states > 0:
+        d_, v_, s_, c_ = WORKLOADS[a.workload]
+        WORKLOADS[a.workload] = (d_ + ' [S = {}]'.format(a.states), v_, a.states, c_)
     if a.vocab > 0:
         d_, _, s_, c_ = WORKLOADS[a.workload]
         WORKLOADS[a.workload] = (d_ + ' [DRY RUN: vocabulary reduced to {}]'.format(a.vocab), a.vocab, s_, c_)

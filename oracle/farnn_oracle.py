@@ -23,9 +23,24 @@ models (model_onehot.py:372) and over ``lengths.max()`` positions for the decomp
 models (model_decompose_single.py:221); this restatement does the same so that
 ``forward_RE`` (pads kept) can be checked too.
 """
+import contextlib
+
 import numpy as np
 
 F32 = np.float32
+
+
+@contextlib.contextmanager
+def precision(dtype):
+    """Evaluate the restatement in another float type (tests only).  float64 gives the value that float32 implementations
+    -- the reference's, numpy's at another batch size, the HIP kernels' -- scatter around: on a locally sensitive sequence
+    two float32 evaluations can sit further from each other than either sits from it."""
+    global F32
+    old, F32 = F32, dtype
+    try:
+        yield
+    finally:
+        F32 = old
 
 NL_NONE, NL_RELU, NL_TANH, NL_RELUTANH, NL_SIGMOID = 0, 1, 2, 3, 4
 NL_CODES = {'none': NL_NONE, 'relu': NL_RELU, 'tanh': NL_TANH, 'relutanh': NL_RELUTANH,

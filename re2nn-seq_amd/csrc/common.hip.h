@@ -229,6 +229,25 @@ __device__ __forceinline__ float wave_max_dpp(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// wave sum on the DPP network (wave-uniform result), the same ladder as wave_max_dpp
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1"
+                 : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 // first index (torch.max's rule) of the maximum of up to 256 candidates held as v[r] = candidate r*64 + lane (lanes
 // beyond the last candidate hold -inf): the wave maximum, then per row of 64 the lanes that equal it -- the lowest set
 // bit of the first non-empty row is the answer.  Wave-uniform result; 0 when nothing compares equal (all NaN).

@@ -123,6 +123,36 @@ __device__ __forceinline__ void rowdots(const float *ml, const float *mg, int nr
     }
 }
 
+// A FEW rows (the rows behind a mixed form's register passes: 6 or 12 of them), all LDS-resident: a 128-row pass would spend a
+// whole pass's reads and FMAs on them.  Here a wavefront takes a row, lane l the columns 4l .. 4l+3 (+ 256): two 16-byte
+// reads of the row, eight FMAs, a wave sum; the input vector's pieces are read once for all of a wavefront's rows.
+template <int NSEQ, typename Epi>
+__device__ __forceinline__ void rowdots_few(const float *ml, int nrows, int ld, int nch, const float *X, int xs, int tid, Epi &&epi) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const int ncol = nch * DR_CHUNK;                            // nch <= 16: two column blocks of 256
+    for (int row = wv; row < nrows; row += DR_THREADS / 64) {
+        lds_cfloat *rl = (lds_cfloat *)ml + row * ld;
+        float acc[NSEQ];
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) acc[s] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {                           // (the input vector's pieces are re-read per row: registers are what
+            const int c = 4 * lane + 256 * i;                   //  a mixed form has least of)
+            if (c < ncol) {
+                const v4f a = *(lds_cv4f *)(rl + c);
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) {
+                    const v4f x = *(lds_cv4f *)((lds_cfloat *)X + s * xs + c);
+                    acc[s] += (a.x * x.x + a.y * x.y) + (a.z * x.z + a.w * x.w);
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) acc[s] = wave_sum_dpp(acc[s]);
+        if (lane == 0) epi(row, acc);
+    }
+}
+
 // The same row dot products with the rows held in REGISTERS for the whole sequence: pass i covers the rows i*128 + tid/4,
 // w[i][2c], w[i][2c+1] are this lane's two 16-byte pieces of chunk c.  The chunk of every x_s is read from LDS once and used
 // by all NP passes.
@@ -201,7 +231,7 @@ __device__ __forceinline__ float dr_nl(float x, int nl) {
 // step (the shipped example configuration's shape, S = 104, rank 250, farnn = 2: 286 KB per workgroup per step, 5.1 us per
 // step).  Eight wavefronts have 512 KB of registers between them: P1 (gates) and P3 in registers + P2 in LDS hold that
 // model whole, and a step touches neither L2 nor HBM for weights.
-template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0>
+template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0, bool MIXED = false>
 __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
     extern __shared__ __align__(16) float smem[];
@@ -262,8 +292,12 @@ decomp_rows_kernel(const DecompRowsParams p) {
             const int idx = (dir == 0) ? k : (k < slen[s] ? slen[s] - 1 - k : k);
             tok[s * Lr + k] = clamp_tok(p.x[(long long)bseq[s] * p.L + idx], p.V);
         }
+    // A register form may hold only a matrix's first NPxR passes (mixed forms: S in 129..160 needs three passes of gate rows or
+    // two of output rows; the registers hold the first passes, the few rows behind them are LDS-resident like any other
+    // matrix's, or streamed): R1 / R2 / R3 = rows held in registers, the resident / streamed rows start there.
+    constexpr int R1 = NP1R * DR_RPP, R2 = NP2R * DR_RPP, R3 = NP3R * DR_RPP;
     {   // resident rows: global -> LDS
-        const float *src[3] = {p.P1, p.P2[dir], p.P3[dir]};
+        const float *src[3] = {p.P1 + (long long)R1 * ld2, p.P2[dir] + (long long)R2 * ld2, p.P3[dir] + (long long)R3 * ld3};
         float *dst[3] = {L1, L2, L3};
         const long long cnt[3] = {(long long)p.res1 * ld2, (long long)p.res2 * ld2, (long long)p.res3 * ld3};
 #pragma unroll
@@ -358,8 +392,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP1R > 0) rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
-                else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
+                if constexpr (NP1R > 0) {
+                    rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
+                    if (MIXED && p.n1 > R1) {                   // (mixed form: the rows behind the register passes)
+                        auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi1(row + R1, acc); };
+                        rowdots_few<NSEQ>(L1, p.n1 - R1, ld2, p.nch2, H, c2p, tid, shifted);   // (the plan keeps them LDS-resident)
+                    }
+                } else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             }
             wg_barrier_lds();
         }
@@ -372,8 +411,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP2R > 0) rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
-                else rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+                if constexpr (NP2R > 0) {
+                    rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
+                    if (MIXED && p.n2 > R2) {                   // (mixed form: the rows behind the register passes)
+                        auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi2(row + R2, acc); };
+                        rowdots_few<NSEQ>(L2, p.n2 - R2, ld2, p.nch2, HBc, c2p, tid, shifted);   // (the plan keeps them LDS-resident)
+                    }
+                } else rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
             }
         }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
@@ -407,8 +451,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP3R > 0) rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3);
-                else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
+                if constexpr (NP3R > 0) {
+                    rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3);
+                    if (MIXED && p.n3 > R3) {                   // (mixed form: the rows behind the register passes)
+                        auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi3(row + R3, acc); };
+                        rowdots_few<NSEQ>(L3, p.n3 - R3, ld3, p.nch3, X3c, c3p, tid, shifted);   // (the plan keeps them LDS-resident)
+                    }
+                } else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
             }
         }
         wg_barrier_lds();
@@ -495,7 +544,13 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 // Rp + SP <= 384 (rank 150 / 250: the shipped example configurations).
 // 4: farnn = 2 at 128 < S <= 160 (the shipped configurations with --additional_states 30 at this automaton size): the gate
 // rows alone in registers, P2 / P3 in LDS as far as it goes, the rest streamed.
-#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(4, 3, 0, 5, 0, 0)
+// 5 / 6 (round 3, MIXED: the registers hold a matrix's first passes, the rows behind them are LDS-resident): farnn = 2 at
+// 128 < S <= 160 with the output rows in registers too: two passes of gate rows + the 12 behind them in LDS, one pass of output
+// rows + the 6 behind it in LDS, P2 in LDS -- 5: Rp + SP <= 288 (rank 150 + additional states: P2 fits whole, nothing is
+// streamed); 6: Rp + SP <= 416 (rank 250 + additional states: P2 as far as the LDS goes, 128 of its 250 rows).  (Three passes
+// of gate rows beside a pass of output rows do not fit the 256 VGPRs of a lane: 46 spilled.)
+#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
+constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6; }
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -518,14 +573,21 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
     if (forms && nseq == 1) {      // (two sequences per workgroup on these forms: measured slower, spills)
         const int np1 = (k.n1 + DR_RPP - 1) / DR_RPP, np2 = (k.n2 + DR_RPP - 1) / DR_RPP, np3 = (k.n3 + DR_RPP - 1) / DR_RPP;
 #define FARNN_ROWS_MATCH(F_, A_, B_, C_, D_, E_)                                                                   \
-        if (!pl.form && (A_ == 0 || (k.n1 > 0 && np1 <= A_ && k.nch2 <= C_)) && (B_ == 0 || (np2 <= B_ && k.nch2 <= C_)) && \
-            (D_ == 0 || (np3 <= D_ && k.nch3 <= E_)) && (A_ > 0 || k.n1 == 0)) {                                  \
+        if (!pl.form && (A_ == 0 || (k.n1 > 0 && (np1 <= A_ || rows_form_mixed(F_)) && k.nch2 <= C_)) &&              \
+            (B_ == 0 || (np2 <= B_ && k.nch2 <= C_)) &&                                                           \
+            (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && k.nch3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
+            (!rows_form_mixed(F_) || (np1 > 2 && np3 > 1))) {     /* (mixed forms: only where forms 1-3 do not reach) */ \
             /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
-               the sizes they were made for), the remainder is streamed as before */                               \
+               the sizes they were made for), the remainder is streamed as before; a mixed form's rows behind its     \
+               register passes first: they are few */                                                             \
             pl.form = F_;                                                                                          \
-            pl.res3 = D_ == 0 ? take(k.n3, k.ld3) : 0;                                                             \
-            pl.res2 = B_ == 0 ? take(k.n2, k.ld2) : 0;                                                             \
-            pl.res1 = A_ == 0 ? take(k.n1, k.ld2) : 0;                                                             \
+            const size_t left0 = left;                                                                             \
+            const int t3 = k.n3 > D_ * DR_RPP ? k.n3 - D_ * DR_RPP : 0, t1 = k.n1 > A_ * DR_RPP ? k.n1 - A_ * DR_RPP : 0; \
+            pl.res3 = take(t3, k.ld3);                                                                             \
+            pl.res1 = take(t1, k.ld2);                                                                             \
+            if (rows_form_mixed(F_) && (pl.res3 < t3 || pl.res1 < t1 || k.nch2 > 16 || k.nch3 > 16)) {             \
+                pl.form = 0; left = left0;              /* its rows behind the register passes must all be LDS-resident */ \
+            } else pl.res2 = take(k.n2 > B_ * DR_RPP ? k.n2 - B_ * DR_RPP : 0, k.ld2);                             \
         }
         FARNN_ROWS_FORMS(FARNN_ROWS_MATCH)
 #undef FARNN_ROWS_MATCH
@@ -568,15 +630,15 @@ inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, in
     return false;
 }
 
-template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0>
+template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0, bool MIXED = false>
 inline int launch_rows_n(const DecompRowsParams &p, int groups, size_t lds, hipStream_t s) {
     static int raised = -1;     // per process and instantiation; the attribute is per (device, function) but monotone in lds
     if ((int)lds > raised) {
-        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_>),
+        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = 160 * 1024;
     }
-    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
+    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -595,7 +657,7 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
     p.lds_floats = (int)(pl.lds / 4);
     const int groups = (B + pl.nseq - 1) / pl.nseq;
-#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_>(p, groups, pl.lds, s);
+#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_)>(p, groups, pl.lds, s);
     FARNN_ROWS_FORMS(FARNN_ROWS_LAUNCH)
 #undef FARNN_ROWS_LAUNCH
     if (pl.nseq == 4) return launch_rows_n<4>(p, groups, pl.lds, s);

@@ -50,9 +50,11 @@ def _snips_model(R, farnn, crf, seed=1234, S=104):
 
 
 @pytest.mark.parametrize('R,farnn,crf,S', [(50, 0, False, 104), (250, 2, True, 104), (100, 1, False, 104), (100, 2, False, 104),
-                                            (150, 2, True, 104), (150, 2, False, 134), (150, 1, False, 134), (120, 0, False, 71)])
+                                            (150, 2, True, 104), (150, 2, False, 134), (150, 1, False, 134), (250, 2, False, 134),
+                                            (150, 2, True, 134), (200, 2, False, 150), (120, 0, False, 71)])
 def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf, S):
-    """(the S = 134 cases: `--additional_states 30` on top of the automaton, as two shipped example configurations have it;
+    """(the S = 134 / 150 cases: `--additional_states 30` on top of the automaton, as two shipped example configurations have it
+    -- the rows kernel's MIXED register forms: first passes of the gate / output rows in registers, the rows behind them in LDS;
     the ungated rank-120 case: the rows kernel's P2-in-registers form)"""
     from re2nn_seq_amd import _lib, synth
     B, L = 256, 64
@@ -77,7 +79,18 @@ def test_decomposed_ifst_at_bench_size_vs_oracle(R, farnn, crf, S):
     ref = fo.decomp_ifst_scores(q, x, lengths)                    # [B, L, K]
     mask = np.arange(L)[None, :] < lengths[:, None]
     got = scores.cpu().numpy()
-    np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
+    if S >= 134:
+        # the rank-250 model of this size has one locally sensitive sequence (b = 77): numpy's own float32 evaluations of it at batch 1 and at batch
+        # 256 differ by 2e-4, the float64 evaluation lies between them.  Held to the float64 value, which every float32
+        # implementation scatters around (the kernels sit 6e-5 from it); the float32 oracle to the bar its own noise allows
+        with fo.precision(np.float64):
+            ref64 = fo.decomp_ifst_scores({k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v)
+                                           for k, v in q.items()}, x, lengths)
+        np.testing.assert_allclose(got[mask], ref64[mask], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=4e-4)
+        assert (np.abs(got - ref)[mask] > 1e-4 + 1e-4 * np.abs(ref[mask])).mean() < 1e-4
+    else:
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=1e-4, atol=1e-4)
     assert (got[~mask] == 0).all()
     tg, tg2 = tags.cpu().numpy(), tags2.cpu().numpy()
     assert (tg[~mask] == -1).all() and (tg2[~mask] == -1).all()
