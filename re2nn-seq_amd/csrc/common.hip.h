@@ -1,5 +1,6 @@
 // Shared helpers for the FA-RNN tagging kernels (gfx950 / CDNA4 only).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -62,6 +63,19 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) const float lds_cfloat;
 typedef __attribute__((address_space(3))) const v4f lds_cv4f;
 typedef __attribute__((address_space(1))) const v4f glb_cv4f;
+
+// LDS reads / counted waits as explicit instructions, for step loops that issue ALL of a phase's reads up front (the forward step
+// of viterbi_hist_kernel, the phases of decomp_regs8_kernel): left to the compiler they were issued piecemeal through one or two
+// recycled register quads -- an exposed LDS round trip per chunk.  The registers a wait releases are its "+v" operands, so no
+// use of them can move in front of it; LDS returns in order, so lgkmcnt(N) = "all but the N youngest have landed".
+template <int OFF> __device__ __forceinline__ void lds_read16_at(v4f &d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait_for(v4f &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+// f(integral_constant<int, I>) for I = I0 .. I1 - 1, unrolled at compile time (asm immediates, register arrays)
+template <int I0, int I1, typename F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I0 < I1) { f(std::integral_constant<int, I0>{}); static_for<I0 + 1, I1>(f); }
+}
 
 // a sequence length as the kernels use it: the API says 1..L; anything else is clamped, never trusted
 __device__ __forceinline__ int clamp_len(long long v, int L) { return v < 0 ? 0 : (v > L ? L : (int)v); }

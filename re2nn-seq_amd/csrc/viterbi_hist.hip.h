@@ -37,14 +37,6 @@ __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, boo
     return a > c ? a : c;
 }
 
-// LDS reads / counted waits as explicit instructions (the forward step of viterbi_hist_kernel issues ALL of a step's reads up
-// front; left to the compiler they were issued piecemeal through a recycled register quad -- three exposed LDS round trips per
-// step).  The registers a wait releases are its "+v" operands, so no use of them can move in front of it.
-template <int OFF> __device__ __forceinline__ void lds_read16_at(v4f &d, unsigned addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
-}
-template <int N> __device__ __forceinline__ void lds_wait_for(v4f &d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
-
 // History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
 // VALUES of every step; the back-pointers the reference stores (crf.py:147-149) are recomputed lazily along the ONE
 // path the backtrace follows: bp_t[j] = first argmax_i ((f_t[j] + tr[i][j]) + part_{t-1}[i]) is the same f32
