@@ -780,9 +780,9 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
             ev[1].record(streams[0])
         drain()                                 # every gather of the K steps is inside the timed region
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if world > 1:                           # (one rank: the synchronize above already closes the region)
             dist.barrier()
-        torch.cuda.synchronize(dev)
+            torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
         sums = [0.0, 0, 0.0, 0]
         if region:
