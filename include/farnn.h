@@ -188,10 +188,13 @@ int farnn_decomp_ifst_create(const farnn_decomp_ifst_desc *desc, int device, far
  *     Vgen[w] = V_embed[w] * beta + nl_add(E[w] @ G) * (1 - beta)                 (model_decompose.py:222-241)
  * and its loader scales V_embed, S1, S2 by the averaged column norms on the host (init_params.py:285-297):
  *     factor = cbrt(avg(V) avg(S1) avg(S2)),  M <- M * factor / avg(M),  avg(M)[c] = ||M[:, c]|| / rows  (utils.py:202-225).
- * Here desc->Vgen is ignored: V_embed / E / G / beta go to the device once, the scaling (per-rank modes) and the fold
+ * Here desc->Vgen is ignored: V_embed / E / G / beta go to the device once, the scaling (all four modes) and the fold
  * run there, and nothing of size V x R comes back to the host.  G = pinv(E) @ V_embed (model_decompose_single.py:73-76)
  * is given for the UN-normalised V_embed; its columns take V_embed's scale (the bridge is linear in them). */
 #define FARNN_NORM_NONE     0
+#define FARNN_NORM_L1       1      /* --normalize_automata l1: numpy's matrix 1-norm (largest column sum) / size          */
+#define FARNN_NORM_L2       2      /* --normalize_automata l2: the spectral norm / size (Gram matrix on the device, its    */
+                                   /*   largest eigenvalue by a Jacobi sweep over R x R doubles on the host)               */
 #define FARNN_NORM_L1_RANK  3      /* --normalize_automata l1-rank */
 #define FARNN_NORM_L2_RANK  4      /* --normalize_automata l2-rank (main.py:55 default) */
 typedef struct farnn_vgen_fold {

@@ -65,7 +65,7 @@ class VgenFold(C.Structure):
                 ('normalize', C.c_int32), ('on_device', C.c_int32)]
 
 
-NORM = {'none': 0, 'l1-rank': 3, 'l2-rank': 4}
+NORM = {'none': 0, 'l1': 1, 'l2': 2, 'l1-rank': 3, 'l2-rank': 4}
 
 
 class DecompInd1Desc(C.Structure):

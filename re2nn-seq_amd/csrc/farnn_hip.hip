@@ -1430,6 +1430,47 @@ __global__ void norm_scales_kernel(const float *avg /*[3][R]*/, float *scale /*[
     scale[c] = f / avg[c]; scale[R + c] = f / avg[R + c]; scale[2 * R + c] = f / avg[2 * R + c];
 }
 
+// G[i][j] = sum_r M[r][i] M[r][j]  (the Gram matrix of the columns, doubles: its largest eigenvalue is the squared spectral norm)
+__global__ void gram_kernel(const float *M, int rows, int cols, double *G) {
+    const int i = blockIdx.x, j = blockIdx.y;
+    if (j > i) return;
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) acc += (double)M[(long long)r * cols + i] * (double)M[(long long)r * cols + j];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { G[(long long)i * cols + j] = red[0]; G[(long long)j * cols + i] = red[0]; }
+}
+
+// largest eigenvalue of a symmetric n x n matrix (cyclic Jacobi, doubles; n <= a few hundred: create time)
+static double jacobi_largest_eigenvalue(std::vector<double> &A, int n) {
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0, diag = 0.0;
+        for (int i = 0; i < n; i++) { diag += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = 0; j < i; j++) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
+        if (off <= 1e-30 * (diag + 1e-300)) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[(size_t)p * n + q];
+                if (apq == 0.0) continue;
+                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; k++) {                // rows / columns p and q
+                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+                    A[(size_t)k * n + p] = c * akp - sn * akq; A[(size_t)k * n + q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+                    A[(size_t)p * n + k] = c * apk - sn * aqk; A[(size_t)q * n + k] = sn * apk + c * aqk;
+                }
+            }
+    }
+    double best = 0.0;
+    for (int i = 0; i < n; i++) best = A[(size_t)i * n + i] > best ? A[(size_t)i * n + i] : best;
+    return best;
+}
+
 __global__ void scale_cols_kernel(float *M, long long n, int cols, const float *scale) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) M[i] *= scale[i % cols];
@@ -1456,8 +1497,8 @@ extern "C" int farnn_decomp_ifst_create_folded(const farnn_decomp_ifst_desc *d, 
     if (d->V <= 0 || d->S <= 0 || d->R <= 0 || f->D <= 0 || !f->V_embed || !f->E || !f->G || !f->beta || !d->S1 || !d->S2)
         return fail(FARNN_EINVAL, "decomp_ifst_create_folded: V_embed / E / G / beta / S1 / S2 and positive sizes needed%s%s");
     if (f->add_nl < FARNN_NL_NONE || f->add_nl > FARNN_NL_SIGMOID) return fail(FARNN_EINVAL, "decomp_ifst_create_folded: bad add_nl%s%s");
-    if (f->normalize != FARNN_NORM_NONE && f->normalize != FARNN_NORM_L1_RANK && f->normalize != FARNN_NORM_L2_RANK)
-        return fail(FARNN_EINVAL, "decomp_ifst_create_folded: only the per-rank norms (l1-rank, l2-rank) are folded on the device%s%s");
+    if (f->normalize < FARNN_NORM_NONE || f->normalize > FARNN_NORM_L2_RANK)
+        return fail(FARNN_EINVAL, "decomp_ifst_create_folded: bad normalize mode%s%s");
     int rc = select_device(device);
     if (rc) return rc;
     const size_t V = d->V, R = d->R, S = d->S, D = f->D;
@@ -1475,7 +1516,43 @@ extern "C" int farnn_decomp_ifst_create_folded(const farnn_decomp_ifst_desc *d, 
         (rc = G.init(f->G, D * R, f->on_device)) || (rc = beta.init(f->beta, R, f->on_device)) ||
         (rc = tmp.get((void **)&Vgen, V * R * 4)) || (rc = tmp.get((void **)&avg, 6 * R * 4))) return rc;
     const float *cv = nullptr;
-    if (f->normalize != FARNN_NORM_NONE) {
+    if (f->normalize == FARNN_NORM_L1 || f->normalize == FARNN_NORM_L2) {
+        // whole-matrix modes (utils.py:211-216): numpy's matrix 1-norm (the largest column sum) or 2-norm (the spectral norm) over
+        // the element count -- one scalar per matrix.  The column sums / the R x R Gram matrix are formed on the device; R floats /
+        // R x R doubles come back, never anything of size V x R.
+        const float *mats[3] = {Vd, S1d, S2d};
+        const size_t rows[3] = {V, S, S};
+        double avgs[3];
+        if (f->normalize == FARNN_NORM_L1) {
+            for (int q = 0; q < 3; q++) col_avg_norm_kernel<<<(unsigned)R, 256>>>(mats[q], (int)rows[q], (int)R, (int)R, 1, avg + q * R);
+            std::vector<float> hv(3 * R);
+            FARNN_HIP_TRY(hipMemcpy(hv.data(), avg, 3 * R * 4, hipMemcpyDeviceToHost));
+            for (int q = 0; q < 3; q++) {
+                float mx = 0.0f;
+                for (size_t c = 0; c < R; c++) mx = hv[q * R + c] > mx ? hv[q * R + c] : mx;       // (column sum / rows)
+                avgs[q] = (double)mx / (double)R;
+            }
+        } else {
+            double *Gd = nullptr;
+            if ((rc = tmp.get((void **)&Gd, R * R * 8))) return rc;
+            std::vector<double> Gh(R * R);
+            for (int q = 0; q < 3; q++) {
+                gram_kernel<<<dim3((unsigned)R, (unsigned)R), 256>>>(mats[q], (int)rows[q], (int)R, Gd);
+                FARNN_HIP_TRY(hipMemcpy(Gh.data(), Gd, R * R * 8, hipMemcpyDeviceToHost));
+                avgs[q] = sqrt(jacobi_largest_eigenvalue(Gh, (int)R)) / ((double)rows[q] * (double)R);
+            }
+        }
+        if (!(avgs[0] > 0.0) || !(avgs[1] > 0.0) || !(avgs[2] > 0.0))
+            return fail(FARNN_EINVAL, "decomp_ifst_create_folded: a factor matrix has zero norm%s%s");
+        const double fac = cbrt(avgs[0] * avgs[1] * avgs[2]);
+        std::vector<float> sc(3 * R);
+        for (int q = 0; q < 3; q++)
+            for (size_t c = 0; c < R; c++) sc[q * R + c] = (float)(fac / avgs[q]);
+        FARNN_HIP_TRY(hipMemcpy(avg + 3 * R, sc.data(), 3 * R * 4, hipMemcpyHostToDevice));
+        scale_cols_kernel<<<(unsigned)((S * R + 255) / 256), 256>>>(S1d, (long long)(S * R), (int)R, avg + 4 * R);
+        scale_cols_kernel<<<(unsigned)((S * R + 255) / 256), 256>>>(S2d, (long long)(S * R), (int)R, avg + 5 * R);
+        cv = avg + 3 * R;
+    } else if (f->normalize != FARNN_NORM_NONE) {
         const int ord = f->normalize == FARNN_NORM_L1_RANK ? 1 : 2;
         col_avg_norm_kernel<<<(unsigned)R, 256>>>(Vd, (int)V, (int)R, (int)R, ord, avg);
         col_avg_norm_kernel<<<(unsigned)R, 256>>>(S1d, (int)S, (int)R, (int)R, ord, avg + R);

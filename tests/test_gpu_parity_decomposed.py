@@ -531,10 +531,11 @@ def test_one_handle_serves_varying_batch_shapes(farnn, semiring, R):
 
 
 @pytest.mark.parametrize('add_nl', ['none', 'relu', 'tanh', 'sigmoid', 'relutanh'])
-@pytest.mark.parametrize('normalize', ['none', 'l2-rank', 'l1-rank'])
+@pytest.mark.parametrize('normalize', ['none', 'l2-rank', 'l1-rank', 'l1', 'l2'])
 def test_word_table_and_normalisation_folded_on_the_device(add_nl, normalize):
     """farnn_decomp_ifst_create_folded computes Vgen = V_embed*beta + nl_add(E@G)*(1-beta)
-    (model_decompose.py:222-241) and the per-rank --normalize_automata scaling (init_params.py:285-297) on the device.
+    (model_decompose.py:222-241) and the --normalize_automata scaling (init_params.py:285-297; all four modes of utils.get_average:
+    per-rank column norms, numpy's matrix 1-norm, the spectral norm) on the device.
     Against the host statement of both (the oracle's generalized_vocab_table on factors normalised with
     utils.get_average) through the regular creator: same scores."""
     from re2nn_seq_amd import _lib, synth
@@ -569,12 +570,12 @@ def test_word_table_and_normalisation_folded_on_the_device(add_nl, normalize):
         h.close()
     assert np.abs(out[0]).max() > 0.1
     np.testing.assert_allclose(out[1], out[0], rtol=2e-5, atol=2e-6)
-    with pytest.raises(_lib.FarnnError):
-        _lib.NORM['l2'] = 2                              # a whole-matrix norm: refused (spectral norm, host only)
+    with pytest.raises(_lib.FarnnError):                 # a mode the header does not name
+        _lib.NORM['bogus'] = 9
         try:
-            _lib.create_decomp_ifst_folded(f(Vemb), f(E), f(G), f(beta), f(S1), f(S2), W, Cout, h0, hT, normalize='l2')
+            _lib.create_decomp_ifst_folded(f(Vemb), f(E), f(G), f(beta), f(S1), f(S2), W, Cout, h0, hT, normalize='bogus')
         finally:
-            del _lib.NORM['l2']
+            del _lib.NORM['bogus']
 
 
 def test_decomposed_random_geometries_vs_oracle():
