@@ -8,6 +8,7 @@ Q="--steps 3 --warmup 2 --no-cpu-baseline --no-pipelined --no-other-configs --no
 timeout 120 python bench.py $Q 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_timeline.txt
 FARNN_DBG=256 timeout 120 python bench.py $Q 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases.txt
 FARNN_DBG=512 timeout 120 python bench.py $Q 2>/dev/null | grep "all wavefronts" | sort | tail -8 > $O/probe_chain_regs_tile_phases.txt
-FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Q 2>/dev/null | grep "^viterbi" | sort | tail -4 > $O/probe_viterbi_phases.txt
+FARNN_DBG=8192 FARNN_NOFUSE=1 timeout 120 python bench.py --workload ifst_crf $Q 2>/dev/null | grep "^viterbi" | sort | tail -4 > $O/probe_viterbi_phases.txt
+FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Q 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
 FARNN_DBG=4096 FARNN_NOFUSE=1 timeout 120 python bench.py --workload decomp $Q 2>/dev/null | grep "^regs" | sort | tail -4 > $O/probe_decomp_regs8_phases.txt
 wc -l $O/*.txt
