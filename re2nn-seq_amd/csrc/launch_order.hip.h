@@ -8,68 +8,67 @@ namespace farnn {
 // every call): the workgroup in launch slot `slot` picks the sequence whose length rank (descending,
 // ties by index) is slot's rank under the fold of batch_prep_*_kernel (slot < B/2: rank = slot, else
 // rank = B-1 - (slot - B/2), so that workgroups i and i + B/2 pair a long with a short sequence).
-// Counting select: histogram of the lengths in LDS, a descending scan by one wavefront finds the
-// length class and the index inside it, a ballot/popcount pass finds the sequence.  Deterministic
-// (no dependence on atomic order), every workgroup of a launch sees the same permutation.
-// `scratch` needs L + 1 + 16 ints of LDS that nothing else uses yet.
+// Deterministic (a pure function of the lengths): every workgroup of a launch sees the same permutation.
+// `scratch`: one int of LDS that nothing else uses yet.
 __device__ __forceinline__ int folded_rank(int slot, int B) {
     const int half = B / 2;
     return slot < half ? slot : (B - 1) - (slot - half);
 }
 
-__device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int rank, int *scratch,
-                                                     int tid, int nthreads) {
-    const int lane = tid & 63, w = tid >> 6, nwaves = nthreads >> 6;
-    int *hist = scratch;                 // [L + 1]
-    int *misc = scratch + L + 1;         // [0] length class, [1] index inside the class, [2] result, [4..] per-wave counts
-    for (int i = tid; i <= L; i += nthreads) hist[i] = 0;
-    __syncthreads();
-    for (int k = tid; k < B; k += nthreads) {
-        int v = (int)len[k];
-        v = v < 0 ? 0 : (v > L ? L : v);
-        atomicAdd(&hist[v], 1);
-    }
-    __syncthreads();
-    if (w == 0) {                        // descending scan: lane i owns the lengths L - i, L - i - 64, ...
-        int above = 0;                   // sequences strictly longer than the chunk being scanned
-        for (int base = L; base >= 0; base -= 64) {
-            const int l = base - lane;
-            const int c = l >= 0 ? hist[l] : 0;
-            int inc = c;                 // inclusive prefix over the lanes (longer lengths first)
+// Round 3: ONE wavefront does the whole selection in registers -- no LDS histogram, no atomics, two workgroup barriers instead of
+// seven.  Lane l holds the lengths of sequences l, l + 64, ...; a binary search over the length finds the class of the rank
+// (counts = popcounts of ballots), a ballot per register finds the sequence inside it.  (The histogram form cost every
+// workgroup ~4.5 k cycles, 1.9 us of a 52 us full-length launch: FARNN_NOSORT A/B.)
+template <int NV>
+__device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, int B, int L, int rank, int lane) {
+    int v[NV];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(inc, off, 64);
-                if (lane >= off) inc += o;
-            }
-            const int before = above + inc - c;
-            if (c > 0 && rank >= before && rank < before + c) { misc[0] = l; misc[1] = rank - before; }
-            above += __shfl(inc, 63, 64);
-            if (above > rank) break;     // uniform: the class has been found
-        }
+    for (int i = 0; i < NV; i++) {
+        const int k = lane + 64 * i;
+        int x = k < B ? (int)len[k] : -1;                // (-1: no sequence; below every class)
+        if (k < B) x = x < 0 ? 0 : (x > L ? L : x);
+        v[i] = x;
+    }
+    auto count_ge = [&](int t) {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NV; i++) c += __popcll(__ballot(v[i] >= t));
+        return c;
+    };
+    int lo = 0, hi = L;                                  // count_ge(lo) > rank holds (count_ge(0) = B > rank); the class is the largest such length
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (count_ge(mid) > rank) lo = mid; else hi = mid - 1;
+    }
+    const int cls = lo;
+    int rem = rank - count_ge(cls + 1);                  // index inside the class (sequences in index order: register-major, then lane)
+    int res = 0;
+    bool found = false;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const unsigned long long m = __ballot(v[i] == cls);
+        const int c = __popcll(m);
+        if (!found && rem < c) {
+            const bool hit = ((m >> lane) & 1ull) && __popcll(m & ((1ull << lane) - 1ull)) == rem;
+            res = 64 * i + (int)__builtin_ctzll(__ballot(hit) | (1ull << 63));
+            found = true;
+        } else if (!found) rem -= c;
+    }
+    return res;
+}
+
+__device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int rank, int *scratch,
+                                                     int tid, int /*nthreads*/) {
+    if ((tid >> 6) == 0) {
+        const int lane = tid & 63;
+        int res;
+        if (B <= 256) res = select_by_length_rank_wave<4>(len, B, L, rank, lane);
+        else if (B <= 512) res = select_by_length_rank_wave<8>(len, B, L, rank, lane);
+        else res = select_by_length_rank_wave<16>(len, B, L, rank, lane);       // B <= 1024
+        if (lane == 0) scratch[0] = res;
     }
     __syncthreads();
-    const int cls = misc[0];
-    int rem = misc[1];
-    for (int q0 = 0; q0 < B; q0 += nthreads) {      // the rem-th sequence (by index) of that length
-        const int k = q0 + tid;
-        int v = k < B ? (int)len[k] : -1;
-        if (k < B) v = v < 0 ? 0 : (v > L ? L : v);
-        const bool flag = v == cls;
-        const unsigned long long m = __ballot(flag);
-        if (lane == 0) misc[4 + w] = __popcll(m);
-        __syncthreads();
-        int pre = 0, tot = 0;
-        for (int ww = 0; ww < nwaves; ww++) { const int c = misc[4 + ww]; pre += ww < w ? c : 0; tot += c; }
-        if (rem < tot) {
-            const int local = rem - pre;
-            if (flag && local >= 0 && __popcll(m & ((1ull << lane) - 1ull)) == local) misc[2] = k;
-            __syncthreads();
-            break;
-        }
-        rem -= tot;
-        __syncthreads();
-    }
-    const int b = misc[2];
+    const int b = scratch[0];
     __syncthreads();                     // the scratch is reused by the caller
     return __builtin_amdgcn_readfirstlane(b);
 }
