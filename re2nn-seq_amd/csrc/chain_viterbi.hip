@@ -89,15 +89,11 @@ int launch_chain_viterbi(const RegsParams &p_in, const ScoreParams &sp, bool max
     const ChainViterbiPlan pl = chain_viterbi_plan(p_in.L, p_in.SP, NP, sp.K, sp.Kp, sp.c16);
     RegsParams p = p_in;
     if (pl.lds_rows && !env_int("FARNN_CV_STASH", 0)) { p.A = nullptr; p.Bk = nullptr; }     // no stash: the rows stay in LDS
-    {   // A workgroup owns a whole sequence here and a compute unit holds one workgroup: with a sequence per compute unit at most,
-        // the launch order changes nothing -- no length-rank selection in the kernel (it costs every workgroup ~1 k cycles)
-        static int ncu = -1;
-        if (ncu < 0) {
-            int dev = 0, v = 0;
-            ncu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) ? v : 0;
-        }
-        if (p.B <= ncu) { p.sort = 0; p.order = nullptr; }
-    }
+    // (Launch order: longest sequence first, as selected in the kernel.  A workgroup owns a whole sequence and a compute unit holds
+    //  one workgroup, so for a lone launch of at most a sequence per compute unit the order changes nothing and the selection costs
+    //  0.8 us of 84 -- FARNN_CV_NOSORT=1 --, but with a second batch in flight on another stream its workgroups fill the compute
+    //  units as this launch's short sequences leave them, and longest-first packs that 22 % tighter: 1.71e8 against 1.40e8 tokens/s.)
+    if (env_int("FARNN_CV_NOSORT", 0)) { p.sort = 0; p.order = nullptr; }
     ChainViterbiPlan plk = pl;
     if (p.A) plk.lds_rows = 0;                       // (diagnostic: the same layout, rows through the stash)
     const size_t lds = pl.bytes;
