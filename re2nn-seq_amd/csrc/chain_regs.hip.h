@@ -283,6 +283,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
 #else
 #define FARNN_RG_PHASE(i) do { } while (0)
 #endif
+            if (RG_D < nsteps) FARNN_RG_BASE(RG_D, nlo, nhi);          // step 0's look-ahead (the window of steps 0 .. 63 is loaded)
 #if FARNN_ABLATE & 512                               /* 512 = no steps at all */
             for (int t0 = 0; t0 < 0; t0 += RG_D) {
 #else
@@ -293,13 +294,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     const int t = t0 + d;
                     if (t >= nsteps) break;
                     static_assert(RG_D == 4 && RG_RQ == 4, "FARNN_RG_WAIT is written out for a 4 x 4 ring");
-                    // where the block of step t + RG_D is: fixed at the step's start, where the wavefront waits for its state exchange
-                    // anyway (the once-per-64-steps window reload is an LDS read: its wait must not sit between the partial-sum
-                    // store and the loads' issue)
-                    if (t + RG_D < nsteps) {
-                        if (((t + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + RG_D);
-                        FARNN_RG_BASE(t + RG_D, nlo, nhi);
-                    }
+                    // (nlo / nhi: where the block of step t + RG_D is -- fixed at the END of the step before, between the issue of
+                    //  its state exchange and the wait for it)
                     FARNN_RG_WAIT(d, nsteps - 1 - t);            // steps issued after this one: min(RG_D - 1, nsteps - 1 - t)
                     FARNN_RG_PHASE(0);                           // wait for this step's block pieces
                     v4f acc = MAXSR ? v4f{ninf, ninf, ninf, ninf} : v4f{0.f, 0.f, 0.f, 0.f};
@@ -370,10 +366,24 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     hptr += hstep;
 #endif
 #if !(FARNN_ABLATE & 4)                              /* 4 = no state exchange (wrong results) */
+                    int bp[RG_RQ];
 #pragma unroll
-                    for (int u = 0; u < RG_RQ; u++) {
-                        const float v = __int_as_float(__builtin_amdgcn_ds_bpermute(bsrc[u], __float_as_int(hx)));
-                        hs[u] = u < RPG ? v : 0.0f;
+                    for (int u = 0; u < RG_RQ; u++) bp[u] = __builtin_amdgcn_ds_bpermute(bsrc[u], __float_as_int(hx));
+                    // Where the block of step (t + 1) + RG_D is: two v_readlane and their scalar bookkeeping (a dozen instructions a lone
+                    // wavefront issues in ~60 cycles), done HERE, while the exchange is in flight -- at the next step's start they sat
+                    // behind the wait for it, on the step's critical path.  (The once-per-64-steps window reload is an LDS read: it
+                    // queues behind the exchange, and its wait must not sit between the partial-sum store and the loads' issue.)
+                    if (t + 1 + RG_D < nsteps) {
+                        if (((t + 1 + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + 1 + RG_D);
+                        FARNN_RG_BASE(t + 1 + RG_D, nlo, nhi);
+                    }
+                    asm volatile("" : "+s"(nlo), "+s"(nhi));   // (pinned here)
+#pragma unroll
+                    for (int u = 0; u < RG_RQ; u++) hs[u] = u < RPG ? __int_as_float(bp[u]) : 0.0f;
+#else
+                    if (t + 1 + RG_D < nsteps) {
+                        if (((t + 1 + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + 1 + RG_D);
+                        FARNN_RG_BASE(t + 1 + RG_D, nlo, nhi);
                     }
 #endif
                     FARNN_RG_PHASE(3);                           // row reduce, nonlinearity, state exchange
