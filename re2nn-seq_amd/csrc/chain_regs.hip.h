@@ -373,10 +373,11 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     // wavefront issues in ~60 cycles), done HERE, while the exchange is in flight -- at the next step's start they sat
                     // behind the wait for it, on the step's critical path.  (The once-per-64-steps window reload is an LDS read: it
                     // queues behind the exchange, and its wait must not sit between the partial-sum store and the loads' issue.)
-                    if (t + 1 + RG_D < nsteps) {
-                        if (((t + 1 + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + 1 + RG_D);
-                        FARNN_RG_BASE(t + 1 + RG_D, nlo, nhi);
-                    }
+                    // No branch around it in three steps of four (t0 is a multiple of RG_D = 4, so only d = 3 can reach a multiple of
+                    // 64): a branch is a basic-block boundary, and behind one the scheduler cannot pull the next step's scalar
+                    // bookkeeping up under the exchange.  Past the last step the v_readlane read some lane of the window: unused.
+                    if (d == RG_D - 1 && ((t + 1 + RG_D) & 63) == 0 && t + 1 + RG_D < nsteps) FARNN_RG_WINDOW(t + 1 + RG_D);
+                    FARNN_RG_BASE(t + 1 + RG_D, nlo, nhi);
                     asm volatile("" : "+s"(nlo), "+s"(nhi));   // (pinned here)
 #pragma unroll
                     for (int u = 0; u < RG_RQ; u++) hs[u] = u < RPG ? __int_as_float(bp[u]) : 0.0f;
