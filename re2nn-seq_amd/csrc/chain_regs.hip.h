@@ -177,6 +177,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             const bool my_valid = rj < rows_w && my_row < S;
             const bool my_writer = my_valid && rs == 0;
             const float my_o = my_valid ? ol[my_row] : 1.0f;
+            const float c_pre = dir == 0 ? my_o : 1.0f, c_post = dir == 0 ? 1.0f : my_o;
             const float ninf = -INFINITY;
             bool okrow[RG_RQ];
 #pragma unroll
@@ -356,11 +357,14 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     if (MAXSR) s = fmaxf(fmaxf(fmaxf(pv[0], pv[1]), fmaxf(pv[2], pv[3])), fmaxf(pv[4], pv[5]));
                     else       s = ((pv[0] + pv[1]) + (pv[2] + pv[3])) + (pv[4] + pv[5]);
                     s = MAXSR ? quad_max(s) : quad_sum(s);
-                    const float pre = dir == 0 ? s * my_o : s;                             // (:377-386) / (:393-402)
+                    // (:377-386) / (:393-402): the forward chain scales by o before the non-linearity, the backward chain after it.
+                    // One multiply each by a per-lane constant (o or exactly 1.0) instead of a select on the direction: three
+                    // dependent instructions fewer on the step's critical path, the same bits
+                    const float pre = s * c_pre;
                     float hn;
                     if (NLX) hn = apply_nl(pre, nl_mode);                                  // tanh, relu-tanh, sigmoid
                     else     hn = nl_relu ? fmaxf(pre, 0.0f) : pre;                        // none / relu: no branch in the step
-                    const float hx = my_valid ? (dir == 0 ? hn : hn * my_o) : 0.0f;        // what the next step multiplies with
+                    const float hx = my_valid ? hn * c_post : 0.0f;                        // what the next step multiplies with
 #if !(FARNN_ABLATE & 64)                             /* 64 = no state store */
                     *hptr = hn;                                                            // row t + 1 of `hist` (or the dump slot)
                     hptr += hstep;
