@@ -213,7 +213,10 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             float hs[RG_RQ];
 #pragma unroll
             for (int u = 0; u < RG_RQ; u++) {
-                bsrc[u] = 16 * (g * RPG + (u < RPG ? u : 0));     // byte address of lane 4 * (g * RPG + u)
+                // byte address of lane 4 * (g * RPG + u); a slot without a row (u >= RPG, i.e. RPG < 4) reads lane 63 instead: with
+                // fewer than four rows per group the wavefront's last row slot (lanes 60-63) holds no row, and a lane without a row
+                // exchanges an exact 0 -- so the result needs no select on u < RPG behind the exchange
+                bsrc[u] = u < RPG ? 16 * (g * RPG + u) : 4 * 63;
                 // (from LDS -- row 0 of `hist`, `ol` -- not from global memory: a compiler-counted global load feeding this
                 //  loop-carried value makes hipcc put s_waitcnt vmcnt(0) into the loop, which drains the ring every step)
                 hs[u] = okrow[u] ? hist[row0 + u] * (dir == 1 ? ol[row0 + u] : 1.0f) : 0.0f;
@@ -384,7 +387,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     FARNN_RG_BASE(t + 1 + RG_D, nlo, nhi);
                     asm volatile("" : "+s"(nlo), "+s"(nhi));   // (pinned here)
 #pragma unroll
-                    for (int u = 0; u < RG_RQ; u++) hs[u] = u < RPG ? __int_as_float(bp[u]) : 0.0f;
+                    for (int u = 0; u < RG_RQ; u++) hs[u] = __int_as_float(bp[u]);
 #else
                     if (t + 1 + RG_D < nsteps) {
                         if (((t + 1 + RG_D) & 63) == 0) FARNN_RG_WINDOW(t + 1 + RG_D);
