@@ -220,23 +220,6 @@ decomp_regs_kernel(const DecompRegsParams p) {
     for (int t = 0; t < nsteps; t++) {
         long long c0 = FARNN_PROBE_ON(p.dbg & 4096) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const int cur = t & 1, nxt = cur ^ 1;
-        if (SCORE && wv == WCOPY && t >= 1) {
-            if (t >= 2) store_row(t - 1);                     // read one step ago
-            read_row(t);                                      // the state the last step finished (complete behind its barrier)
-            if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
-        }
-        if (SCORE && wv == 0) {
-            // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
-            // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
-            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
-            if (t == t_poll + 1) {
-                const int pr = __builtin_amdgcn_readfirstlane(polled);
-                if (pr >= 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (lane == 0) misc[RGM_ACQ] = pr;
-                }
-            }
-        }
         const float v2 = *v_addr(tk2);                        // step t+2's entry: in flight for two steps
         tk2 = tok[t + 3 < nsteps ? t + 3 : nsteps - 1];      // (consumed at the next step's start)
         lds_cfloat *Hc = (lds_cfloat *)(H + cur * c2p) + k * 4;
@@ -270,6 +253,24 @@ decomp_regs_kernel(const DecompRegsParams p) {
                     ph3[i] = __builtin_elementwise_fma(v2f{w3[i][2 * c].z, w3[i][2 * c].w}, v2f{x0.z, x0.w}, ph3[i]);
                     pl3[i] = __builtin_elementwise_fma(v2f{w3[i][2 * c + 1].x, w3[i][2 * c + 1].y}, v2f{x1.x, x1.y}, pl3[i]);
                     ph3[i] = __builtin_elementwise_fma(v2f{w3[i][2 * c + 1].z, w3[i][2 * c + 1].w}, v2f{x1.z, x1.w}, ph3[i]);
+                }
+            }
+        }
+        // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products -- decomp_regs8_kernel)
+        if (SCORE && wv == WCOPY && t >= 1) {
+            if (t >= 2) store_row(t - 1);                     // read one step ago
+            read_row(t);                                      // the state the last step finished (complete behind its barrier)
+            if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
+        }
+        if (SCORE && wv == 0) {
+            // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
+            // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
+            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
+            if (t == t_poll + 1) {
+                const int pr = __builtin_amdgcn_readfirstlane(polled);
+                if (pr >= 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (lane == 0) misc[RGM_ACQ] = pr;
                 }
             }
         }
@@ -459,23 +460,6 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     for (int t = 0; t < nsteps; t++) {
         long long c0 = FARNN_PROBE_ON(p.dbg & 4096) ? (long long)__builtin_amdgcn_s_memtime() : 0;
         const int cur = t & 1, nxt = cur ^ 1;
-        if (SCORE && wv == WCOPY && t >= 1) {
-            if (t >= 2) store_row(t - 1);                     // read one step ago
-            read_row(t);                                      // the state the last step finished (complete behind its barrier)
-            if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
-        }
-        if (SCORE && wv == 0) {
-            // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
-            // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
-            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
-            if (t == t_poll + 1) {
-                const int pr = __builtin_amdgcn_readfirstlane(polled);
-                if (pr >= 0) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (lane == 0) misc[RGM_ACQ] = pr;
-                }
-            }
-        }
         const float v2 = *v_addr(tk2);                        // step t+2's entry: in flight for two steps
         tk2 = tok[t + 3 < nsteps ? t + 3 : nsteps - 1];      // (consumed at the next step's start)
         lds_cfloat *Hc = (lds_cfloat *)(H + cur * c2p) + k * 4;
@@ -513,6 +497,26 @@ decomp_regs8_kernel(const DecompRegsParams p) {
 #pragma unroll
                 for (int i = 0; i < NP3; i++) {
                     dg_fma4(pl3[i], ph3[i], w3[i][c], x0);
+                }
+            }
+        }
+        // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products, so that the step
+        //  starts with its LDS reads -- at the step's top this bookkeeping sat between the barrier and them: 59.6 -> 56.5 us per
+        //  launch.  The word-vector prefetch stays at the top: moved here too it cost 0.7 us.)
+        if (SCORE && wv == WCOPY && t >= 1) {
+            if (t >= 2) store_row(t - 1);                     // read one step ago
+            read_row(t);                                      // the state the last step finished (complete behind its barrier)
+            if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
+        }
+        if (SCORE && wv == 0) {
+            // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
+            // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
+            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
+            if (t == t_poll + 1) {
+                const int pr = __builtin_amdgcn_readfirstlane(polled);
+                if (pr >= 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (lane == 0) misc[RGM_ACQ] = pr;
                 }
             }
         }
