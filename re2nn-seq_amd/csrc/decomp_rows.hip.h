@@ -362,11 +362,15 @@ decomp_rows_kernel(const DecompRowsParams p) {
         int act[NSEQ];
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) act[s] = t < nst[s];
-        // next step's per-token vectors: loads issued now, parked in registers until after P3
+        // next step's per-token vectors: parked in registers until after P2.  Their loads (a token id from LDS, an address, a
+        // global load each) are issued behind P1's products when there is a P1 phase -- at the step's top they sat between the
+        // barrier and the step's first LDS reads (the placement that paid 5 % in decomp_regs8_kernel)
         float pf[DR_MAX_PF];
-#pragma unroll
-        for (int i = 0; i < DR_MAX_PF; i++)
+#define FARNN_DR_ISSUE_PREFETCH()                                                                                  \
+        _Pragma("unroll")                                                                                          \
+        for (int i = 0; i < DR_MAX_PF; i++)                                                                        \
             pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(pf_s[i], pf_e[i], t + 1) : 0.0f;
+        if (farnn != 2) { FARNN_DR_ISSUE_PREFETCH() }
         // The element-wise work rides in the row epilogues: the lane that finishes a row sum turns it into
         // a gate, an rr entry or the new state right away, so a step is 2 barriers (3 with farnn==2).
         // hb and [rr | hb] ping-pong because P3's epilogue writes the next step's hb while other
@@ -400,8 +404,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     }
                 } else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             }
+            FARNN_DR_ISSUE_PREFETCH()
             wg_barrier_lds();
         }
+#undef FARNN_DR_ISSUE_PREFETCH
         {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: z from the same h ------------
             auto epi2 = [&](int row, const float (&acc)[NSEQ]) {
 #pragma unroll
