@@ -67,7 +67,9 @@ WORKLOADS = {
 # the other single-GPU BASELINE configs the default invocation also times: (workload, steps, warmup)
 # (workload, steps, warmup, argument overrides, label): the last decomposed entry is the shape of the reference's shipped example
 # configurations (model_seq/example/*.res: --rank 250 --farnn 2)
-OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('decomp', 1500, 50, {}, 'decomp'),
+# (an 'env' override: library environment switches for that run only -- the CRF step's two-launch form beside its one-launch default)
+OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, {'env': {'FARNN_NOFUSE': '1'}}, 'ifst_crf_two_launches'),
+                 ('decomp', 1500, 50, {}, 'decomp'),
                  ('decomp', 400, 20, {'rank': 250, 'farnn': 2}, 'decomp_r250_farnn2'), ('fst4', 60, 5, {}, 'fst4'))
 
 
@@ -937,9 +939,20 @@ def main():
                 t0 = time.perf_counter()
                 try:
                     a2 = argparse.Namespace(**vars(a))
+                    env = over.get('env', {})
                     for kk, vv in over.items():
-                        setattr(a2, kk, vv)
-                    r = run_tagging(a2, name, st, wu, 1, 0, dev, None, False, auto_event_stride(st), False)
+                        if kk != 'env':
+                            setattr(a2, kk, vv)
+                    saved = {kk: os.environ.get(kk) for kk in env}
+                    os.environ.update(env)
+                    try:
+                        r = run_tagging(a2, name, st, wu, 1, 0, dev, None, False, auto_event_stride(st), False)
+                    finally:
+                        for kk, vv in saved.items():
+                            if vv is None:
+                                os.environ.pop(kk, None)
+                            else:
+                                os.environ[kk] = vv
                     r['workload'] = label
                     name = label
                     r['wall_s'] = time.perf_counter() - t0
