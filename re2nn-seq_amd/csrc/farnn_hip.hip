@@ -845,6 +845,7 @@ static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, 
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     p.dbg = env_int("FARNN_DBG", 0);
+    p.kz = (m->kind == KIND_IFST && m->use_crf && !env_int("FARNN_NOKZ", 0)) ? m->C : 0;      // the library appended the two zero rows itself
     return p;
 }
 

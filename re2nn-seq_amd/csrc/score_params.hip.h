@@ -23,6 +23,8 @@ struct ScoreParams {
     int full, use_crf, o_idx;
     float threshold;
     int dbg;                // diagnostic ablation mask (FARNN_DBG bits 16/32/64); 0 in production
+    int kz;                 // output columns >= kz are exact zero rows of the output matrix BY CONSTRUCTION (the onehot models' CRF
+                            // extension: START / STOP, model_decompose_single.py:78-79), 0 = unknown: every column is computed
 };
 
 constexpr int RG_TT = 16;            // tokens per score tile of the stage when it runs beside a recurrence (beside.hip.h)

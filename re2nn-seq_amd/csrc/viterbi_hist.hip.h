@@ -147,7 +147,15 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int lr = lane & 15, lk = lane >> 4;
-            const int c16 = p.c16, ntb = (n + 15) >> 4, ncb = (K + 15) >> 4, nblk = ntb * ncb;
+            // column blocks whose output rows are zero by construction are not computed: their scores are +0.0 (the fmaf chain of
+            // finite products and zeros, then + 0.0f).  K = 130 = 128 labels + START / STOP: 8 blocks instead of 9, and the 16
+            // (token block, column-block pair) units fall on the eight wavefronts in two even rounds instead of 20 in three
+            const int kz = (p.kz > 0 && p.kz < K) ? p.kz : K;
+            const int c16 = p.c16, ntb = (n + 15) >> 4, ncb = (kz + 15) >> 4, nblk = ntb * ncb;
+            for (int i = tid; i < n * (Kp - 16 * ncb); i += nthreads) {       // (nothing when every block is computed: 16 ncb >= Kp)
+                const int w_ = Kp - 16 * ncb, tok = i / w_, col = 16 * ncb + i - tok * w_;
+                scl[(long long)tok * Kp + col] = 0.0f;
+            }
             const int ngw = nwaves < 8 ? nwaves : 8;
             const int clamp_col = K - 3;                 // model_decompose.py:353
             auto product = [&](auto otm) {               // otm: this lane's entry of the image, typed LDS or global pointer
