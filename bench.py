@@ -64,11 +64,14 @@ WORKLOADS = {
     'synth512': ('synthetic onehot i-FST V=20k S=512 C=256 (T = 21 GB fp32 per GPU, + transposed copy)',
                  20000, 512, 256),
 }
+BASE_STATES = {k: v[2] for k, v in WORKLOADS.items()}      # (before --states edits the table)
 # the other single-GPU BASELINE configs the default invocation also times: (workload, steps, warmup)
 # (workload, steps, warmup, argument overrides, label): the last decomposed entry is the shape of the reference's shipped example
 # configurations (model_seq/example/*.res: --rank 250 --farnn 2)
 # (an 'env' override: library environment switches for that run only -- the CRF step's two-launch form beside its one-launch default)
 OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, {'env': {'FARNN_NOFUSE': '1'}}, 'ifst_crf_two_launches'),
+                 # the onehot path at the state count of the reference's SNIPS-BIO / ATIS-ZH-BIO automata (RE.py:56-60): the wide form
+                 ('ifst', 1000, 50, {'states': 104}, 'ifst_s104'), ('ifst_crf', 600, 30, {'states': 104}, 'ifst_crf_s104'),
                  ('decomp', 1500, 50, {}, 'decomp'),
                  ('decomp', 400, 20, {'rank': 250, 'farnn': 2}, 'decomp_r250_farnn2'), ('fst4', 60, 5, {}, 'fst4'))
 
@@ -81,7 +84,8 @@ def parse():
     ap.add_argument('--workload', default='ifst', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=256, help='sequences per GPU')
     ap.add_argument('--states', type=int, default=0,
-                    help='decomp workloads: automaton states S (default 104; 134 = the shipped configurations with --additional_states 30)')
+                    help='automaton states S (decomp: default 104; 134 = the shipped configurations with --additional_states 30; '
+                         'ifst / ifst_crf: default 71; 104 = the reference\'s SNIPS-BIO / ATIS-ZH-BIO automata)')
     ap.add_argument('--vocab', type=int, default=0,
                     help='dry runs only: override the workload\'s vocabulary size (the line then says so; never a headline number)')
     ap.add_argument('--seqlen', type=int, default=64)
@@ -439,6 +443,9 @@ def load_traffic(name, a):
     shape_ok = {'ifst': (256, 64), 'fst4': (256, 64), 'synth512': (1024, 128)}.get(name)
     if shape_ok != (a.batch, a.seqlen) or a.full_length:
         return None
+    S = WORKLOADS[name][2]
+    if S != BASE_STATES[name]:
+        name = '{}_s{}'.format(name, S)              # a split measured at another state count has its own entry
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(tpath):
         return None
@@ -478,7 +485,7 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
         rf.update(bound='hbm', achieved=0.0, peak=HBM_PEAK_GBS, unit='GB/s', frac=0.0)
         return rf
     L = a.seqlen
-    byte_bound = (('chain_kernel' in kname or 'chain_regs_kernel' in kname) and dom == _lib.KERN_CHAIN) or 'fst4' in kname
+    byte_bound = (('chain_kernel' in kname or 'chain_regs_kernel' in kname or 'chain_wide_kernel' in kname) and dom == _lib.KERN_CHAIN) or 'fst4' in kname
     if byte_bound:
         alg = h.kernel_algorithmic_bytes(dom, tok_local)
         achieved = alg / dom_s / 1e9
@@ -945,9 +952,13 @@ def main():
                             setattr(a2, kk, vv)
                     saved = {kk: os.environ.get(kk) for kk in env}
                     os.environ.update(env)
+                    saved_wl = WORKLOADS[name]
+                    if over.get('states'):
+                        WORKLOADS[name] = (saved_wl[0] + ' [S = {}]'.format(over['states']), saved_wl[1], over['states'], saved_wl[3])
                     try:
                         r = run_tagging(a2, name, st, wu, 1, 0, dev, None, False, auto_event_stride(st), False)
                     finally:
+                        WORKLOADS[name] = saved_wl
                         for kk, vv in saved.items():
                             if vv is None:
                                 os.environ.pop(kk, None)

@@ -68,16 +68,20 @@ __device__ __forceinline__ int lds_flag_get(const int *f) {
 // buffer the step wrote (wavefront i: float 4 i of the buffer's flag area, `fbase` in buffer 0), stored by the same
 // ds_write_b128 as the partial sums.  Writer / scorer count state rows by them: row t + 1 of `hist` is complete once every
 // wavefront's newer flag reads t + 2, or nsteps + 1 after the last step.
+// (PSTR: floats between the two partial-sum buffers -- RG_PART_STRIDE, or RGW_PART_STRIDE in the wide form)
+template <int PSTR = RG_PART_STRIDE>
 __device__ __forceinline__ int regs_flag_newest(const float *fbase, int lane) {
     const int *f = reinterpret_cast<const int *>(fbase) + 4 * (lane < RG_NWC ? lane : 0);
-    const int v0 = lds_flag_get(f), v1 = lds_flag_get(f + RG_PART_STRIDE);
+    const int v0 = lds_flag_get(f), v1 = lds_flag_get(f + PSTR);
     return max(v0, v1);
 }
+template <int PSTR = RG_PART_STRIDE>
 __device__ __forceinline__ bool regs_rows_reached(const float *fbase, int lane, int rows) {
-    return __ballot(regs_flag_newest(fbase, lane) < rows + 1) == 0ull;
+    return __ballot(regs_flag_newest<PSTR>(fbase, lane) < rows + 1) == 0ull;
 }
+template <int PSTR = RG_PART_STRIDE>
 __device__ __forceinline__ int regs_rows_done(const float *fbase, int lane) {
-    int v = regs_flag_newest(fbase, lane);
+    int v = regs_flag_newest<PSTR>(fbase, lane);
 #pragma unroll
     for (int off = 1; off < 8; off <<= 1) v = min(v, __shfl_xor(v, off, WAVE));
     return __builtin_amdgcn_readfirstlane(v) - 1;
@@ -94,6 +98,10 @@ __device__ __forceinline__ float quad_max(float x) {
     return x;
 }
 
+}  // namespace farnn
+#include "chain_wide.hip.h"      // the compute wavefronts of the wide form (72 < S <= 128)
+namespace farnn {
+
 // FARNN_PROBES (profiling build only): s_memtime stamps of the workgroups of full-length sequences, printed at their end
 #if defined(FARNN_PROBES)
 #define FARNN_RG_STAMP(i) do { if (probe && lane == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -105,22 +113,30 @@ __device__ __forceinline__ float quad_max(float x) {
 // it on one workgroup per item; chain_viterbi_kernel (chain_viterbi.hip) runs the two directions of a sequence as the two
 // halves of ONE sixteen-wavefront workgroup and hangs the CRF decode behind them.  Workgroup barriers in here are reached by
 // both halves alike (the same sequence, the same length).  *b_out: the sequence the slot maps to.
-template <bool MAXSR, bool SCORE, bool NLX>
+// RQ / D: rows of 16 bytes per lane and step, steps in flight.  (RG_RQ, RG_D) is the form for S <= 72 (two workgroups per compute
+// unit); RQ > RG_RQ the wide form (chain_wide.hip.h: 72 < S <= 128, one workgroup per compute unit, launch order longest first).
+template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D>
 __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem, const int tid, const int item, int *b_out) {
+    constexpr bool WIDE = RQ != RG_RQ;
+    constexpr int PSTR = WIDE ? RGW_PART_STRIDE : RG_PART_STRIDE;     // floats between the two partial-sum buffers
+    constexpr int NG = WIDE ? RGW_NG : RG_NG;                         // state groups of 16 the scoring stage reaches
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int nthreads = RG_WAVES * 64;
     // ids 2s / 2s + 1: forward chains on the even XCDs, backward chains on the odd ones -- an L2 caches one direction's blocks
     const int dir = item & 1, slot = item >> 1;
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
-    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE);
+    const int PS = WIDE ? p.PS : SP;                                  // floats between two partial-sum vectors
+    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, WIDE);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
     float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
     float *ab = smem + lds.ab, *scl = smem + lds.scl, *obuf = smem + lds.obuf;
     int *misc = reinterpret_cast<int *>(smem + lds.misc);
 
     int b = p.order ? p.order[slot] : slot;
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, folded_rank(slot, p.B), reinterpret_cast<int *>(hist), tid, nthreads);
+    // (a compute unit holds two workgroups of the narrow form: slots i and i + B/2 pair a long with a short sequence; it holds ONE
+    //  of the wide form, and workgroups start in slot order as compute units fall free: longest first)
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, WIDE ? slot : folded_rank(slot, p.B), reinterpret_cast<int *>(hist), tid, nthreads);
     if (b_out) *b_out = b;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
@@ -139,15 +155,16 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     for (int j = tid; j < SP; j += nthreads) ol[j] = (p.o && j < S) ? p.o[j] : 1.0f;
     for (int j = tid; j < (nsteps + 1) * SP; j += nthreads) hist[j] = (j < S) ? hinit[j] : 0.0f;     // row 0; pad columns zero
     if (tid < 32) misc[tid] = tid == RGM_ACQ ? -1 : 0;
-    if (tid < 2) part[tid * RG_PART_STRIDE + RG_PART_STRIDE - 1] = MAXSR ? -INFINITY : 0.0f;     // the reduction's identity (masked reads)
-    if (tid < 2 * 4 * RG_NWC) part[(tid / (4 * RG_NWC)) * RG_PART_STRIDE + NP * SP + tid % (4 * RG_NWC)] = 0.0f;   // the step flags
+    if (tid < 2) part[tid * PSTR + PSTR - 1] = MAXSR ? -INFINITY : 0.0f;     // the reduction's identity (masked reads)
+    if (tid < 2 * 4 * RG_NWC) part[(tid / (4 * RG_NWC)) * PSTR + NP * PS + tid % (4 * RG_NWC)] = 0.0f;   // the step flags
+    if (WIDE && tid < RG_NWC * RGW_XCH) smem[lds.xch + tid] = 0.0f;          // exchange slots without a row stay exact zeros
     __syncthreads();
     if (w == 0) FARNN_RG_STAMP(1);
 #if FARNN_ABLATE & 256                               /* 256 = set-up only */
     return;
 #endif
 
-    const float *sflag = part + NP * SP;            // the step flags (buffer 0; buffer 1 is RG_PART_STRIDE floats on)
+    const float *sflag = part + NP * PS;            // the step flags (buffer 0; buffer 1 is PSTR floats on)
     float *stash = (dir == 0 ? p.A : p.Bk) + (long long)b * (p.L + 1) * SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
     int kmid = 0, pubmax = 0;                        // this workgroup's half of the tiles; the last row the other half needs of it
@@ -160,7 +177,19 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
         // =================================================================================================================
         // compute wavefronts
         // =================================================================================================================
-        if (nsteps > 0) {
+        if constexpr (WIDE) {
+            if (nsteps > 0) {
+                __builtin_amdgcn_s_setprio(2);
+                regs_compute_wide<MAXSR, NLX, RQ, D>(p, dir, w, lane, nsteps, tokoff, part, ol, hist, smem + lds.xch);
+                __builtin_amdgcn_s_setprio(0);
+                if (w == 0) FARNN_RG_STAMP(2);
+#if defined(FARNN_PROBES)
+                if (!SCORE && probe && w == 0 && lane == 0)
+                    printf("seq %d dir %d (wide): setup %lld, chain %lld (%lld per step)\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
+                           (stamps[2] - stamps[1]) / nsteps);
+#endif
+            }
+        } else if (nsteps > 0) {
             __builtin_amdgcn_s_setprio(2);
             int g = lane / p.CPR;
             const int c = lane - g * p.CPR;
@@ -441,14 +470,14 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
         };
         if (!SCORE && !p.A) wr_next = nsteps + 1;                // (chain_viterbi_kernel: the rows are consumed where they lie, in LDS)
         while (wr_next <= nsteps) {
-            if (nsteps > 0 && !regs_rows_reached(sflag, lane, wr_next)) { __builtin_amdgcn_s_sleep(1); continue; }
-            if (SCORE && nsteps > 0 && wr_next > pubmax && regs_rows_reached(sflag, lane, nsteps)) break;   // the chain is done
+            if (nsteps > 0 && !regs_rows_reached<PSTR>(sflag, lane, wr_next)) { __builtin_amdgcn_s_sleep(1); continue; }
+            if (SCORE && nsteps > 0 && wr_next > pubmax && regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;   // the chain is done
             copy_row(wr_next);
             wr_next++;
             // The progress word feeds the other workgroup's tiles: once it covers the last row they need (pubmax), the
             // rest is drained and published once, at the end -- no write-through round trip per row after that.
             if (SCORE && wr_next - 1 < nsteps && published < pubmax &&
-                (wr_next - 1 >= pubmax || !regs_rows_reached(sflag, lane, wr_next))) {   // caught up with the chain, or pubmax reached
+                (wr_next - 1 >= pubmax || !regs_rows_reached<PSTR>(sflag, lane, wr_next))) {   // caught up with the chain, or pubmax reached
                 published = wr_next - 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this (the only storing) wavefront has left
                 if (lane == 0)
@@ -474,14 +503,14 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             bs_tile_need(k, len, nsteps, na, nb);
             const int need_own = dir == 0 ? na : nb, need_oth = dir == 0 ? nb : na;
             if (nsteps - need_own < p.solo_margin) break;             // the chain ends soon: all eight wavefronts will do it
-            while (!regs_rows_reached(sflag, lane, need_own)) __builtin_amdgcn_s_sleep(4);
+            while (!regs_rows_reached<PSTR>(sflag, lane, need_own)) __builtin_amdgcn_s_sleep(4);
             if (need_oth > acq) {
                 int pr = -1;
                 for (;;) {
                     pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
                     pr = __builtin_amdgcn_readfirstlane(pr);
                     if (pr >= need_oth) break;
-                    if (regs_rows_reached(sflag, lane, nsteps)) break;    // our chain is done: no open-ended wait beyond it
+                    if (regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;    // our chain is done: no open-ended wait beyond it
                     __builtin_amdgcn_s_sleep(8);
                 }
                 if (pr < need_oth) break;
@@ -489,8 +518,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                 acq = pr;
             }
             {
-                const rg_f32x4 none[RG_NG] = {};
-                bs_score_tiles<false, RG_WAVES, RG_NG, RG_NWC>(bs, b, dir, len, nsteps, k, -1, hist, nullptr, nullptr, ab, scl, foff, 0, lane, none);
+                const rg_f32x4 none[NG] = {};
+                bs_score_tiles<false, RG_WAVES, NG, RG_NWC>(bs, b, dir, len, nsteps, k, -1, hist, nullptr, nullptr, ab, scl, foff, 0, lane, none);
             }
             mine |= 1u << k;
         }
@@ -509,14 +538,14 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                         pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
                         pr = __builtin_amdgcn_readfirstlane(pr);
                         if (pr >= need_oth) break;
-                        if (regs_rows_reached(sflag, lane, nsteps)) break;
+                        if (regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;
                         __builtin_amdgcn_s_sleep(16);
                     }
                     if (pr < need_oth) break;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     acq = pr;
                 }
-                bs_park_rows<RG_NG>(bs, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
+                bs_park_rows<NG>(bs, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
                 if (lane == 0) misc[RGM_PARK + slot] = k + 1;
                 slot++;
             }
@@ -532,7 +561,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
     if (w == 0) FARNN_RG_STAMP(4);
-    bs_finish<RG_WAVES, RG_NG, RG_WAVES - 1, RG_NWC>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane,
+    bs_finish<RG_WAVES, NG, RG_WAVES - 1, RG_NWC>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane,
         [&]() {                                                      // the state rows the writer had not copied yet: issued now, landed by
             if (w == RG_NWC)                                         // the time the tiles are done (it forms no products meanwhile)
                 for (; wr_next <= nsteps; wr_next++)
@@ -563,6 +592,13 @@ __global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD
 chain_regs_kernel(const RegsParams p) {
     extern __shared__ __align__(16) float smem[];
     chain_regs_body<MAXSR, SCORE, NLX>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
+}
+
+template <bool MAXSR, bool SCORE, bool NLX, int RQ, int D>
+__global__ void __launch_bounds__(RG_WAVES * 64, 2)          // 2 waves per SIMD = 256 VGPRs: one workgroup per compute unit
+chain_wide_kernel(const RegsParams p) {
+    extern __shared__ __align__(16) float smem[];
+    chain_regs_body<MAXSR, SCORE, NLX, RQ, D>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
 }
 
 }  // namespace farnn

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <map>
 #include <new>
 #include <utility>
@@ -57,6 +58,7 @@ struct farnn_model {
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     float *OTm = nullptr; int c16 = 0;       // matrix-core image of OT for score_tiles (ot_to_mfma_kernel)
+    LabelMap lm = {nullptr, 0, 0, -1, 0.0f}; // the output matrix as a label map, when it is one (label_map.hip.h)
     DecompWeights dw;                       // decomposed model weights
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
@@ -215,6 +217,62 @@ static int build_ot_image(farnn_model *m) {
     return FARNN_OK;
 }
 
+// The output matrix as a label map (label_map.hip.h): every state at most one label, weight exactly 1, at most 128 labelled
+// states.  Read back from the final OT[S][Kc] (a few KB), sorted by (label, state) on the host, uploaded as one table.
+static int build_label_map(farnn_model *m) {
+    m->lm.on = 0;
+    if (!m->OT || m->S > 1024 || env_int("FARNN_NOLABELMAP", 0)) return FARNN_OK;
+    std::vector<float> ot((size_t)m->S * m->Kc);
+    FARNN_HIP_TRY(hipMemcpy(ot.data(), m->OT, ot.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<std::pair<int, int>> pos;                // (label, state)
+    for (int s = 0; s < m->S; s++) {
+        int lab = -1;
+        for (int c = 0; c < m->K; c++) {
+            const float v = ot[(size_t)s * m->Kc + c];
+            if (v == 0.0f) continue;
+            if (v != 1.0f || lab >= 0) return FARNN_OK;  // a weight, or a second label: the matrix form
+            lab = c;
+        }
+        if (lab >= 0) pos.push_back({lab, s});
+    }
+    const int n = (int)pos.size();
+    if (n > LM_MAXS) return FARNN_OK;
+    std::sort(pos.begin(), pos.end());
+    const int clampcol = m->use_crf ? m->K - 3 : m->K - 1;     // model_decompose.py:353 / model_onehot.py:166
+    std::vector<unsigned> tab((size_t)LM_ROWS * 128, 0u);
+    auto fbits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+    int lb[128];
+    for (int j = 0; j < 128; j++) lb[j] = j < n ? pos[j].first : m->K + j;
+    for (int j = 0; j < 128; j++) {
+        tab[LM_ST * 128 + j] = j < n ? (unsigned)pos[j].second : 0u;
+        tab[LM_LB * 128 + j] = (unsigned)lb[j];
+        const int base = j & ~63, r = (j & 63) >> 4;
+        const int dd[4] = {1, 2, 4, 8};
+        for (int d = 0; d < 4; d++)
+            tab[(LM_CF + d) * 128 + j] = fbits(((j & 15) >= dd[d] && lb[j - dd[d]] == lb[j]) ? 1.0f : 0.0f);
+        tab[(LM_CF + 4) * 128 + j] = fbits(((r == 1 || r == 3) && lb[base + 16 * r - 1] == lb[j]) ? 1.0f : 0.0f);
+        tab[(LM_CF + 5) * 128 + j] = fbits(((r == 2 || r == 3) && lb[base + 31] == lb[j]) ? 1.0f : 0.0f);
+        tab[LM_CC * 128 + j] = fbits((j >= 64 && lb[j] == lb[63]) ? 1.0f : 0.0f);
+        const bool tail = j < n && (j == n - 1 || lb[j + 1] != lb[j]);
+        tab[LM_TL * 128 + j] = fbits(tail ? 0.0f : -INFINITY);
+        tab[LM_TH * 128 + j] = fbits(lb[j] == clampcol ? m->threshold : INFINITY);
+    }
+    std::vector<char> has((size_t)m->K, 0);
+    for (int j = 0; j < n; j++) has[pos[j].first] = 1;
+    m->lm.e0 = -1;
+    for (int c = 0; c < m->K; c++)
+        if (!has[c]) { m->lm.e0 = c; break; }
+    m->lm.z0 = (m->lm.e0 == clampcol) ? std::min(0.0f, m->threshold) : 0.0f;
+    m->lm.nq = n > 64 ? 2 : 1;
+    unsigned *dv = nullptr;
+    int rc = dev_alloc(m, (void **)&dv, tab.size() * 4);
+    if (rc) return rc;
+    FARNN_HIP_TRY(hipMemcpy(dv, tab.data(), tab.size() * 4, hipMemcpyHostToDevice));
+    m->lm.tab = dv;
+    m->lm.on = 1;
+    return FARNN_OK;
+}
+
 static int alloc_bitmaps(farnn_model *m) {
     m->bmNS = (m->semiring == FARNN_SEMIRING_SUM) ? compact_ns(m->S) : 0;
     if (!m->bmNS) return FARNN_OK;
@@ -315,6 +373,7 @@ static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_m
         FARNN_HIP_TRY(hipGetLastError());
         if ((rc = build_ot_image(m))) return bail(rc);
         FARNN_HIP_TRY(hipDeviceSynchronize());
+        if ((rc = build_label_map(m))) return bail(rc);
     }
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);
     if ((rc = dev_upload(m, &m->hT, d->hT, m->S, m->SP, od))) return bail(rc);
@@ -450,6 +509,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
         case KERN_CHAIN:
             if (m->compact_on) return "compact_chain_kernel";
             if (m->last_regs && m->last_fused && m->use_crf) return "chain_viterbi_kernel<fused: recurrence + scores + CRF decode>";
+            if (m->last_regs && m->rgeom.wide) return m->last_fused ? "chain_wide_kernel<fused: scores + decode beside the recurrence>" : "chain_wide_kernel";
             if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP && m->last_fused && m->last_wave) return "decomp_regs_kernel<fused: scores + decode beside the recurrence>";
@@ -477,7 +537,8 @@ static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64
     rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
     rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
     rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
-    rp.G = rg.G; rp.RPG = rg.RPG; rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
+    rp.G = rg.G; rp.RPG = rg.RPG; rp.RQ = rg.RQ; rp.D = rg.D; rp.PS = rg.PS;
+    rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
     return rp;
 }
 
@@ -488,11 +549,13 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     const ChainGeom &g = m->geom;
     if (fused) *fused = false;
     m->last_regs = false;
-    // ---- the register-fed kernel (chain_regs.hip.h) where its geometry applies: S <= 72, two workgroups per compute unit.
+    // ---- the register-fed kernel (chain_regs.hip.h) where its geometry applies: S <= 72, two workgroups per compute unit, or
+    // its wide form (chain_wide.hip.h): 72 < S <= 128, one workgroup per compute unit.
     // With fuse_sp (threshold/argmax decode, K <= 256) the scores and the decode run beside the recurrence: ONE launch.
     if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0)) {
         const RegsGeom &rg = m->rgeom;
-        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= 5 && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
+        const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
+        bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
         if (score) {
             // the hand-off words carry the launch's epoch, a kernel argument: a captured launch would replay with a frozen one.
@@ -500,12 +563,12 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
             hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
             if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) score = false;
         }
-        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score).total * sizeof(float);
-        if (score && lds > 80 * 1024) {             // the score tiles do not fit beside a second workgroup: recurrence only
+        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.wide).total * sizeof(float);
+        if (score && lds > lds_cap) {               // the score tiles do not fit (beside a second workgroup): recurrence only
             score = false;
-            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false).total * sizeof(float);
+            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.wide).total * sizeof(float);
         }
-        if (lds <= 80 * 1024) {
+        if (lds <= lds_cap) {
             RegsParams rp = make_regs_params(m, x, len, B, full);
             if (score) {
                 if (++m->epoch_u == 0) {            // the epoch wrapped: no word of an earlier launch may look current
@@ -520,7 +583,8 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
                 if (fused) *fused = true;
             }
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
-            const int rc = launch_chain_regs(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1);
+            const int rc = rg.wide ? launch_chain_wide(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1)
+                                   : launch_chain_regs(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1);
             if (rc) return rc;
             m->last_regs = true;
             return FARNN_OK;
@@ -846,6 +910,7 @@ static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, 
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
     p.dbg = env_int("FARNN_DBG", 0);
     p.kz = (m->kind == KIND_IFST && m->use_crf && !env_int("FARNN_NOKZ", 0)) ? m->C : 0;      // the library appended the two zero rows itself
+    p.lm = m->lm;
     return p;
 }
 
@@ -896,7 +961,7 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         // the decode's LDS fits; else the recurrence kernel followed by the (fused score +) Viterbi kernel
         m->last_fused = false;
         const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
-        if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0) && !env_int("FARNN_NOFUSE", 0) && viterbi_can_fuse(m, sp) &&
+        if (m->rgeom.ok && !m->rgeom.wide && !env_int("FARNN_NOREGS", 0) && !env_int("FARNN_NOFUSE", 0) && viterbi_can_fuse(m, sp) &&
             (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp)) {
             const RegsParams rp = make_regs_params(m, x, len, B, full);
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
@@ -1390,6 +1455,7 @@ static int decomp_ifst_create_impl(const farnn_decomp_ifst_desc *d, int device, 
         FARNN_HIP_TRY(hipGetLastError());
         if ((rc = build_ot_image(m))) return bail(rc);
         FARNN_HIP_TRY(hipDeviceSynchronize());
+        if ((rc = build_label_map(m))) return bail(rc);
         w.o = m->o;
     }
     if ((rc = dev_upload(m, &m->h0, d->h0, m->S, m->SP, od))) return bail(rc);

@@ -2,6 +2,7 @@
 // recurrence kernel that runs the stage as it goes (chain_regs.hip.h).
 #pragma once
 #include "common.hip.h"
+#include "label_map.hip.h"
 
 namespace farnn {
 
@@ -25,6 +26,7 @@ struct ScoreParams {
     int dbg;                // diagnostic ablation mask (FARNN_DBG bits 16/32/64); 0 in production
     int kz;                 // output columns >= kz are exact zero rows of the output matrix BY CONSTRUCTION (the onehot models' CRF
                             // extension: START / STOP, model_decompose_single.py:78-79), 0 = unknown: every column is computed
+    LabelMap lm;            // lm.on: the output matrix is a label map (one state, one label, weight 1): label_map.hip.h
 };
 
 constexpr int RG_TT = 16;            // tokens per score tile of the stage when it runs beside a recurrence (beside.hip.h)

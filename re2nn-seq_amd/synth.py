@@ -387,6 +387,47 @@ def random_decomposed_params(V, S, C, R, D, rng, scale=None, contractive=False):
     return p
 
 
+def snips_sized_model(R, farnn, crf, seed=1234, S=104, V=11000, C=73):
+    """BASELINE configs[2] as `bench.py --workload decomp` builds it (same seed, same generator), plus the GRU-style
+    gates (model_decompose_single.py:93-123) and the CRF rows / transitions (:78-79, crf.py:31-46) on demand.  One source
+    for bench.py's shape, tests/test_gpu_parity_bench_size.py and tests/golden/make_golden_bench.py (which feeds
+    exactly these arrays to the reference's FARNN_S_D_W_I_S).  Returns (V, q, gates, crf_transitions): `q` is the
+    parameter dict oracle/farnn_oracle.py's decomp_ifst_scores takes (nl = 2: tanh, semiring = 0: sum)."""
+    wrng = np.random.RandomState(seed)
+    p = random_decomposed_params(V, S, C, R, 100, wrng, contractive=True)
+    f = lambda a: np.asarray(a, np.float32)                       # noqa: E731
+    Cout = f(p['C_output_mat'])
+    tr = None
+    if crf:            # two extra rows for START / STOP, small random values; default transitions + noise
+        Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
+        K = C + 2
+        tr0 = np.zeros((K, K), np.float32)                        # CRF.__init__ (crf.py:31-46)
+        tr0[:, K - 2] = -10000.0
+        tr0[K - 1, :] = -10000.0
+        tr = tr0 + (wrng.randn(K, K) * 1.0).astype(np.float32)
+    q = {'Vgen': f(p['V_embed']), 'S1': f(p['S1']), 'S2': f(p['S2']), 'W': f(p['wildcard_mat']), 'Cout': Cout,
+         'h0': f(p['start_vector']), 'hT': f(p['final_vector']), 'farnn': farnn, 'nl': 2, 'semiring': 0, 'sig_k': 5}
+    gates = None
+    if farnn:
+        gates = {'Wss1': f(wrng.randn(S, S) * 0.03), 'Wrs1': f(wrng.randn(R, S) * 0.03), 'bs1': f(np.full(S, 1.0))}
+        if farnn == 2:
+            gates.update(Wss2=f(wrng.randn(S, S) * 0.03), Wrs2=f(wrng.randn(R, S) * 0.03), bs2=f(np.full(S, 1.0)))
+        q.update(gates)
+    return V, q, gates, tr
+
+
+def atis_sized_crf_model(seed=1234, V=950, S=71, C=128):
+    """BASELINE configs[3] as `bench.py --workload ifst_crf` builds it: the onehot i-FST and the transitions of a CRF over
+    its C labels + START / STOP."""
+    wrng = np.random.RandomState(seed)
+    T, W, O, h0, hT = random_ifst_tensors(V, S, C, wrng)
+    K = C + 2
+    tr = (wrng.randn(K, K) * 0.1).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    return T, W, O, h0, hT, tr
+
+
 # --------------------------------------------------------------------------- on-disk trees
 def write_dataset_tree(root, dataset='ATIS-BIO', n_words=60, n_entity_types=4, n_states=20, seed=0,
                        n_train=48, n_dev=24, n_test=24, max_len=16, embed_dim=16, ranks=(100,),

@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""Golden fixtures AT THE SIZES bench.py times, produced by the REFERENCE itself (SURVEY.md 8c's F5 extended from the
+ATIS onehot shape to BASELINE configs[2] and configs[3] and to the 104-state onehot shape).
+
+Runs only in the build container (the reference checkout at /root/reference cannot travel).  The models are the ones
+`re2nn_seq_amd.synth.snips_sized_model` / `atis_sized_crf_model` build from a seed -- the very arrays bench.py and
+tests/test_gpu_parity_bench_size.py use -- fed to the reference's own classes:
+
+  bench_decomp   FARNN_S_D_W_I_S.forward_local (model_decompose_single.py:207-304), V = 11 000, C = 73, B = 256, L = 64:
+                 (R 50, farnn 0), (R 250, farnn 2, use_crf 1: the shipped example configurations' shape), (R 100, farnn 1),
+                 (R 150, farnn 2) at S = 134 and (R 250, farnn 2) at S = 134 (= the 104-state automaton with
+                 --additional_states 30; built with 134 states outright so that the padded states carry weights).
+  bench_crf      FARNN_S_O_I_S.forward_score (model_onehot.py:351-428) -> two zero columns (START / STOP, cf.
+                 model_decompose_single.py:78-79 at rand_constant 0) -> clamp column C'-3 (model_decompose.py:353) ->
+                 CRF._viterbi_decode (crf.py:102-195) -> C'-3 -> o_idx: SURVEY.md 8a's definition of configs[3], K = 130.
+  bench_ifst104  FARNN_S_O_I_S at V = 950, S = 104, C = 128 (the state count of the reference's SNIPS-BIO / ATIS-ZH-BIO
+                 automata, RE.py:56-60): forward_local / forward_RE.
+
+Stored per case: the seed and shape, every tag the reference decoded (int16), and the reference's float32 score rows of 16
+sampled sequences -- data only, no reference source.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_bench.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, '/root/reference')
+
+import torch  # noqa: E402
+
+from make_golden import ns, quiet, save  # noqa: E402  (imports the reference's classes)
+from re2nn_seq_amd import synth  # noqa: E402
+from src_seq.farnn.model_onehot import FARNN_S_O_I_S  # noqa: E402
+from src_seq.farnn.model_decompose_single import FARNN_S_D_W_I_S  # noqa: E402
+from src_seq.baselines.crf import CRF  # noqa: E402
+from src_seq.utils import get_length_mask, flatten  # noqa: E402
+
+torch.set_num_threads(8)
+B, L = 256, 64
+BATCH_SEED = 4321                                   # bench.py's rank-0 batch
+ROWS = np.array([0, 1, 2, 3, 31, 32, 77, 100, 101, 127, 128, 200, 201, 253, 254, 255])
+DECOMP_ROWS = np.array([0, 1, 77, 128, 254, 255])   # (float scores do not compress: six sequences per case; 77 is the one on which
+                                                    #  float32 evaluations of the rank-250 S = 134 model scatter by 2e-4)
+
+DECOMP_CASES = [                                    # (R, farnn, use_crf, S)
+    (50, 0, 0, 104), (250, 2, 1, 104), (100, 1, 0, 104), (150, 2, 0, 134), (250, 2, 0, 134),
+]
+
+
+def gen_bench_decomp():
+    blob = {}
+    for k, (R, farnn, crf, S) in enumerate(DECOMP_CASES):
+        V, q, gates, tr = synth.snips_sized_model(R, farnn, bool(crf), S=S)
+        C = 73
+        x, lengths = synth.random_batch(V, B, L, np.random.RandomState(BATCH_SEED))
+        a = ns(independent=2, farnn=farnn, use_crf=crf, update_nonlinear='tanh', beta=1.0, sigmoid_exponent=5)
+        E = np.zeros((V, 4))                         # beta = 1: the word vector is V_embed[x] (model_decompose.py:222-241)
+        E[:, 0] = 1.0
+        torch.manual_seed(7)
+        m = quiet(FARNN_S_D_W_I_S, V=q['Vgen'].astype(np.float64), S1=q['S1'].astype(np.float64), S2=q['S2'].astype(np.float64),
+                  C_output_mat=q['Cout'][:C].astype(np.float64), wildcard_mat=q['W'].astype(np.float64),
+                  wildcard_output_vector=np.zeros(S), final_vector=q['hT'].astype(np.float64),
+                  start_vector=q['h0'].astype(np.float64), pretrained_word_embed=E, priority_mat=np.eye(C + (2 if crf else 0) - 1),
+                  args=a, o_idx=0, is_cuda=False)
+        with torch.no_grad():
+            if crf:                                  # the START / STOP rows and the transitions of the seeded model
+                m.C_output_mat[C:] = torch.from_numpy(q['Cout'][C:])
+                m.crf.transitions.copy_(torch.from_numpy(tr))
+            for name in ('Wss1', 'Wrs1', 'Wss2', 'Wrs2'):
+                if gates and name in gates:
+                    getattr(m, name).copy_(torch.from_numpy(gates[name]))
+            for name in ('bs1', 'bs2'):
+                if gates and name in gates:
+                    getattr(m, name).copy_(torch.from_numpy(gates[name]).reshape(1, -1))
+        captured = {}
+        orig_decode = m.decode
+
+        def spy(all_scores, flat, mask, lens, _c=captured, _o=orig_decode):
+            _c['scores'] = all_scores.detach().numpy().copy()
+            return _o(all_scores, flat, mask, lens)
+        m.decode = spy
+        xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+        t0 = time.time()
+        with torch.no_grad():
+            _, pred, _ = m.forward_local(xt, torch.zeros_like(xt), lt, train=False)
+        dt = time.time() - t0
+        sc = captured['scores']
+        pre = 'c{}.'.format(k)
+        blob[pre + 'dims'] = np.array([V, S, C, R, farnn, crf, B, L])
+        blob[pre + 'flat_pred'] = pred.numpy().astype(np.int16)
+        blob[pre + 'sample_scores'] = sc[DECOMP_ROWS].astype(np.float32)
+        print('bench_decomp case', k, (R, farnn, crf, S), 'reference forward_local %.2f s' % dt,
+              'scores', sc.shape, 'max |score| %.3f' % float(np.abs(sc).max()), 'non-O tags', int((pred.numpy() != 0).sum()))
+    save('bench_decomp', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), sample_rows=DECOMP_ROWS, **blob)
+
+
+def run_onehot(T, W, O, h0, hT, x, lengths):
+    S, C = T.shape[1], O.shape[0]
+    a = ns(independent=2)
+    m = quiet(FARNN_S_O_I_S, T.astype(np.float64), O.astype(np.float64), W.astype(np.float64), np.zeros(S),
+              hT.astype(np.float64), h0.astype(np.float64), np.eye(C - 1), a, o_idx=0)
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    label = torch.zeros_like(xt)
+    with torch.no_grad():
+        scores = m.forward_score(xt, label, lt, train=False)
+        _, pred, _ = m.forward_local(xt, label, lt, train=False)
+        re_pred, _ = m.forward_RE(xt, label, lt, train=False)
+    return scores, pred.numpy(), re_pred.numpy()
+
+
+def gen_bench_crf():
+    T, W, O, h0, hT, tr = synth.atis_sized_crf_model()
+    V, S, C = T.shape[0], T.shape[1], O.shape[0]
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(BATCH_SEED))
+    scores, _, _ = run_onehot(T, W, O, h0, hT, x, lengths)
+    K = C + 2
+    lt = torch.from_numpy(lengths)
+    with torch.no_grad():
+        ext = torch.cat([scores, torch.zeros(B, L, 2)], dim=2)                       # START / STOP columns
+        ext[:, :, K - 3] = torch.min(ext[:, :, K - 3], torch.tensor(0.5))            # model_decompose.py:353
+        crf = quiet(CRF, C, False)
+        crf.transitions.copy_(torch.from_numpy(tr))
+        mask = get_length_mask(lt, L)
+        _, paths = crf._viterbi_decode(ext, mask)
+        flat = flatten(paths, lt)
+        flat[flat == K - 3] = 0                                                      # :356, o_idx = 0
+    save('bench_crf', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), dims=np.array([V, S, C, K, B, L]),
+         flat_pred=flat.numpy().astype(np.int16), raw_paths=paths.numpy().astype(np.int16),
+         sample_rows=ROWS, sample_scores=scores.numpy()[ROWS].astype(np.float32))
+    print('bench_crf: valid tokens', int(lengths.sum()), 'non-O tags', int((flat.numpy() != 0).sum()))
+
+
+def gen_bench_ifst104():
+    V, S, C = 950, 104, 128
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, np.random.RandomState(1234))    # bench.py --workload ifst --states 104
+    rng = np.random.RandomState(BATCH_SEED)
+    x, lengths = synth.random_batch(V, B, L, rng)
+    # plant accepting paths in every second sequence so that rules fire (as gen_atis_scale does): walk the automaton from state 0
+    succ = {}
+    for w, s_, j in zip(*np.nonzero(T)):
+        succ.setdefault(int(s_), []).append((int(w), int(j)))
+    for b in range(0, B, 2):
+        n = int(lengths[b]); at = int(rng.randint(0, max(1, n - 4))); st = 0
+        for t in range(at, n):
+            if st not in succ:
+                break
+            w, st = succ[st][int(rng.randint(len(succ[st])))]
+            x[b, t] = w
+    scores, pred, re_pred = run_onehot(T, W, O, h0, hT, x, lengths)
+    save('bench_ifst104', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), dims=np.array([V, S, C, B, L]),
+         x=x.astype(np.int16), lengths=lengths.astype(np.int16),
+         flat_pred=pred.astype(np.int16), tags=re_pred.astype(np.int16), sample_rows=ROWS,
+         sample_scores=scores.numpy()[ROWS].astype(np.float32))
+    print('bench_ifst104: valid tokens', int(lengths.sum()), 'non-O tags', int((pred != 0).sum()))
+
+
+if __name__ == '__main__':
+    gen_bench_ifst104()
+    gen_bench_crf()
+    gen_bench_decomp()

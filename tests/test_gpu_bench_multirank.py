@@ -75,8 +75,9 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert d['parity']['tags_equal'] is True
     assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
     names = [o['workload'] for o in d['other_configs']]
-    assert names == ['ifst_crf', 'ifst_crf_two_launches', 'decomp', 'decomp_r250_farnn2', 'fst4']
+    assert names == ['ifst_crf', 'ifst_crf_two_launches', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2', 'fst4']
     kern = {o['workload']: o['roofline']['kernel'] for o in d['other_configs']}
+    assert 'chain_wide_kernel<fused' in kern['ifst_s104']                # the reference's 104-state automata: the wide form, ONE launch
     assert 'chain_viterbi_kernel' in kern['ifst_crf']                    # config 4: ONE launch by default ...
     assert 'chain_viterbi_kernel' not in kern['ifst_crf_two_launches']   # ... its two-launch form beside it (FARNN_NOFUSE for that run only)
     for o in d['other_configs']:

@@ -1,5 +1,6 @@
 """Random geometries of the onehot i-FST through the one-launch tagging step (csrc/chain_regs.hip.h + beside.hip.h) against the
-oracle: state counts 1..72 (every row-group / idle-lane layout of the register-fed recurrence), label counts up to 256
+oracle: state counts 1..72 (every row-group / idle-lane layout of the register-fed recurrence) and 73..128 (its wide form,
+csrc/chain_wide.hip.h: every ring width, with and without idle lanes, the reference's 104 states), label counts up to 256
 (one to four decode columns per lane), sequence lengths up to 200 (several 16-token tiles per half, the 64-step block-address
 window reloaded, the scorer wavefront scoring tiles alone while the chain runs), batches of 1..70, LOCAL and FULL mode, the four
 non-linearities, both semirings, the priority matrix, scores asked for or not.  Bit-exact for integer-valued automata
@@ -24,7 +25,8 @@ pytestmark = pytest.mark.gpu
 
 def _one(rng, it):
     from re2nn_seq_amd import _lib, synth
-    S = int(rng.choice([1, 2, 5, 15, 16, 17, 31, 48, 63, 64, 65, 68, 71, 72]))
+    S = int(rng.choice([1, 2, 5, 15, 16, 17, 31, 48, 63, 64, 65, 68, 71, 72] if rng.rand() < 0.5 else
+                       [73, 76, 84, 85, 95, 96, 97, 104, 108, 109, 113, 120, 121, 125, 127, 128]))
     C = int(rng.choice([2, 9, 63, 64, 65, 128, 129, 200, 256]))
     L = int(rng.choice([1, 2, 15, 16, 17, 33, 64, 65, 100, 129, 200]))
     B = int(rng.choice([1, 2, 7, 33, 70]))
@@ -67,7 +69,7 @@ def _one(rng, it):
     mask = np.arange(L)[None, :] < lengths[:, None]
     live = np.ones_like(mask) if full else mask
     what = 'S={} C={} L={} B={} nl={} {} full={} P={} scores={} [{}]'.format(S, C, L, B, nl, semiring, full, use_P, want_scores, name)
-    assert name.startswith('chain_regs_kernel'), what      # S <= 72: the register-fed recurrence ...
+    assert name.startswith('chain_regs_kernel' if S <= 72 else 'chain_wide_kernel'), what      # the register-fed recurrence ...
     if L <= 64 and C <= 128:
         assert 'fused' in name, what                       # ... in its one-launch form while states + score tiles fit half a CU's LDS
     tol = 0.0 if exact else 1e-4 * max(1.0, float(np.abs(ref).max()))
@@ -93,7 +95,7 @@ def _one(rng, it):
 
 
 def test_chain_regs_random_shapes_vs_oracle():
-    n = int(os.environ.get('FARNN_SHAPE_SOAK', '40'))
+    n = int(os.environ.get('FARNN_SHAPE_SOAK', '60'))
     rng = np.random.RandomState(int(os.environ.get('FARNN_SHAPE_SEED', '20261003')))
     seen, fused = set(), 0
     for it in range(n):

@@ -1,0 +1,96 @@
+"""Pin the CPU oracle against the REFERENCE's own outputs at the sizes bench.py times (tests/golden/make_golden_bench.py:
+the reference's FARNN_S_D_W_I_S / FARNN_S_O_I_S / CRF classes run on the seeded bench models in the build container).
+
+    bench_decomp    BASELINE configs[2]: V = 11 000, C = 73, B = 256, L = 64; five (rank, farnn, CRF, S) shapes
+    bench_crf       BASELINE configs[3]: onehot scores -> START / STOP columns -> clamp -> CRF._viterbi_decode, K = 130
+    bench_ifst104   the onehot i-FST at the reference's 104-state automata (RE.py:56-60)
+
+The decomposed scores are held to 1e-4 against the reference's rows on the sampled sequences.  One case documents where
+float32 itself scatters: on sequence 77 of the rank-250, 134-state model the REFERENCE's float32 scores lie 1.7e-4 from a
+float64 evaluation (asserted below, from the fixture) -- so GPU tests hold that case to the float64 value at 1e-4 and to the
+reference at 1e-4 plus the reference's own distance from float64."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import farnn_oracle as fo
+from re2nn_seq_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+B, L = 256, 64
+
+
+def _f64(q):
+    return {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v) for k, v in q.items()}
+
+
+@pytest.mark.parametrize('k', range(5))
+def test_decomposed_bench_size_sample_rows(k):
+    g = np.load(os.path.join(GOLDEN, 'bench_decomp.npz'))
+    V, S, C, R, farnn, crf, b_, l_ = (int(v) for v in g['c%d.dims' % k])
+    assert (b_, l_) == (B, L)
+    rows = g['sample_rows']
+    V_, q, gates, tr = synth.snips_sized_model(R, farnn, bool(crf), seed=int(g['seed']), S=S)
+    x, lengths = synth.random_batch(V_, B, L, np.random.RandomState(int(g['batch_seed'])))
+    xs, ls = x[rows], lengths[rows]
+    want = g['c%d.sample_scores' % k]
+    mask = np.arange(L)[None, :] < ls[:, None]
+    got = fo.decomp_ifst_scores(q, xs, ls)
+    assert got.shape == want.shape
+    with fo.precision(np.float64):
+        ref64 = fo.decomp_ifst_scores(_f64(q), xs, ls)
+    ref_err = np.abs(ref64 - want)                                  # the reference's own distance from float64
+    if (R, farnn, S) == (250, 2, 134):
+        # the documented float32 scatter of this shape: on sequence 77 the reference's float32 scores lie 1.7e-4 from float64, and
+        # so do numpy's (which moves by 2e-4 with the batch size it is evaluated at).  Every float32 evaluation within 3e-4 of
+        # float64; the oracle against the reference to 1e-4 plus the reference's own error.
+        assert 1e-4 < float(ref_err[mask].max()) < 3e-4
+        assert float(ref_err[np.arange(len(rows)) != 2][mask[np.arange(len(rows)) != 2]].max()) < 2e-5      # all of it is sequence 77
+        assert float(np.abs(got - ref64)[mask].max()) < 3e-4
+        assert (np.abs(got - want) <= 1e-4 + 1e-4 * np.abs(want) + 2.0 * ref_err)[mask].all()
+    else:
+        assert float(ref_err[mask].max()) < 2e-5
+        np.testing.assert_allclose(got[mask], want[mask], rtol=1e-4, atol=1e-4)
+    # the tags of the sampled sequences: the oracle's decode of its own scores equals the reference's wherever the margin allows
+    flat = g['c%d.flat_pred' % k].astype(np.int64)
+    offs = np.concatenate([[0], np.cumsum(lengths)])
+    assert flat.shape[0] == int(lengths.sum())
+    mine = fo.forward_local_tags(got, ls, 0.5, 0, crf_tr=tr)
+    at = 0
+    n_diff = 0
+    for i, b in enumerate(rows):
+        n = int(ls[i])
+        n_diff += int((mine[at:at + n] != flat[offs[b]:offs[b] + n]).sum())
+        at += n
+    assert n_diff <= (2 if crf else 1), n_diff                      # near-ties only
+
+
+def test_onehot_crf_bench_size_all_tags():
+    g = np.load(os.path.join(GOLDEN, 'bench_crf.npz'))
+    V, S, C, K, b_, l_ = (int(v) for v in g['dims'])
+    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C)
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(int(g['batch_seed'])))
+    sc = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+    rows = g['sample_rows']
+    assert np.array_equal(sc[rows], g['sample_scores'])            # integer-valued: bit-exact
+    ext = fo.onehot_crf_extension_scores(sc)
+    want = fo.decode_crf(ext, lengths, tr, 0.5, 0)
+    assert np.array_equal(fo.flatten(want, lengths), g['flat_pred'].astype(np.int64))
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    clamped = ext.copy(); clamped[..., K - 3] = np.minimum(clamped[..., K - 3], np.float32(0.5))
+    raw = fo.viterbi_paths(clamped, lengths, tr)
+    assert np.array_equal(raw[mask], g['raw_paths'].astype(np.int64)[mask])
+
+
+def test_onehot_ifst_104_states_all_tags():
+    g = np.load(os.path.join(GOLDEN, 'bench_ifst104.npz'))
+    V, S, C, b_, l_ = (int(v) for v in g['dims'])
+    assert S == 104
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, np.random.RandomState(int(g['seed'])))
+    x, lengths = g['x'].astype(np.int64), g['lengths'].astype(np.int64)
+    sc = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+    assert np.array_equal(sc[g['sample_rows']], g['sample_scores'])
+    assert np.array_equal(fo.forward_local_tags(sc, lengths, 0.5, 0), g['flat_pred'].astype(np.int64))
+    assert np.array_equal(fo.decode_argmax(sc, 0.5, 0), g['tags'].astype(np.int64))
+    assert int((g['flat_pred'] != 0).sum()) > 500                   # rules do fire in this batch
