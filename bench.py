@@ -817,10 +817,13 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         pipelined = (2, pel)
 
     tok_local = int(lengths.sum())
+    tok_min = tok_max = tok_local
     if world > 1:
         n = torch.tensor([tok_local], dtype=torch.int64, device=dev)
         dist.all_reduce(n, op=dist.ReduceOp.SUM)
         tok_total = int(n.item())
+        n.fill_(tok_local); dist.all_reduce(n, op=dist.ReduceOp.MIN); tok_min = int(n.item())
+        n.fill_(tok_local); dist.all_reduce(n, op=dist.ReduceOp.MAX); tok_max = int(n.item())
     else:
         tok_total = tok_local
     if rank != 0:
@@ -841,6 +844,7 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
                                        ' R={} farnn={}'.format(a.rank, a.farnn) if name.startswith('decomp') else '',
                                        B, L, 'all {}'.format(L) if a.full_length else 'U[5,{}]'.format(L)),
                    'valid_tokens_per_step': tok_total, 'padded_tokens_per_step': world * B * L,
+                   'valid_tokens_per_rank_min_max': [tok_min, tok_max],
                    'parallelism': 'batch-sharded x{} (weights replicated{}){}'.format(
                        world, ', RCCL all_gather of tag ids' if world > 1 else '',
                        ', {} batches in flight per GPU'.format(n_main) if n_main > 1 else '')},
@@ -925,6 +929,19 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)   # "nccl" is RCCL on ROCm
+        # the N > 1 path must not limp on with a wrong topology: every rank checks what it joined
+        if dist.get_world_size() != world or dist.get_rank() != rank:
+            raise SystemExit('bench.py: process group has world {} / rank {}, the launcher said {} / {}'.format(
+                dist.get_world_size(), dist.get_rank(), world, rank))
+        if not one_dev and torch.cuda.device_count() < world:
+            raise SystemExit('bench.py: {} ranks but only {} GPUs visible to rank {}'.format(world, torch.cuda.device_count(), rank))
+        if rank == 0:
+            try:
+                ver = '.'.join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:                 # noqa: BLE001 -- informational only
+                ver = 'unknown ({})'.format(type(e).__name__)
+            print('bench.py: {} ranks, backend {}, RCCL {}, one device per rank: {}'.format(
+                world, dist.get_backend(), ver, not one_dev), file=sys.stderr, flush=True)
     from re2nn_seq_amd import _lib  # noqa: F401
 
     if a.workload == 'train':

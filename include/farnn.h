@@ -18,7 +18,11 @@
  *     of PyTorch-ROCm tensors used purely as containers); the library never retains them
  *     after the call's work has been enqueued on `stream`;
  *   - one caller thread per handle (the reference is single-threaded Python); one workspace per handle: a call on another
- *     stream than the previous call's is ordered behind that call's work by the library.
+ *     stream than the previous call's is ordered behind that call's work by the library.  The ONE thing the handle keeps of a
+ *     call is its stream handle, until the next call: the first time a handle is called on a different stream, the previous
+ *     call's stream must still exist (the library records its ordering event there); from then on every call leaves the
+ *     handle's own event behind itself and earlier streams are never touched again.  A call that is being captured into a
+ *     HIP graph is not ordered against other streams.
  */
 #ifndef FARNN_H
 #define FARNN_H
@@ -296,7 +300,9 @@ void farnn_destroy(farnn_model *m);
  * x_host / len_host may be reused as soon as submit returns.  PCIe-inclusive path: bench.py reports it as
  * `host_inclusive`, never as the headline value.
  *   x_host    int64 [B,L]   (host)          len_host  int64 [B]  (host)
- *   ticket    out: slot number to pass to farnn_tag_host_wait;  n_flat out (or NULL): sum(clamp(len, 0, L))
+ *   ticket    out: names THIS submit (slot | generation << 8) for farnn_tag_host_wait; a ticket that was already waited for, or
+ *             whose slot has since been reclaimed for a later submit, is refused with FARNN_EINVAL and consumes nothing;
+ *             n_flat out (or NULL): sum(clamp(len, 0, L))
  *   flat_out  int64 [n_flat] (host)         n_out (or NULL): how many were written
  * farnn_flatten_host: utils.flatten (utils.py:153-164) of a host int64 [B,L] array (the flat gold labels the same
  * call returns beside the predictions); returns the element count, -1 on a null argument. */

@@ -12,6 +12,10 @@
 
 namespace farnn {
 
+// the scorer wavefront takes the label-map path (label_map.hip.h: token by token behind the chain) when the output matrix is a
+// label map and the call wants tags only; the matrix form (tiles on the f32 matrix cores) otherwise
+__device__ __forceinline__ bool bs_label_map_path(const ScoreParams &sp) { return sp.lm.on && !sp.P && !sp.scores; }
+
 // what tile k needs: forward rows 0..needA and backward rows 0..needB stored (a row = one state, row 0 the initial one)
 __device__ __forceinline__ void bs_tile_need(int k, int len, int nsteps, int &needA, int &needB) {
     const int lo = k * RG_TT;
@@ -21,6 +25,21 @@ __device__ __forceinline__ void bs_tile_need(int k, int len, int nsteps, int &ne
     if (lo < len) nb = len - lo - 1;
     if (hi >= len) nb = max(nb, hi + 1);
     needB = nb;
+}
+
+// The launch's epoch, from device memory.  `done` counts the sequences whose second workgroup has arrived (bs_finish adds one per
+// sequence); between launches it is a multiple of B, during launch e it runs from e B towards (e + 1) B and reaches that only
+// when every sequence's second arrival is in -- i.e. after every workgroup of the launch has started and read it.  So done / B is
+// the same number for all workgroups of a launch however late they start, and one more for the next launch: no kernel argument,
+// no host-side counter, and a launch captured into a HIP graph replays with the right epoch.  (Never 0: zeroed words carry 0.)
+// ONE lane of the wavefronts that use the epoch reads the counter (all of a launch's workgroups start together: thousands of
+// L1-bypassing loads of one line at once cost the launch microseconds -- measured, +4 us on the 35 us headline step).
+__device__ __forceinline__ unsigned bs_launch_epoch(const unsigned long long *done, int B, int lane) {
+    unsigned long long d = 0ull;
+    if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d >> 32));
+    const unsigned long long q = (((unsigned long long)hi << 32) | lo) / (unsigned long long)(unsigned)B;
+    return (unsigned)(q % 0xffffffffull) + 1u;
 }
 
 __device__ __forceinline__ int bs_read_prog(const unsigned long long *w, unsigned epoch) {
@@ -295,6 +314,64 @@ __device__ __forceinline__ void bs_score_tiles(const BesideParams &p, const int 
 #endif
 }
 
+// ---- the same two tiles when the output matrix is a label map (label_map.hip.h): every wavefront takes tokens w, w + NWV, ... of
+// each tile and scores + decodes them by itself -- no staged products, no matrix-core pass, no workgroup barrier.
+// Straight-line code: every row entry of the wavefront's tokens is fetched before the first token is scanned (tokens that do not
+// exist read token 0's rows and store nothing), two tokens are scanned at a time.  PARKED: the other direction's rows of both
+// tiles are in LDS (par0 / par1), else they come from the stash (sc1 loads; the acquire that covers them is the caller's).
+template <int NWV, bool PARKED>
+__device__ __forceinline__ void bs_label_map_tiles(const BesideParams &p, const int b, const int dir, const int len, const int nsteps,
+                                                   const int k0, const int k1, const float *hist, const float *par0, const float *par1,
+                                                   const long long foff, const int wv, const int lane, const LabelMapRegs &lr) {
+    static_assert(RG_TT % NWV == 0, "whole tokens-per-tile share per wavefront");
+    constexpr int TPT = RG_TT / NWV, NTOK = 2 * TPT;     // tokens per tile and wavefront; two tiles
+    static_assert(NTOK % 2 == 0, "tokens are scanned in pairs");
+    const ScoreParams &sp = p.sp;
+    const int SP = p.SP;
+    float a0[NTOK], a1[NTOK], o0[NTOK], o1[NTOK];
+    int pos[NTOK];
+#pragma unroll
+    for (int q = 0; q < NTOK; q++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int ti = q / TPT, tokl = wv + (q % TPT) * NWV;                 // (compile-time tile, wave-uniform token slot)
+        const int kk = ti ? k1 : k0;
+        const int t0 = (kk >= 0 ? kk : 0) * RG_TT, nt = kk >= 0 ? min(RG_TT, nsteps - t0) : 0;
+        const bool live = tokl < nt;
+        const int tk = live ? tokl : 0;
+        const int i = t0 + tk;
+        pos[q] = live ? i : -1;
+        const int ai = i + 1, bi = (i + 1 <= len) ? len - (i + 1) : i + 1;
+        const float *own = hist + (dir == 0 ? ai : bi) * SP;
+        a0[q] = own[lr.st0]; a1[q] = own[lr.st1];
+        if (PARKED) {
+            const float *par = (ti ? par1 : par0) + tk * SP;
+            o0[q] = par[lr.st0]; o1[q] = par[lr.st1];
+        } else {
+            const float *orow = bs_other_row(p, b, dir, len, i);
+            o0[q] = __hip_atomic_load(orow + lr.st0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            o1[q] = __hip_atomic_load(orow + lr.st1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const float two = sp.lm.nq > 1 ? 1.0f : 0.0f;        // one register in use: the second one's products are zero
+#pragma unroll
+    for (int q = 0; q < NTOK; q += 2) {
+        float ya0, ya1, yb0, yb1;
+        lm_scan_scores2(lr, a0[q] * o0[q], a1[q] * o1[q] * two, a0[q + 1] * o0[q + 1], a1[q + 1] * o1[q + 1] * two, ya0, ya1, yb0, yb1);
+        float ma = fmaxf(ya0, ya1), mb = fmaxf(yb0, yb1);
+        wave_max_dpp2(ma, mb);
+        const int taga = lm_tag_from_candidates(sp.lm, lr, ya0, ya1, ma, sp.K, sp.o_idx);
+        const int tagb = lm_tag_from_candidates(sp.lm, lr, yb0, yb1, mb, sp.K, sp.o_idx);
+        if (lane < 2) {
+            const int i = lane ? pos[q + 1] : pos[q];
+            const int tag = lane ? tagb : taga;
+            if (i >= 0) {
+                if (sp.tags) sp.tags[(long long)b * p.L + i] = tag;
+                if (sp.flat && i < len) sp.flat[foff + i] = tag;
+            }
+        }
+    }
+}
+
 // misc words in LDS
 enum { RGM_FOFF = 16,        // where the sequence starts in the flat output
        RGM_MINE = 17,        // tiles this workgroup's scorer did while the chain ran (bit k = tile k)
@@ -340,16 +417,36 @@ __device__ __forceinline__ void bs_halves(int dir, int len, int nsteps, int &kmi
 // on_meet(): called by every wavefront right behind the meeting barrier (chain_regs: the writer issues the state rows it has not
 // copied yet); publish_all(): called before the second arrival may be acted on -- when it returns on the wavefront that stored
 // this direction's stash rows, they are drained and the progress word says nsteps.
-template <int NWV, int NG, int WDEC, int WSKIP, class OnMeet, class PublishAll>
+// WARM (label-map path): the deciding wavefront is idle while the chain runs its last steps -- it executes the tile code ONCE WITH
+// NOTHING TO STORE before the meeting barrier (the same call site, no tile selected), so that the instructions are in the
+// compute unit's instruction cache when all wavefronts run them for real: run cold, a few KB of straight-line code cost the
+// workgroup ~8 k cycles of instruction fetch (profiles/r04_probe_finish_phases.txt), more than the arithmetic.
+template <int NWV, int NG, int WDEC, int WSKIP, bool WARM = false, class OnMeet, class PublishAll>
 __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, const int dir, const int len, const int nsteps, const int kmid,
                                           const float *hist, float *ab, float *scl, const float *obuf, int *misc,
-                                          const int w, const int lane, OnMeet on_meet, PublishAll publish_all) {
+                                          const int w, const int lane, const unsigned lm_pk0, const unsigned lm_pk1,
+                                          const unsigned epoch,      // the launch's epoch (bs_launch_epoch); read on wavefront WDEC only
+                                          OnMeet on_meet, PublishAll publish_all) {
     const int SP = p.SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
     rg_f32x4 bpre[NG];                                            // this wavefront's column block of O^T: in flight across the barrier
-    bs_load_b<NG>(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
+    const bool label_map = bs_label_map_path(p.sp);               // the tiles go through bs_label_map_tiles, not the matrix cores
+    LabelMapRegs lr;
+    if (label_map) {
+        lm_unpack(p.sp.lm, lm_pk0, lm_pk1, lr);
+#pragma unroll
+        for (int g = 0; g < NG; g++) bpre[g] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
+    } else bs_load_b<NG>(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
     const unsigned all_tiles = ntl >= 32 ? ~0u : ((1u << ntl) - 1u);
     unsigned promised = 0u;
+#if defined(FARNN_PROBES)
+    const bool fprobe = nsteps == p.L && p.L >= 32 && w == WDEC && (p.dbg & 1024);
+    long long fq[6] = {0, 0, 0, 0, 0, 0};
+#define FARNN_BS_STAMP(i) do { if (fprobe) fq[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FARNN_BS_STAMP(i) do { } while (0)
+#endif
+    FARNN_BS_STAMP(0);
     if (w == WDEC) {
         // which tiles of this half can be scored now: those the other direction's progress, as covered by an acquire, allows
         const unsigned mine = (unsigned)misc[RGM_MINE];
@@ -367,7 +464,7 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
                 if ((dir == 0 ? nb : na) <= acq) todo |= 1u << k; else miss++;
             }
             if (!miss || it >= p.spin) break;                         // bounded: what stays open goes to the second arrival
-            int pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
+            int pr = lane == 0 ? bs_read_prog(oprog, epoch) : 0;
             pr = __builtin_amdgcn_readfirstlane(pr);
             if (pr > acq) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -378,24 +475,32 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
         promised = mine | todo;
         if (lane == 0) misc[RGM_TODO] = (int)todo;
     }
+    unsigned long long arrived = 0ull;
+    long long foff = 0;
+    int rep = __builtin_amdgcn_readfirstlane((WARM && label_map && w == WDEC) ? 0 : 1);
+    // (ONE copy of the loop's body, not a peeled dry run beside the real one: the code-object check in tests/ counts the scans)
+#pragma clang loop unroll(disable)
+    for (; rep < 2; rep++) {
+    const bool dry = rep == 0;                                       // (WARM: see above)
+    if (!dry) {
     wg_barrier_lds();                                                // the chain is done, the mask is there (LDS only: this wavefront's
                                                                      // O^T loads and the writer's last stores stay in flight)
-    
+    FARNN_BS_STAMP(1);
     on_meet();
     // ---- arrival: ONE lane exchanges the sequence's arrival word for {epoch, the tiles this workgroup scores}; the
     // exchange is in flight while those tiles are scored.  (The word says nothing about this workgroup's stash rows: they
     // are published through the progress word, below; the workgroup that has to read them waits for that.)
-    unsigned long long arrived = 0ull;
     if (w == WDEC && lane == 0)
-        arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)p.epoch << 32) | 0x80000000ull | promised,
+        arrived = __hip_atomic_exchange(p.arr + b, ((unsigned long long)epoch << 32) | 0x80000000ull | promised,
                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const long long foff = misc[RGM_FOFF];
+    foff = misc[RGM_FOFF];
+    }
     for (int pass = 0; pass < 2; pass++) {
-        unsigned todo = (unsigned)misc[RGM_TODO];
+        unsigned todo = dry ? 1u : (unsigned)misc[RGM_TODO];
         while (todo) {                                               // two tiles per pass
-            const int k0 = __builtin_ctz(todo);
+            int k0 = __builtin_ctz(todo);
             todo &= todo - 1u;
-            const int k1 = todo ? __builtin_ctz(todo) : -1;
+            int k1 = todo ? __builtin_ctz(todo) : -1;
             if (todo) todo &= todo - 1u;
             const float *par0 = nullptr, *par1 = nullptr;
 #pragma unroll
@@ -403,27 +508,35 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
                 if (misc[RGM_PARK + sl] == k0 + 1) par0 = obuf + sl * RG_TT * SP;
                 if (misc[RGM_PARK + sl] == k1 + 1) par1 = obuf + sl * RG_TT * SP;
             }
-            bs_score_tiles<true, NWV, NG, WSKIP>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1, ab, scl, foff, w, lane, bpre);
-            __syncthreads();                                         // the tiles' LDS is free again
+            if (dry) { k0 = -1; k1 = -1; par0 = obuf; par1 = obuf; }
+            if (label_map) {
+                if (par0 && (k1 < 0 || par1)) bs_label_map_tiles<NWV, true>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1 ? par1 : par0, foff, w, lane, lr);
+                else bs_label_map_tiles<NWV, false>(p, b, dir, len, nsteps, k0, k1, hist, nullptr, nullptr, foff, w, lane, lr);
+            } else {
+                bs_score_tiles<true, NWV, NG, WSKIP>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1, ab, scl, foff, w, lane, bpre);
+                __syncthreads();                                     // the tiles' LDS is free again
+            }
         }
-        if (pass == 1) break;
-        
+        if (dry || pass == 1) break;
+        FARNN_BS_STAMP(2);
         wg_barrier_lds();                                            // every wavefront has read this pass's mask (it is rewritten below)
         // every stash row of this direction has been stored by the writer wavefront: it drains them (they had the tiles'
         // time to land) and publishes the full count
         publish_all();
+        FARNN_BS_STAMP(3);
         if (w == WDEC) {
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(arrived >> 32));
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)arrived);
             unsigned rest = 0u;
-            if (hi == p.epoch && (lo & 0x80000000u)) {               // second of the two
+            if (hi == epoch && (lo & 0x80000000u)) {               // second of the two
+                if (lane == 0 && p.done) __hip_atomic_fetch_add(p.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (bs_launch_epoch)
                 rest = all_tiles & ~(promised | (lo & 0x7fffffffu));
                 if (rest) {
                     // The other workgroup has arrived: it is resident, past its chain, and publishes its full row count
                     // after a bounded amount of work of its own (it waits for nobody) -- so this wait ends.
                     const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
                     for (;;) {
-                        int pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
+                        int pr = lane == 0 ? bs_read_prog(oprog, epoch) : 0;
                         pr = __builtin_amdgcn_readfirstlane(pr);
                         if (pr >= nsteps) break;
                         __builtin_amdgcn_s_sleep(8);
@@ -434,9 +547,17 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
             }
             if (lane == 0) misc[RGM_TODO] = (int)rest;
         }
+        FARNN_BS_STAMP(4);
         __syncthreads();
         if (misc[RGM_TODO] == 0) break;
     }
+    }
+#if defined(FARNN_PROBES)
+    if (fprobe && lane == 0)
+        printf("finish seq %d dir %d: decide + meet %lld, own tiles %lld, barrier + publish %lld, arrival known + sweep decision %lld, to the end %lld\n", b, dir,
+               fq[1] - fq[0], fq[2] - fq[1], fq[3] - fq[2], fq[4] - fq[3], (long long)__builtin_amdgcn_s_memtime() - fq[4]);
+#endif
+#undef FARNN_BS_STAMP
 }
 
 }  // namespace farnn

@@ -102,11 +102,32 @@ def build_hip(force=False, verbose=True, probes=None):
     with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 4)) as pool:
         done = list(pool.map(lambda s: _compile(s, flags, force, verbose, objdir), units))
     objs = [o for o, _ in done]
-    if any(changed for _, changed in done) or not os.path.exists(out):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
+    # the link has a stamp of its own: the object list, every unit's digest and the link flags.  A link that failed or was
+    # interrupted after the units were stamped, or a unit that was deleted / renamed, leaves a stamp that no longer matches --
+    # the stale library is never returned as current
+    link_cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs
+    h = hashlib.sha256(' '.join(link_cmd).encode())
+    for o in objs:
+        try:
+            h.update(open(os.path.splitext(o)[0] + '.sha', 'rb').read())
+        except OSError:
+            h.update(b'?')
+    want = h.hexdigest()
+    stamp = os.path.join(objdir, 'link.sha')
+    try:
+        have = open(stamp).read().strip()
+    except OSError:
+        have = ''
+    if any(changed for _, changed in done) or not os.path.exists(out) or have != want:
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        if os.path.exists(out):
+            os.remove(out)
         if verbose:
-            print(' '.join(cmd), flush=True)
-        subprocess.run(cmd, check=True, cwd=HERE)
+            print(' '.join(link_cmd), flush=True)
+        subprocess.run(link_cmd, check=True, cwd=HERE)
+        with open(stamp, 'w') as f:
+            f.write(want)
     return out
 
 

@@ -171,8 +171,14 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     if (SCORE) bs_halves(dir, len, nsteps, kmid, pubmax);
     BesideParams bs;                                 // the scoring stage's view of the parameters (beside.hip.h)
     bs.A = p.A; bs.Bk = p.Bk; bs.B = p.B; bs.L = p.L; bs.SP = p.SP; bs.CPR = p.CPR; bs.prog = p.prog; bs.arr = p.arr;
-    bs.epoch = p.epoch; bs.spin = p.spin; bs.dbg = p.dbg; bs.sp = p.sp;
+    bs.done = p.done; bs.spin = p.spin; bs.dbg = p.dbg; bs.sp = p.sp;
+    bs.epoch = (SCORE && w >= RG_NWC) ? (p.done ? bs_launch_epoch(p.done, p.B, lane) : p.epoch_host) : 0u;   // the writer's and the scorer's wavefront use it
     int wr_next = 0;                                 // (writer wavefront) the next state row to copy to the stash
+    // the output matrix is a label map and only tags are asked for (label_map.hip.h): the tiles left when the chain ends are scored
+    // token by token, a few per wavefront, instead of on the matrix cores.  Every wavefront fetches its two packed words of the map
+    // now (two VGPRs for the length of the chain; fetched at the chain's end they would cost an exposed L2 round trip)
+    unsigned lm_pk0 = 0u, lm_pk1 = 0u;
+    if (SCORE && bs_label_map_path(bs.sp)) lm_load_packed(bs.sp.lm, lane, lm_pk0, lm_pk1);
     if (w < RG_NWC) {
         // =================================================================================================================
         // compute wavefronts
@@ -481,7 +487,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                 published = wr_next - 1;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this (the only storing) wavefront has left
                 if (lane == 0)
-                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)published,
+                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)bs.epoch << 32) | (unsigned)published,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
@@ -507,7 +513,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             if (need_oth > acq) {
                 int pr = -1;
                 for (;;) {
-                    pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
+                    pr = lane == 0 ? bs_read_prog(oprog, bs.epoch) : 0;
                     pr = __builtin_amdgcn_readfirstlane(pr);
                     if (pr >= need_oth) break;
                     if (regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;    // our chain is done: no open-ended wait beyond it
@@ -535,7 +541,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                 if (need_oth > acq) {
                     int pr = -1;
                     for (;;) {
-                        pr = lane == 0 ? bs_read_prog(oprog, p.epoch) : 0;
+                        pr = lane == 0 ? bs_read_prog(oprog, bs.epoch) : 0;
                         pr = __builtin_amdgcn_readfirstlane(pr);
                         if (pr >= need_oth) break;
                         if (regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;
@@ -561,7 +567,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
     if (w == 0) FARNN_RG_STAMP(4);
-    bs_finish<RG_WAVES, NG, RG_WAVES - 1, RG_NWC>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane,
+    bs_finish<RG_WAVES, NG, RG_WAVES - 1, RG_NWC, true>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane, lm_pk0, lm_pk1, bs.epoch,
         [&]() {                                                      // the state rows the writer had not copied yet: issued now, landed by
             if (w == RG_NWC)                                         // the time the tiles are done (it forms no products meanwhile)
                 for (; wr_next <= nsteps; wr_next++)
@@ -572,7 +578,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             if (w == RG_NWC) {                                       // tiles' time to land), then the full count in the progress word
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if (lane == 0)
-                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)p.epoch << 32) | (unsigned)nsteps,
+                    __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)bs.epoch << 32) | (unsigned)nsteps,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         });

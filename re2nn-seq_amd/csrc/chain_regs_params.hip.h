@@ -38,7 +38,8 @@ struct RegsParams {
     int nl, full;
     unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
     unsigned long long *arr;     // [B]    {epoch, 1 << 31 | mask of the tiles it scores} of the workgroup that arrived last
-    unsigned epoch;
+    unsigned long long *done;    // the hand-off's launch counter in device memory (score_params.hip.h, BesideParams::done)
+    unsigned epoch_host;         // diagnostic (FARNN_HOST_EPOCH=1, done == nullptr): the epoch as a kernel argument, the round-3 form
     int spin;                    // polls a finished workgroup spends on the tiles of its own half before it leaves them to the other
     int dbg;                     // FARNN_DBG ablation / probe mask: read by the profiling build (-DFARNN_PROBES) only
     int solo_margin;             // the scorer starts a tile alone only if the chain has at least this many steps left after it
@@ -110,7 +111,7 @@ int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s
 
 // chain_viterbi.hip: the two chains of a sequence and its scores + CRF decode in ONE workgroup, one launch per tagging step
 // (p.prog / p.arr / p.epoch unused).  chain_viterbi_fits: tag sets of 32..159 labels whose decode fits the LDS.
-bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp);
+bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp, bool label_map);
 int launch_chain_viterbi(const RegsParams &p, const ScoreParams &sp, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 
 }  // namespace farnn

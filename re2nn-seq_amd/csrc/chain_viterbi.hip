@@ -30,7 +30,10 @@ struct ChainViterbiPlan {
     size_t bytes;
 };
 
-static ChainViterbiPlan chain_viterbi_plan(int L, int SP, int NP, int K, int Kp, int c16) {
+// label_map: the scores come from the label map (label_map.hip.h) -- no products area, no image; a wavefront writes a token's
+// emission row while others still read state rows, so the halves lie BEHIND the emission rows, in the area the transition table
+// takes over once the scores are done.
+static ChainViterbiPlan chain_viterbi_plan(int L, int SP, int NP, int K, int Kp, int c16, bool label_map = false) {
     ChainViterbiPlan pl;
     const RegsLds rl = regs_lds(L, SP, NP, 0, 0, false);
     pl.half = (rl.total + 3) & ~3;
@@ -43,6 +46,12 @@ static ChainViterbiPlan chain_viterbi_plan(int L, int SP, int NP, int K, int Kp,
     pl.off1 = pl.image_off + pl.image_pieces * 256;
     pl.lds_rows = pl.image_pieces <= tr_pieces && pl.off0 + pl.half <= pl.image_off &&
                   (size_t)(pl.off1 + pl.half) * sizeof(float) <= 158 * 1024;
+    if (label_map) {
+        pl.image_pieces = 0;
+        pl.off0 = pl.image_off;
+        pl.off1 = pl.off0 + pl.half;
+        pl.lds_rows = (size_t)(pl.off1 + pl.half) * sizeof(float) <= 158 * 1024;
+    }
     if (!pl.lds_rows) { pl.off0 = 0; pl.off1 = pl.half; pl.image_pieces = 0; }
     pl.bytes = (size_t)(pl.off1 + pl.half) * sizeof(float);
     if (v > pl.bytes) pl.bytes = v;
@@ -77,16 +86,16 @@ chain_viterbi_kernel(const RegsParams p, const ScoreParams sp, const ChainViterb
         viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b);
 }
 
-bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp) {
+bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp, bool label_map) {
     const int ib4 = viterbi_hist_ib4(K);
     if (ib4 < 1 || ib4 > 4) return false;
-    const ChainViterbiPlan pl = chain_viterbi_plan(L, SP, NP, K, Kp, (SP + 15) / 16);
+    const ChainViterbiPlan pl = chain_viterbi_plan(L, SP, NP, K, Kp, (SP + 15) / 16, label_map);
     return pl.bytes <= 158 * 1024 && viterbi_hist_threads(K) <= 2 * RG_WAVES * 64;
 }
 
 int launch_chain_viterbi(const RegsParams &p_in, const ScoreParams &sp, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int NP = RG_NWC * p_in.G;
-    const ChainViterbiPlan pl = chain_viterbi_plan(p_in.L, p_in.SP, NP, sp.K, sp.Kp, sp.c16);
+    const ChainViterbiPlan pl = chain_viterbi_plan(p_in.L, p_in.SP, NP, sp.K, sp.Kp, sp.c16, sp.lm.on != 0);
     RegsParams p = p_in;
     if (pl.lds_rows && !env_int("FARNN_CV_STASH", 0)) { p.A = nullptr; p.Bk = nullptr; }     // no stash: the rows stay in LDS
     // (Launch order: longest sequence first, as selected in the kernel.  A workgroup owns a whole sequence and a compute unit holds

@@ -159,7 +159,11 @@ decomp_regs_kernel(const DecompRegsParams p) {
     int kmid = 0, pubmax = 0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int WCOPY = DG_WAVES - 1;                       // SCORE: the wavefront that copies state rows to the stash
+    unsigned lm_pk0 = 0u, lm_pk1 = 0u;                        // the output matrix as a label map (label_map.hip.h), when it is one
+    unsigned epoch = 0u;                                      // the launch's epoch, from device memory (beside.hip.h, bs_launch_epoch)
     if (SCORE) {
+        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, p.B, lane);
+        if (bs_label_map_path(p.bs.sp)) lm_load_packed(p.bs.sp.lm, lane, lm_pk0, lm_pk1);
         bs_halves(dir, len, nsteps, kmid, pubmax);
         for (int j = tid; j < (nsteps + 1) * SP; j += DG_THREADS) hist[j] = j < S ? hinit[j] : 0.0f;   // row 0; pad columns zero
         if (tid < 32) misc[tid] = tid == RGM_ACQ ? -1 : 0;
@@ -190,7 +194,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
     auto publish = [&](int r) {                               // every store of this (the only storing) wavefront has left, then the word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
-            __hip_atomic_store(p.bs.prog + (long long)dir * p.B + b, ((unsigned long long)p.bs.epoch << 32) | (unsigned)r,
+            __hip_atomic_store(p.bs.prog + (long long)dir * p.B + b, ((unsigned long long)epoch << 32) | (unsigned)r,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         published = r;
     };
@@ -199,7 +203,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
     int polled = -1;
     if (nsteps <= 0) {
         if (SCORE) {
-            bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane,
+            bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
                 [&]() {}, [&]() { if (wv == WCOPY) publish(0); });
         }
         return;
@@ -265,7 +269,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
         if (SCORE && wv == 0) {
             // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
             // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
-            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
+            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, epoch);
             if (t == t_poll + 1) {
                 const int pr = __builtin_amdgcn_readfirstlane(polled);
                 if (pr >= 0) {
@@ -323,7 +327,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
             if (nsteps >= 2) store_row(nsteps - 1);
             copy_row(nsteps);
         }
-        bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane,
+        bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
             [&]() {}, [&]() { if (wv == WCOPY) publish(nsteps); });
     }
     if (FARNN_PROBE_ON(p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)
@@ -397,7 +401,11 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     int kmid = 0, pubmax = 0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int WCOPY = DG_WAVES - 1;                       // SCORE: the wavefront that copies state rows to the stash
+    unsigned lm_pk0 = 0u, lm_pk1 = 0u;                        // the output matrix as a label map (label_map.hip.h), when it is one
+    unsigned epoch = 0u;                                      // the launch's epoch, from device memory (beside.hip.h, bs_launch_epoch)
     if (SCORE) {
+        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, p.B, lane);
+        if (bs_label_map_path(p.bs.sp)) lm_load_packed(p.bs.sp.lm, lane, lm_pk0, lm_pk1);
         bs_halves(dir, len, nsteps, kmid, pubmax);
         for (int j = tid; j < (nsteps + 1) * SP; j += DG_THREADS) hist[j] = j < S ? hinit[j] : 0.0f;   // row 0; pad columns zero
         if (tid < 32) misc[tid] = tid == RGM_ACQ ? -1 : 0;
@@ -428,7 +436,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     auto publish = [&](int r) {                               // every store of this (the only storing) wavefront has left, then the word
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0)
-            __hip_atomic_store(p.bs.prog + (long long)dir * p.B + b, ((unsigned long long)p.bs.epoch << 32) | (unsigned)r,
+            __hip_atomic_store(p.bs.prog + (long long)dir * p.B + b, ((unsigned long long)epoch << 32) | (unsigned)r,
                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         published = r;
     };
@@ -437,7 +445,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     int polled = -1;
     if (nsteps <= 0) {
         if (SCORE) {
-            bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane,
+            bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
                 [&]() {}, [&]() { if (wv == WCOPY) publish(0); });
         }
         return;
@@ -511,7 +519,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
         if (SCORE && wv == 0) {
             // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
             // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
-            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, p.bs.epoch);
+            if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, epoch);
             if (t == t_poll + 1) {
                 const int pr = __builtin_amdgcn_readfirstlane(polled);
                 if (pr >= 0) {
@@ -566,7 +574,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
             if (nsteps >= 2) store_row(nsteps - 1);
             copy_row(nsteps);
         }
-        bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane,
+        bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
             [&]() {}, [&]() { if (wv == WCOPY) publish(nsteps); });
     }
     if (FARNN_PROBE_ON(p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)

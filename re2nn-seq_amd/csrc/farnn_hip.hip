@@ -58,7 +58,7 @@ struct farnn_model {
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     float *OTm = nullptr; int c16 = 0;       // matrix-core image of OT for score_tiles (ot_to_mfma_kernel)
-    LabelMap lm = {nullptr, 0, 0, -1, 0.0f}; // the output matrix as a label map, when it is one (label_map.hip.h)
+    LabelMap lm = {nullptr, 0, 0, -1, 0.0f, 0, 0.0f}; // the output matrix as a label map, when it is one (label_map.hip.h)
     DecompWeights dw;                       // decomposed model weights
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
@@ -80,7 +80,8 @@ struct farnn_model {
     RegsGeom rgeom;                         // geometry of the register-fed recurrence kernel (chain_regs.hip.h); rgeom.ok: usable
     unsigned long long *hs = nullptr;       // hand-off words of that kernel: progress [2][B], arrival [B] (64-bit each)
     size_t hs_bytes = 0;
-    unsigned epoch_u = 0;                   // launches of that kernel in its scoring form so far (0 is never a launch's epoch)
+    int hs_B = 0;                           // the batch size the hand-off words and their launch counter are valid for (0: zeroed)
+    unsigned epoch_u = 0;                   // diagnostic FARNN_HOST_EPOCH=1: the round-3 host-side epoch
     bool last_regs = false;                 // the last recurrence ran on chain_regs_kernel
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
@@ -101,13 +102,14 @@ struct farnn_model {
         long long total = 0;
         hipEvent_t ev_out = nullptr;
         bool busy = false;
+        unsigned gen = 0;                   // submits this slot has seen: a ticket = slot | gen << 8, so a stale ticket cannot consume a newer batch
     } hslot[FARNN_HOST_SLOTS];
     hipStream_t hs_run = nullptr;
     int hnext = 0;
     // stream ordering of the handle's ONE workspace (stash, hand-off words, launch order): a call on another stream than the
     // previous call's waits for that call's work first
     hipStream_t last_stream = nullptr;
-    bool have_last = false;
+    bool have_last = false, multi_stream = false;
     hipEvent_t ev_order = nullptr;
 };
 
@@ -236,26 +238,23 @@ static int build_label_map(farnn_model *m) {
         if (lab >= 0) pos.push_back({lab, s});
     }
     const int n = (int)pos.size();
-    if (n > LM_MAXS) return FARNN_OK;
+    if (n > LM_MAXS || m->S > 256 || m->K > 510) return FARNN_OK;      // (8 bits of state, 9 of label per packed word)
     std::sort(pos.begin(), pos.end());
     const int clampcol = m->use_crf ? m->K - 3 : m->K - 1;     // model_decompose.py:353 / model_onehot.py:166
-    std::vector<unsigned> tab((size_t)LM_ROWS * 128, 0u);
-    auto fbits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+    std::vector<unsigned> tab(128, 0u);
     int lb[128];
-    for (int j = 0; j < 128; j++) lb[j] = j < n ? pos[j].first : m->K + j;
+    for (int j = 0; j < 128; j++) lb[j] = j < n ? pos[j].first : m->K + j;      // pads: distinct, above every label
     for (int j = 0; j < 128; j++) {
-        tab[LM_ST * 128 + j] = j < n ? (unsigned)pos[j].second : 0u;
-        tab[LM_LB * 128 + j] = (unsigned)lb[j];
+        unsigned wd = j < n ? ((unsigned)pos[j].second | ((unsigned)lb[j] << LM_LB_SHIFT)) : (0x1ffu << LM_LB_SHIFT);
         const int base = j & ~63, r = (j & 63) >> 4;
         const int dd[4] = {1, 2, 4, 8};
         for (int d = 0; d < 4; d++)
-            tab[(LM_CF + d) * 128 + j] = fbits(((j & 15) >= dd[d] && lb[j - dd[d]] == lb[j]) ? 1.0f : 0.0f);
-        tab[(LM_CF + 4) * 128 + j] = fbits(((r == 1 || r == 3) && lb[base + 16 * r - 1] == lb[j]) ? 1.0f : 0.0f);
-        tab[(LM_CF + 5) * 128 + j] = fbits(((r == 2 || r == 3) && lb[base + 31] == lb[j]) ? 1.0f : 0.0f);
-        tab[LM_CC * 128 + j] = fbits((j >= 64 && lb[j] == lb[63]) ? 1.0f : 0.0f);
-        const bool tail = j < n && (j == n - 1 || lb[j + 1] != lb[j]);
-        tab[LM_TL * 128 + j] = fbits(tail ? 0.0f : -INFINITY);
-        tab[LM_TH * 128 + j] = fbits(lb[j] == clampcol ? m->threshold : INFINITY);
+            if ((j & 15) >= dd[d] && lb[j - dd[d]] == lb[j]) wd |= 1u << (LM_CF_SHIFT + d);
+        if ((r == 1 || r == 3) && lb[base + 16 * r - 1] == lb[j]) wd |= 1u << (LM_CF_SHIFT + 4);
+        if ((r == 2 || r == 3) && lb[base + 31] == lb[j]) wd |= 1u << (LM_CF_SHIFT + 5);
+        if (j >= 64 && lb[j] == lb[63]) wd |= 1u << LM_CC_BIT;
+        if (j < n && (j == n - 1 || lb[j + 1] != lb[j])) wd |= 1u << LM_TL_BIT;
+        tab[j] = wd;
     }
     std::vector<char> has((size_t)m->K, 0);
     for (int j = 0; j < n; j++) has[pos[j].first] = 1;
@@ -264,6 +263,7 @@ static int build_label_map(farnn_model *m) {
         if (!has[c]) { m->lm.e0 = c; break; }
     m->lm.z0 = (m->lm.e0 == clampcol) ? std::min(0.0f, m->threshold) : 0.0f;
     m->lm.nq = n > 64 ? 2 : 1;
+    m->lm.clampcol = clampcol; m->lm.threshold = m->threshold;
     unsigned *dv = nullptr;
     int rc = dev_alloc(m, (void **)&dv, tab.size() * 4);
     if (rc) return rc;
@@ -429,9 +429,10 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     FARNN_HIP_TRY(hipMalloc((void **)&m->Bk, stash));
     FARNN_HIP_TRY(hipMalloc((void **)&m->offs, (size_t)(nB + 1) * sizeof(int64_t)));
     FARNN_HIP_TRY(hipMalloc((void **)&m->order, (size_t)nB * sizeof(int)));
-    m->hs_bytes = round_up_sz((size_t)3 * nB * sizeof(unsigned long long), 16);
+    m->hs_bytes = round_up_sz((size_t)(3 * nB + 48) * sizeof(unsigned long long), 16);     // progress [2][nB], arrival [nB], the launch counter
     FARNN_HIP_TRY(hipMalloc((void **)&m->hs, m->hs_bytes));
     FARNN_HIP_TRY(hipMemset(m->hs, 0, m->hs_bytes));
+    m->hs_B = 0;
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     if (m->d1_BSSp)
@@ -542,6 +543,31 @@ static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64
     return rp;
 }
 
+// The hand-off words of the one-launch forms (chain_regs.hip.h / decomp_regs.hip.h + beside.hip.h) and their launch counter.
+// A launch's epoch is (sequences whose second workgroup has arrived so far) / B + 1, read from device memory by the kernel:
+// nothing per launch comes from the host, so the step replays from a HIP graph as the very same launch.  The counter is only
+// meaningful for ONE batch size: when B changes the words and the counter are zeroed -- on the call's stream, or, while that
+// stream is being captured (the zeroing must not become a node that every replay runs), at once on a stream of its own.
+static int handoff_words(farnn_model *m, int B, hipStream_t s, unsigned long long **prog, unsigned long long **arr,
+                         unsigned long long **done) {
+    if (B != m->hs_B) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
+        if (!capturing) FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
+        else {
+            hipStream_t side = nullptr;
+            FARNN_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            hipError_t e = hipMemsetAsync(m->hs, 0, m->hs_bytes, side);
+            if (e == hipSuccess) e = hipStreamSynchronize(side);
+            (void)hipStreamDestroy(side);
+            FARNN_HIP_TRY(e);
+        }
+        m->hs_B = B;
+    }
+    *prog = m->hs; *arr = m->hs + (size_t)2 * m->wsB; *done = m->hs + (size_t)3 * m->wsB + 16;      // (the counter on a 128-byte line of its own)
+    return FARNN_OK;
+}
+
 // fuse_sp != nullptr: ask for the fused launch (scores + argmax decode as the chain kernel's epilogue); *fused tells
 // whether the geometry allowed it (else the caller launches the score kernel itself)
 static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, int B, int L, int full,
@@ -557,12 +583,6 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
-        if (score) {
-            // the hand-off words carry the launch's epoch, a kernel argument: a captured launch would replay with a frozen one.
-            // Under stream capture the step is two launches (recurrence, score kernel) with no state between replays.
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) score = false;
-        }
         size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.wide).total * sizeof(float);
         if (score && lds > lds_cap) {               // the score tiles do not fit (beside a second workgroup): recurrence only
             score = false;
@@ -571,12 +591,12 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         if (lds <= lds_cap) {
             RegsParams rp = make_regs_params(m, x, len, B, full);
             if (score) {
-                if (++m->epoch_u == 0) {            // the epoch wrapped: no word of an earlier launch may look current
-                    FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
-                    m->epoch_u = 1;
+                int hrc = handoff_words(m, B, s, &rp.prog, &rp.arr, &rp.done);
+                if (hrc) return hrc;
+                if (env_int("FARNN_HOST_EPOCH", 0)) {       // diagnostic A/B: the epoch as a kernel argument (not graph-capturable)
+                    if (++m->epoch_u == 0) { FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s)); m->epoch_u = 1; }
+                    rp.done = nullptr; rp.epoch_host = m->epoch_u + 0x40000000u;
                 }
-                rp.prog = m->hs; rp.arr = m->hs + (size_t)2 * m->wsB;
-                rp.epoch = m->epoch_u;
                 rp.spin = env_int("FARNN_FUSE_SPIN", 4);
                 rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 24);
                 rp.sp = *fuse_sp;
@@ -725,18 +745,13 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
         if (score) {
             rp.lds_score = regs_score_lds(rp, m->curL, m->SP, m->c16, m->Kc);
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // (a captured launch would replay with a frozen epoch)
-            if (rp.lds_score > 80 * 1024 || hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)
-                score = false;
+            if (rp.lds_score > 80 * 1024) score = false;
         }
         if (score) {
-            if (++m->epoch_u == 0) {
-                FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
-                m->epoch_u = 1;
-            }
             memset(&bs, 0, sizeof(bs));
             bs.A = m->A; bs.Bk = m->Bk; bs.B = B; bs.L = m->curL; bs.SP = m->SP; bs.CPR = m->SP / 4;
-            bs.prog = m->hs; bs.arr = m->hs + (size_t)2 * m->wsB; bs.epoch = m->epoch_u;
+            int hrc = handoff_words(m, B, s, &bs.prog, &bs.arr, &bs.done);
+            if (hrc) return hrc;
             bs.spin = env_int("FARNN_FUSE_SPIN", 4); bs.dbg = env_int("FARNN_DBG", 0); bs.sp = *fuse_sp;
             use = &bs;
             if (fused) *fused = true;
@@ -962,7 +977,7 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         m->last_fused = false;
         const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
         if (m->rgeom.ok && !m->rgeom.wide && !env_int("FARNN_NOREGS", 0) && !env_int("FARNN_NOFUSE", 0) && viterbi_can_fuse(m, sp) &&
-            (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp)) {
+            (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp, m->lm.on != 0)) {
             const RegsParams rp = make_regs_params(m, x, len, B, full);
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
             if ((rc = launch_chain_viterbi(rp, sp, m->semiring == FARNN_SEMIRING_MAX, s, kt.e0, kt.e1))) return rc;
@@ -1013,12 +1028,22 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
     // through farnn_tag_host_submit are in flight on the handle's own stream, ...) would race on the stash and on the
     // hand-off words.  A stream switch costs one event: recorded NOW on the previous call's stream (i.e. behind all its work),
     // awaited by this call's stream.  Calls that stay on one stream pay nothing.
-    if (m->have_last && m->last_stream != s) {
+    // The FIRST switch records the event on the previous call's stream (which must still exist: include/farnn.h); from then on
+    // the caller is known to alternate streams and every call leaves the handle's event behind itself on its OWN stream, so the
+    // previous stream is never touched again.  A call that is being captured into a graph is not ordered against other streams.
+    hipStreamCaptureStatus cap_ = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap_) != hipSuccess || cap_ != hipStreamCaptureStatusNone;
+    if (m->have_last && m->last_stream != s && !capturing) {
         if (!m->ev_order) FARNN_HIP_TRY(hipEventCreateWithFlags(&m->ev_order, hipEventDisableTiming));
-        FARNN_HIP_TRY(hipEventRecord(m->ev_order, m->last_stream));
+        if (!m->multi_stream) FARNN_HIP_TRY(hipEventRecord(m->ev_order, m->last_stream));
         FARNN_HIP_TRY(hipStreamWaitEvent(s, m->ev_order, 0));
+        m->multi_stream = true;
     }
     m->last_stream = s; m->have_last = true;
+    struct LeaveEvent {            // (multi-stream callers only) the handle's event behind this call's work, on this call's stream
+        farnn_model *m; hipStream_t s; bool on;
+        ~LeaveEvent() { if (on && m->ev_order) (void)hipEventRecord(m->ev_order, s); }
+    } leave_event{m, s, m->multi_stream && !capturing};
     // the workspace arrays are strided with the CALL's L (every kernel writes whatever it later reads, pad columns
     // included), so (B, L) only have to fit the capacity: a loop whose batches vary in size or length allocates once
     if (B > m->wsB || L > m->wsL)
@@ -1848,16 +1873,20 @@ extern "C" int farnn_tag_host_submit(farnn_model *m, const int64_t *x_host, cons
     if (rc) return rc;
     FARNN_HIP_TRY(hipEventRecord(h.ev_out, m->hs_run));
     h.busy = true;
+    h.gen = (h.gen + 1) & 0x7fffffu;
     m->hnext = (slot + 1) % FARNN_HOST_SLOTS;
-    *ticket = slot;
+    *ticket = (int32_t)((unsigned)slot | (h.gen << 8));
     if (n_flat) *n_flat = total;
     return FARNN_OK;
 }
 
 extern "C" int farnn_tag_host_wait(farnn_model *m, int32_t ticket, int64_t *flat_out, int64_t *n_out) {
-    if (!m || ticket < 0 || ticket >= FARNN_HOST_SLOTS) return fail(FARNN_EINVAL, "tag_host_wait: bad ticket%s%s");
-    farnn_model::HostSlot &h = m->hslot[ticket];
-    if (!h.busy) return fail(FARNN_EINVAL, "tag_host_wait: no batch in flight under this ticket%s%s");
+    if (!m || ticket < 0 || (ticket & 0xff) >= FARNN_HOST_SLOTS) return fail(FARNN_EINVAL, "tag_host_wait: bad ticket%s%s");
+    farnn_model::HostSlot &h = m->hslot[ticket & 0xff];
+    // (a ticket names ONE submit: slot | generation << 8.  A ticket whose batch was already waited for, or whose slot was
+    //  reclaimed and handed to a later submit, is refused -- it never consumes the newer batch.)
+    if (!h.busy || h.gen != ((unsigned)ticket >> 8))
+        return fail(FARNN_EINVAL, "tag_host_wait: no batch in flight under this ticket (stale or already waited for)%s%s");
     FARNN_HIP_TRY(hipSetDevice(m->device));
     FARNN_HIP_TRY(hipEventSynchronize(h.ev_out));
     if (flat_out && h.total > 0) memcpy(flat_out, h.flat_pin, (size_t)h.total * 8);

@@ -9,7 +9,7 @@
 //     state's two entries (own direction's row and the other's, both in LDS);
 //   * a segmented inclusive scan over the lanes adds up each label's run: six v_fmac_f32 with a DPP operand per register
 //     (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31), x[j] += x[j - d] * cf[j] with cf = 1 where lane j - d holds the same label and
-//     0 where it does not -- the coefficients are per-lane constants of the model, loaded once;
+//     0 where it does not -- the coefficients are per-lane constants of the model (one packed word per state, two VGPRs);
 //   * the last lane of a run holds the label's score.  Arg-max decode (model_onehot.py:162-180): clamp the `oo` label, wave
 //     maximum, the FIRST lane that holds it (the lanes are sorted by label: that is torch.max's first index), against the score
 //     +0 of the first label without any state.  CRF decode: the runs' scores are scattered into the position's emission row.
@@ -24,20 +24,23 @@
 namespace farnn {
 
 constexpr int LM_MAXS = 128;         // states a label map reaches (two registers of 64 lanes)
-enum { LM_ST = 0, LM_LB = 1, LM_CF = 2, LM_CC = 8, LM_TL = 9, LM_TH = 10, LM_ROWS = 11 };
+
+// One 32-bit word per position j of the sorted states (positions 0..63: register 0, 64..127: register 1):
+//   bits  0- 7  the state at position j (pads: 0 -- a valid address; every coefficient of a pad is zero)
+//   bits  8-16  its label
+//   bits 17-22  scan step d (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) may add its source lane: same label
+//   bit  23     position j >= 64 continues the run that position 63 ends
+//   bit  24     j ends a run: the label's score lands here
+constexpr int LM_LB_SHIFT = 8, LM_CF_SHIFT = 17, LM_CC_BIT = 23, LM_TL_BIT = 24;
 
 struct LabelMap {
-    const unsigned *tab;     // [LM_ROWS][128] 32-bit words per position j (positions 0..63: register 0, 64..127: register 1):
-                             //   LM_ST   state at position j (pads: 0 -- a valid address; their coefficients are all zero)
-                             //   LM_LB   its label (pads: K + j, distinct and above every label)
-                             //   LM_CF+d 1.0f if the scan's step d may add its source lane (same label), else 0.0f
-                             //   LM_CC   1.0f if position j >= 64 continues the run that position 63 ends
-                             //   LM_TL   +0.0f if j ends a run (a label's score lands here), else -inf
-                             //   LM_TH   the clamp of j's label: the threshold for the clamped column, else +inf
+    const unsigned *tab;     // [128] packed words
     int on;                  // 0: the output matrix is not a label map (tab unused)
     int nq;                  // registers in use: 1 (<= 64 labelled states) or 2
     int e0;                  // the first label without any state (its score is +0), -1: none
     float z0;                // that label's clamped score
+    int clampcol;            // the column whose score is capped at the threshold (K - 1; K - 3 under a CRF)
+    float threshold;
 };
 
 struct LabelMapRegs {
@@ -45,27 +48,35 @@ struct LabelMapRegs {
     float c0[6], c1[6], cc1, tl0, tl1, th0, th1;
 };
 
-__device__ __forceinline__ void lm_load(const LabelMap &lm, int lane, LabelMapRegs &r) {
-    const unsigned *t = lm.tab + lane;
-    r.st0 = (int)t[LM_ST * 128]; r.st1 = (int)t[LM_ST * 128 + 64];
-    r.lb0 = (int)t[LM_LB * 128]; r.lb1 = (int)t[LM_LB * 128 + 64];
+// this lane's two packed words (a wavefront keeps them from the kernel's start: two VGPRs) ...
+__device__ __forceinline__ void lm_load_packed(const LabelMap &lm, int lane, unsigned &pk0, unsigned &pk1) {
+    pk0 = lm.tab[lane];
+    pk1 = lm.tab[64 + lane];
+}
+// ... and what a token's scan needs of them, unpacked when the scoring starts (~50 instructions)
+__device__ __forceinline__ void lm_unpack(const LabelMap &lm, unsigned pk0, unsigned pk1, LabelMapRegs &r) {
+    r.st0 = (int)(pk0 & 0xffu); r.st1 = (int)(pk1 & 0xffu);
+    r.lb0 = (int)((pk0 >> LM_LB_SHIFT) & 0x1ffu); r.lb1 = (int)((pk1 >> LM_LB_SHIFT) & 0x1ffu);
 #pragma unroll
     for (int d = 0; d < 6; d++) {
-        r.c0[d] = __uint_as_float(t[(LM_CF + d) * 128]);
-        r.c1[d] = __uint_as_float(t[(LM_CF + d) * 128 + 64]);
+        r.c0[d] = ((pk0 >> (LM_CF_SHIFT + d)) & 1u) ? 1.0f : 0.0f;
+        r.c1[d] = ((pk1 >> (LM_CF_SHIFT + d)) & 1u) ? 1.0f : 0.0f;
     }
-    r.cc1 = __uint_as_float(t[LM_CC * 128 + 64]);
-    r.tl0 = __uint_as_float(t[LM_TL * 128]); r.tl1 = __uint_as_float(t[LM_TL * 128 + 64]);
-    r.th0 = __uint_as_float(t[LM_TH * 128]); r.th1 = __uint_as_float(t[LM_TH * 128 + 64]);
+    r.cc1 = ((pk1 >> LM_CC_BIT) & 1u) ? 1.0f : 0.0f;
+    r.tl0 = ((pk0 >> LM_TL_BIT) & 1u) ? 0.0f : -INFINITY;
+    r.tl1 = ((pk1 >> LM_TL_BIT) & 1u) ? 0.0f : -INFINITY;
+    r.th0 = r.lb0 == lm.clampcol ? lm.threshold : INFINITY;
+    r.th1 = r.lb1 == lm.clampcol ? lm.threshold : INFINITY;
+}
+__device__ __forceinline__ void lm_load(const LabelMap &lm, int lane, LabelMapRegs &r) {
+    unsigned pk0, pk1;
+    lm_load_packed(lm, lane, pk0, pk1);
+    lm_unpack(lm, pk0, pk1, r);
 }
 
-// The candidates of one token: y0 / y1 = the clamped score of label lb0 / lb1 at the lanes that end a run, -inf elsewhere.
-// own / oth: the two directions' state rows of the token (LDS).
-__device__ __forceinline__ void lm_token_scores(const LabelMap &lm, const LabelMapRegs &r, const float *own, const float *oth,
-                                                float &y0, float &y1) {
-    float x0 = own[r.st0] * oth[r.st0];
-    float x1 = 0.0f;
-    if (lm.nq > 1) x1 = own[r.st1] * oth[r.st1];
+// The candidates of one token from its products x0 / x1 = a[s] * b[s] of this lane's states (x1: 0 when one register is in use):
+// y0 / y1 = the clamped score of label lb0 / lb1 at the lanes that end a run, -inf elsewhere.
+__device__ __forceinline__ void lm_scan_scores(const LabelMapRegs &r, float x0, float x1, float &y0, float &y1) {
     // x[j] += x[j - d] * cf_d[j]: the segmented scan, both registers interleaved (a DPP read of a VGPR needs two wait states
     // behind the instruction that wrote it: the other register's step and one s_nop)
     asm volatile("s_nop 1\n\t"
@@ -98,12 +109,89 @@ __device__ __forceinline__ void lm_token_scores(const LabelMap &lm, const LabelM
     y1 = fminf(x1 + r.tl1, r.th1);
 }
 
-// local_decode (model_onehot.py:162-180) of one token: the first index of the maximum of the clamped scores, K-1 -> o_idx.
-// Wave-uniform result.
-__device__ __forceinline__ int lm_token_tag(const LabelMap &lm, const LabelMapRegs &r, const float *own, const float *oth,
-                                            const int K, const int o_idx) {
+// The same for TWO tokens at once: the four registers' scan steps interleave, so no DPP read waits for the instruction before it
+// (two wait states) and a lone wavefront's issue slots carry two tokens' dependency chains instead of one and s_nops.
+__device__ __forceinline__ void lm_scan_scores2(const LabelMapRegs &r, float xa0, float xa1, float xb0, float xb1,
+                                                float &ya0, float &ya1, float &yb0, float &yb1) {
+#define FARNN_LM_STEP(CTRL, C0, C1)                                                            \
+    "v_fmac_f32_dpp %0, %0, " C0 " " CTRL "\n\t"                                               \
+    "v_fmac_f32_dpp %1, %1, " C1 " " CTRL "\n\t"                                               \
+    "v_fmac_f32_dpp %2, %2, " C0 " " CTRL "\n\t"                                               \
+    "v_fmac_f32_dpp %3, %3, " C1 " " CTRL "\n\t"
+    asm volatile("s_nop 1\n\t"
+                 FARNN_LM_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0", "%4", "%10")
+                 FARNN_LM_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0", "%5", "%11")
+                 FARNN_LM_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0", "%6", "%12")
+                 FARNN_LM_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0", "%7", "%13")
+                 FARNN_LM_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf", "%8", "%14")
+                 FARNN_LM_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf", "%9", "%15")
+                 "s_nop 1"
+                 : "+v"(xa0), "+v"(xa1), "+v"(xb0), "+v"(xb1)
+                 : "v"(r.c0[0]), "v"(r.c0[1]), "v"(r.c0[2]), "v"(r.c0[3]), "v"(r.c0[4]), "v"(r.c0[5]),
+                   "v"(r.c1[0]), "v"(r.c1[1]), "v"(r.c1[2]), "v"(r.c1[3]), "v"(r.c1[4]), "v"(r.c1[5]));
+#undef FARNN_LM_STEP
+    const float ca = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xa0), 63));
+    const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xb0), 63));
+    xa1 = fmaf(ca, r.cc1, xa1);
+    xb1 = fmaf(cb, r.cc1, xb1);
+    ya0 = fminf(xa0 + r.tl0, r.th0); ya1 = fminf(xa1 + r.tl1, r.th1);
+    yb0 = fminf(xb0 + r.tl0, r.th0); yb1 = fminf(xb1 + r.tl1, r.th1);
+}
+
+// own / oth: the two directions' state rows of the token (LDS)
+__device__ __forceinline__ void lm_token_scores(const LabelMap &lm, const LabelMapRegs &r, const float *own, const float *oth,
+                                                float &y0, float &y1) {
+    const float x0 = own[r.st0] * oth[r.st0];
+    float x1 = 0.0f;
+    if (lm.nq > 1) x1 = own[r.st1] * oth[r.st1];
+    lm_scan_scores(r, x0, x1, y0, y1);
+}
+
+// CRF decode: the token's emission row [Kp] (zeros, then every label's clamped score at its column: model_decompose.py:351-353).
+// One wavefront; `row` in LDS.  The zeros and the scores are stores of the same wavefront: the LDS keeps their order.
+__device__ __forceinline__ void lm_store_emissions(const LabelMap &lm, const LabelMapRegs &r, float y0, float y1, float *row, int Kp, int lane) {
+    for (int c = lane; c < Kp; c += WAVE) row[c] = 0.0f;
+    asm volatile("" ::: "memory");
+    if (r.tl0 == 0.0f) row[r.lb0] = y0;
+    if (lm.nq > 1 && r.tl1 == 0.0f) row[r.lb1] = y1;
+}
+
+// local_decode (model_onehot.py:162-180) of one token from its candidates (y0 / y1 of lm_scan_scores) and their wave maximum m:
+// the first index of the maximum of the clamped scores, K-1 -> o_idx.  Wave-uniform result.
+__device__ __forceinline__ int lm_tag_from_candidates(const LabelMap &lm, const LabelMapRegs &r, const float y0, const float y1, float m,
+                                                      const int K, const int o_idx) {
+    if (lm.e0 >= 0) m = fmaxf(m, lm.z0);
+    const unsigned long long b0 = __ballot(y0 == m), b1 = __ballot(y1 == m);
+    int idx = 0x7fffffff;
+    // the lanes are sorted by label: the first lane that holds the maximum has the smallest label
+    if (b0) idx = __builtin_amdgcn_readlane(r.lb0, (int)__builtin_ctzll(b0));
+    else if (b1) idx = __builtin_amdgcn_readlane(r.lb1, (int)__builtin_ctzll(b1));
+    if (lm.e0 >= 0 && lm.z0 == m && lm.e0 < idx) idx = lm.e0;
+    if (idx >= K) idx = 0;                               // nothing compares equal (all NaN): 0, like the matrix form
+    return idx == K - 1 ? o_idx : idx;
+}
+
+// the wave maxima of two values at once (wave_max_dpp's ladder, the two chains interleaved)
+__device__ __forceinline__ void wave_max_dpp2(float &a, float &b) {
+#define FARNN_MAX2(CTRL) "v_max_f32_dpp %0, %0, %0 " CTRL "\n\tv_max_f32_dpp %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+    asm volatile("s_nop 1\n\t"
+                 FARNN_MAX2("row_shr:1 row_mask:0xf bank_mask:0xf")
+                 FARNN_MAX2("row_shr:2 row_mask:0xf bank_mask:0xf")
+                 FARNN_MAX2("row_shr:4 row_mask:0xf bank_mask:0xf")
+                 FARNN_MAX2("row_shr:8 row_mask:0xf bank_mask:0xf")
+                 FARNN_MAX2("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 FARNN_MAX2("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#undef FARNN_MAX2
+    a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+    b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b), 63));
+}
+
+__device__ __forceinline__ int lm_tag_from_products(const LabelMap &lm, const LabelMapRegs &r, const float x0, const float x1,
+                                                    const int K, const int o_idx) {
     float y0, y1;
-    lm_token_scores(lm, r, own, oth, y0, y1);
+    lm_scan_scores(r, x0, x1, y0, y1);
     float m = wave_max_dpp(fmaxf(y0, y1));
     if (lm.e0 >= 0) m = fmaxf(m, lm.z0);
     const unsigned long long b0 = __ballot(y0 == m), b1 = __ballot(y1 == m);

@@ -39,7 +39,10 @@ struct BesideParams {
     int B, L, SP, CPR;           // CPR = SP / 4
     unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
     unsigned long long *arr;     // [B]    {epoch, 1 << 31 | mask of the tiles it scores} of the workgroup that arrived last
-    unsigned epoch;
+    unsigned long long *done;    // sequences whose SECOND workgroup has arrived, over all launches since the words were zeroed: a launch's
+                                 // epoch is done / B + 1, read from device memory by every workgroup at its start (beside.hip.h,
+                                 // bs_launch_epoch) -- nothing per launch comes from the host, so a captured launch replays correctly
+    unsigned epoch;              // (filled in by the kernel from `done`)
     int spin;                    // polls a finished workgroup spends on the tiles of its own half before it leaves them to the other
     int dbg;                     // FARNN_DBG probe mask: read by the profiling build (-DFARNN_PROBES) only
     ScoreParams sp;

@@ -97,6 +97,42 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         const int need = (n * Kp * 4 + 1023) / 1024;
         for (int k = wu; k < need; k += nwaves)
             lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(sc), lds0 + (unsigned)k * 1024u);
+    } else if (p.lm.on) {
+        // the output matrix is a label map (label_map.hip.h): a wavefront turns a token's two state rows into its emission row in
+        // ~50 instructions -- no products staged, no matrix-core pass, no image of the output matrix
+        const int SP = p.SP;
+        LabelMapRegs lr;
+        lm_load(p.lm, lane, lr);
+        if (ldsF) {
+            for (int tok = wu; tok < n; tok += nwaves) {
+                float y0, y1;
+                lm_token_scores(p.lm, lr, ldsF + (tok + 1) * SP, ldsB + (n - (tok + 1)) * SP, y0, y1);
+                lm_store_emissions(p.lm, lr, y0, y1, scl + (size_t)tok * Kp, Kp, lane);
+            }
+        } else {
+            // rows from the stash: every load of this wavefront's tokens in flight before the first is used
+            const float *Ab = p.A + (long long)b * (p.L + 1) * SP, *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
+            constexpr int NT = 4;                        // tokens per batch
+            for (int t0 = wu * NT; t0 < n; t0 += nwaves * NT) {
+                float a0[NT], b0[NT], a1[NT], b1[NT];
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const int tok = t0 + u < n ? t0 + u : n - 1;
+                    const float *ar = Ab + (long long)(tok + 1) * SP, *br = Bb + (long long)(n - (tok + 1)) * SP;
+                    a0[u] = ar[lr.st0]; b0[u] = br[lr.st0];
+                    a1[u] = ar[lr.st1]; b1[u] = br[lr.st1];
+                }
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    if (t0 + u >= n) break;
+                    float y0, y1;
+                    lm_scan_scores(lr, a0[u] * b0[u], p.lm.nq > 1 ? a1[u] * b1[u] : 0.0f, y0, y1);
+                    lm_store_emissions(p.lm, lr, y0, y1, scl + (size_t)(t0 + u) * Kp, Kp, lane);
+                }
+            }
+        }
+        __syncthreads();
+        if (probe) { pa = (long long)__builtin_amdgcn_s_memtime(); pb = pa; }
     } else {
         const int SP = p.SP, SP4 = SP >> 2, Lq = ((p.L + 3) & ~3) + 16;   // row stride of the products: the four state rows of an
                                                                             // A-fragment read land in different banks (L = 64: 80)

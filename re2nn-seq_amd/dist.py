@@ -32,13 +32,12 @@ def balanced_assignment(lengths, world_size):
     rank's time is its longest chain, then its token count).  Deterministic: every rank derives the same assignment from
     the replicated `lengths`.  Returns a list of W int64 index tensors (rank r tags x[idx[r]])."""
     n = int(lengths.shape[0])
-    lens = lengths.detach().to('cpu', torch.int64)
-    order = sorted(range(n), key=lambda i: (-int(lens[i]), i))
-    per = [[] for _ in range(world_size)]
-    for i, idx in enumerate(order):
-        rnd, pos = divmod(i, world_size)
-        per[pos if rnd % 2 == 0 else world_size - 1 - pos].append(idx)
-    return [torch.tensor(sorted(p), dtype=torch.int64) for p in per]
+    lens = lengths.detach().to('cpu', torch.int64)                 # (one device sync; everything after it is vectorised)
+    order = torch.sort(lens, descending=True, stable=True).indices           # longest first, ties by index
+    i = torch.arange(n, dtype=torch.int64)
+    rnd, pos = torch.div(i, world_size, rounding_mode='floor'), i % world_size
+    rank_of = torch.where(rnd % 2 == 0, pos, world_size - 1 - pos)           # the rank that is dealt the i-th longest sequence
+    return [torch.sort(order[rank_of == r]).values for r in range(world_size)]
 
 
 def shard_batch_balanced(x, lengths, rank=None, world_size=None):
@@ -64,11 +63,11 @@ def gather_tags_balanced(local_tags, assign, n_total, group=None):
         buf = torch.cat([buf, pad], dim=0)
     out = torch.empty((w * biggest, L), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
-    res = torch.empty((n_total, L), dtype=buf.dtype, device=buf.device)
+    # ONE inverse-permutation gather instead of a copy per rank: row j of the batch sits at out[src[j]]
+    src = torch.empty((n_total,), dtype=torch.int64)
     for r, a in enumerate(assign):
-        if a.shape[0]:
-            res.index_copy_(0, a.to(buf.device), out[r * biggest: r * biggest + int(a.shape[0])])
-    return res
+        src[a] = r * biggest + torch.arange(int(a.shape[0]), dtype=torch.int64)
+    return out.index_select(0, src.to(buf.device))
 
 
 def shard_batch(x, lengths, rank=None, world_size=None):

@@ -28,14 +28,17 @@ class PendingLocal:
         self._owner, self._ticket, self._total, self._true = owner, ticket, total, true
         self._out_device, self._dev_result = out_device, dev_result
         self._pred = None
+        self._handle = owner._h                           # the device handle this ticket belongs to (never the lazy `handle` property)
 
     def result(self):
         if self._pred is None:
             if self._dev_result is not None:              # device tensors in: device tensors out
                 self._pred = self._dev_result.to(self._out_device)
             else:
+                if self._handle is None or self._handle is not self._owner._h:
+                    raise _lib.FarnnError('this batch was submitted to a device handle that has since been dropped (invalidate())')
                 pred = torch.empty((self._total,), dtype=torch.int64)
-                n = self._owner.handle.tag_host_wait(self._ticket, pred.data_ptr())
+                n = self._handle.tag_host_wait(self._ticket, pred.data_ptr())
                 assert n == self._total
                 self._owner._in_flight -= 1
                 self._pred = pred
@@ -43,11 +46,15 @@ class PendingLocal:
 
     def __del__(self):
         # a ticket dropped without result() (an exception in the caller's loop): wait for its batch so that the library's
-        # slot and this model's in-flight count are released (the library also reclaims a completed slot by itself)
+        # slot and this model's in-flight count are released.  Only on the handle the batch was submitted to, and only if that
+        # handle is still the model's (never build a new one here); a ticket carries its submit's generation, so a finalizer
+        # that runs late -- the slot reclaimed and handed to a newer batch meanwhile -- is refused by the library and changes nothing
         if self._pred is None and self._dev_result is None and self._ticket >= 0:
             try:
-                self._owner.handle.tag_host_wait(self._ticket, None)
-                self._owner._in_flight -= 1
+                h = self._handle
+                if h is not None and h is getattr(self._owner, '_h', None):
+                    h.tag_host_wait(self._ticket, None)
+                    self._owner._in_flight -= 1
             except Exception:
                 pass
 

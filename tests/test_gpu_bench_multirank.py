@@ -102,3 +102,29 @@ def test_bench_config5_path_two_ranks_dry_run():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 2 and d['value'] > 0 and 'DRY RUN' in d['config']['workload']
     assert d['config']['padded_tokens_per_step'] == 2 * 64 * 128
+
+
+@pytest.mark.parametrize('extra', [['--workload', 'ifst', '--batch', '32'],
+                                   ['--workload', 'synth512', '--vocab', '200', '--batch', '16', '--seqlen', '128']])
+def test_bench_eight_ranks_dry_run(extra):
+    """What the driver's `--gpus 8` run executes, on one device over gloo: eight ranks, each its own shard and handle, the
+    overlapped gather of eight blocks, max-over-ranks timing, ONE line with every rank's tokens counted and the per-rank spread
+    reported.  (Reduced batch / vocabulary so that eight replicas share one GPU; the first real 8-GPU run must not be the first
+    execution of this branch.)"""
+    env = dict(os.environ, FARNN_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '3', '--warmup', '1',
+           '--no-cpu-baseline'] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    B = int(extra[extra.index('--batch') + 1])
+    L = 128 if 'synth512' in extra else 64
+    assert d['n_gpus'] == 8 and d['value'] > 0 and d['scaling'] == 'weak'
+    assert d['config']['padded_tokens_per_step'] == 8 * B * L
+    lo, hi = d['config']['valid_tokens_per_rank_min_max']
+    assert 0 < lo <= hi and 8 * lo <= d['config']['valid_tokens_per_step'] <= 8 * hi
+    assert '8 ranks' in r.stderr

@@ -277,7 +277,10 @@ def test_tag_call_captures_into_a_hip_graph():
     with torch.cuda.graph(g, stream=side):
         h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None,
               torch.cuda.current_stream(dev).cuda_stream)
-    for seed in (1, 2, 3):
+    # the captured step is the ONE-launch form (round 4: the hand-off's epoch comes from device memory, nothing per launch from
+    # the host), i.e. a graph replays the kernel the headline is quoted on
+    assert 'fused' in h.kernel_name(_lib.KERN_CHAIN), h.kernel_name(_lib.KERN_CHAIN)
+    for seed in (1, 2, 3, 4, 5, 6, 7):
         x, lengths = synth.random_batch(V, B, L, np.random.RandomState(seed), min_len=1)
         xd.copy_(_t(x)); ld.copy_(_t(lengths))
         g.replay()
@@ -485,6 +488,39 @@ def test_host_buffer_path_matches_the_device_path():
         _, pred_dev, true_dev = m.forward_local(x.cuda(), lab.cuda(), ln.cuda(), train=False)     # device tensors in
         assert pred_dev.is_cuda and np.array_equal(pred_dev.cpu().numpy(), pred.numpy())
         assert np.array_equal(true_dev.cpu().numpy(), true.numpy())
+
+
+def test_a_stale_host_ticket_cannot_consume_a_newer_batch():
+    """A ticket names ONE submit (slot | generation << 8).  The scenario of the round-3 advice: a PendingLocal is dropped without
+    result() and its finalizer runs LATE -- after the library reclaimed its (completed) slot and handed it to a newer batch.
+    The late wait must be refused and the newer batch's result() must still work; a ticket waited for twice is refused too."""
+    import time
+    from re2nn_seq_amd import _lib, synth
+    from re2nn_seq_amd.farnn.model_onehot import FARNN_S_O_I_S
+    rng = np.random.RandomState(5)
+    V, S, C = 60, 23, 9
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    m = FARNN_S_O_I_S(T, O, W, np.zeros(S), hT, h0, None, ns(), o_idx=1)
+    mk = lambda: tuple(torch.from_numpy(a) for a in (lambda x, l: (x, np.zeros_like(x), l))(*synth.random_batch(V, 8, 10, rng, min_len=1)))   # noqa: E731
+    dropped = m.submit_local(*mk())
+    stale_ticket = dropped._ticket
+    dropped._ticket = -1                                   # "the finalizer has not run yet": keep the ticket, disarm __del__
+    others = [m.submit_local(*mk()) for _ in range(_lib.HOST_SLOTS - 1)] if hasattr(_lib, 'HOST_SLOTS') else [m.submit_local(*mk()) for _ in range(3)]
+    for p in others:
+        p.result()
+    time.sleep(0.05)                                       # the dropped batch has long completed: its slot is reclaimable
+    newer_batch = mk()
+    newer = m.submit_local(*newer_batch)                   # reuses the dropped ticket's slot, with a new generation
+    assert (newer._ticket & 0xff) == (stale_ticket & 0xff) and newer._ticket != stale_ticket
+    with pytest.raises(_lib.FarnnError):
+        m.handle.tag_host_wait(stale_ticket, None)         # the late finalizer's wait: refused, consumes nothing
+    _, pred, _ = newer.result()
+    x, _, ln = newer_batch
+    ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x.numpy(), ln.numpy())
+    assert np.array_equal(pred.numpy(), fo.forward_local_tags(ref, ln.numpy(), 0.5, 1))
+    with pytest.raises(_lib.FarnnError):
+        m.handle.tag_host_wait(newer._ticket, None)        # already waited for
+    assert m._in_flight == 1                               # (only the deliberately dropped one is still counted)
 
 
 @pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (64, 9, 17, 5), (65, 130, 9, 3), (71, 128, 64, 40),
