@@ -23,6 +23,20 @@
  *     call's stream must still exist (the library records its ordering event there); from then on every call leaves the
  *     handle's own event behind itself and earlier streams are never touched again.  A call that is being captured into a
  *     HIP graph is not ordered against other streams.
+ *
+ * Environment switches (read ONCE per handle, when farnn_*_create / farnn_train_create builds it; no call on the tagging path
+ * touches the environment).  Every one selects between code paths that the test suite holds to the same results:
+ *   FARNN_NOFUSE=1          the multi-launch forms (recurrence kernel, then score / Viterbi kernel) instead of one launch per step
+ *   FARNN_NOREGS=1          the LDS-ring recurrence kernel where the register-fed one (S <= 128) would run
+ *   FARNN_NOLABELMAP=1      scores on the matrix cores even when the output matrix is a label map (one state, one label, weight 1)
+ *   FARNN_CV_WIDE=1         72 < S <= 108 with a CRF: recurrence + scores + Viterbi in ONE launch (default there: two, which is faster)
+ *   FARNN_CV_STASH=1        the one-launch CRF kernel with the state rows through the stash instead of LDS
+ *   FARNN_VITERBI_BP=1 / FARNN_VITERBI_UNFUSED=1   the stored-back-pointer Viterbi kernel / scores through HBM in front of it
+ *   FARNN_PREP=1, FARNN_NOSORT=1                   the separate batch-prep kernel / the batch's own launch order
+ *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1, FARNN_DECOMP_OLD=1   the decomposed recurrence's earlier kernels
+ *   FARNN_TRAIN_NOLDS=1|2, FARNN_TRAIN_NSEQ=2|4    training chains with the matrices read through L2 / sequences per workgroup
+ * Diagnostic switches (ablations, geometry overrides: FARNN_DBG, FARNN_KS, FARNN_RPG, FARNN_NLD, FARNN_FUSE_SPIN, FARNN_SOLO_MARGIN,
+ * ...) exist only in the profiling build of the library (csrc/build.py --probes); the production library ignores them.
  */
 #ifndef FARNN_H
 #define FARNN_H

@@ -30,12 +30,27 @@ static float nlf(float v, int nl) {            /* model_onehot.py:379-386 */
 }
 
 /* Tf = T + W premixed [V,S,S]; O [C,S]; x [B,L]; len [B]; tags [B,L] (-1 at pads);
- * scores [B,L,C] or NULL (zero at pads). semiring: 0 sum, 1 max. Returns threads used. */
-int oracle_onehot_ifst_tag(const float *Tf, const float *O, const float *h0, const float *hT,
-                           int V, int S, int C, const int64_t *x, const int64_t *len, int B, int L,
-                           int nl, int semiring, float threshold, int o_idx, int32_t *tags,
-                           float *scores, int nthreads) {
+ * scores [B,L,C] or NULL (zero at pads). semiring: 0 sum, 1 max. Returns threads used.
+ * reps > 1 (bench.py's cpu_baseline only): the same batch `reps` times inside ONE parallel region -- the thread team stays hot
+ * between passes (libgomp's barriers spin), so the rate is the steady state of a serving loop on all host cores and not the
+ * fork / wake-up latency of a 256-thread team per 2 ms batch (which is where the round-3 port stopped scaling, at 16 threads). */
+int oracle_onehot_ifst_tag_reps(const float *Tf, const float *O, const float *h0, const float *hT,
+                                int V, int S, int C, const int64_t *x, const int64_t *len, int B, int L,
+                                int nl, int semiring, float threshold, int o_idx, int32_t *tags,
+                                float *scores, int nthreads, int reps) {
     (void)V;
+    /* the 2B chains longest first (counting sort by length): with dynamic scheduling no thread is handed a 64-step chain last */
+    int *order = (int *)malloc(sizeof(int) * 2 * (size_t)B);
+    {
+        int *cnt = (int *)calloc((size_t)L + 2, sizeof(int));
+        for (int b = 0; b < B; b++) { int n = (int)len[b]; n = n < 0 ? 0 : (n > L ? L : n); cnt[L - n + 1] += 2; }
+        for (int i = 1; i <= L + 1; i++) cnt[i] += cnt[i - 1];
+        for (int b = 0; b < B; b++) {
+            int n = (int)len[b]; n = n < 0 ? 0 : (n > L ? L : n);
+            order[cnt[L - n]++] = 2 * b; order[cnt[L - n]++] = 2 * b + 1;
+        }
+        free(cnt);
+    }
     float *o = (float *)calloc((size_t)S, sizeof(float));
     for (int c = 0; c < C; c++)                        /* :368 (CE1) */
         for (int s = 0; s < S; s++) o[s] += O[(size_t)c * S + s];
@@ -52,12 +67,14 @@ int oracle_onehot_ifst_tag(const float *Tf, const float *O, const float *h0, con
     {
         float *tmp = (float *)malloc(sizeof(float) * (size_t)S);
         float *sc = (float *)malloc(sizeof(float) * (size_t)C);
+        for (int rep_ = 0; rep_ < (reps > 1 ? reps : 1); rep_++) {
         /* phase 1: the 2B independent chains (sequence x direction), longest first would be the GPU's order;
          * dynamic scheduling balances the ragged lengths here */
 #ifdef _OPENMP
 #pragma omp for schedule(dynamic, 1)
 #endif
-        for (int item = 0; item < 2 * B; item++) {
+        for (int it_ = 0; it_ < 2 * B; it_++) {
+            const int item = order[it_];
             const int b = item >> 1, dir = item & 1;
             const int n = (int)len[b];
             const int64_t *xb = x + (size_t)b * L;
@@ -123,11 +140,19 @@ int oracle_onehot_ifst_tag(const float *Tf, const float *O, const float *h0, con
             if (so) memcpy(so, sc, sizeof(float) * C);
             if (tg) *tg = (best == C - 1) ? o_idx : best;                  /* :169 */
         }
+        }   /* reps (the omp for's implicit barrier separates a pass's scoring from the next pass's chains) */
         free(tmp); free(sc);
     }
     free(A); free(BT);
-    free(o);
+    free(o); free(order);
     return used;
+}
+
+int oracle_onehot_ifst_tag(const float *Tf, const float *O, const float *h0, const float *hT,
+                           int V, int S, int C, const int64_t *x, const int64_t *len, int B, int L,
+                           int nl, int semiring, float threshold, int o_idx, int32_t *tags,
+                           float *scores, int nthreads) {
+    return oracle_onehot_ifst_tag_reps(Tf, O, h0, hT, V, S, C, x, len, B, L, nl, semiring, threshold, o_idx, tags, scores, nthreads, 1);
 }
 
 int oracle_max_threads(void) {

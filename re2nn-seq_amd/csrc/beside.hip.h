@@ -446,6 +446,9 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
 #else
 #define FARNN_BS_STAMP(i) do { } while (0)
 #endif
+#if defined(FARNN_PROBES)
+    __shared__ long long bs_arrive[16];                              // when each wavefront reached the meeting barrier
+#endif
     FARNN_BS_STAMP(0);
     if (w == WDEC) {
         // which tiles of this half can be scored now: those the other direction's progress, as covered by an acquire, allows
@@ -483,6 +486,9 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
     for (; rep < 2; rep++) {
     const bool dry = rep == 0;                                       // (WARM: see above)
     if (!dry) {
+#if defined(FARNN_PROBES)
+    if (lane == 0) bs_arrive[w] = (long long)__builtin_amdgcn_s_memtime();
+#endif
     wg_barrier_lds();                                                // the chain is done, the mask is there (LDS only: this wavefront's
                                                                      // O^T loads and the writer's last stores stay in flight)
     FARNN_BS_STAMP(1);
@@ -553,9 +559,15 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
     }
     }
 #if defined(FARNN_PROBES)
-    if (fprobe && lane == 0)
+    if (fprobe && lane == 0) {
         printf("finish seq %d dir %d: decide + meet %lld, own tiles %lld, barrier + publish %lld, arrival known + sweep decision %lld, to the end %lld\n", b, dir,
                fq[1] - fq[0], fq[2] - fq[1], fq[3] - fq[2], fq[4] - fq[3], (long long)__builtin_amdgcn_s_memtime() - fq[4]);
+        long long lo = bs_arrive[0];
+        for (int i = 1; i < NWV; i++) lo = bs_arrive[i] < lo ? bs_arrive[i] : lo;
+        printf("meet seq %d dir %d: wavefronts reach the barrier at +%lld %lld %lld %lld %lld %lld %lld %lld (first = 0), released at +%lld\n", b, dir,
+               bs_arrive[0] - lo, bs_arrive[1 % NWV] - lo, bs_arrive[2 % NWV] - lo, bs_arrive[3 % NWV] - lo, bs_arrive[4 % NWV] - lo,
+               bs_arrive[5 % NWV] - lo, bs_arrive[6 % NWV] - lo, bs_arrive[7 % NWV] - lo, fq[1] - lo);
+    }
 #endif
 #undef FARNN_BS_STAMP
 }

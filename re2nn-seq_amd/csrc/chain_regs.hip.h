@@ -68,7 +68,7 @@ __device__ __forceinline__ int lds_flag_get(const int *f) {
 // buffer the step wrote (wavefront i: float 4 i of the buffer's flag area, `fbase` in buffer 0), stored by the same
 // ds_write_b128 as the partial sums.  Writer / scorer count state rows by them: row t + 1 of `hist` is complete once every
 // wavefront's newer flag reads t + 2, or nsteps + 1 after the last step.
-// (PSTR: floats between the two partial-sum buffers -- RG_PART_STRIDE, or RGW_PART_STRIDE in the wide form)
+// (PSTR: floats between the two partial-sum buffers -- RG_PART_STRIDE, or rgw_part_stride(RQ) in the wide form)
 template <int PSTR = RG_PART_STRIDE>
 __device__ __forceinline__ int regs_flag_newest(const float *fbase, int lane) {
     const int *f = reinterpret_cast<const int *>(fbase) + 4 * (lane < RG_NWC ? lane : 0);
@@ -118,7 +118,7 @@ namespace farnn {
 template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D>
 __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem, const int tid, const int item, int *b_out) {
     constexpr bool WIDE = RQ != RG_RQ;
-    constexpr int PSTR = WIDE ? RGW_PART_STRIDE : RG_PART_STRIDE;     // floats between the two partial-sum buffers
+    constexpr int PSTR = WIDE ? rgw_part_stride(RQ) : RG_PART_STRIDE;     // floats between the two partial-sum buffers
     constexpr int NG = WIDE ? RGW_NG : RG_NG;                         // state groups of 16 the scoring stage reaches
     const int lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -127,7 +127,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     const int dir = item & 1, slot = item >> 1;
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
     const int PS = WIDE ? p.PS : SP;                                  // floats between two partial-sum vectors
-    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, WIDE);
+    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, RQ);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
     float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
     float *ab = smem + lds.ab, *scl = smem + lds.scl, *obuf = smem + lds.obuf;

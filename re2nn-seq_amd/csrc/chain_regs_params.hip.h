@@ -20,7 +20,9 @@ constexpr int RGW_G = 2;                       // row groups per compute wavefro
 constexpr int RGW_NP = RG_NWC * RGW_G;         // partial-sum vectors per step
 constexpr int RGW_MAXSP = 128;
 constexpr int RGW_MAXRQ = 11;                  // rows per lane per step the instantiations reach (12 groups x 11 rows >= 128)
-constexpr int RGW_PART_STRIDE = 2048;          // floats between the two partial-sum buffers (12 vectors of <= 144 floats, flags, dump slots)
+// floats between the two partial-sum buffers of the wide form: 12 vectors of PS floats, six flag slots, the idle lanes' dump slots,
+// the identity word.  RQ <= 9 means SP <= 108, PS = 112 (1 344 + 24 + <= 104 floats); RQ = 11: PS <= 144
+__host__ __device__ constexpr int rgw_part_stride(int rq) { return rq <= 9 ? 1536 : 2048; }
 constexpr int RGW_XCH = 32;                    // floats of a compute wavefront's state-exchange area (2 groups x 12 rows)
 
 struct RegsParams {
@@ -78,7 +80,7 @@ inline RegsGeom regs_geometry(int S) {
         g.D = 4;
         g.rows = g.NP * g.RPG;                      // (a lane's row slots past RPG re-read its last row: nothing beyond NP * RPG rows)
         g.PS = ((g.SP + 15) & ~31) + 16;            // >= SP, = 16 mod 32
-        g.ok = g.RPG <= RGW_MAXRQ && g.NP * g.PS + 4 * RG_NWC + 4 * (64 - g.G * g.CPR) < RGW_PART_STRIDE;
+        g.ok = g.RPG <= RGW_MAXRQ && g.NP * g.PS + 4 * RG_NWC + 4 * (64 - g.G * g.CPR) < rgw_part_stride(g.RQ);
     }
     return g;
 }
@@ -87,12 +89,14 @@ inline RegsGeom regs_geometry(int S) {
 struct RegsLds {
     int tok, hp, part, ol, hist, ab, scl, obuf, misc, xch, total;
 };
-__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, bool wide = false) {
+// rq: rows per lane and step of the form (RG_RQ: S <= 72; larger: the wide form, whose partial-sum buffers and exchange area differ)
+__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, int rq = RG_RQ) {
+    const bool wide = rq != RG_RQ;
     RegsLds l;
     int at = 0;
     l.tok = at;  at += 2 * ((L + 1) & ~1);             // a 64-bit block offset per step
     l.hp = at;
-    l.part = at; at += 2 * (wide ? RGW_PART_STRIDE : RG_PART_STRIDE) + 64 * 4;     // two partial-sum buffers + the idle lanes' dump slots
+    l.part = at; at += 2 * (wide ? rgw_part_stride(rq) : RG_PART_STRIDE) + 64 * 4;     // two partial-sum buffers + the idle lanes' dump slots
     l.ol = at;   at += SP;
     l.hist = at; at += (L + 1) * SP + 16;          // + the launch-order scratch's tail
     l.ab = at;   at += score ? 2 * RG_TT * (16 * c16 + 4) : 0;    // two tiles' products
@@ -111,7 +115,7 @@ int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s
 
 // chain_viterbi.hip: the two chains of a sequence and its scores + CRF decode in ONE workgroup, one launch per tagging step
 // (p.prog / p.arr / p.epoch unused).  chain_viterbi_fits: tag sets of 32..159 labels whose decode fits the LDS.
-bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp, bool label_map);
+bool chain_viterbi_fits(int L, int SP, int NP, int K, int Kp, bool label_map, int rq = RG_RQ);
 int launch_chain_viterbi(const RegsParams &p, const ScoreParams &sp, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 
 }  // namespace farnn

@@ -11,7 +11,7 @@
 namespace farnn {
 
 int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = (size_t)regs_lds(p.L, p.SP, RGW_NP, p.sp.c16, p.sp.Kc, score, true).total * sizeof(float);
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, RGW_NP, p.sp.c16, p.sp.Kc, score, p.RQ).total * sizeof(float);
     const dim3 grid(2 * p.B), block(RG_WAVES * 64);
     int rc;
     const bool nlx = p.nl != FARNN_NL_NONE && p.nl != FARNN_NL_RELU;

@@ -37,7 +37,7 @@ __device__ __forceinline__ void regs_compute_wide(const RegsParams &p, const int
                                                   const long long *tokoff, float *part, const float *ol, float *hist, float *xch) {
     static_assert(RQ == 8 || RQ == 9 || RQ == 11, "the ring's wait statements are written out for 8, 9 and 11 rows per lane");
     static_assert(D == 2 || D == 4, "an even ring depth that divides 64 (the two partial-sum buffers and the address window)");
-    constexpr int PSTR = RGW_PART_STRIDE;
+    constexpr int PSTR = rgw_part_stride(RQ);
     constexpr int G = RGW_G, NP = RGW_NP;
     constexpr int NQ4 = (RQ + 3) / 4;                    // 16-byte reads of the exchanged state entries
     constexpr int NQI = NP / 2;                          // partial sums per reducing lane (two lanes per row)

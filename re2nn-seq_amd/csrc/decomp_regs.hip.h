@@ -598,12 +598,12 @@ inline bool regs_has_geometry(int nch2, int nch3, int np3, int cs) {
 // Can the register kernel serve this model?  (farnn = 0, rank <= 64 so that P2 is one pass, an instantiated geometry)
 inline bool regs_plan(const DecompRowsPack &k, const DecompWeights &w, int L, RegsPlan &pl) {
     if (!k.ok || w.farnn != 0 || k.n1 != 0 || k.n2 != w.R || k.n3 != w.S || w.R > DG_ROWS) return false;
-    if (getenv("FARNN_DECOMP_NOREGS")) return false;
+    if (tun(TUN_DECOMP_NOREGS)) return false;
     pl.nch2 = k.nch2; pl.nch3 = k.nch3; pl.np3 = (w.S + DG_ROWS - 1) / DG_ROWS;
     pl.cs = (w.Rp + DR_CHUNK - 1) / DR_CHUNK;
     // the eight-lanes-per-row form (half the LDS reads per step) where it is instantiated: S in 65..128, R <= 64
     pl.np2 = (w.R + 31) / 32;
-    pl.eight = !getenv("FARNN_DECOMP_FOUR") && (pl.nch2 == 3 || pl.nch2 == 4) && pl.np2 >= 1 && pl.np2 <= 2 &&
+    pl.eight = !tun(TUN_DECOMP_FOUR) && (pl.nch2 == 3 || pl.nch2 == 4) && pl.np2 >= 1 && pl.np2 <= 2 &&
                (w.Rp + 31) / 32 == pl.np2 && (w.S + 31) / 32 == pl.nch2 && (pl.nch3 == pl.nch2 + pl.np2 || pl.nch3 == pl.nch2 + pl.np2 - 1);
     if (!pl.eight && !regs_has_geometry(pl.nch2, pl.nch3, pl.np3, pl.cs)) return false;
     const int Lr = (L + 3) & ~3;
@@ -631,7 +631,7 @@ inline int launch_decomp_regs(const DecompRowsPack &k, const DecompWeights &w, c
     p.ld2 = k.ld2; p.ld3 = k.ld3;
     p.Vgen = w.Vgen; p.h0 = w.h0; p.hT = w.hT; p.x = x; p.len = len; p.order = order; p.sort = sort; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.nl = w.nl; p.full = full; p.V = w.V;
-    { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = tun(TUN_DBG);
 #define FARNN_REGS8_CASE(A_, B_, C_)                                                                          \
     if (pl.eight && pl.nch2 == A_ && pl.nch3 == B_ && pl.np2 == C_) {                                         \
         if (bs) {                                                                                             \

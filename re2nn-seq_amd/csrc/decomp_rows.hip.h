@@ -614,9 +614,8 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
 }
 
 inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, int L, RowsPlan &pl) {
-    const bool forms = !getenv("FARNN_ROWS_NOREGS");
-    if (const char *e = getenv("FARNN_ROWS_NSEQ")) {
-        const int v = atoi(e);
+    const bool forms = !tun(TUN_ROWS_NOREGS);
+    if (const int v = tun(TUN_ROWS_NSEQ)) {
         if (v == 1 || v == 2 || v == 4) {
             for (int n = v; n >= 1; n /= 2)
                 if (rows_plan_try(k, w, L, n, forms, pl)) return true;
@@ -660,7 +659,7 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     p.x = x; p.len = len; p.order = order; p.sort = sort_in_kernel; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;
     p.full = full; p.V = w.V; p.sig_k = w.sig_k;
-    { const char *e = getenv("FARNN_DBG"); p.dbg = e ? atoi(e) : 0; }
+    p.dbg = tun(TUN_DBG);
     p.lds_floats = (int)(pl.lds / 4);
     const int groups = (B + pl.nseq - 1) / pl.nseq;
 #define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_)>(p, groups, pl.lds, s);

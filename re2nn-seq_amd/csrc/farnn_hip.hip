@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.hip.h"
+#include "host_util.hip.h"
 #include "chain.hip.h"
 #include "score_decode.hip.h"
 #include "layout.hip.h"
@@ -24,6 +25,7 @@
 
 namespace farnn {
 thread_local char g_err[512] = "";
+thread_local const Tunables *g_tun = nullptr;
 }
 using namespace farnn;
 
@@ -43,6 +45,7 @@ struct Prof {
 };
 
 struct farnn_model {
+    Tunables tun;                           // the FARNN_* switches as they stood when the handle was created (host_util.hip.h)
     int kind = 0, device = 0;
     int V = 0, S = 0, SP = 0, C = 0, K = 0, Kp = 0, Kc = 0, R = 0, Rp = 0;
     int nl = 0, semiring = 0, o_idx = 0, use_crf = 0, farnn_gate = 0, mask_by_output = 0;
@@ -179,7 +182,7 @@ static int upload_transposed(farnn_model *m, float **dst, const float *src, int 
 // the dense-block recurrence's geometries: the ring kernel's (chain.hip.h) and the register-fed kernel's (chain_regs.hip.h);
 // the blocks get enough zero rows for either
 static void pick_chain_geometry(farnn_model *m) {
-    m->geom = chain_geometry(m->S, env_int("FARNN_RPG", 12), env_int("FARNN_NLD", 4));
+    m->geom = chain_geometry(m->S, tun(TUN_RPG), tun(TUN_NLD));
     m->rgeom = regs_geometry(m->S);
     if (m->rgeom.SP != m->geom.SP) m->rgeom.ok = false;
     if (m->rgeom.ok && m->rgeom.rows > m->geom.SR) m->geom.SR = m->rgeom.rows;
@@ -223,7 +226,7 @@ static int build_ot_image(farnn_model *m) {
 // states.  Read back from the final OT[S][Kc] (a few KB), sorted by (label, state) on the host, uploaded as one table.
 static int build_label_map(farnn_model *m) {
     m->lm.on = 0;
-    if (!m->OT || m->S > 1024 || env_int("FARNN_NOLABELMAP", 0)) return FARNN_OK;
+    if (!m->OT || m->S > 1024 || tun(TUN_NOLABELMAP)) return FARNN_OK;
     std::vector<float> ot((size_t)m->S * m->Kc);
     FARNN_HIP_TRY(hipMemcpy(ot.data(), m->OT, ot.size() * 4, hipMemcpyDeviceToHost));
     std::vector<std::pair<int, int>> pos;                // (label, state)
@@ -321,6 +324,7 @@ static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_m
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_IFST; m->device = device;
     m->V = d->V; m->S = d->S; m->C = d->C;
     m->use_crf = d->use_crf ? 1 : 0;
@@ -328,7 +332,7 @@ static int ifst_create_impl(const farnn_onehot_ifst_desc *d, int device, farnn_m
     m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = d->nl; m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     pick_chain_geometry(m);
-    m->chain_ks = env_int("FARNN_KS", 3);
+    m->chain_ks = tun(TUN_KS);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -412,6 +416,7 @@ extern "C" int farnn_set_compact(farnn_model *m, int32_t enable) {
 extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     if (!m || B <= 0 || L <= 0) return fail(FARNN_EINVAL, "reserve: bad arguments%s%s");
     if (B <= m->wsB && L <= m->wsL) return FARNN_OK;
+    TunScope tun_scope(&m->tun);
     FARNN_HIP_TRY(hipSetDevice(m->device));
     int nB = B > m->wsB ? B : m->wsB, nL = L > m->wsL ? L : m->wsL;
     if (m->A) {
@@ -506,6 +511,7 @@ extern "C" int farnn_kernel_time(farnn_model *m, int32_t which, double *total_ms
 
 extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     if (!m) return "";
+    TunScope tun_scope(&m->tun);
     switch (which) {
         case KERN_CHAIN:
             if (m->compact_on) return "compact_chain_kernel";
@@ -515,7 +521,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
             if (m->dense_decomp) return "chain_kernel";
             if (m->kind == KIND_DECOMP && m->last_fused && m->last_wave) return "decomp_regs_kernel<fused: scores + decode beside the recurrence>";
             if (m->kind == KIND_DECOMP || m->kind == KIND_DECOMP1 || m->kind == KIND_DECOMP0)
-                return m->rows.ok ? ((m->last_wave || (m->calls == 0 && m->dw.farnn == 0 && m->dw.R <= DG_ROWS && !getenv("FARNN_DECOMP_NOREGS"))) ? "decomp_regs_kernel" : "decomp_rows_kernel") : "decomp_chain_kernel";
+                return m->rows.ok ? ((m->last_wave || (m->calls == 0 && m->dw.farnn == 0 && m->dw.R <= DG_ROWS && !tun(TUN_DECOMP_NOREGS))) ? "decomp_regs_kernel" : "decomp_rows_kernel") : "decomp_chain_kernel";
             return "chain_kernel";
         case KERN_SCORE: return m->kind == KIND_FST4 ? "fst4_score_kernel"
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
@@ -539,7 +545,7 @@ static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64
     rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
     rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
     rp.G = rg.G; rp.RPG = rg.RPG; rp.RQ = rg.RQ; rp.D = rg.D; rp.PS = rg.PS;
-    rp.nl = m->nl; rp.full = full; rp.dbg = env_int("FARNN_DBG", 0);
+    rp.nl = m->nl; rp.full = full; rp.dbg = tun(TUN_DBG);
     return rp;
 }
 
@@ -578,27 +584,27 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     // ---- the register-fed kernel (chain_regs.hip.h) where its geometry applies: S <= 72, two workgroups per compute unit, or
     // its wide form (chain_wide.hip.h): 72 < S <= 128, one workgroup per compute unit.
     // With fuse_sp (threshold/argmax decode, K <= 256) the scores and the decode run beside the recurrence: ONE launch.
-    if (m->rgeom.ok && !env_int("FARNN_NOREGS", 0)) {
+    if (m->rgeom.ok && !tun(TUN_NOREGS)) {
         const RegsGeom &rg = m->rgeom;
         const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
-                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
-        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.wide).total * sizeof(float);
+                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
+        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ).total * sizeof(float);
         if (score && lds > lds_cap) {               // the score tiles do not fit (beside a second workgroup): recurrence only
             score = false;
-            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.wide).total * sizeof(float);
+            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.RQ).total * sizeof(float);
         }
         if (lds <= lds_cap) {
             RegsParams rp = make_regs_params(m, x, len, B, full);
             if (score) {
                 int hrc = handoff_words(m, B, s, &rp.prog, &rp.arr, &rp.done);
                 if (hrc) return hrc;
-                if (env_int("FARNN_HOST_EPOCH", 0)) {       // diagnostic A/B: the epoch as a kernel argument (not graph-capturable)
+                if (tun(TUN_HOST_EPOCH)) {       // diagnostic A/B: the epoch as a kernel argument (not graph-capturable)
                     if (++m->epoch_u == 0) { FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s)); m->epoch_u = 1; }
                     rp.done = nullptr; rp.epoch_host = m->epoch_u + 0x40000000u;
                 }
-                rp.spin = env_int("FARNN_FUSE_SPIN", 4);
-                rp.solo_margin = env_int("FARNN_SOLO_MARGIN", 24);
+                rp.spin = tun(TUN_FUSE_SPIN);
+                rp.solo_margin = tun(TUN_SOLO_MARGIN);
                 rp.sp = *fuse_sp;
                 if (fused) *fused = true;
             }
@@ -618,7 +624,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     p.sort = m->sort_in_kernel ? 1 : 0;
     p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.CPR = g.CPR; p.V = m->V;
     p.NW = g.NW; p.NLD = g.NLD; p.G = g.G; p.LPR = g.LPR; p.RPG = g.RPG; p.RPGp = g.RPGp; p.NQ = g.NQ;
-    p.nl = m->nl; p.full = full; p.dbg = env_int("FARNN_DBG", 0);
+    p.nl = m->nl; p.full = full; p.dbg = tun(TUN_DBG);
     // ring shape: a whole step per phase when it fits, KS phases deep
     int ks = 2, nqp = g.NQ;
     if (!g.pick_ring(m->curL, m->chain_ks, ks, nqp))
@@ -628,7 +634,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     dim3 grid(2 * B), block((g.NW + g.NLD + 1) * 64);         // compute + loader + writer wavefronts
     const bool mx = m->semiring == FARNN_SEMIRING_MAX;
     int rc = FARNN_OK;
-    if (env_int("FARNN_CHAIN_HELPER", 0) && block.x < 512) block = dim3(block.x + 64);     // experiment: an idle eighth wavefront
+    if (tun(TUN_CHAIN_HELPER) && block.x < 512) block = dim3(block.x + 64);     // experiment: an idle eighth wavefront
 #define FARNN_LAUNCH_CHAIN(NCH, MX, FQ)                                                       \
     do {                                                                                      \
         if ((rc = raise_lds_limit(chain_kernel<NCH, MX, FQ>, lds))) return rc;                \
@@ -641,7 +647,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
     do { if (mx) FARNN_LAUNCH_CHAIN(NCH, true, FQ); else FARNN_LAUNCH_CHAIN(NCH, false, FQ); } while (0)
     KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
     const int fq_max = block.x <= 384 ? 6 : 3;
-    const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= fq_max && !env_int("FARNN_NOFAST", 0)) ? g.NQ : 0;
+    const int fq = (g.NCH == 1 && p.PPS == 1 && g.NQ <= fq_max && !tun(TUN_NOFAST)) ? g.NQ : 0;
     if (g.NCH == 1) {
         if (fq == 1) FARNN_LAUNCH_CHAIN_MX(1, 1);
         else if (fq == 2) FARNN_LAUNCH_CHAIN_MX(1, 2);
@@ -662,9 +668,9 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 // ---- decomposed modes whose step matrix is materialised anyway: dense per-word blocks + the chain kernel ----
 static int build_dense_blocks(farnn_model *m) {
     const DecompWeights &w = m->dw;
-    if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask) || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
+    if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask) || tun(TUN_DECOMP_OLD)) return FARNN_OK;
     pick_chain_geometry(m);
-    m->chain_ks = env_int("FARNN_KS", 3);
+    m->chain_ks = tun(TUN_KS);
     if (m->geom.NCH > 4 || m->geom.SP != m->SP) return FARNN_OK;
     const size_t nM = (size_t)m->V * m->geom.SR * m->SP;
     if (nM * 8 > (size_t)64 << 30) return FARNN_OK;               // keep it under 64 GB; else the generic kernel
@@ -686,7 +692,7 @@ static int build_rows_pack(farnn_model *m) {
     DecompWeights &w = m->dw;
     DecompRowsPack &k = m->rows;
     k.ok = false;
-    if (w.semiring != FARNN_SEMIRING_SUM || w.mask || env_int("FARNN_DECOMP_OLD", 0)) return FARNN_OK;
+    if (w.semiring != FARNN_SEMIRING_SUM || w.mask || tun(TUN_DECOMP_OLD)) return FARNN_OK;
     const int tvl = m->Rp + (w.farnn >= 1 ? m->SP : 0) + (w.farnn == 2 ? m->SP : 0);
     if (tvl > DR_MAX_PF * DR_THREADS) return FARNN_OK;
     k.nch2 = (m->S + DR_CHUNK - 1) / DR_CHUNK; k.nch3 = (m->Rp + m->S + DR_CHUNK - 1) / DR_CHUNK;
@@ -742,7 +748,7 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
         BesideParams bs;
         const BesideParams *use = nullptr;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= DG_NG && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
-                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !env_int("FARNN_NOFUSE", 0);
+                     (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
         if (score) {
             rp.lds_score = regs_score_lds(rp, m->curL, m->SP, m->c16, m->Kc);
             if (rp.lds_score > 80 * 1024) score = false;
@@ -752,7 +758,7 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
             bs.A = m->A; bs.Bk = m->Bk; bs.B = B; bs.L = m->curL; bs.SP = m->SP; bs.CPR = m->SP / 4;
             int hrc = handoff_words(m, B, s, &bs.prog, &bs.arr, &bs.done);
             if (hrc) return hrc;
-            bs.spin = env_int("FARNN_FUSE_SPIN", 4); bs.dbg = env_int("FARNN_DBG", 0); bs.sp = *fuse_sp;
+            bs.spin = tun(TUN_FUSE_SPIN); bs.dbg = tun(TUN_DBG); bs.sp = *fuse_sp;
             use = &bs;
             if (fused) *fused = true;
         }
@@ -770,14 +776,14 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
 static bool viterbi_can_fuse(const farnn_model *m, const ScoreParams &p) {
     return m->use_crf && !p.scores && !p.P && p.A && p.OT && m->K <= 256 &&
            viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, true) <= 158 * 1024 &&
-           !env_int("FARNN_VITERBI_BP", 0) && !env_int("FARNN_VITERBI_UNFUSED", 0);
+           !tun(TUN_VITERBI_BP) && !tun(TUN_VITERBI_UNFUSED);
 }
 
 static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream_t s, bool fused = false) {
     int rc;
     if (m->K > 256) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
     const size_t hlds = viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, fused);
-    if (hlds <= 158 * 1024 && !env_int("FARNN_VITERBI_BP", 0)) {
+    if (hlds <= 158 * 1024 && !tun(TUN_VITERBI_BP)) {
         // partition history in LDS, back-pointers recomputed along the path
         const int threads = viterbi_hist_threads(m->K);
 #define FARNN_LAUNCH_VITH(N)                                                                  \
@@ -923,8 +929,8 @@ static ScoreParams make_score_params(farnn_model *m, const int64_t *len, int B, 
     p.B = B; p.L = m->curL; p.S = m->S; p.SP = m->SP; p.K = m->K; p.Kp = m->Kp; p.Kc = m->Kc;
     p.kch = m->Kc / 64;
     p.full = full; p.use_crf = m->use_crf; p.o_idx = m->o_idx; p.threshold = m->threshold;
-    p.dbg = env_int("FARNN_DBG", 0);
-    p.kz = (m->kind == KIND_IFST && m->use_crf && !env_int("FARNN_NOKZ", 0)) ? m->C : 0;      // the library appended the two zero rows itself
+    p.dbg = tun(TUN_DBG);
+    p.kz = (m->kind == KIND_IFST && m->use_crf && !tun(TUN_NOKZ)) ? m->C : 0;      // the library appended the two zero rows itself
     p.lm = m->lm;
     return p;
 }
@@ -976,8 +982,11 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         // the decode's LDS fits; else the recurrence kernel followed by the (fused score +) Viterbi kernel
         m->last_fused = false;
         const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
-        if (m->rgeom.ok && !m->rgeom.wide && !env_int("FARNN_NOREGS", 0) && !env_int("FARNN_NOFUSE", 0) && viterbi_can_fuse(m, sp) &&
-            (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp, m->lm.on != 0)) {
+        // (wide form, 72 < S <= 108: the one launch exists -- FARNN_CV_WIDE=1, parity-tested -- but is not the default: a compute
+        //  unit then holds BOTH chains of a sequence, each of which alone keeps its L2 port busy at this block size; measured at
+        //  S = 104, K = 130: 113.8 us per step in one launch against 95.7 in two, profiles/r04_*)
+        if (m->rgeom.ok && (!m->rgeom.wide || tun(TUN_CV_WIDE)) && !tun(TUN_NOREGS) && !tun(TUN_NOFUSE) && viterbi_can_fuse(m, sp) &&
+            (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp, m->lm.on != 0, m->rgeom.RQ)) {
             const RegsParams rp = make_regs_params(m, x, len, B, full);
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
             if ((rc = launch_chain_viterbi(rp, sp, m->semiring == FARNN_SEMIRING_MAX, s, kt.e0, kt.e1))) return rc;
@@ -1021,6 +1030,7 @@ extern "C" int farnn_tag(farnn_model *m, const int64_t *x, const int64_t *length
 
 static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, int32_t B, int32_t L,
                     int32_t mode, int32_t *tags, int64_t *flat_tags, float *scores, void *stream) {
+    TunScope tun_scope(&m->tun);
     FARNN_HIP_TRY(hipSetDevice(m->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     int rc;
@@ -1053,11 +1063,11 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
     m->prof_this_call = m->profiling > 0 && (m->calls++ % m->profiling) == 0;
     // batch preparation: flat-output offsets and the length-sorted launch order (full mode runs
     // every sequence for L steps, so there is nothing to balance)
-    const bool want_order = !full && B > 2 && !env_int("FARNN_NOSORT", 0);
+    const bool want_order = !full && B > 2 && !tun(TUN_NOSORT);
     // the plain i-FST path needs no prep launch up to B = 1024: the chain workgroups select their sequence
     // by length rank themselves and the score workgroups sum the lengths in front of theirs
     m->prep_in_kernel = (m->kind == KIND_IFST || (m->kind == KIND_DECOMP && m->rows.ok)) && B <= 1024 && L <= 1023 &&
-                        !env_int("FARNN_PREP", 0);
+                        !tun(TUN_PREP);
     m->order_valid = want_order && !m->prep_in_kernel;
     m->sort_in_kernel = want_order && m->prep_in_kernel;
     // the decomposed independent=1 scoring kernel slices the batch by flat offsets even when no flat output is asked for
@@ -1082,7 +1092,7 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
                 CompactParams cp;
                 cp.bitsF = m->bmF; cp.bitsB = m->bmB; cp.wF = m->bmWF; cp.wB = m->bmWB; cp.o = m->o; cp.h0 = m->h0; cp.hT = m->hT;
                 cp.x = x; cp.len = lengths; cp.order = m->order_valid ? m->order : nullptr; cp.A = m->A; cp.Bk = m->Bk;
-                cp.B = B; cp.L = L; cp.S = m->S; cp.SP = m->SP; cp.V = m->V; cp.nl = m->nl; cp.full = full; cp.dbg = env_int("FARNN_DBG", 0);
+                cp.B = B; cp.L = L; cp.S = m->S; cp.SP = m->SP; cp.V = m->V; cp.nl = m->nl; cp.full = full; cp.dbg = tun(TUN_DBG);
                 m->last_fused = false;
                 {
                     KernelTimer kt(m, KERN_CHAIN, s);
@@ -1308,12 +1318,13 @@ extern "C" int farnn_onehot_fst4_create(const farnn_onehot_fst4_desc *d, int dev
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_FST4; m->device = device;
     m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu is unconditional (model_onehot.py:93-94)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     pick_chain_geometry(m);
-    m->chain_ks = env_int("FARNN_KS", 3);
+    m->chain_ks = tun(TUN_KS);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -1348,13 +1359,14 @@ extern "C" int farnn_onehot_ind1_create(const farnn_onehot_ind1_desc *d, int dev
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_IND1; m->device = device;
     m->V = d->V; m->S = d->S; m->C = d->C; m->K = d->C; m->Kp = round_up(m->K, 4); m->Kc = round_up(m->K, 64);
     m->nl = FARNN_NL_RELU;                       // relu always (model_onehot.py:266, :278)
     m->semiring = d->semiring; m->threshold = d->threshold; m->o_idx = d->o_idx;
     m->mask_by_output = d->mask_by_output;
     pick_chain_geometry(m);
-    m->chain_ks = env_int("FARNN_KS", 3);
+    m->chain_ks = tun(TUN_KS);
     m->SP = m->geom.SP;
     const int od = d->weights_on_device;
     auto bail = [&](int code) { farnn_destroy(m); return code; };
@@ -1455,6 +1467,7 @@ static int decomp_ifst_create_impl(const farnn_decomp_ifst_desc *d, int device, 
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_DECOMP; m->device = device;
     m->V = d->V; m->S = d->S; m->R = d->R; m->K = d->K; m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);
     m->C = d->use_crf ? d->K - 2 : d->K;
@@ -1676,6 +1689,7 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_DECOMP1; m->device = device;
     m->V = d->V; m->S = d->S; m->R = d->R; m->RO = d->RO; m->K = d->K;
     m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);
@@ -1713,7 +1727,7 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
-    if (m->RO <= 16 * D1M_MAXNT && m->S <= 16 * D1M_MAXKQ4 && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !env_int("FARNN_DECOMP_OLD", 0)) {
+    if (m->RO <= 16 * D1M_MAXNT && m->S <= 16 * D1M_MAXKQ4 && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !tun(TUN_DECOMP_OLD)) {
         // per-word bss table for the MFMA scoring kernel (unmasked: the mask only enters the recurrence),
         // materialised row-major in a scratch buffer, then re-laid-out in MFMA operand order
         const int MT = (m->S + 15) / 16, NT = (m->RO + 15) / 16, KQ4 = MT;
@@ -1758,6 +1772,7 @@ extern "C" int farnn_decomp_fst_create(const farnn_decomp_fst_desc *d, int devic
     if (rc) return rc;
     farnn_model *m = new (std::nothrow) farnn_model();
     if (!m) return fail(FARNN_ENOMEM, "host allocation failed%s%s");
+    TunScope tun_scope(&m->tun);
     m->kind = KIND_DECOMP0; m->device = device;
     m->V = d->V; m->S = d->S; m->R = d->R; m->RW = d->RW; m->K = d->K;
     m->Kp = round_up(d->K, 4); m->Kc = round_up(d->K, 64);

@@ -15,6 +15,7 @@ using namespace farnn;
 
 // ---- training step (decomposed i-FST) ------------------------------------------
 struct farnn_train_ctx {
+    Tunables tun;                 // the FARNN_* switches as they stood when the context was created (host_util.hip.h)
     farnn_train_dims d;
     int device = 0;
     float *ws = nullptr;          // per-batch workspace (zeroed every step)
@@ -141,6 +142,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
                                             const int64_t *lengths, const int64_t *labels, int32_t B, int32_t L,
                                             int64_t valid_tokens, const farnn_train_outputs *o, void *stream) {
     if (!c || !w || !x || !lengths || !labels || !o) return fail(FARNN_EINVAL, "train_step: null argument%s%s");
+    TunScope tun_scope(&c->tun);
     if (!w->Vgen || !w->S1 || !w->S2 || !w->W || !w->C || !w->h0 || !w->hT)
         return fail(FARNN_EINVAL, "train_step: null weight%s%s");
     if (!o->loss || !o->dVgen || !o->dS1 || !o->dS2 || !o->dW || !o->dC || !o->dh0 || !o->dhT || !o->tags)
@@ -276,13 +278,13 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     auto vecb = [&](size_t ns) { return (2 * ns * SPd + ns * RPd + 2 * ns * nwv * SR + ns * nwv * S + ns * (size_t)L +
                                          (farnn ? 2 * ns * SPd : 0)) * sizeof(float); };
     const size_t mat_f = ((2 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float), mat_b = ((3 * S * R + S * S + 3) & ~(size_t)3) * sizeof(float);
-    const bool ldsw_f = vecf(TR_NSEQ) + mat_f <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
-    const bool ldsw_b = vecb(TR_NSEQ) + mat_b <= 160 * 1024 && !env_int("FARNN_TRAIN_NOLDS", 0);
+    const bool ldsw_f = vecf(TR_NSEQ) + mat_f <= 160 * 1024 && !tun(TUN_TRAIN_NOLDS);
+    const bool ldsw_b = vecb(TR_NSEQ) + mat_b <= 160 * 1024 && !tun(TUN_TRAIN_NOLDS);
     // sequences per workgroup: two with the matrices in LDS; four when they are read through L2 every step (that mode
     // is bound by the L2 rate, and every element read then feeds four sequences) if the batch still fills the chip
     const size_t lds_cap = 156 * 1024;
     auto pick_ns = [&](bool ldsw, size_t vec4) -> int {
-        const int forced = env_int("FARNN_TRAIN_NSEQ", 0);
+        const int forced = tun(TUN_TRAIN_NSEQ);
         if (ldsw) return TR_NSEQ;
         const bool fits = TR_NSEQ_L2 * SR <= (size_t)TR_VPT * TR_THREADS && vec4 + 16 <= lds_cap;
         if (forced == 2 || !fits) return TR_NSEQ;
@@ -300,7 +302,7 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
     const size_t want_ss = farnn == 2 ? 3 : (farnn == 1 ? 2 : 1);
     p.nss_f = ldsw_f || vec_f + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_f - 16) / ssb);
     p.nss_b = ldsw_b || vec_b + 16 > lds_cap ? 0 : (int)std::min(want_ss, (lds_cap - vec_b - 16) / ssb);
-    if (env_int("FARNN_TRAIN_NOLDS", 0) > 1) p.nss_f = p.nss_b = 0;
+    if (tun(TUN_TRAIN_NOLDS) > 1) p.nss_f = p.nss_b = 0;
     const size_t lds_f = vec_f + (ldsw_f ? mat_f : 16 + p.nss_f * ssb), lds_b = vec_b + (ldsw_b ? mat_b : 16 + p.nss_b * ssb);
     int rc;
     // instantiation: weights in LDS or through L2, with or without the gate state, slots per thread, sequences per workgroup

@@ -392,7 +392,7 @@ def snips_sized_model(R, farnn, crf, seed=1234, S=104, V=11000, C=73):
     gates (model_decompose_single.py:93-123) and the CRF rows / transitions (:78-79, crf.py:31-46) on demand.  One source
     for bench.py's shape, tests/test_gpu_parity_bench_size.py and tests/golden/make_golden_bench.py (which feeds
     exactly these arrays to the reference's FARNN_S_D_W_I_S).  Returns (V, q, gates, crf_transitions): `q` is the
-    parameter dict oracle/farnn_oracle.py's decomp_ifst_scores takes (nl = 2: tanh, semiring = 0: sum)."""
+    parameter dict the tests' checker takes for the decomposed i-FST (nl = 2: tanh, semiring = 0: sum)."""
     wrng = np.random.RandomState(seed)
     p = random_decomposed_params(V, S, C, R, 100, wrng, contractive=True)
     f = lambda a: np.asarray(a, np.float32)                       # noqa: E731

@@ -21,7 +21,7 @@ for f in glob.glob(os.path.join(src, 'bench_*.json')):
 for f in glob.glob(os.path.join(src, '*.txt')):
     shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
 for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_two_kernels'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
-                  ('trace_fst4', 'fst4')):
+                  ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(dst, '{}_{}_kernel_stats.csv'.format(tag, name)))
@@ -43,7 +43,8 @@ def agg(path):
 rows = []
 runs = [('pmc_fetch', 'ifst ragged U[5,64]'), ('pmc_write', 'ifst ragged U[5,64]'), ('pmc_l2', 'ifst ragged U[5,64]'),
         ('pmc_fetch_full', 'ifst full-length'), ('pmc_fetch_synth512', 'synth512 B1024 L128'),
-        ('pmc_fetch_fst4', 'fst4')]
+        ('pmc_fetch_fst4', 'fst4'), ('pmc_fetch_s104', 'ifst S=104 ragged U[5,64]'), ('pmc_write_s104', 'ifst S=104 ragged U[5,64]'),
+        ('pmc_l2_s104', 'ifst S=104 ragged U[5,64]')]
 for run, label in runs:
     for (k, c), (mean, n) in sorted(agg(run).items()):
         if 'farnn::' in k and any(t in k for t in ('chain', 'score', 'viterbi', 'decomp_regs', 'decomp_rows')):
@@ -68,6 +69,9 @@ note = ('(2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch from separate rocprofv3
 f_, w_ = pick('ifst ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
     traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel', 'source': note}
+f_, w_ = pick('ifst S=104 ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst S=104 ragged U[5,64]', 'chain', 'WRITE_SIZE')
+if f_ is not None:
+    traffic['ifst_s104'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_wide_kernel', 'source': note}
 f_ = pick('synth512 B1024 L128', 'chain', 'FETCH_SIZE')
 if f_ is not None:
     traffic['synth512'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'chain_kernel', 'source': note + ' (reads only)'}
@@ -85,7 +89,7 @@ for d in sorted(glob.glob(os.path.join(src, 'sq*_*'))):
         continue
     for row in csv.DictReader(open(files[-1])):
         kn = row['Kernel_Name'].split('(')[0].replace('void ', '')
-        if 'farnn::' in kn and any(t in kn for t in ('chain_kernel', 'chain_regs', 'score_tile', 'viterbi', 'decomp_regs', 'decomp_rows')):
+        if 'farnn::' in kn and any(t in kn for t in ('chain_kernel', 'chain_regs', 'chain_wide', 'score_tile', 'viterbi', 'decomp_regs', 'decomp_rows')):
             key = (wl, kn, row['Counter_Name'])
             sq[key][0] += float(row['Counter_Value']); sq[key][1] += 1
 with open(os.path.join(dst, tag + '_pmc_sq.csv'), 'w') as f:

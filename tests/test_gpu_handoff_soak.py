@@ -54,8 +54,9 @@ def _soak(B, L, launches, seed, full):
     mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
     nb = 6
     batches = []
-    os.environ['FARNN_NOFUSE'] = '1'                       # the reference form: two kernels, no hand-off
-    try:
+    os.environ['FARNN_NOFUSE'] = '1'                       # the reference form: two kernels, no hand-off (the switches are read
+    try:                                                   # when a handle is created: a second handle of the same model)
+        href = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
         for k in range(nb):
             x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
             if k == 1:
@@ -64,10 +65,11 @@ def _soak(B, L, launches, seed, full):
                 lengths[:] = np.maximum(1, lengths // 4)   # short chains: everything is "the last tile"
             xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
             ref = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
-            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, ref.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
+            href.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, ref.data_ptr(), None, None, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert 'fused' not in h.kernel_name(_lib.KERN_CHAIN)
+            assert 'fused' not in href.kernel_name(_lib.KERN_CHAIN)
             batches.append((xd, ld, ref))
+        href.close()
     finally:
         del os.environ['FARNN_NOFUSE']
     noise = _Noise()
