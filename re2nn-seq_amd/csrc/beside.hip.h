@@ -14,7 +14,7 @@ namespace farnn {
 
 // the scorer wavefront takes the label-map path (label_map.hip.h: token by token behind the chain) when the output matrix is a
 // label map and the call wants tags only; the matrix form (tiles on the f32 matrix cores) otherwise
-__device__ __forceinline__ bool bs_label_map_path(const ScoreParams &sp) { return sp.lm.on && !sp.P && !sp.scores; }
+__host__ __device__ __forceinline__ bool bs_label_map_path(const ScoreParams &sp) { return sp.lm.on && !sp.P && !sp.scores; }
 
 // what tile k needs: forward rows 0..needA and backward rows 0..needB stored (a row = one state, row 0 the initial one)
 __device__ __forceinline__ void bs_tile_need(int k, int len, int nsteps, int &needA, int &needB) {
@@ -66,24 +66,29 @@ __device__ __forceinline__ const float *bs_other_row(const BesideParams &p, int 
 }
 
 // park the other direction's rows of tile k in LDS (obuf[16][SP]); one wavefront, after the acquire that covers them
-template <int NG>
+// (NB: loads in flight per batch -- NG of them, or fewer batches' worth where registers are short)
+template <int NG, int NB = NG>
 __device__ __forceinline__ void bs_park_rows(const BesideParams &p, int b, int dir, int len, int nsteps, int k, float *obuf, int lane_in) {
     int lane = lane_in;
     asm volatile("" : "+v"(lane));
     const int SP = p.SP, CPR = p.CPR, t0 = k * RG_TT, nt = min(RG_TT, nsteps - t0);
     constexpr int NIT = NG;                              // 16 tokens x CPR <= 4 NG chunks of 16 bytes over 64 lanes
-    float4 v[NIT];
+    static_assert(NIT % NB == 0, "whole batches");
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += NB) {
+        float4 v[NB];
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
-        v[it] = ld4_agent(bs_other_row(p, b, dir, len, t0 + (tok < nt ? tok : 0)) + c4);
-    }
+        for (int it = 0; it < NB; it++) {
+            const int idx = (it0 + it) * 64 + lane;
+            const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
+            v[it] = ld4_agent(bs_other_row(p, b, dir, len, t0 + (tok < nt ? tok : 0)) + c4);
+        }
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-        const int idx = it * 64 + lane;
-        const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
-        if (tok < nt) st4(obuf + tok * SP + c4, v[it]);
+        for (int it = 0; it < NB; it++) {
+            const int idx = (it0 + it) * 64 + lane;
+            const int tok = idx / CPR, c4 = (idx - tok * CPR) * 4;
+            if (tok < nt) st4(obuf + tok * SP + c4, v[it]);
+        }
     }
 }
 
@@ -421,7 +426,9 @@ __device__ __forceinline__ void bs_halves(int dir, int len, int nsteps, int &kmi
 // NOTHING TO STORE before the meeting barrier (the same call site, no tile selected), so that the instructions are in the
 // compute unit's instruction cache when all wavefronts run them for real: run cold, a few KB of straight-line code cost the
 // workgroup ~8 k cycles of instruction fetch (profiles/r04_probe_finish_phases.txt), more than the arithmetic.
-template <int NWV, int NG, int WDEC, int WSKIP, bool WARM = false, class OnMeet, class PublishAll>
+// LMO: the instantiation serves the label-map path only (the caller guarantees bs_label_map_path): the matrix-core tile code
+// is not compiled in -- its B fragments and accumulators are what the 128-VGPR wide form has no room for.
+template <int NWV, int NG, int WDEC, int WSKIP, bool WARM = false, bool LMO = false, class OnMeet, class PublishAll>
 __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, const int dir, const int len, const int nsteps, const int kmid,
                                           const float *hist, float *ab, float *scl, const float *obuf, int *misc,
                                           const int w, const int lane, const unsigned lm_pk0, const unsigned lm_pk1,
@@ -430,13 +437,13 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
     const int SP = p.SP;
     const int ntl = (nsteps + RG_TT - 1) / RG_TT;
     rg_f32x4 bpre[NG];                                            // this wavefront's column block of O^T: in flight across the barrier
-    const bool label_map = bs_label_map_path(p.sp);               // the tiles go through bs_label_map_tiles, not the matrix cores
+    const bool label_map = LMO || bs_label_map_path(p.sp);        // the tiles go through bs_label_map_tiles, not the matrix cores
     LabelMapRegs lr;
     if (label_map) {
         lm_unpack(p.sp.lm, lm_pk0, lm_pk1, lr);
 #pragma unroll
         for (int g = 0; g < NG; g++) bpre[g] = rg_f32x4{0.f, 0.f, 0.f, 0.f};
-    } else bs_load_b<NG>(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
+    } else if constexpr (!LMO) bs_load_b<NG>(p.sp, w < p.sp.Kc / 16 ? w : 0, lane, bpre);
     const unsigned all_tiles = ntl >= 32 ? ~0u : ((1u << ntl) - 1u);
     unsigned promised = 0u;
 #if defined(FARNN_PROBES)
@@ -518,7 +525,7 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
             if (label_map) {
                 if (par0 && (k1 < 0 || par1)) bs_label_map_tiles<NWV, true>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1 ? par1 : par0, foff, w, lane, lr);
                 else bs_label_map_tiles<NWV, false>(p, b, dir, len, nsteps, k0, k1, hist, nullptr, nullptr, foff, w, lane, lr);
-            } else {
+            } else if constexpr (!LMO) {
                 bs_score_tiles<true, NWV, NG, WSKIP>(p, b, dir, len, nsteps, k0, k1, hist, par0, par1, ab, scl, foff, w, lane, bpre);
                 __syncthreads();                                     // the tiles' LDS is free again
             }

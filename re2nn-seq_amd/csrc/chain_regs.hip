@@ -13,24 +13,27 @@ namespace farnn {
 
 int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int NP = RG_NWC * p.G;
-    const size_t lds = (size_t)regs_lds(p.L, p.SP, NP, p.sp.c16, p.sp.Kc, score).total * sizeof(float);
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, NP, p.sp.c16, p.sp.Kc, score, RG_RQ, score && bs_label_map_path(p.sp)).total * sizeof(float);
     const dim3 grid(2 * p.B), block(RG_WAVES * 64);
     int rc;
     // NLX: tanh / relu-tanh / sigmoid between the steps (the kernel's none / relu form has no branch in the step)
     const bool nlx = p.nl != FARNN_NL_NONE && p.nl != FARNN_NL_RELU;
-#define FARNN_LAUNCH_REGS3(MX, SC, NX)                                                         \
+    const bool lmo = score && bs_label_map_path(p.sp);                     // the label-map instantiation (no matrix-core tile code)
+#define FARNN_LAUNCH_REGS4(MX, SC, NX, LM)                                                     \
     do {                                                                                       \
-        if ((rc = raise_lds_limit(chain_regs_kernel<MX, SC, NX>, lds))) return rc;             \
+        if ((rc = raise_lds_limit(chain_regs_kernel<MX, SC, NX, LM>, lds))) return rc;         \
         if (e0 && e1)                                                                          \
-            hipExtLaunchKernelGGL((chain_regs_kernel<MX, SC, NX>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
+            hipExtLaunchKernelGGL((chain_regs_kernel<MX, SC, NX, LM>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
         else                                                                                   \
-            chain_regs_kernel<MX, SC, NX><<<grid, block, lds, s>>>(p);                        \
+            chain_regs_kernel<MX, SC, NX, LM><<<grid, block, lds, s>>>(p);                    \
     } while (0)
+#define FARNN_LAUNCH_REGS3(MX, SC, NX) do { if (SC && lmo) FARNN_LAUNCH_REGS4(MX, SC, NX, SC); else FARNN_LAUNCH_REGS4(MX, SC, NX, false); } while (0)
 #define FARNN_LAUNCH_REGS(MX, SC) do { if (nlx) FARNN_LAUNCH_REGS3(MX, SC, true); else FARNN_LAUNCH_REGS3(MX, SC, false); } while (0)
     if (maxsr) { if (score) FARNN_LAUNCH_REGS(true, true); else FARNN_LAUNCH_REGS(true, false); }
     else       { if (score) FARNN_LAUNCH_REGS(false, true); else FARNN_LAUNCH_REGS(false, false); }
 #undef FARNN_LAUNCH_REGS
 #undef FARNN_LAUNCH_REGS3
+#undef FARNN_LAUNCH_REGS4
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }

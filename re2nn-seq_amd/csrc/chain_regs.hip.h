@@ -115,7 +115,8 @@ namespace farnn {
 // both halves alike (the same sequence, the same length).  *b_out: the sequence the slot maps to.
 // RQ / D: rows of 16 bytes per lane and step, steps in flight.  (RG_RQ, RG_D) is the form for S <= 72 (two workgroups per compute
 // unit); RQ > RG_RQ the wide form (chain_wide.hip.h: 72 < S <= 128, one workgroup per compute unit, launch order longest first).
-template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D>
+// LMO: label-map path only (the paired wide form): the matrix-core tile code is compiled out.
+template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D, bool LMO = false>
 __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem, const int tid, const int item, int *b_out) {
     constexpr bool WIDE = RQ != RG_RQ;
     constexpr int PSTR = WIDE ? rgw_part_stride(RQ) : RG_PART_STRIDE;     // floats between the two partial-sum buffers
@@ -127,7 +128,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     const int dir = item & 1, slot = item >> 1;
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
     const int PS = WIDE ? p.PS : SP;                                  // floats between two partial-sum vectors
-    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, RQ);
+    const bool lm_path = SCORE && (LMO || bs_label_map_path(p.sp));     // the tiles are scored through the label map: no tile areas in LDS
+    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, RQ, lm_path);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
     float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
     float *ab = smem + lds.ab, *scl = smem + lds.scl, *obuf = smem + lds.obuf;
@@ -136,7 +138,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     int b = p.order ? p.order[slot] : slot;
     // (a compute unit holds two workgroups of the narrow form: slots i and i + B/2 pair a long with a short sequence; it holds ONE
     //  of the wide form, and workgroups start in slot order as compute units fall free: longest first)
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, WIDE ? slot : folded_rank(slot, p.B), reinterpret_cast<int *>(hist), tid, nthreads);
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, p.pair ? folded_rank(slot, p.B) : slot, reinterpret_cast<int *>(hist), tid, nthreads);
     if (b_out) *b_out = b;
     const int len = clamp_len(p.len[b], p.L);
     const int nsteps = p.full ? p.L : len;
@@ -178,7 +180,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     // token by token, a few per wavefront, instead of on the matrix cores.  Every wavefront fetches its two packed words of the map
     // now (two VGPRs for the length of the chain; fetched at the chain's end they would cost an exposed L2 round trip)
     unsigned lm_pk0 = 0u, lm_pk1 = 0u;
-    if (SCORE && bs_label_map_path(bs.sp)) lm_load_packed(bs.sp.lm, lane, lm_pk0, lm_pk1);
+    if (lm_path) lm_load_packed(bs.sp.lm, lane, lm_pk0, lm_pk1);
     if (w < RG_NWC) {
         // =================================================================================================================
         // compute wavefronts
@@ -504,7 +506,10 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
         int acq = -1;                 // the other direction's progress as polled before this workgroup's latest acquire
         const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;
         const int kfirst = dir == 0 ? kmid : kmid - 1, kstep = dir == 0 ? 1 : -1, klast = dir == 0 ? ntl : -1;
-        for (int k = kfirst; k != klast; k += kstep) {
+        // (label-map path: no tile is scored by this wavefront alone -- the whole workgroup scores a pair of tiles in a fraction of a
+        //  chain step once the chain is done, and the matrix-core tile areas do not exist in LDS; it parks rows, below)
+        if constexpr (!LMO)
+        for (int k = kfirst; k != klast && !lm_path; k += kstep) {
             int na, nb;
             bs_tile_need(k, len, nsteps, na, nb);
             const int need_own = dir == 0 ? na : nb, need_oth = dir == 0 ? nb : na;
@@ -551,7 +556,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     acq = pr;
                 }
-                bs_park_rows<NG>(bs, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
+                bs_park_rows<NG, (LMO && WIDE) ? NG / 2 : NG>(bs, b, dir, len, nsteps, k, obuf + slot * RG_TT * SP, lane);
                 if (lane == 0) misc[RGM_PARK + slot] = k + 1;
                 slot++;
             }
@@ -567,7 +572,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     // mask of this workgroup's tiles, and the workgroup that finds the other's word there scores whatever neither has.
     // =====================================================================================================================
     if (w == 0) FARNN_RG_STAMP(4);
-    bs_finish<RG_WAVES, NG, RG_WAVES - 1, RG_NWC, true>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane, lm_pk0, lm_pk1, bs.epoch,
+    bs_finish<RG_WAVES, NG, RG_WAVES - 1, RG_NWC, true, LMO>(bs, b, dir, len, nsteps, kmid, hist, ab, scl, obuf, misc, w, lane, lm_pk0, lm_pk1, bs.epoch,
         [&]() {                                                      // the state rows the writer had not copied yet: issued now, landed by
             if (w == RG_NWC)                                         // the time the tiles are done (it forms no products meanwhile)
                 for (; wr_next <= nsteps; wr_next++)
@@ -593,11 +598,13 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
 #endif
 }
 
-template <bool MAXSR, bool SCORE, bool NLX>
+// LMO: the instantiation for the label-map path (scores on, the output matrix a label map, tags only): the matrix-core tile
+// code is not compiled in -- a quarter of the instructions, 40 instead of 260 spilled SGPRs
+template <bool MAXSR, bool SCORE, bool NLX, bool LMO = false>
 __global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD = 128 VGPRs: two workgroups per compute unit
 chain_regs_kernel(const RegsParams p) {
     extern __shared__ __align__(16) float smem[];
-    chain_regs_body<MAXSR, SCORE, NLX>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
+    chain_regs_body<MAXSR, SCORE, NLX, RG_RQ, RG_D, LMO>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
 }
 
 template <bool MAXSR, bool SCORE, bool NLX, int RQ, int D>
@@ -605,6 +612,14 @@ __global__ void __launch_bounds__(RG_WAVES * 64, 2)          // 2 waves per SIMD
 chain_wide_kernel(const RegsParams p) {
     extern __shared__ __align__(16) float smem[];
     chain_regs_body<MAXSR, SCORE, NLX, RQ, D>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
+}
+
+// the wide form PAIRED: a ring of two steps fits 128 VGPRs (RQ <= 9), the label-map path's LDS half a compute unit
+template <bool MAXSR, bool NLX, int RQ>
+__global__ void __launch_bounds__(RG_WAVES * 64, 4)
+chain_wide_paired_kernel(const RegsParams p) {
+    extern __shared__ __align__(16) float smem[];
+    chain_regs_body<MAXSR, true, NLX, RQ, 2, true>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
 }
 
 }  // namespace farnn

@@ -36,6 +36,8 @@ struct RegsParams {
     int B, L, S, SP, CPR, V;
     int G, RPG;                  // row groups per compute wavefront, rows per group
     int RQ, D;                   // rows per lane per step and ring depth (RG_RQ, RG_D: the form for S <= 72; else the wide form)
+    int pair;                    // launch order: 1 = folded (slots i and i + B/2 pair a long with a short sequence: two workgroups
+                                 // per compute unit), 0 = longest first (one workgroup per compute unit)
     int PS;                      // wide form: floats between two partial-sum vectors (>= SP, = 16 mod 32: the two lanes of a row read different bank halves)
     int nl, full;
     unsigned long long *prog;    // [2][B] {epoch, rows stored} per (direction, sequence)
@@ -90,7 +92,8 @@ struct RegsLds {
     int tok, hp, part, ol, hist, ab, scl, obuf, misc, xch, total;
 };
 // rq: rows per lane and step of the form (RG_RQ: S <= 72; larger: the wide form, whose partial-sum buffers and exchange area differ)
-__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, int rq = RG_RQ) {
+// lm: the label-map path scores the tiles (label_map.hip.h): no products, no score tiles in LDS
+__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, int rq = RG_RQ, bool lm = false) {
     const bool wide = rq != RG_RQ;
     RegsLds l;
     int at = 0;
@@ -99,8 +102,8 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
     l.part = at; at += 2 * (wide ? rgw_part_stride(rq) : RG_PART_STRIDE) + 64 * 4;     // two partial-sum buffers + the idle lanes' dump slots
     l.ol = at;   at += SP;
     l.hist = at; at += (L + 1) * SP + 16;          // + the launch-order scratch's tail
-    l.ab = at;   at += score ? 2 * RG_TT * (16 * c16 + 4) : 0;    // two tiles' products
-    l.scl = at;  at += score ? 2 * RG_TT * Kc : 0;               // two tiles' scores
+    l.ab = at;   at += (score && !lm) ? 2 * RG_TT * (16 * c16 + 4) : 0;    // two tiles' products
+    l.scl = at;  at += (score && !lm) ? 2 * RG_TT * Kc : 0;               // two tiles' scores
     l.obuf = at; at += score ? 2 * RG_TT * SP : 0;    // RG_NOB tiles of the other direction's rows
     l.misc = at; at += 32;
     l.xch = at;  at += wide ? RG_NWC * RGW_XCH : 0;     // wide form: where a compute wavefront hands its new state entries to its own lanes
@@ -112,6 +115,9 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
 int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 // chain_wide.hip: the same for the wide form (p.RQ > RG_RQ), one workgroup per compute unit
 int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
+// ... in its PAIRED form: a ring of two steps (128 VGPRs) and the label-map path's smaller LDS let two workgroups share a compute
+// unit like the form for S <= 72 -- one's end-of-chain tiles overlap the other's chain (p.D == 2, p.pair == 1, scores on)
+int launch_chain_wide_paired(const RegsParams &p, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1);
 
 // chain_viterbi.hip: the two chains of a sequence and its scores + CRF decode in ONE workgroup, one launch per tagging step
 // (p.prog / p.arr / p.epoch unused).  chain_viterbi_fits: tag sets of 32..159 labels whose decode fits the LDS.

@@ -11,7 +11,7 @@
 namespace farnn {
 
 int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    const size_t lds = (size_t)regs_lds(p.L, p.SP, RGW_NP, p.sp.c16, p.sp.Kc, score, p.RQ).total * sizeof(float);
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, RGW_NP, p.sp.c16, p.sp.Kc, score, p.RQ, score && bs_label_map_path(p.sp)).total * sizeof(float);
     const dim3 grid(2 * p.B), block(RG_WAVES * 64);
     int rc;
     const bool nlx = p.nl != FARNN_NL_NONE && p.nl != FARNN_NL_RELU;
@@ -37,6 +37,34 @@ int launch_chain_wide(const RegsParams &p, bool maxsr, bool score, hipStream_t s
 #undef FARNN_LAUNCH_WIDE
 #undef FARNN_LAUNCH_WIDE3
 #undef FARNN_LAUNCH_WIDE5
+    FARNN_HIP_TRY(hipGetLastError());
+    return FARNN_OK;
+}
+
+int launch_chain_wide_paired(const RegsParams &p, bool maxsr, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, RGW_NP, p.sp.c16, p.sp.Kc, true, p.RQ, true).total * sizeof(float);
+    const dim3 grid(2 * p.B), block(RG_WAVES * 64);
+    int rc;
+    const bool nlx = p.nl != FARNN_NL_NONE && p.nl != FARNN_NL_RELU;
+    if (p.G != RGW_G || p.D != 2 || !p.pair || p.RPG > p.RQ || !bs_label_map_path(p.sp)) return fail(FARNN_EINVAL, "chain_wide_paired: geometry%s%s");
+#define FARNN_LAUNCH_WP3(MX, NX, RQ_)                                                          \
+    do {                                                                                       \
+        if ((rc = raise_lds_limit(chain_wide_paired_kernel<MX, NX, RQ_>, lds))) return rc;     \
+        if (e0 && e1)                                                                          \
+            hipExtLaunchKernelGGL((chain_wide_paired_kernel<MX, NX, RQ_>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
+        else                                                                                   \
+            chain_wide_paired_kernel<MX, NX, RQ_><<<grid, block, lds, s>>>(p);                 \
+    } while (0)
+#define FARNN_LAUNCH_WP2(MX, NX)                                                               \
+    do {                                                                                       \
+        if (p.RQ == 8) FARNN_LAUNCH_WP3(MX, NX, 8);                                            \
+        else if (p.RQ == 9) FARNN_LAUNCH_WP3(MX, NX, 9);                                       \
+        else return fail(FARNN_EINVAL, "chain_wide_paired: no instantiation for this ring width%s%s"); \
+    } while (0)
+    if (maxsr) { if (nlx) FARNN_LAUNCH_WP2(true, true); else FARNN_LAUNCH_WP2(true, false); }
+    else       { if (nlx) FARNN_LAUNCH_WP2(false, true); else FARNN_LAUNCH_WP2(false, false); }
+#undef FARNN_LAUNCH_WP2
+#undef FARNN_LAUNCH_WP3
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }

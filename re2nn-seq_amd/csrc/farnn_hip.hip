@@ -544,7 +544,7 @@ static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64
     rp.o = m->o; rp.h0 = m->h0; rp.hT = m->hT; rp.x = x; rp.len = len;
     rp.order = m->order_valid ? m->order : nullptr; rp.sort = m->sort_in_kernel ? 1 : 0;
     rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
-    rp.G = rg.G; rp.RPG = rg.RPG; rp.RQ = rg.RQ; rp.D = rg.D; rp.PS = rg.PS;
+    rp.G = rg.G; rp.RPG = rg.RPG; rp.RQ = rg.RQ; rp.D = rg.D; rp.PS = rg.PS; rp.pair = rg.wide ? 0 : 1;
     rp.nl = m->nl; rp.full = full; rp.dbg = tun(TUN_DBG);
     return rp;
 }
@@ -589,7 +589,10 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
-        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ).total * sizeof(float);
+        const bool lm_path = score && bs_label_map_path(*fuse_sp);
+        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ, lm_path).total * sizeof(float);
+        // the wide form PAIRED (two workgroups per compute unit, like S <= 72): a ring of two steps and the label-map path's LDS
+        const bool paired = rg.wide && lm_path && rg.RQ <= 9 && lds <= 80 * 1024 && !tun(TUN_WIDE_UNPAIRED);
         if (score && lds > lds_cap) {               // the score tiles do not fit (beside a second workgroup): recurrence only
             score = false;
             lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.RQ).total * sizeof(float);
@@ -609,8 +612,10 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
                 if (fused) *fused = true;
             }
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
-            const int rc = rg.wide ? launch_chain_wide(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1)
-                                   : launch_chain_regs(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1);
+            if (paired && score) { rp.D = 2; rp.pair = 1; }
+            const int rc = (paired && score) ? launch_chain_wide_paired(rp, m->semiring == FARNN_SEMIRING_MAX, s, kt.e0, kt.e1)
+                           : rg.wide ? launch_chain_wide(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1)
+                                     : launch_chain_regs(rp, m->semiring == FARNN_SEMIRING_MAX, score, s, kt.e0, kt.e1);
             if (rc) return rc;
             m->last_regs = true;
             return FARNN_OK;
