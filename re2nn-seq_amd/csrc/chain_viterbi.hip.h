@@ -53,6 +53,10 @@ chain_viterbi_kernel(const RegsParams p, const ScoreParams sp, const ChainViterb
     extern __shared__ __align__(16) float smem[];
     const int tid = (int)threadIdx.x;
     const int half = __builtin_amdgcn_readfirstlane(tid >> 9);               // 0: forward chain, 1: backward chain
+    // the decode's wavefronts fetch their packed label-map words now: two VGPRs for the length of the chains instead of an L2
+    // round trip in front of the first token (label_map.hip.h)
+    unsigned lm_pk[2] = {0u, 0u};
+    if (sp.lm.on && tid < vthreads) lm_load_packed(sp.lm, tid & 63, lm_pk[0], lm_pk[1]);
     if (pl.image_pieces) {                           // the output matrix's matrix-core image: in flight while the chains run
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(smem + pl.image_off));
@@ -70,9 +74,10 @@ chain_viterbi_kernel(const RegsParams p, const ScoreParams sp, const ChainViterb
     if (tid >= vthreads) return;
     const int hist_off = regs_lds(p.L, p.SP, RG_NWC * p.G, 0, 0, false, RQ).hist;
     if (pl.lds_rows)
-        viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b, smem + pl.off0 + hist_off, smem + pl.off1 + hist_off, true);
+        viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b, smem + pl.off0 + hist_off, smem + pl.off1 + hist_off, true,
+                                     sp.lm.on ? lm_pk : nullptr);
     else
-        viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b);
+        viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b, nullptr, nullptr, false, sp.lm.on ? lm_pk : nullptr);
 }
 
 

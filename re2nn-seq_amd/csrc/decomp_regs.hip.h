@@ -340,7 +340,8 @@ decomp_regs_kernel(const DecompRegsParams p) {
 // per step: what bounds its step.  With eight lanes on a row, lane k owns piece k of every 32-column chunk: ONE read per chunk
 // (9 per step), the same weights per lane (a pass covers 32 rows: P2 takes NP2 = ceil(R / 32) passes, P3 NP3 = ceil(S / 32)),
 // one more DPP level per row sum.  Lane k finishes row pass k of either product (NP2, NP3 <= 8).
-template <int NCH2, int NCH3, int NP2, bool SCORE>
+// LMO: the label-map instantiation of the scores + decode stage (beside.hip.h: the matrix-core tile code is not compiled in)
+template <int NCH2, int NCH3, int NP2, bool SCORE, bool LMO = false>
 __global__ void __launch_bounds__(DG_THREADS, 2)
 decomp_regs8_kernel(const DecompRegsParams p) {
     constexpr int NP3 = NCH2, CS = NP2;                       // S <= 32 NCH2 rows of P3; the rr entries fill the first NP2 chunks of [rr | h]
@@ -445,7 +446,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     int polled = -1;
     if (nsteps <= 0) {
         if (SCORE) {
-            bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
+            bs_finish<DG_WAVES, DG_NG, 0, -1, false, LMO>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
                 [&]() {}, [&]() { if (wv == WCOPY) publish(0); });
         }
         return;
@@ -574,7 +575,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
             if (nsteps >= 2) store_row(nsteps - 1);
             copy_row(nsteps);
         }
-        bs_finish<DG_WAVES, DG_NG, 0, -1>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
+        bs_finish<DG_WAVES, DG_NG, 0, -1, false, LMO>(p.bs, b, dir, len, nsteps, kmid, hist, ab, scl, hist, misc, wv, lane, lm_pk0, lm_pk1, epoch,
             [&]() {}, [&]() { if (wv == WCOPY) publish(nsteps); });
     }
     if (FARNN_PROBE_ON(p.dbg & 4096) && blockIdx.x < 2 && (tid & 63) == 0)
@@ -634,7 +635,11 @@ inline int launch_decomp_regs(const DecompRowsPack &k, const DecompWeights &w, c
     p.dbg = tun(TUN_DBG);
 #define FARNN_REGS8_CASE(A_, B_, C_)                                                                          \
     if (pl.eight && pl.nch2 == A_ && pl.nch3 == B_ && pl.np2 == C_) {                                         \
-        if (bs) {                                                                                             \
+        if (bs && bs_label_map_path(bs->sp)) {                                                                \
+            FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_regs8_kernel<A_, B_, C_, true, true>), \
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));        \
+            decomp_regs8_kernel<A_, B_, C_, true, true><<<dim3(2 * B), dim3(DG_THREADS), lds, s>>>(p);        \
+        } else if (bs) {                                                                                      \
             FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_regs8_kernel<A_, B_, C_, true>), \
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));        \
             decomp_regs8_kernel<A_, B_, C_, true><<<dim3(2 * B), dim3(DG_THREADS), lds, s>>>(p);              \

@@ -1553,32 +1553,48 @@ __global__ void gram_kernel(const float *M, int rows, int cols, double *G) {
     if (threadIdx.x == 0) { G[(long long)i * cols + j] = red[0]; G[(long long)j * cols + i] = red[0]; }
 }
 
-// largest eigenvalue of a symmetric n x n matrix (cyclic Jacobi, doubles; n <= a few hundred: create time)
+// largest eigenvalue of a symmetric positive semi-definite n x n matrix (a Gram matrix; doubles; n <= a few hundred: create time).
+// Only the top eigenvalue is needed (the spectral norm of a factor matrix): power iteration on A -- with A squared a few times
+// first, so that the eigenvalue ratio that governs convergence is raised to the 2^k-th power -- instead of diagonalising the
+// matrix (a cyclic Jacobi sweep is n^2/2 rotations of 4n updates; 60 sweeps at n = 250 were seconds of host time per create).
 static double jacobi_largest_eigenvalue(std::vector<double> &A, int n) {
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0, diag = 0.0;
-        for (int i = 0; i < n; i++) { diag += A[(size_t)i * n + i] * A[(size_t)i * n + i]; for (int j = 0; j < i; j++) off += A[(size_t)i * n + j] * A[(size_t)i * n + j]; }
-        if (off <= 1e-30 * (diag + 1e-300)) break;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[(size_t)p * n + q];
-                if (apq == 0.0) continue;
-                const double theta = (A[(size_t)q * n + q] - A[(size_t)p * n + p]) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < n; k++) {                // rows / columns p and q
-                    const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
-                    A[(size_t)k * n + p] = c * akp - sn * akq; A[(size_t)k * n + q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < n; k++) {
-                    const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
-                    A[(size_t)p * n + k] = c * apk - sn * aqk; A[(size_t)q * n + k] = sn * apk + c * aqk;
-                }
+    if (n <= 0) return 0.0;
+    auto matmul_sq = [&](std::vector<double> &M) {       // M <- M . M / trace-scale (keeps the numbers in range)
+        double tr = 0.0;
+        for (int i = 0; i < n; i++) tr += M[(size_t)i * n + i];
+        if (!(tr > 0.0)) return 0.0;
+        std::vector<double> N((size_t)n * n, 0.0);
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < n; k++) {
+                const double a = M[(size_t)i * n + k] / tr;
+                if (a == 0.0) continue;
+                for (int j = 0; j < n; j++) N[(size_t)i * n + j] += a * (M[(size_t)k * n + j] / tr);
             }
+        M.swap(N);
+        return tr;
+    };
+    // lambda_max(A) from the Rayleigh quotient of the dominant eigenvector of A^(2^k): same eigenvector
+    std::vector<double> B = A;
+    for (int k = 0; k < 6; k++)
+        if (!(matmul_sq(B) > 0.0)) return 0.0;
+    std::vector<double> v((size_t)n), w((size_t)n);
+    for (int i = 0; i < n; i++) v[i] = 1.0 + 1e-3 * ((i * 2654435761u) % 1000);   // (not orthogonal to anything in particular)
+    double lam = 0.0;
+    for (int it = 0; it < 200; it++) {
+        const std::vector<double> &M = it < 8 ? B : A;   // a few steps on A^(64) to land on the eigenvector, then refine on A itself
+        double nrm = 0.0;
+        for (int i = 0; i < n; i++) { double acc = 0.0; for (int j = 0; j < n; j++) acc += M[(size_t)i * n + j] * v[j]; w[i] = acc; nrm += acc * acc; }
+        nrm = sqrt(nrm);
+        if (!(nrm > 0.0)) return 0.0;
+        for (int i = 0; i < n; i++) v[i] = w[i] / nrm;
+        if (it >= 8) {
+            double num = 0.0;                            // Rayleigh quotient v^T A v (v has unit length)
+            for (int i = 0; i < n; i++) { double acc = 0.0; for (int j = 0; j < n; j++) acc += A[(size_t)i * n + j] * v[j]; num += v[i] * acc; }
+            if (fabs(num - lam) <= 1e-14 * fabs(num)) { lam = num; break; }
+            lam = num;
+        }
     }
-    double best = 0.0;
-    for (int i = 0; i < n; i++) best = A[(size_t)i * n + i] > best ? A[(size_t)i * n + i] : best;
-    return best;
+    return lam;
 }
 
 __global__ void scale_cols_kernel(float *M, long long n, int cols, const float *scale) {

@@ -68,9 +68,12 @@ __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, boo
 // ldsF / ldsB (FUSED only): the sequence's forward / backward state rows [L + 1][SP] where they still lie in LDS (they must not
 // overlap the products' area, the first SP * (L + 16) floats), else nullptr: the rows are read from the stash.  image_staged:
 // the output matrix's matrix-core image is already in the transition table's LDS area.
+// lm_pk: the caller's copy of this lane's two packed label-map words (label_map.hip.h), fetched long ago (chain_viterbi_kernel: at
+// the kernel's start), or nullptr: they are fetched here, an L2 round trip in front of the first token
 template <int IB4, bool FUSED>
 __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *smem, const int tid, const int nthreads, const int b,
-                                                  const float *ldsF = nullptr, const float *ldsB = nullptr, const bool image_staged = false) {
+                                                  const float *ldsF = nullptr, const float *ldsB = nullptr, const bool image_staged = false,
+                                                  const unsigned *lm_pk = nullptr) {
     constexpr int IB = IB4 * 4;
     const int lane = tid & 63, w = tid >> 6;
     const int n = clamp_len(p.len[b], p.L);
@@ -102,12 +105,21 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         // ~50 instructions -- no products staged, no matrix-core pass, no image of the output matrix
         const int SP = p.SP;
         LabelMapRegs lr;
-        lm_load(p.lm, lane, lr);
+        if (lm_pk) lm_unpack(p.lm, lm_pk[0], lm_pk[1], lr);
+        else lm_load(p.lm, lane, lr);
         if (ldsF) {
-            for (int tok = wu; tok < n; tok += nwaves) {
-                float y0, y1;
-                lm_token_scores(p.lm, lr, ldsF + (tok + 1) * SP, ldsB + (n - (tok + 1)) * SP, y0, y1);
-                lm_store_emissions(p.lm, lr, y0, y1, scl + (size_t)tok * Kp, Kp, lane);
+            // two tokens at a time (their scans interleave: label_map.hip.h), every row entry fetched before the scan
+            const float two = p.lm.nq > 1 ? 1.0f : 0.0f;
+            for (int tok = wu; tok < n; tok += 2 * nwaves) {
+                const int tk2 = tok + nwaves < n ? tok + nwaves : tok;             // (an odd token out: scored twice, stored once)
+                const float *fa = ldsF + (tok + 1) * SP, *ba = ldsB + (n - (tok + 1)) * SP;
+                const float *fb = ldsF + (tk2 + 1) * SP, *bb = ldsB + (n - (tk2 + 1)) * SP;
+                const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = fa[lr.st1] * ba[lr.st1] * two;
+                const float xb0 = fb[lr.st0] * bb[lr.st0], xb1 = fb[lr.st1] * bb[lr.st1] * two;
+                float ya0, ya1, yb0, yb1;
+                lm_scan_scores2(lr, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1);
+                lm_store_emissions(p.lm, lr, ya0, ya1, scl + (size_t)tok * Kp, Kp, lane);
+                if (tk2 != tok) lm_store_emissions(p.lm, lr, yb0, yb1, scl + (size_t)tk2 * Kp, Kp, lane);
             }
         } else {
             // rows from the stash: every load of this wavefront's tokens in flight before the first is used
