@@ -564,7 +564,20 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
         if (lane == 0) { misc[RGM_MINE] = (int)mine; misc[RGM_ACQ] = acq; }
         FARNN_RG_STAMP(3);
     }
-    if constexpr (!SCORE) return;
+    if constexpr (!SCORE) {
+        // chain_viterbi_kernel (b_out set): the forward half's scorer wavefront has nothing to do while the chains run -- it leaves
+        // the decode {length, flat-output offset} in LDS (misc[RGM_FOFF + 1], misc[RGM_FOFF]): two global round trips the decode
+        // would otherwise open with (viterbi_hist_body, `pre`)
+        if (b_out && dir == 0 && w == RG_WAVES - 1) {
+            int partsum = 0;
+            if (p.sp.flat && !p.sp.offs)
+                for (int j = lane; j < b; j += WAVE) partsum += clamp_len(p.len[j], p.L);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) partsum += __shfl_xor(partsum, off, WAVE);
+            if (lane == 0) { misc[RGM_FOFF] = partsum; misc[RGM_FOFF + 1] = len; }
+        }
+        return;
+    }
 
     // =====================================================================================================================
     // the chain is done.  Before the arrival a workgroup touches only the tiles of its own half: those the other direction's

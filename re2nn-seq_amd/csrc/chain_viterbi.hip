@@ -30,6 +30,7 @@ int launch_chain_viterbi(const RegsParams &p_in, const ScoreParams &sp, bool max
     const int NP = RG_NWC * p_in.G;
     const ChainViterbiPlan pl = chain_viterbi_plan(p_in.L, p_in.SP, NP, sp.K, sp.Kp, sp.c16, sp.lm.on != 0, p_in.RQ);
     RegsParams p = p_in;
+    p.sp = sp;                                       // (the chains' idle wavefront works out the flat-output offset: it needs len / flat / offs)
     if (pl.lds_rows && !tun(TUN_CV_STASH)) { p.A = nullptr; p.Bk = nullptr; }     // no stash: the rows stay in LDS
     // (Launch order: longest sequence first, as selected in the kernel.  A workgroup owns a whole sequence and a compute unit holds
     //  one workgroup, so for a lone launch of at most a sequence per compute unit the order changes nothing and the selection costs

@@ -72,10 +72,16 @@ chain_viterbi_kernel(const RegsParams p, const ScoreParams sp, const ChainViterb
     chain_regs_body<MAXSR, false, NLX, RQ, D>(p, mine, role_tid, 2 * (int)blockIdx.x + half, &b);
     __syncthreads();                                 // (s_waitcnt vmcnt(0) in front of it: the image / every stash row has landed)
     if (tid >= vthreads) return;
-    const int hist_off = regs_lds(p.L, p.SP, RG_NWC * p.G, 0, 0, false, RQ).hist;
+    const RegsLds rl = regs_lds(p.L, p.SP, RG_NWC * p.G, 0, 0, false, RQ);
+    const int hist_off = rl.hist;
+    // {length, flat offset} of the sequence: left in the forward half's misc words by its idle scorer wavefront (chain_regs_body).
+    // Only where those words survive the decode's first writes: the rows-in-LDS plans (the halves lie behind the emission rows).
+    const int *pre = pl.lds_rows ? reinterpret_cast<const int *>(smem + pl.off0 + rl.misc) + RGM_FOFF : nullptr;
+    int pre_regs[2] = {0, 0};
+    if (pre) { pre_regs[0] = pre[1]; pre_regs[1] = pre[0]; }
     if (pl.lds_rows)
         viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b, smem + pl.off0 + hist_off, smem + pl.off1 + hist_off, true,
-                                     sp.lm.on ? lm_pk : nullptr);
+                                     sp.lm.on ? lm_pk : nullptr, pre_regs);
     else
         viterbi_hist_body<IB4, true>(sp, smem, tid, vthreads, b, nullptr, nullptr, false, sp.lm.on ? lm_pk : nullptr);
 }

@@ -73,10 +73,12 @@ __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, boo
 template <int IB4, bool FUSED>
 __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *smem, const int tid, const int nthreads, const int b,
                                                   const float *ldsF = nullptr, const float *ldsB = nullptr, const bool image_staged = false,
-                                                  const unsigned *lm_pk = nullptr) {
+                                                  const unsigned *lm_pk = nullptr, const int *pre = nullptr) {
+    // pre (chain_viterbi_kernel): {the sequence's length, its flat-output offset} in LDS, worked out by an idle wavefront while the
+    // chains ran -- else two global round trips (the length, then the lengths in front of it) open the decode
     constexpr int IB = IB4 * 4;
     const int lane = tid & 63, w = tid >> 6;
-    const int n = clamp_len(p.len[b], p.L);
+    const int n = pre ? pre[0] : clamp_len(p.len[b], p.L);
     (void)p.full;
     const int K = p.K, Kp = p.Kp;
     const int PW = Kp;                                   // partition row stride (K rounded up to 4), pads -inf
@@ -85,7 +87,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     float *scl = hist + viterbi_hist_floats(Kp, p.SP, p.L, FUSED);   // [L][Kp] clamped scores of this sequence (whole KiB)
     float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
-    const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
+    const long long foff = p.offs ? p.offs[b] : (p.flat ? (pre ? (long long)pre[1] : flat_offset_in_kernel(p.len, b, p.L, tid, nthreads)) : 0);
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
@@ -487,6 +489,18 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         const unsigned sc_off = (unsigned)(size_t)scl - h0;
         int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
         for (int t = n - 1; t >= 0; t--) {
+            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values.  The step's LDS
+            // reads are ISSUED first; the tag's bookkeeping (a v_writelane through M0, the flush of 64 positions) runs under their
+            // round trip -- in front of them it sat on the chain ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
+            const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
+            const unsigned a_pre = hq0 + 4u * (unsigned)(tp * PW), a_tr = tq0 + 4u * (unsigned)(ptr * Kp);
+            const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
+            f32x4 pre4, tr;
+            float m, f;
+            // one statement, so that the order is this one: the row fetched ahead first (its latency hides behind the others'
+            // -- LDS reads return in order), then the three the step waits for
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7"
+                         : "=&v"(pre4), "=&v"(tr), "=&v"(m), "=&v"(f) : "v"(a_pre), "v"(a_tr), "v"(a_m), "v"(a_f) : "memory");
             {
                 const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
                 const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
@@ -500,21 +514,11 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
                     if (p.flat) p.flat[foff + t + lane] = mytag;
                 }
             }
-            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre4), "+v"(tr), "+v"(m), "+v"(f) : : "memory");
             if (t > 0) {
-                const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
-                const unsigned a_pre = hq0 + 4u * (unsigned)(tp * PW), a_tr = tq0 + 4u * (unsigned)(ptr * Kp);
-                const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;     // (PW == Kp)
-                f32x4 pre, tr;
-                float m, f;
-                // one statement, so that the order is this one: the row fetched ahead first (its latency hides behind the others'
-                // -- LDS reads return in order), then the three the step waits for
-                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(pre), "=&v"(tr), "=&v"(m), "=&v"(f) : "v"(a_pre), "v"(a_tr), "v"(a_m), "v"(a_f) : "memory");
                 c = candidates(f, make_float4(tr.x, tr.y, tr.z, tr.w), prv);
                 ptr = first_equal(c, m);
-                prv = make_float4(pre.x, pre.y, pre.z, pre.w);
+                prv = make_float4(pre4.x, pre4.y, pre4.z, pre4.w);
             }
         }
     }

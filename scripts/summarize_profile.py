@@ -19,7 +19,17 @@ for f in glob.glob(os.path.join(src, 'bench_*.json')):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
 for f in glob.glob(os.path.join(src, '*.txt')):
-    shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
+    # (a probe's printf lines and the bench's JSON line share stdout: keep the probe text only)
+    keep = []
+    for ln in open(f, errors='replace').read().splitlines():
+        if '{"metric"' in ln:
+            ln = ln.split('{"metric"')[0].rstrip()
+            if len(ln) < 40:
+                continue
+            ln += ' [...]'
+        keep.append(ln)
+    with open(os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))), 'w') as g:
+        g.write('\n'.join(keep) + '\n')
 for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_two_kernels'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
                   ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
