@@ -49,6 +49,11 @@ constexpr int DR_LPR = 4;             // lanes per row
 constexpr int DR_RPP = DR_THREADS / DR_LPR;   // rows per pass (128)
 constexpr int DR_CHUNK = 32;          // floats of a row one quad covers per chunk (2 x 16 bytes per lane)
 constexpr int DR_MAX_PF = 4;          // prefetch registers per thread for the per-token vectors
+constexpr int DR_MIXED_NCH3 = 9;      // chunks of an output row a mixed form keeps in registers (the rest: streamed per step)
+constexpr int DR_T3_CHUNKS = 2;       // 64-column chunks of an output row that the all-in-registers form keeps in LDS instead
+constexpr int DR_T3LD = DR_T3_CHUNKS * 64 + 32;   // row stride (floats) of that LDS copy: the two rows of a 16-lane access group land in
+                                      // different halves of the banks
+constexpr int DR_FORM_PF = 2;         // ... of a register-resident form (one sequence; rows_plan_try: its per-token vector <= 1024 floats)
 
 struct DecompRowsParams {
     const float *P1;              // [2S][ld2]   gate rows (farnn==2) or nullptr
@@ -74,6 +79,15 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float quad_sum(float v) {
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm:[1,0,3,2]
     v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm:[2,3,0,1]
+    return v;
+}
+
+// sum over the LPR (4 or 8) adjacent lanes that share a row, result in all of them
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v = quad_sum(v);
+    if constexpr (LPR == 8)       // the other quad of the eight: row_half_mirror (lane i <-> 7 - i), both hold their quad's total
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
     return v;
 }
 
@@ -159,9 +173,22 @@ __device__ __forceinline__ void rowdots_few(const float *ml, int nrows, int ld, 
 // NP and NCH are upper bounds: passes past the last row are not written; chunks past the model's hold zero weights, and their
 // x reads run on into the LDS vectors behind x (state / gate / row floats, or past the allocation: zeros) -- finite times
 // zero.  (Clamping the chunk index instead turned the reads' immediate offsets into address arithmetic: +7 % per step.)
-template <int NSEQ, int NP, int NCH, typename Epi>
-__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi) {
-    const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+// NCHG > 0 (one pass only): the row's chunks NCH .. NCH + NCHG - 1 are not register-resident -- g holds this step's copy of them,
+// fetched from L2 by the caller a phase ahead (decomp_rows_kernel: a form whose rows do not fit the registers whole).
+// LPR = lanes per row (4 or 8): a pass covers 512 / LPR rows, a chunk 8 LPR columns (two 16-byte pieces per lane: columns
+// c 8 LPR + 4 k and + 4 LPR behind them).  Eight lanes per row HALVE the reads of x a wavefront issues for the same products
+// (every lane of the workgroup reads its piece of x once per chunk, whatever the number of passes that share it), and the step
+// of the large gated models is bound by exactly those LDS reads: 64 ds_read_b128 per lane and step at rank 250, farnn 2 with four
+// lanes per row = 4 096 LDS cycles of the step's ~3 700 (round 3: 209 us per batch).
+// NCHL > 0 (eight lanes per row): the chunks NCH .. NCH + NCHL - 1 of every row lie in LDS, [row][DR_T3LD] at tail_lds (the
+// form with all three matrices register-resident but for the output rows' last chunk).
+template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, typename Epi>
+__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
+                                             const v4f *g = nullptr, const float *tail_lds = nullptr) {
+    static_assert(NCHG == 0 || NP == 1, "streamed tail chunks: one pass");
+    static_assert(NCHL == 0 || (LPR == 8 && NCHL == DR_T3_CHUNKS && NCHG == 0), "LDS tail: eight lanes per row");
+    constexpr int RPP = DR_THREADS / LPR, CH = 8 * LPR;
+    const int k = tid & (LPR - 1), rloc = tid / LPR;
     lds_cfloat *xl = (lds_cfloat *)X + k * 4;
     v2f tl[NP][NSEQ], th[NP][NSEQ];
 #pragma unroll
@@ -172,8 +199,8 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
     for (int c = 0; c < NCH; c++)
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) {
-            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * DR_CHUNK);   // compile-time offsets: the reads stay `ds_read ... offset:`
-            const v4f x0 = xp[0], x1 = xp[4];
+            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * CH);   // compile-time offsets: the reads stay `ds_read ... offset:`
+            const v4f x0 = xp[0], x1 = xp[LPR];
 #pragma unroll
             for (int i = 0; i < NP; i++) {
                 const v4f a0 = w[i][2 * c], a1 = w[i][2 * c + 1];
@@ -183,31 +210,160 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
                 th[i][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[i][s]);
             }
         }
+    if constexpr (NCHG > 0) {
 #pragma unroll
-    for (int i = 0; i < NP; i++) {
+        for (int c = 0; c < NCHG; c++)
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) {
+                lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + (NCH + c) * CH);
+                const v4f x0 = xp[0], x1 = xp[LPR];
+                const v4f a0 = g[2 * c], a1 = g[2 * c + 1];
+                tl[0][s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tl[0][s]);
+                th[0][s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, th[0][s]);
+                tl[0][s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tl[0][s]);
+                th[0][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[0][s]);
+            }
+    }
+    // every lane of the group holds every pass's sum: lane k turns pass k's into its row's result -- ONE run of the epilogue
+    // (a sigmoid or tanh between LDS reads and writes: a latency chain) for all passes, not one per pass
+#pragma unroll
+    for (int c = 0; c < NCHL; c++) {
+        v4f a0[NP], a1[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int row = i * RPP + rloc;
+            lds_cv4f *src = (lds_cv4f *)((lds_cfloat *)tail_lds + (row < nrows ? row : nrows - 1) * DR_T3LD + c * CH + k * 4);
+            a0[i] = src[0]; a1[i] = src[LPR];
+        }
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) {
+            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + (NCH + c) * CH);
+            const v4f x0 = xp[0], x1 = xp[LPR];
+#pragma unroll
+            for (int i = 0; i < NP; i++) {
+                tl[i][s] = __builtin_elementwise_fma(v2f{a0[i].x, a0[i].y}, v2f{x0.x, x0.y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a0[i].z, a0[i].w}, v2f{x0.z, x0.w}, th[i][s]);
+                tl[i][s] = __builtin_elementwise_fma(v2f{a1[i].x, a1[i].y}, v2f{x1.x, x1.y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a1[i].z, a1[i].w}, v2f{x1.z, x1.w}, th[i][s]);
+            }
+        }
+    }
+    if constexpr (LPR == 8) {
+        static_assert(NP <= LPR, "one lane of the group per pass");
         float acc[NSEQ];
 #pragma unroll
-        for (int s = 0; s < NSEQ; s++) { const v2f t = tl[i][s] + th[i][s]; acc[s] = quad_sum(t.x + t.y); }
-        const int row = i * DR_RPP + rloc;
-        if (k == 0 && row < nrows) epi(row, acc);
+        for (int s = 0; s < NSEQ; s++) acc[s] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) {
+                const v2f t = tl[i][s] + th[i][s];
+                const float v = group_sum<LPR>(t.x + t.y);
+                acc[s] = k == i ? v : acc[s];
+            }
+        int row = k * RPP + rloc;
+        asm volatile("" : "+v"(row));     // (opaque: as a loop invariant every address the epilogue derives from it is hoisted out of
+                                          //  the time loop into a register of its own -- the register forms have none to spare)
+        if (k < NP && row < nrows) epi(row, acc);
+    } else {                              // (four lanes per row: round 3's form, one run of the epilogue per pass)
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            float acc[NSEQ];
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) { const v2f t = tl[i][s] + th[i][s]; acc[s] = group_sum<LPR>(t.x + t.y); }
+            const int row = i * RPP + rloc;
+            if (k == 0 && row < nrows) epi(row, acc);
+        }
     }
 }
 
-// this lane's pieces of the rows of a packed matrix (rows past the last one: a copy of the last, never used)
-template <int NP, int NCH>
+// this lane's pieces of the rows of a packed matrix (rows past the last one: a copy of the last, never used; pieces past the
+// model's last 32-column block: zeros -- nch counts 32-column blocks whatever LPR is)
+template <int NP, int NCH, int LPR = DR_LPR>
 __device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const float *M, int nrows, int ld, int nch, int tid) {
-    const int k = tid & (DR_LPR - 1), rloc = tid >> 2;
+    constexpr int RPP = DR_THREADS / LPR;
+    const int k = tid & (LPR - 1), rloc = tid / LPR;
     const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-        const int row = i * DR_RPP + rloc;
+        const int row = i * RPP + rloc;
         glb_cv4f *src = (glb_cv4f *)(M + (long long)(row < nrows ? row : nrows - 1) * ld + k * 4);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            w[i][2 * c] = c < nch ? src[c * 8] : zero;
-            w[i][2 * c + 1] = c < nch ? src[c * 8 + 4] : zero;
+            w[i][2 * c] = (2 * c) * LPR / 8 < nch ? src[c * 2 * LPR] : zero;               // (the piece's 32-column block)
+            w[i][2 * c + 1] = (2 * c + 1) * LPR / 8 < nch ? src[c * 2 * LPR + LPR] : zero;
         }
     }
+}
+
+// LDS-resident rows, EIGHT lanes per row, NPASS passes of 64 rows in ONE sweep over the columns: x is read once per chunk for all
+// passes (rowdots re-reads it per pass).  Passes past the last row re-read the last row (their sums are dropped).  nch counts
+// 32-column blocks; an odd count's last half chunk is skipped (behind it lie the row's pad and the next row).
+template <int NSEQ, int NPASS, typename Epi>
+__device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld, int nch, const float *X, int xs, int tid, Epi &&epi) {
+    constexpr int LPR = 8, RPP = DR_THREADS / LPR, CH = 8 * LPR;
+    const int k = tid & (LPR - 1), rloc = tid / LPR;
+    lds_cfloat *xl = (lds_cfloat *)X + k * 4;
+    lds_cv4f *src[NPASS];
+#pragma unroll
+    for (int i = 0; i < NPASS; i++) {
+        const int row = i * RPP + rloc;
+        src[i] = (lds_cv4f *)((lds_cfloat *)ml + (row < nrows ? row : nrows - 1) * ld + k * 4);
+    }
+    v2f tl[NPASS][NSEQ], th[NPASS][NSEQ];
+#pragma unroll
+    for (int i = 0; i < NPASS; i++)
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) { tl[i][s] = v2f{0.f, 0.f}; th[i][s] = v2f{0.f, 0.f}; }
+    const int nfull = nch >> 1;                                // whole 64-column chunks
+#pragma unroll 2
+    for (int c = 0; c < nfull; c++) {
+        v4f x0[NSEQ], x1[NSEQ];
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) {
+            lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * CH);
+            x0[s] = xp[0]; x1[s] = xp[LPR];
+        }
+#pragma unroll
+        for (int i = 0; i < NPASS; i++) {
+            const v4f a0 = src[i][c * 2 * LPR], a1 = src[i][c * 2 * LPR + LPR];
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) {
+                tl[i][s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0[s].x, x0[s].y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0[s].z, x0[s].w}, th[i][s]);
+                tl[i][s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1[s].x, x1[s].y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1[s].z, x1[s].w}, th[i][s]);
+            }
+        }
+    }
+    if (nch & 1) {                                             // the odd 32-column block: first pieces only
+        const int c = nfull;
+#pragma unroll
+        for (int i = 0; i < NPASS; i++) {
+            const v4f a0 = src[i][c * 2 * LPR];
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) {
+                const v4f x0 = *(lds_cv4f *)(xl + s * xs + c * CH);
+                tl[i][s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tl[i][s]);
+                th[i][s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, th[i][s]);
+            }
+        }
+    }
+    static_assert(NPASS <= LPR, "one lane of the group per pass");
+    float acc[NSEQ];
+#pragma unroll
+    for (int s = 0; s < NSEQ; s++) acc[s] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NPASS; i++)
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++) {
+            const v2f t = tl[i][s] + th[i][s];
+            const float v = group_sum<LPR>(t.x + t.y);
+            acc[s] = k == i ? v : acc[s];
+        }
+    int row = k * RPP + rloc;
+    asm volatile("" : "+v"(row));     // (opaque: rowdots_regs)
+    if (k < NPASS && row < nrows) epi(row, acc);
 }
 
 __device__ __forceinline__ float gate_sigmoid(float x, float k) { return 1.0f / (1.0f + __expf(-(x * k))); }
@@ -231,9 +387,13 @@ __device__ __forceinline__ float dr_nl(float x, int nl) {
 // step (the shipped example configuration's shape, S = 104, rank 250, farnn = 2: 286 KB per workgroup per step, 5.1 us per
 // step).  Eight wavefronts have 512 KB of registers between them: P1 (gates) and P3 in registers + P2 in LDS hold that
 // model whole, and a step touches neither L2 nor HBM for weights.
-template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0, bool MIXED = false>
+// LPR = 8 (forms 7, 8): eight lanes per row for the register-resident matrices and for P2's LDS-resident rows (rowdots_regs) --
+// NPxR then count passes of 64 rows and NCHxR chunks of 64 columns.
+template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0, bool MIXED = false, int LPR = DR_LPR>
 __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
+    static_assert(LPR == 4 || (LPR == 8 && !MIXED), "eight lanes per row: P1 / P3 in registers, P2 in LDS (one sweep) or in registers");
+    constexpr int RPPR = DR_THREADS / LPR;                    // rows per pass of a register-resident matrix
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x;
     const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
@@ -276,9 +436,11 @@ decomp_rows_kernel(const DecompRowsParams p) {
     }
     const float *hinit = dir == 0 ? p.h0 : p.hT;
     float *stash_base = dir == 0 ? p.A : p.Bk;
-    auto pick = [&](const int (&arr)[NSEQ], int s) { int v = arr[0];
+    // (a sum of selects against zero, not a chain of selects between the entries: the compiler turns the chain into ONE load
+    // through a selected address, and the array stays in scratch memory for it -- r03: 32 B at NSEQ = 4)
+    auto pick = [&](const int (&arr)[NSEQ], int s) { int v = 0;
 #pragma unroll
-        for (int q = 1; q < NSEQ; q++) v = s == q ? arr[q] : v;
+        for (int q = 0; q < NSEQ; q++) v |= (s == q || NSEQ == 1) ? arr[q] : 0;
         return v; };
 
     // ---- set-up ------------------------------------------------------------------------------------
@@ -295,7 +457,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // A register form may hold only a matrix's first NPxR passes (mixed forms: S in 129..160 needs three passes of gate rows or
     // two of output rows; the registers hold the first passes, the few rows behind them are LDS-resident like any other
     // matrix's, or streamed): R1 / R2 / R3 = rows held in registers, the resident / streamed rows start there.
-    constexpr int R1 = NP1R * DR_RPP, R2 = NP2R * DR_RPP, R3 = NP3R * DR_RPP;
+    constexpr int R1 = NP1R * RPPR, R2 = NP2R * RPPR, R3 = NP3R * RPPR;
     {   // resident rows: global -> LDS
         const float *src[3] = {p.P1 + (long long)R1 * ld2, p.P2[dir] + (long long)R2 * ld2, p.P3[dir] + (long long)R3 * ld3};
         float *dst[3] = {L1, L2, L3};
@@ -304,13 +466,37 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int q = 0; q < 3; q++)
             for (long long i = (long long)tid * 4; i < cnt[q]; i += DR_THREADS * 4) st4(dst[q] + i, ld4(src[q] + i));
         float *tail = L3 + cnt[2];
+        if constexpr (LPR == 8 && NP2R > 0 && NP3R > 0) {      // the output rows' last chunk (NCH3L below): [n3][DR_T3LD], zero past the model
+            constexpr int QPR = DR_T3_CHUNKS * 16;              // 16-byte pieces per row
+            const int c0 = (NCH3R - DR_T3_CHUNKS) * 64;
+            for (int i = tid; i < p.n3 * QPR; i += DR_THREADS) {
+                const int row = i / QPR, q = (i % QPR) * 4;
+                const bool in = c0 + q < p.nch3 * DR_CHUNK;
+                st4(tail + row * DR_T3LD + q, in ? ld4(p.P3[dir] + (long long)row * ld3 + c0 + q) : make_float4(0.f, 0.f, 0.f, 0.f));
+            }
+            for (int i = tid; i < p.n3 * 32; i += DR_THREADS) tail[(i >> 5) * DR_T3LD + DR_T3_CHUNKS * 64 + (i & 31)] = 0.0f;
+            tail += p.n3 * DR_T3LD;
+        }
         for (int i = tid; tail + i < smem + p.lds_floats; i += DR_THREADS) tail[i] = 0.0f;
     }
+    const float *T3 = L3 + (long long)p.res3 * ld3;
     v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1)], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
-    v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3R > 0 ? NCH3R : 1)];
-    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R>(w1, p.P1, p.n1, ld2, p.nch2, tid);
-    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
-    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3R>(w3, p.P3[dir], p.n3, ld3, p.nch3, tid);
+    // (a mixed form with more than DR_MIXED_NCH3 chunks of output row: two passes of gate rows + 13 chunks are 184 registers of
+    // weights, and the compiler kept ~50 of them in scratch memory -- a reload per step from the same L2.  The chunks behind
+    // the first DR_MIXED_NCH3 are fetched from L2 explicitly instead, a phase ahead of their use: no scratch, same bits)
+    // (eight lanes per row with P2 in registers too: 64 + 64 registers of gate and P2 rows leave 64 for the output rows -- four chunks
+    // of a rank-250 model's six; the others lie in LDS, which this form hardly uses otherwise.  Five in registers: 8 spilled)
+    constexpr int NCH3L = (LPR == 8 && NP2R > 0 && NP3R > 0) ? DR_T3_CHUNKS : 0;
+    constexpr int NCH3G = (MIXED && NP3R == 1 && NCH3R > DR_MIXED_NCH3) ? NCH3R - DR_MIXED_NCH3 : 0, NCH3K = NCH3R - NCH3G - NCH3L;
+    v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3K > 0 ? NCH3K : 1)];
+    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR>(w1, p.P1, p.n1, ld2, p.nch2, tid);
+    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
+    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid);
+    glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
+    if constexpr (NCH3G > 0) {
+        const int row = tid >> 2;
+        g3src = (glb_cv4f *)(p.P3[dir] + (long long)(row < p.n3 ? row : p.n3 - 1) * ld3 + (tid & (DR_LPR - 1)) * 4);
+    }
     __syncthreads();
     for (int j = tid; j < S; j += DR_THREADS) {
         const float hv = hinit[j];
@@ -337,26 +523,34 @@ decomp_rows_kernel(const DecompRowsParams p) {
         const int n = pick(nst, s);
         if (n <= 0) return 0.0f;
         const int tk = tok[s * Lr + (t < n ? t : n - 1)];
-        if (e < Rp) return p.Vgen[(long long)tk * Rp + e];
-        if (e < Rp + SP) return p.Gz[(long long)tk * SP + (e - Rp)];
-        return p.Gr[(long long)tk * SP + (e - Rp - SP)];
+        // one load through a selected base (three loads behind branches kept three hoisted 64-bit addresses per prefetch slot alive
+        // over the step: the mixed register forms spilled them)
+        const int seg = e < Rp ? 0 : (e < Rp + SP ? 1 : 2);
+        const float *base = seg == 0 ? p.Vgen : (seg == 1 ? p.Gz : p.Gr);
+        const int col = e - (seg == 0 ? 0 : (seg == 1 ? Rp : Rp + SP)), ld = seg == 0 ? Rp : SP;
+        return base[(long long)tk * ld + col];
     };
     const int ntv = NSEQ * tvl;
-    int pf_s[DR_MAX_PF], pf_e[DR_MAX_PF];                     // loop-invariant split of the prefetch slots
+    constexpr int NPF = (NP1R > 0 || NP2R > 0 || NP3R > 0) ? DR_FORM_PF : DR_MAX_PF;
+    int pf_s[NPF], pf_e[NPF];                                 // loop-invariant split of the prefetch slots
 #pragma unroll
-    for (int i = 0; i < DR_MAX_PF; i++) {
+    for (int i = 0; i < NPF; i++) {
         const int e = tid + i * DR_THREADS;
         pf_s[i] = e < ntv ? e / tvl : 0;
         pf_e[i] = e < ntv ? e % tvl : -1;
     }
-    for (int i = 0; i < DR_MAX_PF; i++)
+    for (int i = 0; i < NPF; i++)
         if (pf_e[i] >= 0) TV[tid + i * DR_THREADS] = tv_load(pf_s[i], pf_e[i], 0);
     __syncthreads();
 
     const float sig_k = p.sig_k;
     const int nl_mode = p.nl;
+    const bool probe = FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0;     // diagnostic: cycle counts of the phases of a step
+    long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
     for (int t = 0; t < nmax; t++) {
+        const bool pr = probe && t == 8;
+        if (pr) pt[0] = (long long)__builtin_amdgcn_s_memtime();
         const int cur = t & 1, nxt = cur ^ 1;
         const float *TVc = TV + cur * ntv;
         int act[NSEQ];
@@ -365,10 +559,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
         // next step's per-token vectors: parked in registers until after P2.  Their loads (a token id from LDS, an address, a
         // global load each) are issued behind P1's products when there is a P1 phase -- at the step's top they sat between the
         // barrier and the step's first LDS reads (the placement that paid 5 % in decomp_regs8_kernel)
-        float pf[DR_MAX_PF];
+        float pf[NPF];
 #define FARNN_DR_ISSUE_PREFETCH()                                                                                  \
         _Pragma("unroll")                                                                                          \
-        for (int i = 0; i < DR_MAX_PF; i++)                                                                        \
+        for (int i = 0; i < NPF; i++)                                                                              \
             pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(pf_s[i], pf_e[i], t + 1) : 0.0f;
         if (farnn != 2) { FARNN_DR_ISSUE_PREFETCH() }
         // The element-wise work rides in the row epilogues: the lane that finishes a row sum turns it into
@@ -379,17 +573,21 @@ decomp_rows_kernel(const DecompRowsParams p) {
         float *X3c = X3 + cur * NSEQ * c3p, *X3n = X3 + nxt * NSEQ * c3p;
         if (farnn == 2) {
             // ---- P1: z, r from h; hb = (1-r) h_init + r h  (:143-151) -----------------------------------
+            // (one sigmoid for both kinds of row, every LDS operand read up front: the lanes of a wavefront hold update-gate and
+            // reset-gate rows side by side, and two branches ran as two latency chains one after the other)
             auto epi1 = [&](int row, const float (&acc)[NSEQ]) {
+                const bool isr = row >= S;
+                const int j = isr ? row - S : row;
+                const float hi = Hinit[j];
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (!act[s]) continue;
-                    const float *tv = TVc + s * tvl;
-                    if (row < S) {
-                        Z[s * SP + row] = gate_sigmoid(acc[s] + tv[Rp + row], sig_k);
+                    const float gpre = TVc[s * tvl + Rp + (isr ? SP : 0) + j], hh = H[s * c2p + j];
+                    const float g = gate_sigmoid(acc[s] + gpre, sig_k);
+                    if (!isr) {
+                        Z[s * SP + j] = g;
                     } else {
-                        const int j = row - S;
-                        const float rg = gate_sigmoid(acc[s] + tv[Rp + SP + j], sig_k);
-                        const float hb = (1.0f - rg) * Hinit[j] + rg * H[s * c2p + j];
+                        const float hb = (1.0f - g) * hi + g * hh;
                         HBc[s * c2p + j] = hb;
                         X3c[s * c3p + Rp + j] = hb;
                     }
@@ -397,15 +595,17 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP1R > 0) {
-                    rowdots_regs<NSEQ, NP1R, NCH2R>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
                     if (MIXED && p.n1 > R1) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi1(row + R1, acc); };
                         rowdots_few<NSEQ>(L1, p.n1 - R1, ld2, p.nch2, H, c2p, tid, shifted);   // (the plan keeps them LDS-resident)
                     }
                 } else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             }
+            if (pr) pt[1] = (long long)__builtin_amdgcn_s_memtime();
             FARNN_DR_ISSUE_PREFETCH()
             wg_barrier_lds();
+            if (pr) pt[2] = (long long)__builtin_amdgcn_s_memtime();
         }
 #undef FARNN_DR_ISSUE_PREFETCH
         {   // ---- P2: rr = v * (Sa^T . hb)  (:169-170 / :174-175); farnn==1: z from the same h ------------
@@ -417,7 +617,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP2R > 0) {
+                if constexpr (LPR == 8 && NP2R > 0) {
+                    rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
+                } else if constexpr (LPR == 8) {                // (rows_plan_try: all of P2 LDS-resident, at most 256 rows)
+                    if (p.n2 <= 2 * RPPR) rowdots_lds8<NSEQ, 2>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+                    else if (p.n2 <= 3 * RPPR) rowdots_lds8<NSEQ, 3>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+                    else rowdots_lds8<NSEQ, 4>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+                } else if constexpr (NP2R > 0) {
                     rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
                     if (MIXED && p.n2 > R2) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi2(row + R2, acc); };
@@ -426,14 +632,27 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 } else rowdots<NSEQ>(L2, p.P2[dir], p.res2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
             }
         }
+        if (pr) pt[3] = (long long)__builtin_amdgcn_s_memtime();
+        // (issued behind P2's products: in front of them the 8 NCH3G registers were live beside P2's working set)
+        v4f g3[NCH3G > 0 ? 2 * NCH3G : 1];
+        if constexpr (NCH3G > 0) {
+            const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NCH3G; c++) {
+                const bool in = NCH3K + c < p.nch3;
+                g3[2 * c] = in ? g3src[(NCH3K + c) * 8] : zero;
+                g3[2 * c + 1] = in ? g3src[(NCH3K + c) * 8 + 4] : zero;
+            }
+        }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
             float *TVn = TV + nxt * ntv;
 #pragma unroll
-            for (int i = 0; i < DR_MAX_PF; i++)
+            for (int i = 0; i < NPF; i++)
                 if (pf_e[i] >= 0) TVn[tid + i * DR_THREADS] = pf[i];
         }
         wg_barrier_lds();
+        if (pr) pt[4] = (long long)__builtin_amdgcn_s_memtime();
         {   // ---- P3: nx = Sb . rr + W(^T) . hb, non-linearity, gate mix, stash  (:171-196) -----------------
             auto epi3 = [&](int row, const float (&acc)[NSEQ]) {
 #pragma unroll
@@ -458,7 +677,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP3R > 0) {
-                    rowdots_regs<NSEQ, NP3R, NCH3R>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3);
+                    rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, g3, T3);
                     if (MIXED && p.n3 > R3) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi3(row + R3, acc); };
                         rowdots_few<NSEQ>(L3, p.n3 - R3, ld3, p.nch3, X3c, c3p, tid, shifted);   // (the plan keeps them LDS-resident)
@@ -466,7 +685,14 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 } else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
             }
         }
+        if (pr) pt[5] = (long long)__builtin_amdgcn_s_memtime();
         wg_barrier_lds();
+        if (pr) {
+            pt[6] = (long long)__builtin_amdgcn_s_memtime();
+            if ((tid & 63) == 0)
+                printf("rows wg 0 wave %d step 8: P1 %lld (+barrier %lld), P2 %lld (+park, barrier %lld), P3 %lld (+barrier %lld), step %lld cycles\n",
+                       tid >> 6, pt[1] - pt[0], pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5], pt[6] - pt[0]);
+        }
     }
 }
 
@@ -555,8 +781,13 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 // rows + the 6 behind it in LDS, P2 in LDS -- 5: Rp + SP <= 288 (rank 150 + additional states: P2 fits whole, nothing is
 // streamed); 6: Rp + SP <= 416 (rank 250 + additional states: P2 as far as the LDS goes, 128 of its 250 rows).  (Three passes
 // of gate rows beside a pass of output rows do not fit the 256 VGPRs of a lane: 46 spilled.)
-#define FARNN_ROWS_FORMS(X) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
+// 7 / 8 (round 4): farnn = 2, S <= 128 like 1 / 3, with EIGHT lanes per row (passes of 64 rows, chunks of 64 columns: half the x
+// reads per wavefront) and P2's rows (rank <= 256, all LDS-resident) swept in one go -- 8: Rp + SP <= 256, 7: Rp + SP <= 384.  They
+// come first; FARNN_ROWS_LPR4=1 leaves them out.
+#define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
 constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6; }
+constexpr int rows_form_lpr(int form) { return (form == 7 || form == 8 || form == 9) ? 8 : DR_LPR; }
+constexpr bool rows_form_tail3(int form) { return form == 9; }       // the output rows' last 64-column chunk in LDS
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -576,24 +807,37 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
         return res;
     };
     pl.form = 0;
-    if (forms && nseq == 1) {      // (two sequences per workgroup on these forms: measured slower, spills)
-        const int np1 = (k.n1 + DR_RPP - 1) / DR_RPP, np2 = (k.n2 + DR_RPP - 1) / DR_RPP, np3 = (k.n3 + DR_RPP - 1) / DR_RPP;
+    if (forms && nseq == 1 && tvl <= DR_FORM_PF * DR_THREADS) {     // (two sequences per workgroup on these forms: measured slower, spills)
+        const bool lpr4_only = tun(TUN_ROWS_LPR4) == 1, no_tail3 = tun(TUN_ROWS_LPR4) == 2;     // (2: without the all-in-registers form)
 #define FARNN_ROWS_MATCH(F_, A_, B_, C_, D_, E_)                                                                   \
-        if (!pl.form && (A_ == 0 || (k.n1 > 0 && (np1 <= A_ || rows_form_mixed(F_)) && k.nch2 <= C_)) &&              \
-            (B_ == 0 || (np2 <= B_ && k.nch2 <= C_)) &&                                                           \
-            (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && k.nch3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
-            (!rows_form_mixed(F_) || (np1 > 2 && np3 > 1))) {     /* (mixed forms: only where forms 1-3 do not reach) */ \
-            /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
-               the sizes they were made for), the remainder is streamed as before; a mixed form's rows behind its     \
-               register passes first: they are few */                                                             \
-            pl.form = F_;                                                                                          \
-            const size_t left0 = left;                                                                             \
-            const int t3 = k.n3 > D_ * DR_RPP ? k.n3 - D_ * DR_RPP : 0, t1 = k.n1 > A_ * DR_RPP ? k.n1 - A_ * DR_RPP : 0; \
-            pl.res3 = take(t3, k.ld3);                                                                             \
-            pl.res1 = take(t1, k.ld2);                                                                             \
-            if (rows_form_mixed(F_) && (pl.res3 < t3 || pl.res1 < t1 || k.nch2 > 16 || k.nch3 > 16)) {             \
-                pl.form = 0; left = left0;              /* its rows behind the register passes must all be LDS-resident */ \
-            } else pl.res2 = take(k.n2 > B_ * DR_RPP ? k.n2 - B_ * DR_RPP : 0, k.ld2);                             \
+        if (!pl.form && !(rows_form_lpr(F_) == 8 && lpr4_only) && !(rows_form_tail3(F_) && no_tail3)) {                                            \
+            /* passes and chunks in the form's own units (LPR = 8: 64 rows, 64 columns) */                         \
+            constexpr int rpp = DR_THREADS / rows_form_lpr(F_), cpc = rows_form_lpr(F_) / 4;                       \
+            const int np1 = (k.n1 + rpp - 1) / rpp, np2 = (k.n2 + rpp - 1) / rpp, np3 = (k.n3 + rpp - 1) / rpp;    \
+            const int nc2 = (k.nch2 + cpc - 1) / cpc, nc3 = (k.nch3 + cpc - 1) / cpc;                              \
+            if ((A_ == 0 || (k.n1 > 0 && (np1 <= A_ || rows_form_mixed(F_)) && nc2 <= C_)) &&                      \
+                (B_ == 0 || (np2 <= B_ && nc2 <= C_)) &&                                                           \
+                (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && nc3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
+                (!rows_form_mixed(F_) || (np1 > 2 && np3 > 1)) &&  /* (mixed forms: only where forms 1-3 do not reach) */ \
+                (rows_form_lpr(F_) != 8 || (k.n2 <= 4 * rpp && nc2 <= C_ && k.nch3 >= 8))) {  /* (shorter rows: form 1 is faster) */ \
+                /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
+                   the sizes they were made for), the remainder is streamed as before; a mixed form's rows behind its     \
+                   register passes first: they are few */                                                          \
+                pl.form = F_;                                                                                      \
+                const size_t left0 = left;                                                                         \
+                const int t3 = k.n3 > D_ * rpp ? k.n3 - D_ * rpp : 0, t1 = k.n1 > A_ * rpp ? k.n1 - A_ * rpp : 0;  \
+                pl.res3 = take(t3, k.ld3);                                                                         \
+                pl.res1 = take(t1, k.ld2);                                                                         \
+                if (rows_form_mixed(F_) && (pl.res3 < t3 || pl.res1 < t1 || k.nch2 > 16 || k.nch3 > 16)) {         \
+                    pl.form = 0; left = left0;          /* its rows behind the register passes must all be LDS-resident */ \
+                } else {                                                                                           \
+                    const int t2 = k.n2 > B_ * rpp ? k.n2 - B_ * rpp : 0;                                          \
+                    pl.res2 = take(t2, k.ld2);                                                                     \
+                    const size_t tail3 = rows_form_tail3(F_) ? (size_t)k.n3 * DR_T3LD * 4 : 0;                     \
+                    if (rows_form_lpr(F_) == 8 && (pl.res2 < t2 || left < tail3)) { pl.form = 0; left = left0; }   /* (its P2 sweep: all rows resident) */ \
+                    else left -= tail3;                                                                            \
+                }                                                                                                  \
+            }                                                                                                      \
         }
         FARNN_ROWS_FORMS(FARNN_ROWS_MATCH)
 #undef FARNN_ROWS_MATCH
@@ -635,15 +879,15 @@ inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, in
     return false;
 }
 
-template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0, bool MIXED = false>
+template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0, bool MIXED = false, int LPR = DR_LPR>
 inline int launch_rows_n(const DecompRowsParams &p, int groups, size_t lds, hipStream_t s) {
     static int raised = -1;     // per process and instantiation; the attribute is per (device, function) but monotone in lds
     if ((int)lds > raised) {
-        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED>),
+        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = 160 * 1024;
     }
-    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
+    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
@@ -662,7 +906,7 @@ inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, c
     p.dbg = tun(TUN_DBG);
     p.lds_floats = (int)(pl.lds / 4);
     const int groups = (B + pl.nseq - 1) / pl.nseq;
-#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_)>(p, groups, pl.lds, s);
+#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_), rows_form_lpr(F_)>(p, groups, pl.lds, s);
     FARNN_ROWS_FORMS(FARNN_ROWS_LAUNCH)
 #undef FARNN_ROWS_LAUNCH
     if (pl.nseq == 4) return launch_rows_n<4>(p, groups, pl.lds, s);

@@ -780,7 +780,7 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
 // fused: the Viterbi kernel computes the scores itself (no score_tile launch went before it)
 static bool viterbi_can_fuse(const farnn_model *m, const ScoreParams &p) {
     return m->use_crf && !p.scores && !p.P && p.A && p.OT && m->K <= 256 &&
-           viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, true) <= 158 * 1024 &&
+           viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, true) <= 158 * 1024 && viterbi_hist_ib4(m->K) <= 6 &&
            !tun(TUN_VITERBI_BP) && !tun(TUN_VITERBI_UNFUSED);
 }
 
@@ -788,7 +788,8 @@ static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream
     int rc;
     if (m->K > 256) return fail(FARNN_ERANGE, "Viterbi: more than 256 tags%s%s");
     const size_t hlds = viterbi_hist_lds_bytes(m->K, m->Kp, p.SP, p.L, fused);
-    if (hlds <= 158 * 1024 && !tun(TUN_VITERBI_BP)) {
+    // (K >= 224 never takes this form: the transposed transition table alone is 196 KiB -- no IB4 = 7, 8 instantiations)
+    if (hlds <= 158 * 1024 && viterbi_hist_ib4(m->K) <= 6 && !tun(TUN_VITERBI_BP)) {
         // partition history in LDS, back-pointers recomputed along the path
         const int threads = viterbi_hist_threads(m->K);
 #define FARNN_LAUNCH_VITH(N)                                                                  \
@@ -803,7 +804,7 @@ static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream
         break;
         switch (viterbi_hist_ib4(m->K)) {
             FARNN_LAUNCH_VITH(0) FARNN_LAUNCH_VITH(1) FARNN_LAUNCH_VITH(2) FARNN_LAUNCH_VITH(3) FARNN_LAUNCH_VITH(4)
-            FARNN_LAUNCH_VITH(5) FARNN_LAUNCH_VITH(6) FARNN_LAUNCH_VITH(7) FARNN_LAUNCH_VITH(8)
+            FARNN_LAUNCH_VITH(5) FARNN_LAUNCH_VITH(6)
         }
 #undef FARNN_LAUNCH_VITH
         FARNN_HIP_TRY(hipGetLastError());

@@ -161,6 +161,12 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         return fail(FARNN_ERANGE, "train_step: CRF tag set too large for this sequence length (K(K+1)*4 + 9*L*K + ... bytes of LDS must fit 160 KiB)%s%s");
     if (c->d.S > TR_VPT * TR_THREADS / TR_NSEQ || c->d.R > TR_VPT * TR_THREADS / TR_NSEQ)
         return fail(FARNN_ERANGE, "train_step: more than 512 states or rank above 512%s%s");
+    {   // the chain kernels address their per-step arrays [B (L+1)][S | R] and the per-word tables [V][S | R] by 32-bit element
+        // offsets against scalar base pointers (train.hip.h)
+        const unsigned long long wide = (unsigned long long)(c->d.S > c->d.R ? c->d.S : c->d.R);
+        if ((unsigned long long)B * (L + 1) * wide >= (1ull << 30) || (unsigned long long)c->d.V * wide >= (1ull << 30))
+            return fail(FARNN_ERANGE, "train_step: B (L+1) max(S, R) and V max(S, R) must stay below 2^30 elements%s%s");
+    }
     FARNN_HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (*c->err_host) {        // set by an earlier step's kernels straight in pinned host memory (no sync here)
@@ -288,9 +294,9 @@ extern "C" int farnn_decomp_ifst_train_step(farnn_train_ctx *c, const farnn_trai
         if (ldsw) return TR_NSEQ;
         const bool fits = TR_NSEQ_L2 * SR <= (size_t)TR_VPT * TR_THREADS && vec4 + 16 <= lds_cap;
         if (forced == 2 || !fits) return TR_NSEQ;
-        // the gated four-sequence kernels with two register slots per thread (4 R or 4 S above 512, e.g. the shipped rank
-        // 250) need more than the 256 VGPRs a 512-thread workgroup has and spill 80-320 bytes per lane: two sequences then
-        if (farnn && forced != 4 && (TR_NSEQ_L2 * S > (size_t)TR_THREADS || TR_NSEQ_L2 * R > (size_t)TR_THREADS)) return TR_NSEQ;
+        // (rounds 2-3 kept the gated four-sequence kernels with two register slots per thread -- 4 R or 4 S above 512, e.g. the
+        // shipped rank 250 -- away: they spilled 80-320 bytes per lane.  Round 4 retired the scratch (train.hip.h: 32-bit offsets,
+        // no hoisted per-call-site addresses): at B = 1024, rank 250, farnn 2 four sequences per workgroup run 5.3 ms against 7.1)
         // measured at rank 250: with 256 sequences four per workgroup leave half the CUs idle (2.98 vs 2.63 ms per step),
         // with 1024 they win (6.5 vs 8.3 ms): four once two-sequence workgroups would outnumber the CUs two to one
         return (forced == 4 || (size_t)B >= 2 * (size_t)c->n_cu) ? TR_NSEQ_L2 : TR_NSEQ;

@@ -344,11 +344,18 @@ viterbi_kernel(const ScoreParams p) {
     float *scl = part + 2 * PW;                          // [L][Kp] clamped scores of this sequence
     unsigned short *bp = reinterpret_cast<unsigned short *>(scl + (size_t)p.L * Kp);   // [L][Kp]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
-    const long long foff = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
+    const long long foff_v = p.offs ? p.offs[b] : (p.flat ? flat_offset_in_kernel(p.len, b, p.L, tid, nthreads) : 0);
+    // (the same value in every lane: kept in scalar registers over the forward pass)
+    const long long foff = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(foff_v >> 32)) << 32) |
+                                       (unsigned)__builtin_amdgcn_readfirstlane((int)foff_v));
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
 
+    // (the set-up loops stay rolled and index in 32 bits: unrolled by four with 64-bit addresses they took registers the 128 of a
+    // sixteen-wavefront workgroup do not have beside the IB transition entries -- r03: 5 / 1 VGPRs in scratch at IB4 = 13 / 16)
+#pragma unroll 1
     for (int i = tid * 4; i < n * Kp; i += nthreads * 4) st4(scl + i, ld4(sc + i));
+#pragma unroll 1
     for (int i = tid; i < 2 * PW; i += nthreads) part[i] = ninf;
     const int j = tid >> 2, q = tid & 3;
     const bool owner = j < K;
@@ -359,8 +366,9 @@ viterbi_kernel(const ScoreParams p) {
         trr[k] = (owner && i < K) ? p.trT[(long long)j * Kp + i] : ninf;
     }
     __syncthreads();
+#pragma unroll 1
     for (int jj = tid; jj < K; jj += nthreads)
-        part[jj] = scl[jj] + p.trT[(long long)jj * Kp + START];              // crf.py:135
+        part[jj] = scl[jj] + p.trT[jj * Kp + START];                         // crf.py:135 (K * Kp < 2^17)
     __syncthreads();
     int pc = 0;
     for (int t = 1; t < n; t++) {
@@ -378,11 +386,13 @@ viterbi_kernel(const ScoreParams p) {
                 if (v > best) { best = v; bi = q * IB + k4 * 4 + u; }
             }
         }
-#pragma unroll
-        for (int off = 1; off <= 2; off <<= 1) {
-            const float ov = __shfl_xor(best, off, WAVE);
-            const int oi = __shfl_xor(bi, off, WAVE);
-            argmax_combine(best, bi, ov, oi);
+        {   // the quad: lanes xor 1, then xor 2 (DPP quad_perm: no address registers, no LDS crossbar)
+            const float ov1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0xB1, 0xf, 0xf, false));
+            const int oi1 = __builtin_amdgcn_update_dpp(0, bi, 0xB1, 0xf, 0xf, false);
+            argmax_combine(best, bi, ov1, oi1);
+            const float ov2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, best), 0x4E, 0xf, 0xf, false));
+            const int oi2 = __builtin_amdgcn_update_dpp(0, bi, 0x4E, 0xf, 0xf, false);
+            argmax_combine(best, bi, ov2, oi2);
         }
         if (owner && q == 0) {
             pout[j] = best;
@@ -392,6 +402,8 @@ viterbi_kernel(const ScoreParams p) {
         pc ^= 1;
     }
     if (w == 0) {
+        int lane;                                        // re-derived here: at IB4 = 16 the copy made at the kernel's top was the one
+        asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane) : "v"(tid));   // register too many over the forward pass (r03: in scratch)
         const float *pin = part + pc * PW;
         float bv = ninf; int bi = 0x7fffffff;
         for (int i = lane; i < K; i += WAVE) {

@@ -91,7 +91,8 @@ __device__ __forceinline__ void matvec2_partial(float *part, const float *in, in
     const int w = tid >> 6, lane = tid & 63;
     const int jb = w % njb, ks = w / njb;
     if (ks >= nks) return;
-    const int j = jb * 64 + lane;
+    int j = jb * 64 + lane;
+    asm volatile("" : "+v"(j));       // (opaque: the offsets derived from it are per-call-site loop invariants -- see part2_sum)
     const int K4 = (K + 3) >> 2;
     const int k0 = 4 * ((K4 * ks) / nks), k1r = 4 * ((K4 * (ks + 1)) / nks), k1 = k1r < K ? k1r : K;
     const bool jok = j < J;
@@ -149,8 +150,12 @@ __device__ __forceinline__ float part2_sum(const float *part, int J, int q, int 
     constexpr int NW = TR_THREADS / 64;
     const int nks = mv_nks(J);
     float v[NW];
+    // (the element's index is opaque to the optimiser: as a loop invariant each of the eight addresses of each call site and slot
+    // was hoisted out of the time loop into a register of its own -- ~100 of them in the gated two-slot kernels, spilled)
+    int idx = q * J + j;
+    asm volatile("" : "+v"(idx));
 #pragma unroll
-    for (int w = 0; w < NW; w++) v[w] = w < nks ? part[((w < nks ? w : 0) * NS + q) * J + j] : 0.0f;
+    for (int w = 0; w < NW; w++) v[w] = w < nks ? part[(w < nks ? w : 0) * NS * J + idx] : 0.0f;
     float s = 0.0f;
 #pragma unroll
     for (int w = 0; w < NW; w++) s += v[w];
@@ -301,21 +306,21 @@ train_forward_kernel(const TrainParams p) {
     // kernel, so the time loop has no divisions and steps its stash rows by S
     int sq[VPT], ss[VPT], rq[VPT], rr_[VPT];
     bool sv[VPT], rv[VPT];
-    long long srow[VPT];
+    unsigned srow[VPT];                                // (32-bit element offsets: train_backward_kernel)
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const int e = tid + k * nt;
         // slot k of a kind that needs fewer slots than the other is dead at compile time (VPS, VPR): its registers vanish
         sv[k] = k < VPS && e < NS * S; sq[k] = sv[k] ? e / S : 0; ss[k] = sv[k] ? e - sq[k] * S : 0;
         rv[k] = k < VPR && e < NS * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
-        srow[k] = (long long)(b0 + sq[k]) * (p.L + 1) * S + ss[k];
+        srow[k] = (unsigned)(b0 + sq[k]) * (unsigned)((p.L + 1) * S) + (unsigned)ss[k];
     }
     float *stash_out = dir == 0 ? p.A : p.Bk;
     // v_t = Vgen[token] is fetched one step ahead into registers (VPT values per thread cover 2 R)
     float vcur[VPT], vnext[VPT], osum[VPT], hk[VPT], hin[VPT], zk[VPT], rk[VPT];
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
-        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L] * R + rr_[k]] : 0.0f;
+        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(unsigned)(toks[rq[k] * p.L] * R + rr_[k])] : 0.0f;
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
         hin[k] = sv[k] ? (dir == 0 ? p.h0[ss[k]] : p.hT[ss[k]]) : 0.0f;
         hk[k] = hin[k]; zk[k] = 1.0f; rk[k] = 1.0f;
@@ -325,7 +330,7 @@ train_forward_kernel(const TrainParams p) {
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const bool ok = farnn && sv[k] && maxlen >= 1;
-        const long long go = ok ? (long long)toks[sq[k] * p.L] * S + ss[k] : 0;
+        const unsigned go = ok ? (unsigned)(toks[sq[k] * p.L] * S + ss[k]) : 0u;
         g1c[k] = ok ? p.GV1[go] : 0.0f;
         g2c[k] = (ok && farnn == 2) ? p.GV2[go] : 0.0f;
         g1n[k] = g2n[k] = 0.0f;
@@ -333,10 +338,10 @@ train_forward_kernel(const TrainParams p) {
     for (int t = 1; t <= maxlen; t++) {
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
-            vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(long long)toks[rq[k] * p.L + t] * R + rr_[k]] : 0.0f;
+            vnext[k] = (rv[k] && t < maxlen) ? p.Vgen[(unsigned)(toks[rq[k] * p.L + t] * R + rr_[k])] : 0.0f;
             if (farnn) {
                 const bool ok = sv[k] && t < maxlen;
-                const long long go = ok ? (long long)toks[sq[k] * p.L + t] * S + ss[k] : 0;
+                const unsigned go = ok ? (unsigned)(toks[sq[k] * p.L + t] * S + ss[k]) : 0u;
                 g1n[k] = ok ? p.GV1[go] : 0.0f;
                 g2n[k] = (ok && farnn == 2) ? p.GV2[go] : 0.0f;
             }
@@ -384,7 +389,7 @@ train_forward_kernel(const TrainParams p) {
         for (int k = 0; k < VPT; k++) {
             if (sv[k] && t <= len[sq[k]]) {
                 const float pre = part2_sum<NS>(part, S, sq[k], ss[k], nw) + part2_sum<NS>(part2, S, sq[k], ss[k], nw);
-                const long long row = srow[k] + (long long)t * S;
+                const unsigned row = srow[k] + (unsigned)(t * S);
                 float h;
                 if (dir == 0) { p.PRE[row] = pre; h = apply_nl(pre * osum[k], p.nl); }      // (:181)
                 else          { h = apply_nl(pre, p.nl); }
@@ -858,7 +863,9 @@ train_backward_kernel(const TrainParams p) {
     // ever touched by its owner, so they live in registers
     int sq[VPT], ss[VPT], rq[VPT], rr_[VPT];
     bool sv[VPT], rv[VPT];
-    long long srow[VPT], rrow[VPT];
+    // (32-bit element offsets against the scalar base pointers -- farnn_train_create bounds the arrays: 64-bit rows made every
+    // stash array of a slot its own 64-bit pointer over the loop, and the gated two-slot kernels spilled 28 registers)
+    unsigned srow[VPT], rrow[VPT];
     float osum[VPT], gacc[VPT], dOacc[VPT], yk[VPT];
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
@@ -868,8 +875,8 @@ train_backward_kernel(const TrainParams p) {
         rv[k] = k < VPR && e < NS * R; rq[k] = rv[k] ? e / R : 0; rr_[k] = rv[k] ? e - rq[k] * R : 0;
         sv[k] = sv[k] && b0 + sq[k] < p.B;
         rv[k] = rv[k] && b0 + rq[k] < p.B;
-        srow[k] = (long long)(b0 + (sv[k] ? sq[k] : 0)) * (p.L + 1) * S + ss[k];
-        rrow[k] = (long long)(b0 + (rv[k] ? rq[k] : 0)) * (p.L + 1) * R + rr_[k];
+        srow[k] = (unsigned)(b0 + (sv[k] ? sq[k] : 0)) * (unsigned)((p.L + 1) * S) + (unsigned)ss[k];
+        rrow[k] = (unsigned)(b0 + (rv[k] ? rq[k] : 0)) * (unsigned)((p.L + 1) * R) + (unsigned)rr_[k];
         osum[k] = sv[k] ? p.Osum[ss[k]] : 0.0f;
         gacc[k] = 0.0f; dOacc[k] = 0.0f; yk[k] = 0.0f;
     }
@@ -889,31 +896,31 @@ train_backward_kernel(const TrainParams p) {
 #pragma unroll
     for (int k = 0; k < VPT; k++) {
         const bool ok = sv[k] && maxlen >= 1;
-        const long long row = srow[k] + (long long)maxlen * S;
+        const unsigned row = srow[k] + (unsigned)(maxlen * S);
         hcur[k] = ok ? stash_base[row] : 0.0f;
         hprev[k] = ok ? stash_base[row - S] : 0.0f;
         gs[k] = ok ? G_base[row] : 0.0f;
         pr[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
         if (farnn) { zc[k] = ok ? ZG[row] : 1.0f; rc[k] = ok ? RG[row] : 1.0f; cc[k] = ok ? CD[row] : 0.0f; }
-        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(long long)toks[rq[k] * p.L + (maxlen - 1 < len[rq[k]] ? maxlen - 1 : 0)] * R + rr_[k]] : 0.0f;
+        vcur[k] = (rv[k] && maxlen >= 1) ? p.Vgen[(unsigned)(toks[rq[k] * p.L + (maxlen - 1 < len[rq[k]] ? maxlen - 1 : 0)] * R + rr_[k])] : 0.0f;
     }
     for (int t = maxlen; t >= 1; t--) {
 #pragma unroll
         for (int k = 0; k < VPT; k++) {                        // prefetch for step t-1
             const bool ok = sv[k] && t >= 2;
-            const long long row = srow[k] + (long long)(t - 1) * S;
+            const unsigned row = srow[k] + (unsigned)((t - 1) * S);
             hpp[k] = ok ? stash_base[row - S] : 0.0f;
             gsn[k] = ok ? G_base[row] : 0.0f;
             prn[k] = (ok && dir == 0) ? p.PRE[row] : 0.0f;
             if (farnn) { zn[k] = ok ? ZG[row] : 1.0f; rn[k] = ok ? RG[row] : 1.0f; cn[k] = ok ? CD[row] : 0.0f; }
-            vnext[k] = (rv[k] && t >= 2) ? p.Vgen[(long long)toks[rq[k] * p.L + (t - 2 < len[rq[k]] ? t - 2 : 0)] * R + rr_[k]] : 0.0f;
+            vnext[k] = (rv[k] && t >= 2) ? p.Vgen[(unsigned)(toks[rq[k] * p.L + (t - 2 < len[rq[k]] ? t - 2 : 0)] * R + rr_[k])] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < VPT; k++) {
             if (sv[k]) {
                 const int li = sq[k] * SP + ss[k];
                 if (t <= len[sq[k]]) {
-                    const long long row = srow[k] + (long long)t * S;
+                    const unsigned row = srow[k] + (unsigned)(t * S);
                     const float gt = gacc[k] + gs[k];
                     float yy, hp = hprev[k];
                     if (farnn) {                                      // h_t = (1-z) h_{t-1} + z cand (:193-196)
@@ -923,7 +930,7 @@ train_backward_kernel(const TrainParams p) {
                         const float daz = gt * (cc[k] - hp) * p.sig_k * zc[k] * (1.0f - zc[k]);
                         dazv[li] = daz;
                         DAZ[row] = daz;
-                        atomicAdd(p.dGV1 + (long long)toks[sq[k] * p.L + t - 1] * S + ss[k], daz);   // az = h Wss1 + GV1[token] + bs1
+                        atomicAdd(p.dGV1 + (unsigned)(toks[sq[k] * p.L + t - 1] * S + ss[k]), daz);   // az = h Wss1 + GV1[token] + bs1
                         if (farnn == 2) hp = (1.0f - rc[k]) * hin[k] + rc[k] * hp;          // hbar (:150-151)
                     } else {
                         yy = gt * nl_grad_from_output(hcur[k], p.nl);
@@ -957,13 +964,13 @@ train_backward_kernel(const TrainParams p) {
             if (rv[k]) {
                 float dd = 0.0f;
                 if (t <= len[rq[k]]) {
-                    const long long row = rrow[k] + (long long)t * R;
+                    const unsigned row = rrow[k] + (unsigned)(t * R);
                     const float rvv = part2_sum<NS>(pa, R, rq[k], rr_[k], nw), uv = part2_sum<NS>(pb, R, rq[k], rr_[k], nw);
                     const float vv = vcur[k];
                     dd = uv * vv;
                     D1o[row] = dd;
                     To[row] = vv * rvv;
-                    atomicAdd(p.dVgen + (long long)toks[rq[k] * p.L + t - 1] * R + rr_[k], uv * rvv);   // d v_t = u * rr
+                    atomicAdd(p.dVgen + (unsigned)(toks[rq[k] * p.L + t - 1] * R + rr_[k]), uv * rvv);   // d v_t = u * rr
                 }
                 d1[rq[k] * RP + rr_[k]] = dd;
             }
@@ -985,8 +992,8 @@ train_backward_kernel(const TrainParams p) {
                         dar = dhb * (hprev[k] - hin[k]) * p.sig_k * rc[k] * (1.0f - rc[k]);
                         dhin[k] = fmaf(dhb, 1.0f - rc[k], dhin[k]);
                         dhk[k] = fmaf(dhb, rc[k], dhk[k]);
-                        DAR[srow[k] + (long long)t * S] = dar;
-                        atomicAdd(p.dGV2 + (long long)toks[sq[k] * p.L + t - 1] * S + ss[k], dar);
+                        DAR[srow[k] + (unsigned)(t * S)] = dar;
+                        atomicAdd(p.dGV2 + (unsigned)(toks[sq[k] * p.L + t - 1] * S + ss[k]), dar);
                     } else {
                         dhk[k] += dhb;
                     }

@@ -76,6 +76,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
                                                   const unsigned *lm_pk = nullptr, const int *pre = nullptr) {
     // pre (chain_viterbi_kernel): {the sequence's length, its flat-output offset} in LDS, worked out by an idle wavefront while the
     // chains ran -- else two global round trips (the length, then the lengths in front of it) open the decode
+    static_assert(IB4 <= 6, "K >= 224: the transition table does not fit the LDS beside a history (launch_viterbi: viterbi_kernel)");
     constexpr int IB = IB4 * 4;
     const int lane = tid & 63, w = tid >> 6;
     const int n = pre ? pre[0] : clamp_len(p.len[b], p.L);
@@ -378,7 +379,6 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             if constexpr (IB4 > 3) lds_read16_at<384>(p4[3], pin_lane + row);
             if constexpr (IB4 > 4) lds_read16_at<512>(p4[4], pin_lane + row);
             if constexpr (IB4 > 5) lds_read16_at<640>(p4[5], pin_lane + row);
-            if constexpr (IB4 > 6) lds_read16_at<768>(p4[6], pin_lane + row);
 #pragma unroll
             for (int xk = 0; xk < XSC; xk++) asm volatile("ds_read_b32 %0, %1" : "=v"(px[xk]) : "v"(px_lane[xk] + row));
             auto block = [&](int k4) {
@@ -393,7 +393,6 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             if constexpr (IB4 > 3) { lds_wait_for<IB4 + XSC - 4>(p4[3]); block(3); }
             if constexpr (IB4 > 4) { lds_wait_for<IB4 + XSC - 5>(p4[4]); block(4); }
             if constexpr (IB4 > 5) { lds_wait_for<IB4 + XSC - 6>(p4[5]); block(5); }
-            if constexpr (IB4 > 6) { lds_wait_for<IB4 + XSC - 7>(p4[6]); block(6); }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fnext));
 #pragma unroll
             for (int xk = 0; xk < XSC; xk++) {
@@ -532,7 +531,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
 }
 
 template <int IB4, bool FUSED>
-__global__ void __launch_bounds__(IB4 < 7 ? 128 * IB4 + 128 : 1024)        // K < 32*IB4 + 32: 8 lanes per tag pair
+__global__ void __launch_bounds__(128 * IB4 + 128)                          // K < 32*IB4 + 32: 8 lanes per tag pair
 viterbi_hist_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
     viterbi_hist_body<IB4, FUSED>(p, smem, (int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x);
