@@ -96,3 +96,17 @@ def test_ctypes_struct_layouts_match_the_header(tmp_path):
         assert int(got[cname + ' sizeof']) == ctypes.sizeof(cls), cname
         for fname, _ in cls._fields_:
             assert int(got['{}.{}'.format(cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
+
+
+def test_no_kernel_of_the_library_uses_scratch_memory():
+    """Round 4 retired the scratch: every kernel's registers fit (the code objects' metadata: private_segment_fixed_size = 0)."""
+    import subprocess
+    import sys
+    from re2nn_seq_amd import _lib
+    if not os.path.exists('/opt/rocm/lib/llvm/bin/llvm-readelf'):
+        pytest.skip('no llvm-readelf')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'kernel_metadata.py'), _lib.LIB_PATH],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-500:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith('#') and last.endswith('with scratch: 0'), last

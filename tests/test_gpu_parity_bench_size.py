@@ -163,11 +163,13 @@ def test_onehot_ifst_crf_at_bench_size_vs_oracle():
     h.close()
 
 
-def test_register_forms_do_not_see_what_earlier_kernels_left_in_lds():
+@pytest.mark.parametrize('R', [100, 250])
+def test_register_forms_do_not_see_what_earlier_kernels_left_in_lds(R):
     """The rows kernel's register forms read whole (upper-bound) chunk counts of their input vectors and run on into the LDS
     behind them with zero weights; LDS keeps what earlier workgroups wrote there -- the Viterbi kernel's -inf pads would
     turn 0 x garbage into NaN.  A Viterbi launch that covers every CU, then a gated decomposed model: scores finite and
-    equal to the oracle's."""
+    equal to the oracle's.  (Rank 100: four lanes per row; rank 250: round 4's form with eight lanes per row, every matrix
+    register-resident and the output rows' last two chunks in LDS.)"""
     from re2nn_seq_amd import _lib, synth
     rng = np.random.RandomState(3)
     Vc, Sc, Cc = 300, 71, 128
@@ -178,7 +180,7 @@ def test_register_forms_do_not_see_what_earlier_kernels_left_in_lds():
     xcd, lcd = _t(xc).cuda(), _t(lc).cuda()
     tc = torch.empty((512, 64), dtype=torch.int32, device='cuda')
     B, L = 256, 64
-    V, q, gates, tr = _snips_model(100, 2, False)
+    V, q, gates, tr = _snips_model(R, 2, False)
     x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4321))
     h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=2, gates=gates,
                                 sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0)
@@ -321,3 +323,39 @@ def test_onehot_ifst_104_states_at_bench_size_vs_reference(mode):
     got = scores.cpu().numpy()[rows]
     lr = live[rows]
     assert np.array_equal(got[lr], g['sample_scores'][lr])
+
+
+@pytest.mark.parametrize('R,S', [(250, 104), (150, 104), (200, 120), (130, 97)])
+def test_gated_rows_forms_with_four_and_eight_lanes_per_row_agree(R, S, monkeypatch):
+    """farnn = 2 at S <= 128 with long output rows runs the rows kernel with EIGHT lanes per row (round 4: all three matrices in
+    registers, or P2 swept from LDS); FARNN_ROWS_LPR4=1 / =2 select round 3's four-lane forms / the eight-lane forms with P2 in
+    LDS.  All three against the oracle at bench size, and the same tags from each (the switch is read when the handle is created)."""
+    from re2nn_seq_amd import _lib, synth
+    B, L = 256, 64
+    V, q, gates, tr = _snips_model(R, 2, False, S=S)
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(977))
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    K = q['Cout'].shape[0]
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    out = {}
+    for sw in ('0', '1', '2'):
+        monkeypatch.setenv('FARNN_ROWS_LPR4', sw)
+        h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=2, gates=gates,
+                                    sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0)
+        scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, scores.data_ptr())
+        torch.cuda.synchronize()
+        assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+        got = scores.cpu().numpy()
+        assert np.isfinite(got).all()
+        np.testing.assert_allclose(got[mask], ref[mask], rtol=2e-4, atol=2e-4)
+        out[sw] = (got, tags.cpu().numpy())
+        h.close()
+    for sw in ('1', '2'):
+        np.testing.assert_allclose(out[sw][0][mask], out['0'][0][mask], rtol=2e-4, atol=2e-4)
+        # tags: equal wherever the two leading scores of the reference are further apart than the forms' float noise
+        srt = np.sort(ref, axis=-1)
+        clear = mask & ((srt[..., -1] - srt[..., -2]) > 1e-3) & (np.abs(srt[..., -1] - 0.5) > 1e-3)
+        assert np.array_equal(out[sw][1][clear], out['0'][1][clear])

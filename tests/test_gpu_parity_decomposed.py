@@ -122,7 +122,7 @@ def test_viterbi_atis_scale_vs_oracle(variant, monkeypatch):
 
 
 @pytest.mark.parametrize('variant', ['fused', 'history'])
-@pytest.mark.parametrize('C', [2, 3, 6, 13, 28, 29, 30, 31, 45, 62, 73, 94, 98, 125, 126, 127, 129, 135, 158, 198, 253, 254])
+@pytest.mark.parametrize('C', [2, 3, 6, 13, 28, 29, 30, 31, 45, 62, 73, 94, 95, 98, 110, 125, 126, 127, 128, 129, 135, 158, 198, 253, 254])
 def test_viterbi_tag_set_sizes_vs_oracle(C, variant, monkeypatch):
     """Every shape of the Viterbi kernel's work split (csrc/score_decode.hip.h: eight lanes per tag pair, 32-source blocks +
     0..4 leftover slots, the tail wavefront at 64 / 32 / 16 / 8 lanes per pair, K = C + 2 from 4 to 256), scores
