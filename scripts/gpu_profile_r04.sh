@@ -25,11 +25,16 @@ python bench.py --workload decomp $Q --steps 300 2>/dev/null > $O/bench_decomp.j
 FARNN_NOLABELMAP=1 python bench.py --workload decomp $Q --steps 300 2>/dev/null > $O/bench_decomp_matrix_core_scores.json
 python bench.py --workload decomp --rank 100 --farnn 1 $Q --steps 100 2>/dev/null > $O/bench_decomp_r100_farnn1.json
 python bench.py --workload decomp --rank 250 --farnn 2 $Q --steps 100 2>/dev/null > $O/bench_decomp_r250_farnn2.json
+FARNN_ROWS_LPR4=1 python bench.py --workload decomp --rank 250 --farnn 2 $Q --steps 100 2>/dev/null > $O/bench_decomp_r250_farnn2_four_lanes_r03.json
+python bench.py --workload decomp --rank 150 --farnn 2 $Q --steps 100 2>/dev/null > $O/bench_decomp_r150_farnn2.json
+FARNN_ROWS_LPR4=1 python bench.py --workload decomp --rank 150 --farnn 2 $Q --steps 100 2>/dev/null > $O/bench_decomp_r150_farnn2_four_lanes_r03.json
 python bench.py --workload decomp1 $Q --steps 100 2>/dev/null > $O/bench_decomp1.json
 python bench.py --workload decomp0 $Q --steps 100 2>/dev/null > $O/bench_decomp0.json
 python bench.py --workload fst4 $Q --steps 20 --warmup 3 2>/dev/null > $O/bench_fst4.json
 python bench.py --workload synth512 --batch 1024 --seqlen 128 --steps 3 --warmup 1 $Q --event-stride 1 2>/dev/null > $O/bench_synth512.json
 python bench.py --workload train --no-cpu-baseline --steps 50 2>/dev/null > $O/bench_train.json
+python bench.py --workload train --rank 250 --farnn 2 --no-cpu-baseline --steps 20 --warmup 3 2>/dev/null > $O/bench_train_r250_farnn2.json
+python bench.py --workload train --rank 250 --farnn 2 --batch 1024 --no-cpu-baseline --steps 10 --warmup 2 2>/dev/null > $O/bench_train_r250_farnn2_b1024.json
 python scripts/host_inclusive_rate.py 2>/dev/null | grep host-inclusive > $O/host_inclusive.txt
 R="--no-cpu-baseline --no-other-configs --no-pipelined --no-parity --event-stride 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 200 --warmup 20 $R > $O/trace.log 2>&1
@@ -37,6 +42,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s104 -- python3
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_crf -- python3 bench.py --workload ifst_crf --steps 100 --warmup 10 $R > $O/trace_crf.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_crf_s104 -- python3 bench.py --workload ifst_crf --states 104 --steps 100 --warmup 10 $R > $O/trace_crf_s104.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_decomp -- python3 bench.py --workload decomp --steps 100 --warmup 10 $R > $O/trace_decomp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_decomp_r250 -- python3 bench.py --workload decomp --rank 250 --farnn 2 --steps 100 --warmup 10 $R > $O/trace_decomp_r250.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_fst4 -- python3 bench.py --workload fst4 --steps 10 --warmup 2 $R > $O/trace_fst4.log 2>&1
 P="--steps 20 --warmup 5 $R"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py $P > $O/pmc_fetch.log 2>&1
@@ -65,6 +71,8 @@ timeout 120 python bench.py --workload ifst --states 104 $Z 2>/dev/null | grep "
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf --states 104 $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_s104_recurrence_then_viterbi_phases.txt
 FARNN_DBG=4096 FARNN_NOFUSE=1 timeout 120 python bench.py --workload decomp $Z 2>/dev/null | grep "^regs" | sort | tail -4 > $O/probe_decomp_regs8_phases.txt
+FARNN_DBG=16 timeout 120 python bench.py --workload decomp --rank 250 --farnn 2 --full-length --batch 128 $Z 2>/dev/null | grep "^rows wg" | sort | tail -8 > $O/probe_decomp_rows_r250_step_phases.txt
+FARNN_ROWS_LPR4=1 FARNN_DBG=16 timeout 120 python bench.py --workload decomp --rank 250 --farnn 2 --full-length --batch 128 $Z 2>/dev/null | grep "^rows wg" | sort | tail -8 > $O/probe_decomp_rows_r250_step_phases_four_lanes_r03.txt
 unset FARNN_LIB
 # keep only the small summaries (kernel_stats + counter collection), drop per-dispatch traces > 4 MB
 find $O -name '*.csv' -size +4M -delete

@@ -31,7 +31,7 @@ for f in glob.glob(os.path.join(src, '*.txt')):
     with open(os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))), 'w') as g:
         g.write('\n'.join(keep) + '\n')
 for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_two_kernels'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
-                  ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104')):
+                  ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104'), ('trace_decomp_r250', 'decomp_r250_farnn2')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(dst, '{}_{}_kernel_stats.csv'.format(tag, name)))
