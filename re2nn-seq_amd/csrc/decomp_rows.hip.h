@@ -38,6 +38,7 @@
 //     barrier/element-wise skeleton); whole farnn_tag 145 us at R=50 (was 237), 374 us for the gated
 //     rank-250 model (was 5960).
 #pragma once
+#include <type_traits>
 #include "common.hip.h"
 #include "decomp_chain.hip.h"
 #include "chain.hip.h"      // select_by_length_rank
@@ -182,14 +183,25 @@ __device__ __forceinline__ void rowdots_few(const float *ml, int nrows, int ld, 
 // lanes per row = 4 096 LDS cycles of the step's ~3 700 (round 3: 209 us per batch).
 // NCHL > 0 (eight lanes per row): the chunks NCH .. NCH + NCHL - 1 of every row lie in LDS, [row][DR_T3LD] at tail_lds (the
 // form with all three matrices register-resident but for the output rows' last chunk).
-template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, typename Epi>
+// pre (LPR = 8, optional): row -> the epilogue's LDS operands (they depend on the row only); called in FRONT of the products with
+// the lane's row clamped into the matrix, its result handed to epi(row, acc, operands) -- the reads run under the products instead
+// of opening the epilogue's latency chain behind the reduction.
+template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, typename Epi, typename Pre = int>
 __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
-                                             const v4f *g = nullptr, const float *tail_lds = nullptr) {
+                                             const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0) {
+    constexpr bool PRE = std::is_invocable_v<Pre, int>;
+    static_assert(!PRE || LPR == 8, "operands ahead: the eight-lane forms");
     static_assert(NCHG == 0 || NP == 1, "streamed tail chunks: one pass");
     static_assert(NCHL == 0 || (LPR == 8 && NCHL == DR_T3_CHUNKS && NCHG == 0), "LDS tail: eight lanes per row");
     constexpr int RPP = DR_THREADS / LPR, CH = 8 * LPR;
     const int k = tid & (LPR - 1), rloc = tid / LPR;
     lds_cfloat *xl = (lds_cfloat *)X + k * 4;
+    // the row this lane finishes (LPR = 8), opaque to the optimiser: as a loop invariant every address the epilogue derives from it
+    // is hoisted out of the time loop into a register of its own -- the register forms have none to spare.  Made opaque HERE, in
+    // front of the products, so that the epilogue's LDS operands (they depend on the row only) can be fetched under them.
+    int myrow = k * RPP + rloc;
+    asm volatile("" : "+v"(myrow));
+    auto ops = [&]() { if constexpr (PRE) return pre(myrow < nrows ? myrow : nrows - 1); else return 0; }();
     v2f tl[NP][NSEQ], th[NP][NSEQ];
 #pragma unroll
     for (int i = 0; i < NP; i++)
@@ -261,10 +273,10 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
                 const float v = group_sum<LPR>(t.x + t.y);
                 acc[s] = k == i ? v : acc[s];
             }
-        int row = k * RPP + rloc;
-        asm volatile("" : "+v"(row));     // (opaque: as a loop invariant every address the epilogue derives from it is hoisted out of
-                                          //  the time loop into a register of its own -- the register forms have none to spare)
-        if (k < NP && row < nrows) epi(row, acc);
+        if (k < NP && myrow < nrows) {
+            if constexpr (PRE) epi(myrow, acc, ops);
+            else epi(myrow, acc);
+        }
     } else {                              // (four lanes per row: round 3's form, one run of the epilogue per pass)
 #pragma unroll
         for (int i = 0; i < NP; i++) {
@@ -299,10 +311,14 @@ __device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const floa
 // LDS-resident rows, EIGHT lanes per row, NPASS passes of 64 rows in ONE sweep over the columns: x is read once per chunk for all
 // passes (rowdots re-reads it per pass).  Passes past the last row re-read the last row (their sums are dropped).  nch counts
 // 32-column blocks; an odd count's last half chunk is skipped (behind it lie the row's pad and the next row).
-template <int NSEQ, int NPASS, typename Epi>
-__device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld, int nch, const float *X, int xs, int tid, Epi &&epi) {
+template <int NSEQ, int NPASS, typename Epi, typename Pre = int>
+__device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld, int nch, const float *X, int xs, int tid, Epi &&epi, Pre pre = 0) {
     constexpr int LPR = 8, RPP = DR_THREADS / LPR, CH = 8 * LPR;
+    constexpr bool PRE = std::is_invocable_v<Pre, int>;
     const int k = tid & (LPR - 1), rloc = tid / LPR;
+    int myrow = k * RPP + rloc;
+    asm volatile("" : "+v"(myrow));       // (opaque: rowdots_regs)
+    auto ops = [&]() { if constexpr (PRE) return pre(myrow < nrows ? myrow : nrows - 1); else return 0; }();
     lds_cfloat *xl = (lds_cfloat *)X + k * 4;
     lds_cv4f *src[NPASS];
 #pragma unroll
@@ -361,23 +377,39 @@ __device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld,
             const float v = group_sum<LPR>(t.x + t.y);
             acc[s] = k == i ? v : acc[s];
         }
-    int row = k * RPP + rloc;
-    asm volatile("" : "+v"(row));     // (opaque: rowdots_regs)
-    if (k < NPASS && row < nrows) epi(row, acc);
+    if (k < NPASS && myrow < nrows) {
+        if constexpr (PRE) epi(myrow, acc, ops);
+        else epi(myrow, acc);
+    }
 }
 
-__device__ __forceinline__ float gate_sigmoid(float x, float k) { return 1.0f / (1.0f + __expf(-(x * k))); }
-
-// update non-linearity on the hardware exponential: |error| ~1e-7 against the 1e-4 parity bar
+// Gates and update non-linearity on the hardware exponential; |error| ~1e-7 against the 1e-4 parity bar.  FAST (the eight-lane
+// forms, round 4): the quotient by v_rcp_f32 and one Newton step -- two dependent FMAs, within rounding of the division -- instead
+// of the IEEE division the `/` compiles to (v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup: a dozen dependent instructions
+// on every phase's epilogue chain; rank 250, farnn 2: 157.5 -> 152.0 us per batch).  The other forms keep the division: the gated
+// 134-state models are sensitive enough that ANY change of the last bit moves one bench-size case across its 1e-4 bar against
+// float64, and their fixtures were captured with it.
+__device__ __forceinline__ float dr_rcp(float d) {       // d finite and >= 1
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
+template <bool FAST = false>
+__device__ __forceinline__ float gate_sigmoid(float x, float k) {
+    if constexpr (FAST) return dr_rcp(1.0f + __expf(fminf(-(x * k), 80.0f)));     // (the clamp keeps the Newton step off infinity)
+    else return 1.0f / (1.0f + __expf(-(x * k)));
+}
+template <bool FAST = false>
 __device__ __forceinline__ float dr_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow for any x
-    return copysignf((1.0f - e) / (1.0f + e), x);
+    if constexpr (FAST) return copysignf((1.0f - e) * dr_rcp(1.0f + e), x);
+    else return copysignf((1.0f - e) / (1.0f + e), x);
 }
+template <bool FAST = false>
 __device__ __forceinline__ float dr_nl(float x, int nl) {
     switch (nl) {
         case FARNN_NL_RELU: return fmaxf(x, 0.0f);
-        case FARNN_NL_TANH: return dr_tanh(x);
-        case FARNN_NL_RELUTANH: return dr_tanh(fmaxf(x, 0.0f));
+        case FARNN_NL_TANH: return dr_tanh<FAST>(x);
+        case FARNN_NL_RELUTANH: return dr_tanh<FAST>(fmaxf(x, 0.0f));
         default: return x;
     }
 }
@@ -593,8 +625,36 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     }
                 }
             };
+            struct Ops1 { float gpre[NSEQ], hh[NSEQ], hi; };
+            auto pre1 = [&](int row) {
+                Ops1 o;
+                const bool isr = row >= S;
+                const int j = isr ? row - S : row;
+                o.hi = Hinit[j];
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) { o.gpre[s] = TVc[s * tvl + Rp + (isr ? SP : 0) + j]; o.hh[s] = H[s * c2p + j]; }
+                return o;
+            };
+            auto epi1o = [&](int row, const float (&acc)[NSEQ], const Ops1 &o) {
+                const bool isr = row >= S;
+                const int j = isr ? row - S : row;
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) {
+                    if (!act[s]) continue;
+                    const float g = gate_sigmoid<true>(acc[s] + o.gpre[s], sig_k);
+                    if (!isr) {
+                        Z[s * SP + j] = g;
+                    } else {
+                        const float hb = (1.0f - g) * o.hi + g * o.hh[s];
+                        HBc[s * c2p + j] = hb;
+                        X3c[s * c3p + Rp + j] = hb;
+                    }
+                }
+            };
             if (!(p.dbg & 1)) {
-                if constexpr (NP1R > 0) {
+                if constexpr (NP1R > 0 && LPR == 8) {
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1);
+                } else if constexpr (NP1R > 0) {
                     rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
                     if (MIXED && p.n1 > R1) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi1(row + R1, acc); };
@@ -616,13 +676,27 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     else Z[s * SP + (row - R)] = gate_sigmoid(acc[s] + TVc[s * tvl + Rp + (row - R)], sig_k);
                 }
             };
+            struct Ops2 { float tv[NSEQ]; };
+            auto pre2 = [&](int row) {
+                Ops2 o;
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) o.tv[s] = TVc[s * tvl + (row < R ? row : Rp + (row - R))];
+                return o;
+            };
+            auto epi2o = [&](int row, const float (&acc)[NSEQ], const Ops2 &o) {
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) {
+                    if (row < R) X3c[s * c3p + row] = acc[s] * o.tv[s];
+                    else Z[s * SP + (row - R)] = gate_sigmoid<true>(acc[s] + o.tv[s], sig_k);
+                }
+            };
             if (!(p.dbg & 1)) {
                 if constexpr (LPR == 8 && NP2R > 0) {
-                    rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
+                    rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2o, nullptr, nullptr, pre2);
                 } else if constexpr (LPR == 8) {                // (rows_plan_try: all of P2 LDS-resident, at most 256 rows)
-                    if (p.n2 <= 2 * RPPR) rowdots_lds8<NSEQ, 2>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
-                    else if (p.n2 <= 3 * RPPR) rowdots_lds8<NSEQ, 3>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
-                    else rowdots_lds8<NSEQ, 4>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2);
+                    if (p.n2 <= 2 * RPPR) rowdots_lds8<NSEQ, 2>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
+                    else if (p.n2 <= 3 * RPPR) rowdots_lds8<NSEQ, 3>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
+                    else rowdots_lds8<NSEQ, 4>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
                 } else if constexpr (NP2R > 0) {
                     rowdots_regs<NSEQ, NP2R, NCH2R>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2);
                     if (MIXED && p.n2 > R2) {                   // (mixed form: the rows behind the register passes)
@@ -675,8 +749,27 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
             };
+            struct Ops3 { float z[NSEQ], h[NSEQ]; };             // (the eight-lane forms: farnn = 2)
+            auto pre3 = [&](int row) {
+                Ops3 o;
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) { o.z[s] = Z[s * SP + row]; o.h[s] = H[s * c2p + row]; }
+                return o;
+            };
+            auto epi3o = [&](int row, const float (&acc)[NSEQ], const Ops3 &o) {
+#pragma unroll
+                for (int s = 0; s < NSEQ; s++) {
+                    if (!act[s]) continue;
+                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl<true>(acc[s], nl_mode);
+                    const float hn = (1.0f - o.z[s]) * o.h[s] + o.z[s] * nx;
+                    H[s * c2p + row] = hn;
+                    if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
+                }
+            };
             if (!(p.dbg & 1)) {
-                if constexpr (NP3R > 0) {
+                if constexpr (NP3R > 0 && LPR == 8) {
+                    rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);
+                } else if constexpr (NP3R > 0) {
                     rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, g3, T3);
                     if (MIXED && p.n3 > R3) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi3(row + R3, acc); };
