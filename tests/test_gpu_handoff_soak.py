@@ -45,10 +45,10 @@ class _Noise:
         self.i += 1
 
 
-def _soak(B, L, launches, seed, full):
+def _soak(B, L, launches, seed, full, S=71):
     from re2nn_seq_amd import _lib, synth
     rng = np.random.RandomState(seed)
-    V, S, C = 950, 71, 128
+    V, C = 950, 128
     T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng)
     h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
     mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
@@ -98,3 +98,14 @@ def test_fused_handoff_soak(B, L, launches, full):
     n = max(64, int(launches * scale))
     bad = _soak(B, L, n, seed=B * 131 + L + int(full), full=full)
     assert bad == 0, '{} wrong tags over {} fused launches (B={}, L={}, full={})'.format(bad, n, B, L, full)
+
+
+@pytest.mark.parametrize('S,B,L,launches,full', [(104, 256, 64, 12000, False), (104, 8, 64, 12000, False), (104, 301, 50, 5000, True),
+                                                (128, 256, 64, 5000, False), (97, 64, 33, 5000, False)])
+def test_fused_handoff_soak_wide_form(S, B, L, launches, full):
+    """The same soak for round 4's wide form of the recurrence (chain_wide.hip.h: 72 < S <= 128; S = 104: two workgroups per
+    compute unit, S = 128: one) -- the same progress / arrival words, the device-side epoch, other code around them."""
+    scale = float(os.environ.get('FARNN_SOAK_SCALE', '1'))
+    n = max(64, int(launches * scale))
+    bad = _soak(B, L, n, seed=S * 977 + B * 131 + L + int(full), full=full, S=S)
+    assert bad == 0, '{} wrong tags over {} fused launches (S={}, B={}, L={}, full={})'.format(bad, n, S, B, L, full)
