@@ -190,7 +190,7 @@ template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 
 __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
                                              const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0) {
     constexpr bool PRE = std::is_invocable_v<Pre, int>;
-    static_assert(!PRE || LPR == 8, "operands ahead: the eight-lane forms");
+    static_assert(!PRE || NP <= LPR, "operands ahead: one lane of the group per pass");
     static_assert(NCHG == 0 || NP == 1, "streamed tail chunks: one pass");
     static_assert(NCHL == 0 || (LPR == 8 && NCHL == DR_T3_CHUNKS && NCHG == 0), "LDS tail: eight lanes per row");
     constexpr int RPP = DR_THREADS / LPR, CH = 8 * LPR;
@@ -260,7 +260,7 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
             }
         }
     }
-    if constexpr (LPR == 8) {
+    if constexpr (LPR == 8 || PRE) {
         static_assert(NP <= LPR, "one lane of the group per pass");
         float acc[NSEQ];
 #pragma unroll
@@ -426,6 +426,10 @@ __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
     static_assert(LPR == 4 || (LPR == 8 && !MIXED), "eight lanes per row: P1 / P3 in registers, P2 in LDS (one sweep) or in registers");
     constexpr int RPPR = DR_THREADS / LPR;                    // rows per pass of a register-resident matrix
+    // register-resident matrices: lane k finishes pass k in ONE run of the epilogue, its LDS operands fetched ahead of the products,
+    // quotients by reciprocal (not the mixed forms -- their rows behind the register passes go through rowdots_few's epilogue --
+    // and not form 3: twelve chunks of output row beside two passes of gate rows leave it no register, 56 spilled)
+    constexpr bool OPA = !MIXED && (LPR == 8 || NCH3R <= 8);
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x;
     const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
@@ -652,7 +656,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP1R > 0 && LPR == 8) {
+                if constexpr (NP1R > 0 && OPA) {
                     rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1);
                 } else if constexpr (NP1R > 0) {
                     rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
@@ -691,7 +695,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (LPR == 8 && NP2R > 0) {
+                if constexpr (OPA && NP2R > 0) {
                     rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2o, nullptr, nullptr, pre2);
                 } else if constexpr (LPR == 8) {                // (rows_plan_try: all of P2 LDS-resident, at most 256 rows)
                     if (p.n2 <= 2 * RPPR) rowdots_lds8<NSEQ, 2>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
@@ -767,7 +771,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             if (!(p.dbg & 1)) {
-                if constexpr (NP3R > 0 && LPR == 8) {
+                if constexpr (NP3R > 0 && OPA) {
                     rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);
                 } else if constexpr (NP3R > 0) {
                     rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, g3, T3);
