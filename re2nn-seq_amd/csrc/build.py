@@ -131,5 +131,30 @@ def build_hip(force=False, verbose=True, probes=None):
     return out
 
 
+def build_rccl(force=False, verbose=True):
+    """libfarnn_rccl.so (include/farnn_rccl.h): the tag gather over RCCL as a C-ABI of its own; host code only, links librccl.so.
+    A library of its own so that libfarnn_hip.so does not depend on RCCL."""
+    src = os.path.join(HERE, 'rccl', 'farnn_rccl.cpp')
+    out = os.path.join(HERE, 'libfarnn_rccl.so')
+    hdr = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'include', 'farnn_rccl.h')
+    cmd = [HIPCC, '-O2', '-std=c++17', '-fPIC', '-shared', '-D__HIP_PLATFORM_AMD__', '-x', 'c++', src, '-o', out, '-I/opt/rocm/include',
+           '-L/opt/rocm/lib', '-lrccl', '-lamdhip64', '-Wl,-rpath,/opt/rocm/lib']
+    want = _digest([src, hdr], cmd)
+    stamp = os.path.join(OBJ, 'rccl.sha')
+    os.makedirs(OBJ, exist_ok=True)
+    try:
+        have = open(stamp).read().strip()
+    except OSError:
+        have = ''
+    if force or not os.path.exists(out) or have != want:
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=HERE)
+        with open(stamp, 'w') as f:
+            f.write(want or '')
+    return out
+
+
 if __name__ == '__main__':
     build_hip(force='--force' in sys.argv, probes=True if '--probes' in sys.argv else None)
+    build_rccl(force='--force' in sys.argv)

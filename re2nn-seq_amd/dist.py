@@ -70,6 +70,25 @@ def gather_tags_balanced(local_tags, assign, n_total, group=None):
     return out.index_select(0, src.to(buf.device))
 
 
+def gather_tags_balanced_native(local_tags, assign, n_total, comm):
+    """gather_tags_balanced over the C-ABI collective (include/farnn_rccl.h, `_rccl.Communicator`) instead of
+    torch.distributed: the same padded blocks, the same inverse permutation."""
+    w = len(assign)
+    if w == 1:
+        return local_tags
+    L = local_tags.shape[1]
+    biggest = max(int(a.shape[0]) for a in assign)
+    buf = local_tags
+    if buf.shape[0] < biggest:
+        pad = torch.full((biggest - buf.shape[0], L), -1, dtype=buf.dtype, device=buf.device)
+        buf = torch.cat([buf, pad], dim=0)
+    out = comm.gather_tags(buf.contiguous())
+    src = torch.empty((n_total,), dtype=torch.int64)
+    for r, a in enumerate(assign):
+        src[a] = r * biggest + torch.arange(int(a.shape[0]), dtype=torch.int64)
+    return out.index_select(0, src.to(buf.device))
+
+
 def shard_batch(x, lengths, rank=None, world_size=None):
     r, w = world()
     rank = r if rank is None else rank

@@ -110,3 +110,22 @@ def test_no_kernel_of_the_library_uses_scratch_memory():
     assert r.returncode == 0, r.stderr[-500:]
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith('#') and last.endswith('with scratch: 0'), last
+
+
+def test_rccl_gather_library_exports_its_header():
+    """include/farnn_rccl.h (the tag gather over RCCL without torch.distributed): every declared symbol is exported by
+    libfarnn_rccl.so and bound by re2nn_seq_amd._rccl; nothing is called that needs a GPU."""
+    import torch  # noqa: F401  (one HIP runtime per process: the libraries are loaded after torch)
+    from re2nn_seq_amd import _rccl
+    with open(os.path.join(ROOT, 'include', 'farnn_rccl.h')) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    declared = sorted(set(re.findall(r'\b(farnn_rccl_[a-z0-9_]+)\s*\(', text)))
+    assert declared == sorted(_rccl.SIGNATURES)
+    if not os.path.exists(_rccl.LIB_PATH):
+        pytest.skip('libfarnn_rccl.so not built (optional)')
+    try:
+        lib = ctypes.CDLL(_rccl.LIB_PATH)
+    except OSError as e:
+        pytest.skip('librccl.so does not load here: %s' % e)
+    for name in declared:
+        assert hasattr(lib, name), name

@@ -128,3 +128,24 @@ def test_bench_eight_ranks_dry_run(extra):
     lo, hi = d['config']['valid_tokens_per_rank_min_max']
     assert 0 < lo <= hi and 8 * lo <= d['config']['valid_tokens_per_step'] <= 8 * hi
     assert '8 ranks' in r.stderr
+
+
+def test_rccl_gather_c_abi_one_rank():
+    """The torch-free tag gather (include/farnn_rccl.h) on a communicator of ONE rank -- what a single-GPU box can run: id,
+    communicator, an all-gather of int32 tag blocks on a side stream, the balanced-assignment un-permutation on top of it."""
+    import torch
+    from re2nn_seq_amd import _rccl, dist as fdist
+    if not os.path.exists(_rccl.LIB_PATH):
+        pytest.skip('libfarnn_rccl.so not built (optional)')
+    assert _rccl.lib().farnn_rccl_version() > 0
+    comm = _rccl.Communicator(_rccl.unique_id(), 1, 0, 0)
+    local = torch.randint(-1, 128, (37, 64), dtype=torch.int32, device='cuda')
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    out = comm.gather_tags(local, stream=side.cuda_stream)
+    side.synchronize()
+    assert out.shape == (37, 64) and torch.equal(out, local)
+    lengths = torch.randint(1, 65, (37,))
+    assign = fdist.balanced_assignment(lengths, 1)
+    assert torch.equal(fdist.gather_tags_balanced_native(local, assign, 37, comm), local)
+    comm.close()
