@@ -186,8 +186,9 @@ __device__ __forceinline__ void rowdots_few(const float *ml, int nrows, int ld, 
 // pre (LPR = 8, optional): row -> the epilogue's LDS operands (they depend on the row only); called in FRONT of the products with
 // the lane's row clamped into the matrix, its result handed to epi(row, acc, operands) -- the reads run under the products instead
 // of opening the epilogue's latency chain behind the reduction.
-template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, typename Epi, typename Pre = int>
-__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
+// HALF = 1: the last chunk holds its first piece only (w[.][2 NCH - 1]): a matrix of 2.5 chunks does not pay registers for three.
+template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, int HALF = 0, typename Epi, typename Pre = int>
+__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
                                              const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0) {
     constexpr bool PRE = std::is_invocable_v<Pre, int>;
     static_assert(!PRE || NP <= LPR, "operands ahead: one lane of the group per pass");
@@ -212,14 +213,18 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) {
             lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * CH);   // compile-time offsets: the reads stay `ds_read ... offset:`
-            const v4f x0 = xp[0], x1 = xp[LPR];
+            const bool second = !(HALF && c == NCH - 1);
+            const v4f x0 = xp[0], x1 = second ? xp[LPR] : v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NP; i++) {
-                const v4f a0 = w[i][2 * c], a1 = w[i][2 * c + 1];
+                const v4f a0 = w[i][2 * c];
                 tl[i][s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tl[i][s]);
                 th[i][s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, th[i][s]);
-                tl[i][s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tl[i][s]);
-                th[i][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[i][s]);
+                if (second) {
+                    const v4f a1 = w[i][2 * c + (second ? 1 : 0)];
+                    tl[i][s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tl[i][s]);
+                    th[i][s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, th[i][s]);
+                }
             }
         }
     if constexpr (NCHG > 0) {
@@ -291,8 +296,8 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH], int nr
 
 // this lane's pieces of the rows of a packed matrix (rows past the last one: a copy of the last, never used; pieces past the
 // model's last 32-column block: zeros -- nch counts 32-column blocks whatever LPR is)
-template <int NP, int NCH, int LPR = DR_LPR>
-__device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const float *M, int nrows, int ld, int nch, int tid) {
+template <int NP, int NCH, int LPR = DR_LPR, int HALF = 0>
+__device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH - HALF], const float *M, int nrows, int ld, int nch, int tid) {
     constexpr int RPP = DR_THREADS / LPR;
     const int k = tid & (LPR - 1), rloc = tid / LPR;
     const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
@@ -303,7 +308,7 @@ __device__ __forceinline__ void load_rows_regs(v4f (&w)[NP][2 * NCH], const floa
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             w[i][2 * c] = (2 * c) * LPR / 8 < nch ? src[c * 2 * LPR] : zero;               // (the piece's 32-column block)
-            w[i][2 * c + 1] = (2 * c + 1) * LPR / 8 < nch ? src[c * 2 * LPR + LPR] : zero;
+            if (!(HALF && c == NCH - 1)) w[i][2 * c + 1] = (2 * c + 1) * LPR / 8 < nch ? src[c * 2 * LPR + LPR] : zero;
         }
     }
 }
@@ -315,7 +320,9 @@ template <int NSEQ, int NPASS, typename Epi, typename Pre = int>
 __device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld, int nch, const float *X, int xs, int tid, Epi &&epi, Pre pre = 0) {
     constexpr int LPR = 8, RPP = DR_THREADS / LPR, CH = 8 * LPR;
     constexpr bool PRE = std::is_invocable_v<Pre, int>;
-    const int k = tid & (LPR - 1), rloc = tid / LPR;
+    const int k = tid & (LPR - 1);
+    int rloc = tid / LPR;
+    asm volatile("" : "+v"(rloc));        // (opaque, like the row below: the NPASS row addresses stay out of the time loop's live set)
     int myrow = k * RPP + rloc;
     asm volatile("" : "+v"(myrow));       // (opaque: rowdots_regs)
     auto ops = [&]() { if constexpr (PRE) return pre(myrow < nrows ? myrow : nrows - 1); else return 0; }();
@@ -424,7 +431,7 @@ __device__ __forceinline__ float dr_nl(float x, int nl) {
 template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0, bool MIXED = false, int LPR = DR_LPR>
 __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
-    static_assert(LPR == 4 || (LPR == 8 && !MIXED), "eight lanes per row: P1 / P3 in registers, P2 in LDS (one sweep) or in registers");
+    static_assert(LPR == 4 || (LPR == 8 && (!MIXED || NP2R == 0)), "eight lanes per row: P1 / P3 in registers, P2 in LDS (one sweep) or in registers");
     constexpr int RPPR = DR_THREADS / LPR;                    // rows per pass of a register-resident matrix
     // register-resident matrices: lane k finishes pass k in ONE run of the epilogue, its LDS operands fetched ahead of the products,
     // quotients by reciprocal (not the mixed forms -- their rows behind the register passes go through rowdots_few's epilogue --
@@ -516,7 +523,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int i = tid; tail + i < smem + p.lds_floats; i += DR_THREADS) tail[i] = 0.0f;
     }
     const float *T3 = L3 + (long long)p.res3 * ld3;
-    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1)], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
+    // (the mixed eight-lane form: 128 < S <= 160 columns are 2.5 chunks of 64 -- the sixth piece would be 16 registers of zeros)
+    constexpr int HALF2 = (MIXED && LPR == 8 && NCH2R > 0) ? 1 : 0;
+    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
     // (a mixed form with more than DR_MIXED_NCH3 chunks of output row: two passes of gate rows + 13 chunks are 184 registers of
     // weights, and the compiler kept ~50 of them in scratch memory -- a reload per step from the same L2.  The chunks behind
     // the first DR_MIXED_NCH3 are fetched from L2 explicitly instead, a phase ahead of their use: no scratch, same bits)
@@ -525,7 +534,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     constexpr int NCH3L = (LPR == 8 && NP2R > 0 && NP3R > 0) ? DR_T3_CHUNKS : 0;
     constexpr int NCH3G = (MIXED && NP3R == 1 && NCH3R > DR_MIXED_NCH3) ? NCH3R - DR_MIXED_NCH3 : 0, NCH3K = NCH3R - NCH3G - NCH3L;
     v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3K > 0 ? NCH3K : 1)];
-    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR>(w1, p.P1, p.n1, ld2, p.nch2, tid);
+    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR, HALF2>(w1, p.P1, p.n1, ld2, p.nch2, tid);
     if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
     if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid);
     glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
@@ -657,9 +666,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP1R > 0 && OPA) {
-                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1);
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1);
                 } else if constexpr (NP1R > 0) {
-                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
                     if (MIXED && p.n1 > R1) {                   // (mixed form: the rows behind the register passes)
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi1(row + R1, acc); };
                         rowdots_few<NSEQ>(L1, p.n1 - R1, ld2, p.nch2, H, c2p, tid, shifted);   // (the plan keeps them LDS-resident)
@@ -881,9 +890,11 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 // 7 / 8 (round 4): farnn = 2, S <= 128 like 1 / 3, with EIGHT lanes per row (passes of 64 rows, chunks of 64 columns: half the x
 // reads per wavefront) and P2's rows (rank <= 256, all LDS-resident) swept in one go -- 8: Rp + SP <= 256, 7: Rp + SP <= 384.  They
 // come first; FARNN_ROWS_LPR4=1 leaves them out.
-#define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
-constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6; }
-constexpr int rows_form_lpr(int form) { return (form == 7 || form == 8 || form == 9) ? 8 : DR_LPR; }
+// 10 (round 4, MIXED with eight lanes per row): farnn = 2 at 128 < S <= 160 with rank <= 192 (`--additional_states 30` at rank 150):
+// four passes of gate rows and two of output rows in registers, the few rows behind them and all of P2 (swept in one go) in LDS.
+#define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(10, 4, 0, 3, 2, 5) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
+constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6 || form == 10; }
+constexpr int rows_form_lpr(int form) { return (form == 7 || form == 8 || form == 9 || form == 10) ? 8 : DR_LPR; }
 constexpr bool rows_form_tail3(int form) { return form == 9; }       // the output rows' last 64-column chunk in LDS
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
@@ -915,8 +926,9 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
             if ((A_ == 0 || (k.n1 > 0 && (np1 <= A_ || rows_form_mixed(F_)) && nc2 <= C_)) &&                      \
                 (B_ == 0 || (np2 <= B_ && nc2 <= C_)) &&                                                           \
                 (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && nc3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
-                (!rows_form_mixed(F_) || (np1 > 2 && np3 > 1)) &&  /* (mixed forms: only where forms 1-3 do not reach) */ \
-                (rows_form_lpr(F_) != 8 || (k.n2 <= 4 * rpp && nc2 <= C_ && k.nch3 >= 8))) {  /* (shorter rows: form 1 is faster) */ \
+                (!rows_form_mixed(F_) || (np1 > A_ && np3 > D_)) &&  /* (mixed forms: only where the whole-matrix forms do not reach) */ \
+                (rows_form_lpr(F_) != 8 || (k.n2 <= 4 * rpp && nc2 <= C_ && k.nch3 >= 8)) &&  /* (shorter rows: form 1 is faster) */ \
+                (!(rows_form_mixed(F_) && rows_form_lpr(F_) == 8) || k.nch2 <= 2 * C_ - 1)) {  /* (its last chunk of gate row: the first piece only) */ \
                 /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
                    the sizes they were made for), the remainder is streamed as before; a mixed form's rows behind its     \
                    register passes first: they are few */                                                          \

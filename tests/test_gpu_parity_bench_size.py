@@ -325,11 +325,12 @@ def test_onehot_ifst_104_states_at_bench_size_vs_reference(mode):
     assert np.array_equal(got[lr], g['sample_scores'][lr])
 
 
-@pytest.mark.parametrize('R,S', [(250, 104), (150, 104), (200, 120), (130, 97)])
+@pytest.mark.parametrize('R,S', [(250, 104), (150, 104), (200, 120), (130, 97), (150, 134)])
 def test_gated_rows_forms_with_four_and_eight_lanes_per_row_agree(R, S, monkeypatch):
     """farnn = 2 at S <= 128 with long output rows runs the rows kernel with EIGHT lanes per row (round 4: all three matrices in
     registers, or P2 swept from LDS); FARNN_ROWS_LPR4=1 / =2 select round 3's four-lane forms / the eight-lane forms with P2 in
-    LDS.  All three against the oracle at bench size, and the same tags from each (the switch is read when the handle is created)."""
+    LDS.  All three against the oracle at bench size, and the same tags from each (the switch is read when the handle is created).
+    (150, 134): `--additional_states 30` -- the MIXED eight-lane form against round 3's mixed four-lane one.)"""
     from re2nn_seq_amd import _lib, synth
     B, L = 256, 64
     V, q, gates, tr = _snips_model(R, 2, False, S=S)
