@@ -187,10 +187,15 @@ __device__ __forceinline__ void rowdots_few(const float *ml, int nrows, int ld, 
 // the lane's row clamped into the matrix, its result handed to epi(row, acc, operands) -- the reads run under the products instead
 // of opening the epilogue's latency chain behind the reduction.
 // HALF = 1: the last chunk holds its first piece only (w[.][2 NCH - 1]): a matrix of 2.5 chunks does not pay registers for three.
-template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, int HALF = 0, typename Epi, typename Pre = int>
-__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF], int nrows, int /*nch*/, const float *X, int xs, int tid, Epi &&epi,
-                                             const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0) {
+// NPL = 1 (the mixed forms): the rows BEHIND the NP register passes (fewer than a pass) lie in LDS, [.][ldl] at rows_lds; they are
+// swept as pass NP of the same loop -- their pieces read beside the x pieces every pass shares, their sums reduced and finished
+// like any pass's.  (Round 3 gave them to rowdots_few: a wavefront per row, a six-level reduction and an epilogue run per round.)
+template <int NSEQ, int NP, int NCH, int NCHG = 0, int LPR = DR_LPR, int NCHL = 0, int HALF = 0, int NPL = 0, typename Epi, typename Pre = int>
+__device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF], int nrows, int nch, const float *X, int xs, int tid, Epi &&epi,
+                                             const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0,
+                                             const float *rows_lds = nullptr, int ldl = 0) {
     constexpr bool PRE = std::is_invocable_v<Pre, int>;
+    static_assert(NPL == 0 || (NP + 1 <= LPR && NCHG == 0 && NCHL == 0), "rows behind the register passes: one more pass");
     static_assert(!PRE || NP <= LPR, "operands ahead: one lane of the group per pass");
     static_assert(NCHG == 0 || NP == 1, "streamed tail chunks: one pass");
     static_assert(NCHL == 0 || (LPR == 8 && NCHL == DR_T3_CHUNKS && NCHG == 0), "LDS tail: eight lanes per row");
@@ -208,6 +213,16 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
     for (int i = 0; i < NP; i++)
 #pragma unroll
         for (int s = 0; s < NSEQ; s++) { tl[i][s] = v2f{0.f, 0.f}; th[i][s] = v2f{0.f, 0.f}; }
+    v2f tlx[NSEQ], thx[NSEQ];                                 // (NPL) the pass from LDS
+#pragma unroll
+    for (int s = 0; s < NSEQ; s++) { tlx[s] = v2f{0.f, 0.f}; thx[s] = v2f{0.f, 0.f}; }
+    const int ntail = nrows - NP * RPP;                       // rows behind the register passes (NPL; <= RPP by the plan)
+    lds_cv4f *xsrc = nullptr;
+    if constexpr (NPL > 0) {
+        int rl = tid / LPR;
+        asm volatile("" : "+v"(rl));                          // (opaque: the address stays out of the time loop's live set)
+        xsrc = (lds_cv4f *)((lds_cfloat *)rows_lds + (rl < ntail ? rl : (ntail > 0 ? ntail - 1 : 0)) * ldl + k * 4);
+    }
 #pragma unroll
     for (int c = 0; c < NCH; c++)
 #pragma unroll
@@ -215,6 +230,17 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
             lds_cv4f *xp = (lds_cv4f *)(xl + s * xs + c * CH);   // compile-time offsets: the reads stay `ds_read ... offset:`
             const bool second = !(HALF && c == NCH - 1);
             const v4f x0 = xp[0], x1 = second ? xp[LPR] : v4f{0.f, 0.f, 0.f, 0.f};
+            if constexpr (NPL > 0) {
+                // (a piece past the row's last 32-column block lies in its pad / the next row: its products are dropped)
+                const bool ok0 = (2 * c) * LPR / 8 < nch, ok1 = second && (2 * c + 1) * LPR / 8 < nch;
+                const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+                const v4f b0 = xsrc[ok0 ? c * 2 * LPR : 0], b1 = xsrc[ok1 ? c * 2 * LPR + LPR : 0];
+                const v4f a0 = ok0 ? b0 : zero, a1 = ok1 ? b1 : zero;
+                tlx[s] = __builtin_elementwise_fma(v2f{a0.x, a0.y}, v2f{x0.x, x0.y}, tlx[s]);
+                thx[s] = __builtin_elementwise_fma(v2f{a0.z, a0.w}, v2f{x0.z, x0.w}, thx[s]);
+                tlx[s] = __builtin_elementwise_fma(v2f{a1.x, a1.y}, v2f{x1.x, x1.y}, tlx[s]);
+                thx[s] = __builtin_elementwise_fma(v2f{a1.z, a1.w}, v2f{x1.z, x1.w}, thx[s]);
+            }
 #pragma unroll
             for (int i = 0; i < NP; i++) {
                 const v4f a0 = w[i][2 * c];
@@ -278,7 +304,15 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
                 const float v = group_sum<LPR>(t.x + t.y);
                 acc[s] = k == i ? v : acc[s];
             }
-        if (k < NP && myrow < nrows) {
+        if constexpr (NPL > 0) {
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) {
+                const v2f t = tlx[s] + thx[s];
+                const float v = group_sum<LPR>(t.x + t.y);
+                acc[s] = k == NP ? v : acc[s];
+            }
+        }
+        if (k < NP + NPL && myrow < nrows) {
             if constexpr (PRE) epi(myrow, acc, ops);
             else epi(myrow, acc);
         }
@@ -289,6 +323,13 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
 #pragma unroll
             for (int s = 0; s < NSEQ; s++) { const v2f t = tl[i][s] + th[i][s]; acc[s] = group_sum<LPR>(t.x + t.y); }
             const int row = i * RPP + rloc;
+            if (k == 0 && row < nrows) epi(row, acc);
+        }
+        if constexpr (NPL > 0) {
+            float acc[NSEQ];
+#pragma unroll
+            for (int s = 0; s < NSEQ; s++) { const v2f t = tlx[s] + thx[s]; acc[s] = group_sum<LPR>(t.x + t.y); }
+            const int row = NP * RPP + rloc;
             if (k == 0 && row < nrows) epi(row, acc);
         }
     }
@@ -436,7 +477,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // register-resident matrices: lane k finishes pass k in ONE run of the epilogue, its LDS operands fetched ahead of the products,
     // quotients by reciprocal (not the mixed forms -- their rows behind the register passes go through rowdots_few's epilogue --
     // and not form 3: twelve chunks of output row beside two passes of gate rows leave it no register, 56 spilled)
-    constexpr bool OPA = !MIXED && (LPR == 8 || NCH3R <= 8);
+    constexpr int NPLX = (MIXED && LPR == 8) ? 1 : 0;         // the rows behind the register passes as one more pass of the sweep
+    constexpr bool OPA = (!MIXED && (LPR == 8 || NCH3R <= 8)) || NPLX;
+    constexpr bool FASTQ = !MIXED;                            // (the 134-state fixtures sit at the 1e-4 bar: the mixed form keeps the division)
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x;
     const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
@@ -654,7 +697,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (!act[s]) continue;
-                    const float g = gate_sigmoid<true>(acc[s] + o.gpre[s], sig_k);
+                    const float g = gate_sigmoid<FASTQ>(acc[s] + o.gpre[s], sig_k);
                     if (!isr) {
                         Z[s * SP + j] = g;
                     } else {
@@ -666,12 +709,14 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP1R > 0 && OPA) {
-                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1);
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2, NPLX>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1, L1, ld2);
                 } else if constexpr (NP1R > 0) {
-                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2>(w1, p.n1, p.nch2, H, c2p, tid, epi1);
-                    if (MIXED && p.n1 > R1) {                   // (mixed form: the rows behind the register passes)
+                    // (mixed forms: the rows behind the register passes -- the plan keeps them LDS-resident -- ride as one more pass of
+                    //  the eight-lane sweep; the four-lane forms' chunk counts leave no register for that: rowdots_few)
+                    rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2, NPLX>(w1, p.n1, p.nch2, H, c2p, tid, epi1, nullptr, nullptr, 0, L1, ld2);
+                    if (MIXED && !NPLX && p.n1 > R1) {
                         auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi1(row + R1, acc); };
-                        rowdots_few<NSEQ>(L1, p.n1 - R1, ld2, p.nch2, H, c2p, tid, shifted);   // (the plan keeps them LDS-resident)
+                        rowdots_few<NSEQ>(L1, p.n1 - R1, ld2, p.nch2, H, c2p, tid, shifted);
                     }
                 } else rowdots<NSEQ>(L1, p.P1, p.res1, p.n1, ld2, p.nch2, H, c2p, tid, epi1);
             }
@@ -700,7 +745,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (row < R) X3c[s * c3p + row] = acc[s] * o.tv[s];
-                    else Z[s * SP + (row - R)] = gate_sigmoid<true>(acc[s] + o.tv[s], sig_k);
+                    else Z[s * SP + (row - R)] = gate_sigmoid<FASTQ>(acc[s] + o.tv[s], sig_k);
                 }
             };
             if (!(p.dbg & 1)) {
@@ -773,7 +818,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (!act[s]) continue;
-                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl<true>(acc[s], nl_mode);
+                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl<FASTQ>(acc[s], nl_mode);
                     const float hn = (1.0f - o.z[s]) * o.h[s] + o.z[s] * nx;
                     H[s * c2p + row] = hn;
                     if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
@@ -781,12 +826,17 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP3R > 0 && OPA) {
-                    rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);
+                    if constexpr (NPLX) rowdots_regs<NSEQ, NP3R, NCH3K, 0, LPR, 0, 0, 1>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, nullptr, nullptr, pre3, L3, ld3);
+                    else rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);
                 } else if constexpr (NP3R > 0) {
-                    rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, g3, T3);
-                    if (MIXED && p.n3 > R3) {                   // (mixed form: the rows behind the register passes)
-                        auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi3(row + R3, acc); };
-                        rowdots_few<NSEQ>(L3, p.n3 - R3, ld3, p.nch3, X3c, c3p, tid, shifted);   // (the plan keeps them LDS-resident)
+                    if constexpr (NPLX)
+                        rowdots_regs<NSEQ, NP3R, NCH3K, 0, LPR, 0, 0, 1>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, nullptr, nullptr, 0, L3, ld3);
+                    else {
+                        rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3, g3, T3);
+                        if (MIXED && p.n3 > R3) {               // (the four-lane mixed forms)
+                            auto shifted = [&](int row, const float (&acc)[NSEQ]) { epi3(row + R3, acc); };
+                            rowdots_few<NSEQ>(L3, p.n3 - R3, ld3, p.nch3, X3c, c3p, tid, shifted);
+                        }
                     }
                 } else rowdots<NSEQ>(L3, p.P3[dir], p.res3, p.n3, ld3, p.nch3, X3c, c3p, tid, epi3);
             }
