@@ -195,7 +195,7 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
                                              const v4f *g = nullptr, const float *tail_lds = nullptr, Pre pre = 0,
                                              const float *rows_lds = nullptr, int ldl = 0) {
     constexpr bool PRE = std::is_invocable_v<Pre, int>;
-    static_assert(NPL == 0 || (NP + 1 <= LPR && NCHG == 0 && NCHL == 0), "rows behind the register passes: one more pass");
+    static_assert(NPL == 0 || (NP + 1 <= LPR && NCHG == 0), "rows behind the register passes: one more pass");
     static_assert(!PRE || NP <= LPR, "operands ahead: one lane of the group per pass");
     static_assert(NCHG == 0 || NP == 1, "streamed tail chunks: one pass");
     static_assert(NCHL == 0 || (LPR == 8 && NCHL == DR_T3_CHUNKS && NCHG == 0), "LDS tail: eight lanes per row");
@@ -288,6 +288,16 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
                 th[i][s] = __builtin_elementwise_fma(v2f{a0[i].z, a0[i].w}, v2f{x0.z, x0.w}, th[i][s]);
                 tl[i][s] = __builtin_elementwise_fma(v2f{a1[i].x, a1[i].y}, v2f{x1.x, x1.y}, tl[i][s]);
                 th[i][s] = __builtin_elementwise_fma(v2f{a1[i].z, a1[i].w}, v2f{x1.z, x1.w}, th[i][s]);
+            }
+            if constexpr (NPL > 0) {                          // the rows behind the register passes: these chunks from their own full rows
+                const bool ok0 = (2 * (NCH + c)) * LPR / 8 < nch, ok1 = (2 * (NCH + c) + 1) * LPR / 8 < nch;
+                const v4f zero = v4f{0.f, 0.f, 0.f, 0.f};
+                const v4f b0 = xsrc[ok0 ? (NCH + c) * 2 * LPR : 0], b1 = xsrc[ok1 ? (NCH + c) * 2 * LPR + LPR : 0];
+                const v4f e0 = ok0 ? b0 : zero, e1 = ok1 ? b1 : zero;
+                tlx[s] = __builtin_elementwise_fma(v2f{e0.x, e0.y}, v2f{x0.x, x0.y}, tlx[s]);
+                thx[s] = __builtin_elementwise_fma(v2f{e0.z, e0.w}, v2f{x0.z, x0.w}, thx[s]);
+                tlx[s] = __builtin_elementwise_fma(v2f{e1.x, e1.y}, v2f{x1.x, x1.y}, tlx[s]);
+                thx[s] = __builtin_elementwise_fma(v2f{e1.z, e1.w}, v2f{x1.z, x1.w}, thx[s]);
             }
         }
     }
@@ -472,7 +482,7 @@ __device__ __forceinline__ float dr_nl(float x, int nl) {
 template <int NSEQ, int NP1R = 0, int NP2R = 0, int NCH2R = 0, int NP3R = 0, int NCH3R = 0, bool MIXED = false, int LPR = DR_LPR>
 __global__ void __launch_bounds__(DR_THREADS)
 decomp_rows_kernel(const DecompRowsParams p) {
-    static_assert(LPR == 4 || (LPR == 8 && (!MIXED || NP2R == 0)), "eight lanes per row: P1 / P3 in registers, P2 in LDS (one sweep) or in registers");
+    static_assert(LPR == 4 || LPR == 8, "lanes per row");
     constexpr int RPPR = DR_THREADS / LPR;                    // rows per pass of a register-resident matrix
     // register-resident matrices: lane k finishes pass k in ONE run of the epilogue, its LDS operands fetched ahead of the products,
     // quotients by reciprocal (not the mixed forms -- their rows behind the register passes go through rowdots_few's epilogue --
@@ -568,7 +578,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     const float *T3 = L3 + (long long)p.res3 * ld3;
     // (the mixed eight-lane form: 128 < S <= 160 columns are 2.5 chunks of 64 -- the sixth piece would be 16 registers of zeros)
     constexpr int HALF2 = (MIXED && LPR == 8 && NCH2R > 0) ? 1 : 0;
-    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1)];
+    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2];
     // (a mixed form with more than DR_MIXED_NCH3 chunks of output row: two passes of gate rows + 13 chunks are 184 registers of
     // weights, and the compiler kept ~50 of them in scratch memory -- a reload per step from the same L2.  The chunks behind
     // the first DR_MIXED_NCH3 are fetched from L2 explicitly instead, a phase ahead of their use: no scratch, same bits)
@@ -578,7 +588,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     constexpr int NCH3G = (MIXED && NP3R == 1 && NCH3R > DR_MIXED_NCH3) ? NCH3R - DR_MIXED_NCH3 : 0, NCH3K = NCH3R - NCH3G - NCH3L;
     v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3K > 0 ? NCH3K : 1)];
     if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR, HALF2>(w1, p.P1, p.n1, ld2, p.nch2, tid);
-    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
+    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR, HALF2>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
     if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid);
     glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
     if constexpr (NCH3G > 0) {
@@ -750,7 +760,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (OPA && NP2R > 0) {
-                    rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2o, nullptr, nullptr, pre2);
+                    rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR, 0, HALF2, NPLX>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2o, nullptr, nullptr, pre2, L2, ld2);
                 } else if constexpr (LPR == 8) {                // (rows_plan_try: all of P2 LDS-resident, at most 256 rows)
                     if (p.n2 <= 2 * RPPR) rowdots_lds8<NSEQ, 2>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
                     else if (p.n2 <= 3 * RPPR) rowdots_lds8<NSEQ, 3>(L2, p.n2, ld2, p.nch2, HBc, c2p, tid, epi2o, pre2);
@@ -826,7 +836,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             };
             if (!(p.dbg & 1)) {
                 if constexpr (NP3R > 0 && OPA) {
-                    if constexpr (NPLX) rowdots_regs<NSEQ, NP3R, NCH3K, 0, LPR, 0, 0, 1>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, nullptr, nullptr, pre3, L3, ld3);
+                    if constexpr (NPLX) rowdots_regs<NSEQ, NP3R, NCH3K, 0, LPR, NCH3L, 0, 1>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, nullptr, T3, pre3, L3, ld3);
                     else rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);
                 } else if constexpr (NP3R > 0) {
                     if constexpr (NPLX)
@@ -941,11 +951,12 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 // reads per wavefront) and P2's rows (rank <= 256, all LDS-resident) swept in one go -- 8: Rp + SP <= 256, 7: Rp + SP <= 384.  They
 // come first; FARNN_ROWS_LPR4=1 leaves them out.
 // 10 (round 4, MIXED with eight lanes per row): farnn = 2 at 128 < S <= 160 with rank <= 192 (`--additional_states 30` at rank 150):
-// four passes of gate rows and two of output rows in registers, the few rows behind them and all of P2 (swept in one go) in LDS.
-#define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(10, 4, 0, 3, 2, 5) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
+// four passes of gate rows, two of P2 and two of output rows (their first three chunks) in registers; in LDS the rows behind the
+// register passes (12 gate rows, up to 64 of P2, 6 output rows) -- swept as one more pass -- and the output rows' last two chunks.
+#define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(10, 4, 2, 3, 2, 5) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
 constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6 || form == 10; }
 constexpr int rows_form_lpr(int form) { return (form == 7 || form == 8 || form == 9 || form == 10) ? 8 : DR_LPR; }
-constexpr bool rows_form_tail3(int form) { return form == 9; }       // the output rows' last 64-column chunk in LDS
+constexpr bool rows_form_tail3(int form) { return form == 9 || form == 10; }       // the output rows' last 64-column chunk in LDS
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -974,7 +985,7 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
             const int np1 = (k.n1 + rpp - 1) / rpp, np2 = (k.n2 + rpp - 1) / rpp, np3 = (k.n3 + rpp - 1) / rpp;    \
             const int nc2 = (k.nch2 + cpc - 1) / cpc, nc3 = (k.nch3 + cpc - 1) / cpc;                              \
             if ((A_ == 0 || (k.n1 > 0 && (np1 <= A_ || rows_form_mixed(F_)) && nc2 <= C_)) &&                      \
-                (B_ == 0 || (np2 <= B_ && nc2 <= C_)) &&                                                           \
+                (B_ == 0 || ((np2 <= B_ || (rows_form_mixed(F_) && rows_form_lpr(F_) == 8 && np2 == B_ + 1)) && nc2 <= C_)) && \
                 (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && nc3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
                 (!rows_form_mixed(F_) || (np1 > A_ && np3 > D_)) &&  /* (mixed forms: only where the whole-matrix forms do not reach) */ \
                 (rows_form_lpr(F_) != 8 || (k.n2 <= 4 * rpp && nc2 <= C_ && k.nch3 >= 8)) &&  /* (shorter rows: form 1 is faster) */ \
