@@ -83,6 +83,13 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v;
 }
 
+// the epilogue's operands for `row` (rowdots_regs' `pre` callback), or nothing
+template <bool PRE, typename Pre>
+__device__ __forceinline__ auto opa_fetch(Pre &pre, int row) {
+    if constexpr (PRE) return pre(row);
+    else return 0;
+}
+
 // sum over the LPR (4 or 8) adjacent lanes that share a row, result in all of them
 template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
@@ -207,7 +214,7 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
     // front of the products, so that the epilogue's LDS operands (they depend on the row only) can be fetched under them.
     int myrow = k * RPP + rloc;
     asm volatile("" : "+v"(myrow));
-    auto ops = [&]() { if constexpr (PRE) return pre(myrow < nrows ? myrow : nrows - 1); else return 0; }();
+    const auto ops = opa_fetch<PRE>(pre, myrow < nrows ? myrow : nrows - 1);
     v2f tl[NP][NSEQ], th[NP][NSEQ];
 #pragma unroll
     for (int i = 0; i < NP; i++)
@@ -376,7 +383,7 @@ __device__ __forceinline__ void rowdots_lds8(const float *ml, int nrows, int ld,
     asm volatile("" : "+v"(rloc));        // (opaque, like the row below: the NPASS row addresses stay out of the time loop's live set)
     int myrow = k * RPP + rloc;
     asm volatile("" : "+v"(myrow));       // (opaque: rowdots_regs)
-    auto ops = [&]() { if constexpr (PRE) return pre(myrow < nrows ? myrow : nrows - 1); else return 0; }();
+    const auto ops = opa_fetch<PRE>(pre, myrow < nrows ? myrow : nrows - 1);
     lds_cfloat *xl = (lds_cfloat *)X + k * 4;
     lds_cv4f *src[NPASS];
 #pragma unroll
@@ -491,6 +498,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     constexpr bool OPA = (!MIXED && (LPR == 8 || NCH3R <= 8)) || NPLX;
     constexpr bool FASTQ = !MIXED;                            // (the 134-state fixtures sit at the 1e-4 bar: the mixed form keeps the division)
     extern __shared__ __align__(16) float smem[];
+    const long long t_start = FARNN_PROBE_ON((p.dbg & 16) != 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x;
     const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
     const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, ld2 = p.ld2, ld3 = p.ld3;
@@ -511,6 +519,36 @@ decomp_rows_kernel(const DecompRowsParams p) {
     float *L2 = L1 + (long long)p.res1 * ld2;
     float *L3 = L2 + (long long)p.res2 * ld2;
 
+    // ---- this lane's slices of the register-resident matrices: issued FIRST (round 4) -- they depend on the direction only, and
+    // the ~0.5 MB a workgroup pulls in (64 B per clock per compute unit: ~8 k cycles) used to start behind the length-rank selection,
+    // the token loads and the LDS zeroing (set-up 17.7 k cycles, twice per compute unit at B = 256)
+    // (the mixed eight-lane form: 128 < S <= 160 columns are 2.5 chunks of 64 -- the sixth piece would be 16 registers of zeros)
+    constexpr int HALF2 = (MIXED && LPR == 8 && NCH2R > 0) ? 1 : 0;
+    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2];
+    // (a mixed form with more than DR_MIXED_NCH3 chunks of output row: two passes of gate rows + 13 chunks are 184 registers of
+    // weights, and the compiler kept ~50 of them in scratch memory -- a reload per step from the same L2.  The chunks behind
+    // the first DR_MIXED_NCH3 are fetched from L2 explicitly instead, a phase ahead of their use: no scratch, same bits)
+    // (eight lanes per row with P2 in registers too: 64 + 64 registers of gate and P2 rows leave 64 for the output rows -- four chunks
+    // of a rank-250 model's six; the others lie in LDS, which this form hardly uses otherwise.  Five in registers: 8 spilled)
+    constexpr int NCH3L = (LPR == 8 && NP2R > 0 && NP3R > 0) ? DR_T3_CHUNKS : 0;
+    constexpr int NCH3G = (MIXED && NP3R == 1 && NCH3R > DR_MIXED_NCH3) ? NCH3R - DR_MIXED_NCH3 : 0, NCH3K = NCH3R - NCH3G - NCH3L;
+    v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3K > 0 ? NCH3K : 1)];
+    // (not the mixed eight-lane form: issued early, its code object keeps a 20-byte stack object nothing reads or writes, and with it
+    // the private segment -- the compiler's bookkeeping, but "no scratch" is a property the library asserts)
+    constexpr bool EARLYW = !(MIXED && LPR == 8);
+#define FARNN_DR_LOAD_WEIGHTS()                                                                                              \
+    do {                                                                                                                     \
+        if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR, HALF2>(w1, p.P1, p.n1, ld2, p.nch2, tid);                   \
+        if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR, HALF2>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);              \
+        if constexpr (NP3R > 0)                                                                                              \
+            load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid); \
+    } while (0)
+    if constexpr (EARLYW) FARNN_DR_LOAD_WEIGHTS();
+    glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
+    if constexpr (NCH3G > 0) {
+        const int row = tid >> 2;
+        g3src = (glb_cv4f *)(p.P3[dir] + (long long)(row < p.n3 ? row : p.n3 - 1) * ld3 + (tid & (DR_LPR - 1)) * 4);
+    }
     // ---- sequences of this workgroup -------------------------------------------------------------
     int bseq[NSEQ], nst[NSEQ], slen[NSEQ];
     int nmax = 0;
@@ -539,6 +577,8 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int q = 0; q < NSEQ; q++) v |= (s == q || NSEQ == 1) ? arr[q] : 0;
         return v; };
 
+    long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_4 = 0;      // (set-up stamps of the profiling build; scalars: an array stayed behind as a dead stack object)
+    if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_0 = (long long)__builtin_amdgcn_s_memtime();
     // ---- set-up ------------------------------------------------------------------------------------
     // everything a vector read can touch is initialised: the register forms read whole (upper-bound) chunk counts and run on
     // into the arrays behind the vector -- with zero weights, but LDS keeps what earlier workgroups left there (-inf pads of the
@@ -554,6 +594,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // two of output rows; the registers hold the first passes, the few rows behind them are LDS-resident like any other
     // matrix's, or streamed): R1 / R2 / R3 = rows held in registers, the resident / streamed rows start there.
     constexpr int R1 = NP1R * RPPR, R2 = NP2R * RPPR, R3 = NP3R * RPPR;
+    if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_1 = (long long)__builtin_amdgcn_s_memtime();
     {   // resident rows: global -> LDS
         const float *src[3] = {p.P1 + (long long)R1 * ld2, p.P2[dir] + (long long)R2 * ld2, p.P3[dir] + (long long)R3 * ld3};
         float *dst[3] = {L1, L2, L3};
@@ -576,25 +617,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int i = tid; tail + i < smem + p.lds_floats; i += DR_THREADS) tail[i] = 0.0f;
     }
     const float *T3 = L3 + (long long)p.res3 * ld3;
-    // (the mixed eight-lane form: 128 < S <= 160 columns are 2.5 chunks of 64 -- the sixth piece would be 16 registers of zeros)
-    constexpr int HALF2 = (MIXED && LPR == 8 && NCH2R > 0) ? 1 : 0;
-    v4f w1[NP1R > 0 ? NP1R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2], w2[NP2R > 0 ? NP2R : 1][2 * (NCH2R > 0 ? NCH2R : 1) - HALF2];
-    // (a mixed form with more than DR_MIXED_NCH3 chunks of output row: two passes of gate rows + 13 chunks are 184 registers of
-    // weights, and the compiler kept ~50 of them in scratch memory -- a reload per step from the same L2.  The chunks behind
-    // the first DR_MIXED_NCH3 are fetched from L2 explicitly instead, a phase ahead of their use: no scratch, same bits)
-    // (eight lanes per row with P2 in registers too: 64 + 64 registers of gate and P2 rows leave 64 for the output rows -- four chunks
-    // of a rank-250 model's six; the others lie in LDS, which this form hardly uses otherwise.  Five in registers: 8 spilled)
-    constexpr int NCH3L = (LPR == 8 && NP2R > 0 && NP3R > 0) ? DR_T3_CHUNKS : 0;
-    constexpr int NCH3G = (MIXED && NP3R == 1 && NCH3R > DR_MIXED_NCH3) ? NCH3R - DR_MIXED_NCH3 : 0, NCH3K = NCH3R - NCH3G - NCH3L;
-    v4f w3[NP3R > 0 ? NP3R : 1][2 * (NCH3K > 0 ? NCH3K : 1)];
-    if constexpr (NP1R > 0) load_rows_regs<NP1R, NCH2R, LPR, HALF2>(w1, p.P1, p.n1, ld2, p.nch2, tid);
-    if constexpr (NP2R > 0) load_rows_regs<NP2R, NCH2R, LPR, HALF2>(w2, p.P2[dir], p.n2, ld2, p.nch2, tid);
-    if constexpr (NP3R > 0) load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid);
-    glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
-    if constexpr (NCH3G > 0) {
-        const int row = tid >> 2;
-        g3src = (glb_cv4f *)(p.P3[dir] + (long long)(row < p.n3 ? row : p.n3 - 1) * ld3 + (tid & (DR_LPR - 1)) * 4);
-    }
+    if constexpr (!EARLYW) FARNN_DR_LOAD_WEIGHTS();
+#undef FARNN_DR_LOAD_WEIGHTS
+    if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) { st_2 = st_3 = (long long)__builtin_amdgcn_s_memtime(); }
     __syncthreads();
     for (int j = tid; j < S; j += DR_THREADS) {
         const float hv = hinit[j];
@@ -639,12 +664,14 @@ decomp_rows_kernel(const DecompRowsParams p) {
     }
     for (int i = 0; i < NPF; i++)
         if (pf_e[i] >= 0) TV[tid + i * DR_THREADS] = tv_load(pf_s[i], pf_e[i], 0);
+    if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_4 = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
 
     const float sig_k = p.sig_k;
     const int nl_mode = p.nl;
     const bool probe = FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0;     // diagnostic: cycle counts of the phases of a step
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (probe && tid == 0) printf("rows wg 0: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
     // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
     for (int t = 0; t < nmax; t++) {
         const bool pr = probe && t == 8;
