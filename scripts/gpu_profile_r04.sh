@@ -60,6 +60,8 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_IN
     rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_$wl -- python3 bench.py --workload $wl --steps 10 --warmup 3 $R > $O/sq${i}_$wl.log 2>&1
   done
   rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifst104 -- python3 bench.py --workload ifst --states 104 --steps 10 --warmup 3 $R > $O/sq${i}_ifst104.log 2>&1
+  rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_rows250 -- python3 bench.py --workload decomp --rank 250 --farnn 2 --steps 10 --warmup 3 $R > $O/sq${i}_rows250.log 2>&1
+  FARNN_ROWS_LPR4=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_rows250lpr4 -- python3 bench.py --workload decomp --rank 250 --farnn 2 --steps 10 --warmup 3 $R > $O/sq${i}_rows250lpr4.log 2>&1
 done
 # in-kernel probes (profiling build)
 export FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so
