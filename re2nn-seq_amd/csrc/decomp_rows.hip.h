@@ -95,8 +95,36 @@ template <int LPR>
 __device__ __forceinline__ float group_sum(float v) {
     v = quad_sum(v);
     if constexpr (LPR == 8)       // the other quad of the eight: row_half_mirror (lane i <-> 7 - i), both hold their quad's total
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));   // (bound_ctrl: every lane has a
+                                                                                                         //  source; lets the add fold the DPP move)
     return v;
+}
+
+// group_sum of N values at once, every level ONE v_add_f32_dpp per value (left to the compiler, a third of the levels became a
+// v_mov_b32_dpp + v_add_f32 pair).  The s_nop in front of a level covers the two wait states between a vector write and a DPP read
+// of the same register when fewer than two other instructions separate them.
+#define FARNN_DPP_ADD(V, CTRL) "v_add_f32_dpp " V ", " V ", " V " " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define FARNN_DPP_LEVEL1(CTRL) "s_nop 1\n\t" FARNN_DPP_ADD("%0", CTRL)
+#define FARNN_DPP_LEVEL2(CTRL) "s_nop 1\n\t" FARNN_DPP_ADD("%0", CTRL) FARNN_DPP_ADD("%1", CTRL)
+#define FARNN_DPP_LEVEL3(CTRL) "s_nop 1\n\t" FARNN_DPP_ADD("%0", CTRL) FARNN_DPP_ADD("%1", CTRL) FARNN_DPP_ADD("%2", CTRL)
+#define FARNN_DPP_LEVEL4(CTRL) "s_nop 1\n\t" FARNN_DPP_ADD("%0", CTRL) FARNN_DPP_ADD("%1", CTRL) FARNN_DPP_ADD("%2", CTRL) FARNN_DPP_ADD("%3", CTRL)
+#define FARNN_DPP_LEVEL5(CTRL) "s_nop 1\n\t" FARNN_DPP_ADD("%0", CTRL) FARNN_DPP_ADD("%1", CTRL) FARNN_DPP_ADD("%2", CTRL) FARNN_DPP_ADD("%3", CTRL) FARNN_DPP_ADD("%4", CTRL)
+template <int LPR, int N>
+__device__ __forceinline__ void group_sum_n(float (&v)[N]) {
+    static_assert(N >= 1 && N <= 5, "up to five passes");
+#define FARNN_GS(LV, ...)                                                                                                   \
+    do {                                                                                                                    \
+        if constexpr (LPR == 8)                                                                                             \
+            asm volatile(LV("quad_perm:[1,0,3,2]") LV("quad_perm:[2,3,0,1]") LV("row_half_mirror") "s_nop 0" : __VA_ARGS__); \
+        else                                                                                                                \
+            asm volatile(LV("quad_perm:[1,0,3,2]") LV("quad_perm:[2,3,0,1]") "s_nop 0" : __VA_ARGS__);                      \
+    } while (0)
+    if constexpr (N == 1) FARNN_GS(FARNN_DPP_LEVEL1, "+v"(v[0]));
+    if constexpr (N == 2) FARNN_GS(FARNN_DPP_LEVEL2, "+v"(v[0]), "+v"(v[1]));
+    if constexpr (N == 3) FARNN_GS(FARNN_DPP_LEVEL3, "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    if constexpr (N == 4) FARNN_GS(FARNN_DPP_LEVEL4, "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+    if constexpr (N == 5) FARNN_GS(FARNN_DPP_LEVEL5, "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
+#undef FARNN_GS
 }
 
 // out[row] = <M[row, :], x_s> for s < NSEQ.  Four adjacent lanes share a row; per chunk of 32 columns a
@@ -312,22 +340,15 @@ __device__ __forceinline__ void rowdots_regs(const v4f (&w)[NP][2 * NCH - HALF],
         static_assert(NP <= LPR, "one lane of the group per pass");
         float acc[NSEQ];
 #pragma unroll
-        for (int s = 0; s < NSEQ; s++) acc[s] = 0.0f;
+        for (int s = 0; s < NSEQ; s++) {
+            float v[NP + NPL];
 #pragma unroll
-        for (int i = 0; i < NP; i++)
+            for (int i = 0; i < NP; i++) { const v2f t = tl[i][s] + th[i][s]; v[i] = t.x + t.y; }
+            if constexpr (NPL > 0) { const v2f t = tlx[s] + thx[s]; v[NP] = t.x + t.y; }
+            group_sum_n<LPR, NP + NPL>(v);
+            acc[s] = v[0];
 #pragma unroll
-            for (int s = 0; s < NSEQ; s++) {
-                const v2f t = tl[i][s] + th[i][s];
-                const float v = group_sum<LPR>(t.x + t.y);
-                acc[s] = k == i ? v : acc[s];
-            }
-        if constexpr (NPL > 0) {
-#pragma unroll
-            for (int s = 0; s < NSEQ; s++) {
-                const v2f t = tlx[s] + thx[s];
-                const float v = group_sum<LPR>(t.x + t.y);
-                acc[s] = k == NP ? v : acc[s];
-            }
+            for (int i = 1; i < NP + NPL; i++) acc[s] = k == i ? v[i] : acc[s];
         }
         if (k < NP + NPL && myrow < nrows) {
             if constexpr (PRE) epi(myrow, acc, ops);
