@@ -71,3 +71,9 @@ class Communicator:
         if self._h:
             _check(lib().farnn_rccl_comm_destroy(self._h))
             self._h = None
+
+    def __del__(self):                       # (a communicator that was never closed: destroyed with its owner, errors swallowed)
+        try:
+            self.close()
+        except Exception:
+            pass

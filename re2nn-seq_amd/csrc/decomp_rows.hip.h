@@ -126,6 +126,12 @@ __device__ __forceinline__ void group_sum_n(float (&v)[N]) {
     if constexpr (N == 5) FARNN_GS(FARNN_DPP_LEVEL5, "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]));
 #undef FARNN_GS
 }
+#undef FARNN_DPP_LEVEL5
+#undef FARNN_DPP_LEVEL4
+#undef FARNN_DPP_LEVEL3
+#undef FARNN_DPP_LEVEL2
+#undef FARNN_DPP_LEVEL1
+#undef FARNN_DPP_ADD
 
 // out[row] = <M[row, :], x_s> for s < NSEQ.  Four adjacent lanes share a row; per chunk of 32 columns a
 // lane reads two 16-byte pieces of the row and of every x_s and does packed f32 FMAs (v_pk_fma_f32), so
