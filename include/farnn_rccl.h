@@ -33,6 +33,10 @@ int farnn_rccl_comm_create(const void *id, int nranks, int rank, int device, voi
  * gathered: device int32 [nranks * rows_per_rank][L]; stream: a hipStream_t (0 = the null stream). */
 int farnn_rccl_gather_tags(void *comm, const int32_t *local, int64_t rows_per_rank, int L, int32_t *gathered, void *stream);
 
+/* the number of ranks RCCL itself reports for the communicator (ncclCommCount), or a negative error: what the N > 1 bench line
+ * prints and asserts equal to the launcher's world size */
+int farnn_rccl_comm_count(void *comm);
+
 int farnn_rccl_comm_destroy(void *comm);
 
 /* RCCL's version code (ncclGetVersion), or a negative error */

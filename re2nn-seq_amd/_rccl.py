@@ -13,6 +13,7 @@ SIGNATURES = {
     'farnn_rccl_unique_id': (C.c_int, [C.c_void_p]),
     'farnn_rccl_comm_create': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     'farnn_rccl_gather_tags': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]),
+    'farnn_rccl_comm_count': (C.c_int, [C.c_void_p]),
     'farnn_rccl_comm_destroy': (C.c_int, [C.c_void_p]),
     'farnn_rccl_version': (C.c_int, []),
     'farnn_rccl_last_error': (C.c_char_p, []),
@@ -66,6 +67,13 @@ class Communicator:
         s = torch.cuda.current_stream(local.device).cuda_stream if stream is None else stream
         _check(lib().farnn_rccl_gather_tags(self._h, C.c_void_p(local.data_ptr()), rows, L, C.c_void_p(out.data_ptr()), C.c_void_p(s)))
         return out
+
+    def count(self):
+        """the number of ranks RCCL reports for this communicator (ncclCommCount)"""
+        n = lib().farnn_rccl_comm_count(self._h)
+        if n < 0:
+            _check(n)
+        return n
 
     def close(self):
         if self._h:

@@ -27,20 +27,28 @@ __device__ __forceinline__ void bs_tile_need(int k, int len, int nsteps, int &ne
     needB = nb;
 }
 
-// The launch's epoch, from device memory.  `done` counts the sequences whose second workgroup has arrived (bs_finish adds one per
-// sequence); between launches it is a multiple of B, during launch e it runs from e B towards (e + 1) B and reaches that only
-// when every sequence's second arrival is in -- i.e. after every workgroup of the launch has started and read it.  So done / B is
-// the same number for all workgroups of a launch however late they start, and one more for the next launch: no kernel argument,
-// no host-side counter, and a launch captured into a HIP graph replays with the right epoch.  (Never 0: zeroed words carry 0.)
+// The launch's epoch, from device memory, for ANY sequence of batch sizes.  `done` is a 64-bit counter to which the second workgroup
+// to arrive of every sequence adds once (bs_finish): 1, except for sequence 0, which adds BS_EPOCH_SPAN - (B - 1) -- a launch adds
+// exactly BS_EPOCH_SPAN in all, whatever its B, and any proper subset of its adds less than that.  Between launches the counter is a
+// multiple of the span; during launch e it runs from e SPAN towards (e + 1) SPAN and reaches that only with the launch's LAST second
+// arrival -- i.e. after every workgroup of the launch has started and read it.  So done >> BS_EPOCH_SHIFT is the same number for all
+// workgroups of a launch however late they start, and one more for the next launch: no kernel argument, no host-side counter, no
+// reset when the batch size changes, and launches captured into HIP graphs at different B replay and interleave with eager calls
+// (stream-ordered) with the right epoch.  (Round 4 divided a count of sequences by B: valid for one batch size only -- a replayed
+// graph behind an eager call of another B read an epoch that changed mid-launch.)  Never 0: zeroed words carry 0.
 // ONE lane of the wavefronts that use the epoch reads the counter (all of a launch's workgroups start together: thousands of
 // L1-bypassing loads of one line at once cost the launch microseconds -- measured, +4 us on the 35 us headline step).
-__device__ __forceinline__ unsigned bs_launch_epoch(const unsigned long long *done, int B, int lane) {
+constexpr int BS_EPOCH_SHIFT = 24;                              // B <= 2^24 sequences per launch; 2^40 launches per handle
+constexpr unsigned long long BS_EPOCH_SPAN = 1ull << BS_EPOCH_SHIFT;
+__device__ __forceinline__ unsigned bs_launch_epoch(const unsigned long long *done, int lane) {
     unsigned long long d = 0ull;
     if (lane == 0) d = __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)d), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(d >> 32));
-    const unsigned long long q = (((unsigned long long)hi << 32) | lo) / (unsigned long long)(unsigned)B;
+    const unsigned long long q = (((unsigned long long)hi << 32) | lo) >> BS_EPOCH_SHIFT;
     return (unsigned)(q % 0xffffffffull) + 1u;
 }
+// what the second arrival of sequence b adds to the counter
+__device__ __forceinline__ unsigned long long bs_epoch_add(int b, int B) { return b == 0 ? BS_EPOCH_SPAN - (unsigned long long)(B - 1) : 1ull; }
 
 __device__ __forceinline__ int bs_read_prog(const unsigned long long *w, unsigned epoch) {
     const unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -542,7 +550,7 @@ __device__ __forceinline__ void bs_finish(const BesideParams &p, const int b, co
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)arrived);
             unsigned rest = 0u;
             if (hi == epoch && (lo & 0x80000000u)) {               // second of the two
-                if (lane == 0 && p.done) __hip_atomic_fetch_add(p.done, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (bs_launch_epoch)
+                if (lane == 0 && p.done) __hip_atomic_fetch_add(p.done, bs_epoch_add(b, p.B), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (bs_launch_epoch)
                 rest = all_tiles & ~(promised | (lo & 0x7fffffffu));
                 if (rest) {
                     // The other workgroup has arrived: it is resident, past its chain, and publishes its full row count

@@ -13,20 +13,22 @@ namespace farnn {
 
 int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
     const int NP = RG_NWC * p.G;
-    const size_t lds = (size_t)regs_lds(p.L, p.SP, NP, p.sp.c16, p.sp.Kc, score, RG_RQ, score && bs_label_map_path(p.sp)).total * sizeof(float);
+    const bool dest = p.dest && !maxsr;                                   // the destination-split compute wavefronts (chain_dest.hip.h)
+    const size_t lds = (size_t)regs_lds(p.L, p.SP, NP, p.sp.c16, p.sp.Kc, score, RG_RQ, score && bs_label_map_path(p.sp), dest).total * sizeof(float);
     const dim3 grid(2 * p.B), block(RG_WAVES * 64);
     int rc;
     // NLX: tanh / relu-tanh / sigmoid between the steps (the kernel's none / relu form has no branch in the step)
     const bool nlx = p.nl != FARNN_NL_NONE && p.nl != FARNN_NL_RELU;
     const bool lmo = score && bs_label_map_path(p.sp);                     // the label-map instantiation (no matrix-core tile code)
-#define FARNN_LAUNCH_REGS4(MX, SC, NX, LM)                                                     \
+#define FARNN_LAUNCH_REGS5(MX, SC, NX, LM, DS)                                                 \
     do {                                                                                       \
-        if ((rc = raise_lds_limit(chain_regs_kernel<MX, SC, NX, LM>, lds))) return rc;         \
+        if ((rc = raise_lds_limit(chain_regs_kernel<MX, SC, NX, LM, DS>, lds))) return rc;     \
         if (e0 && e1)                                                                          \
-            hipExtLaunchKernelGGL((chain_regs_kernel<MX, SC, NX, LM>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
+            hipExtLaunchKernelGGL((chain_regs_kernel<MX, SC, NX, LM, DS>), grid, block, (uint32_t)lds, s, e0, e1, 0, p); \
         else                                                                                   \
-            chain_regs_kernel<MX, SC, NX, LM><<<grid, block, lds, s>>>(p);                    \
+            chain_regs_kernel<MX, SC, NX, LM, DS><<<grid, block, lds, s>>>(p);                \
     } while (0)
+#define FARNN_LAUNCH_REGS4(MX, SC, NX, LM) do { if (!MX && dest) FARNN_LAUNCH_REGS5(MX, SC, NX, LM, !MX); else FARNN_LAUNCH_REGS5(MX, SC, NX, LM, false); } while (0)
 #define FARNN_LAUNCH_REGS3(MX, SC, NX) do { if (SC && lmo) FARNN_LAUNCH_REGS4(MX, SC, NX, SC); else FARNN_LAUNCH_REGS4(MX, SC, NX, false); } while (0)
 #define FARNN_LAUNCH_REGS(MX, SC) do { if (nlx) FARNN_LAUNCH_REGS3(MX, SC, true); else FARNN_LAUNCH_REGS3(MX, SC, false); } while (0)
     if (maxsr) { if (score) FARNN_LAUNCH_REGS(true, true); else FARNN_LAUNCH_REGS(true, false); }
@@ -34,8 +36,18 @@ int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s
 #undef FARNN_LAUNCH_REGS
 #undef FARNN_LAUNCH_REGS3
 #undef FARNN_LAUNCH_REGS4
+#undef FARNN_LAUNCH_REGS5
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
 
 }  // namespace farnn
+
+#if defined(FARNN_PROBES)
+// profiling build only (not part of include/farnn.h): the per-workgroup stamps of the last chain_regs_kernel launch under FARNN_DBG=2048
+extern "C" int farnn_debug_wg_stamps(long long *out, int n_workgroups) {
+    if (!out || n_workgroups < 0 || n_workgroups > farnn::WG_STAMP_MAX) return FARNN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return FARNN_EIO;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(farnn::g_wg_stamps), sizeof(long long) * 16 * (size_t)n_workgroups) == hipSuccess ? FARNN_OK : FARNN_EIO;
+}
+#endif

@@ -100,10 +100,14 @@ __device__ __forceinline__ float quad_max(float x) {
 
 }  // namespace farnn
 #include "chain_wide.hip.h"      // the compute wavefronts of the wide form (72 < S <= 128)
+#include "chain_dest.hip.h"      // the compute wavefronts of the destination-split form (S <= 72, sum semiring)
 namespace farnn {
 
 // FARNN_PROBES (profiling build only): s_memtime stamps of the workgroups of full-length sequences, printed at their end
 #if defined(FARNN_PROBES)
+constexpr int WG_STAMP_MAX = 4096;
+__device__ long long g_wg_stamps[16 * WG_STAMP_MAX];    // FARNN_DBG & 2048 (chain_regs_kernel): {seq, len, start, end, cycles, xcc, se, cu,
+                                                        //  setup, chain, scorer done - chain end, meeting - chain end, tiles + arrival} per workgroup
 #define FARNN_RG_STAMP(i) do { if (probe && lane == 0) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FARNN_RG_STAMP(i) do { } while (0)
@@ -116,9 +120,11 @@ namespace farnn {
 // RQ / D: rows of 16 bytes per lane and step, steps in flight.  (RG_RQ, RG_D) is the form for S <= 72 (two workgroups per compute
 // unit); RQ > RG_RQ the wide form (chain_wide.hip.h: 72 < S <= 128, one workgroup per compute unit, launch order longest first).
 // LMO: label-map path only (the paired wide form): the matrix-core tile code is compiled out.
-template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D, bool LMO = false>
+// DEST: the compute wavefronts split the block by destination (chain_dest.hip.h; narrow form, sum semiring).
+template <bool MAXSR, bool SCORE, bool NLX, int RQ = RG_RQ, int D = RG_D, bool LMO = false, bool DEST = false>
 __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem, const int tid, const int item, int *b_out) {
     constexpr bool WIDE = RQ != RG_RQ;
+    static_assert(!DEST || (!WIDE && !MAXSR), "the destination-split form exists for the narrow kernel and the sum semiring");
     constexpr int PSTR = WIDE ? rgw_part_stride(RQ) : RG_PART_STRIDE;     // floats between the two partial-sum buffers
     constexpr int NG = WIDE ? RGW_NG : RG_NG;                         // state groups of 16 the scoring stage reaches
     const int lane = tid & 63;
@@ -129,7 +135,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     const int S = p.S, SP = p.SP, G = p.G, RPG = p.RPG, NP = RG_NWC * G;
     const int PS = WIDE ? p.PS : SP;                                  // floats between two partial-sum vectors
     const bool lm_path = SCORE && (LMO || bs_label_map_path(p.sp));     // the tiles are scored through the label map: no tile areas in LDS
-    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, RQ, lm_path);
+    const RegsLds lds = regs_lds(p.L, SP, NP, p.sp.c16, p.sp.Kc, SCORE, RQ, lm_path, DEST);
     long long *tokoff = reinterpret_cast<long long *>(smem + lds.tok);     // [nsteps] byte offset of step k's block
     float *part = smem + lds.part, *ol = smem + lds.ol, *hist = smem + lds.hist;
     float *ab = smem + lds.ab, *scl = smem + lds.scl, *obuf = smem + lds.obuf;
@@ -145,7 +151,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     const float *hinit = dir == 0 ? p.h0 : p.hT;
 #if defined(FARNN_PROBES)
     __shared__ long long stamps[8];
-    const bool probe = nsteps == p.L && p.L >= 32;
+    const bool quiet = (p.dbg & 2048) != 0;                               // 2048: every workgroup stamps, nobody prints (g_wg_stamps)
+    const bool probe = (nsteps == p.L && p.L >= 32) || quiet;
     if (w == 0) FARNN_RG_STAMP(0);
 #endif
 
@@ -158,7 +165,15 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     for (int j = tid; j < (nsteps + 1) * SP; j += nthreads) hist[j] = (j < S) ? hinit[j] : 0.0f;     // row 0; pad columns zero
     if (tid < 32) misc[tid] = tid == RGM_ACQ ? -1 : 0;
     if (tid < 2) part[tid * PSTR + PSTR - 1] = MAXSR ? -INFINITY : 0.0f;     // the reduction's identity (masked reads)
-    if (tid < 2 * 4 * RG_NWC) part[(tid / (4 * RG_NWC)) * PSTR + NP * PS + tid % (4 * RG_NWC)] = 0.0f;   // the step flags
+    if (tid < 2 * 4 * RG_NWC) {                     // the step flags (DEST, chain_dest.hip.h: a flag of 1 = "row 0 is there", buffer 0 only)
+        const int fb = tid / (4 * RG_NWC), fk = tid % (4 * RG_NWC);
+        part[fb * PSTR + NP * PS + fk] = (DEST && fb == 0 && (fk & 3) == 0) ? __int_as_float(1) : 0.0f;
+    }
+    if constexpr (DEST) {
+        // exchange row 0 = the initial state (scaled by o for the backward chain, model_onehot.py:393), zeros behind S and in row 1
+        for (int j = tid; j < 2 * RD_XS; j += nthreads)
+            smem[lds.xd + j] = j < S ? hinit[j] * ((dir == 1 && p.o) ? p.o[j] : 1.0f) : 0.0f;
+    }
     if (WIDE && tid < RG_NWC * RGW_XCH) smem[lds.xch + tid] = 0.0f;          // exchange slots without a row stay exact zeros
     __syncthreads();
     if (w == 0) FARNN_RG_STAMP(1);
@@ -174,7 +189,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     BesideParams bs;                                 // the scoring stage's view of the parameters (beside.hip.h)
     bs.A = p.A; bs.Bk = p.Bk; bs.B = p.B; bs.L = p.L; bs.SP = p.SP; bs.CPR = p.CPR; bs.prog = p.prog; bs.arr = p.arr;
     bs.done = p.done; bs.spin = p.spin; bs.dbg = p.dbg; bs.sp = p.sp;
-    bs.epoch = (SCORE && w >= RG_NWC) ? (p.done ? bs_launch_epoch(p.done, p.B, lane) : p.epoch_host) : 0u;   // the writer's and the scorer's wavefront use it
+    bs.epoch = (SCORE && w >= RG_NWC) ? (p.done ? bs_launch_epoch(p.done, lane) : p.epoch_host) : 0u;   // the writer's and the scorer's wavefront use it
     int wr_next = 0;                                 // (writer wavefront) the next state row to copy to the stash
     // the output matrix is a label map and only tags are asked for (label_map.hip.h): the tiles left when the chain ends are scored
     // token by token, a few per wavefront, instead of on the matrix cores.  Every wavefront fetches its two packed words of the map
@@ -192,8 +207,25 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                 __builtin_amdgcn_s_setprio(0);
                 if (w == 0) FARNN_RG_STAMP(2);
 #if defined(FARNN_PROBES)
-                if (!SCORE && probe && w == 0 && lane == 0)
+                if (!SCORE && probe && !quiet && w == 0 && lane == 0)
                     printf("seq %d dir %d (wide): setup %lld, chain %lld (%lld per step)\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
+                           (stamps[2] - stamps[1]) / nsteps);
+#endif
+            }
+        } else if constexpr (DEST) {
+            if (nsteps > 0) {
+                __builtin_amdgcn_s_setprio(2);
+#if defined(FARNN_PROBES)
+                const bool probe_ = probe;
+#else
+                const bool probe_ = false;
+#endif
+                regs_compute_dest<NLX, RD_D, RD_LPR>(p, dir, w, lane, nsteps, tokoff, part + NP * PS, ol, hist, smem + lds.xd, probe_, b);
+                __builtin_amdgcn_s_setprio(0);
+                if (w == 0) FARNN_RG_STAMP(2);
+#if defined(FARNN_PROBES)
+                if (!SCORE && probe && !quiet && w == 0 && lane == 0)
+                    printf("seq %d dir %d (destination split): setup %lld, chain %lld (%lld per step)\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
                            (stamps[2] - stamps[1]) / nsteps);
 #endif
             }
@@ -448,7 +480,7 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             __builtin_amdgcn_s_setprio(0);
             if (w == 0) FARNN_RG_STAMP(2);
 #if defined(FARNN_PROBES)
-            if (!SCORE && probe && w == 0 && lane == 0)
+            if (!SCORE && probe && !quiet && w == 0 && lane == 0)
                 printf("seq %d dir %d: setup %lld, chain %lld (%lld per step)\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
                        (stamps[2] - stamps[1]) / nsteps);
 #endif
@@ -464,29 +496,37 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
                 for (long long e = (long long)nsteps * p.sp.K + lane; e < (long long)p.L * p.sp.K; e += WAVE)
                     p.sp.scores[(long long)b * p.L * p.sp.K + e] = 0.0f;
         }
-        // rows 0 .. wr_next - 1 are stored.  One row per pass; when the chain is done the wavefront goes to the workgroup's
-        // meeting point at once: what it has not copied yet it copies after the tiles, before the final publish.
+        // rows 0 .. wr_next - 1 are stored.  A pass copies EVERY row the chain has finished since the last one (`hist` and the stash
+        // are both [row][SP]: rows a .. b are one contiguous run of floats) -- round 4 copied one row per pass, which the
+        // destination-split chain outruns: at 780 cycles per step the writer (priority 0 beside six compute wavefronts at 2) fell
+        // behind, the progress word reached `pubmax` late, the other workgroup's scorer found nothing to park before its own chain
+        // ended and the tiles behind the chains took 20 k cycles instead of 9 k (profiles/r05_wg_lifetimes_*.txt).  When the chain
+        // is done the wavefront goes to the workgroup's meeting point at once: what it has not copied yet it copies after the tiles,
+        // before the final publish.
         int published = -1;
-        auto copy_row = [&](int rr) {
-            const float *src = hist + rr * SP;
-            float *dst = stash + (long long)rr * SP;
+        auto copy_rows = [&](int r0, int r1) {                    // rows r0 .. r1
+            const float *src = hist + r0 * SP;
+            float *dst = stash + (long long)r0 * SP;
+            const int nfl = (r1 - r0 + 1) * SP;
             if (SCORE) {
-                for (int j = 2 * lane; j < SP; j += 2 * WAVE) st2_agent(dst + j, src[j], src[j + 1]);
+                for (int j = 2 * lane; j < nfl; j += 2 * WAVE) st2_agent(dst + j, src[j], src[j + 1]);
             } else {
-                for (int j = lane; j < SP; j += WAVE) dst[j] = src[j];
+                for (int j = lane; j < nfl; j += WAVE) dst[j] = src[j];
             }
         };
         if (!SCORE && !p.A) wr_next = nsteps + 1;                // (chain_viterbi_kernel: the rows are consumed where they lie, in LDS)
         while (wr_next <= nsteps) {
-            if (nsteps > 0 && !regs_rows_reached<PSTR>(sflag, lane, wr_next)) { __builtin_amdgcn_s_sleep(1); continue; }
-            if (SCORE && nsteps > 0 && wr_next > pubmax && regs_rows_reached<PSTR>(sflag, lane, nsteps)) break;   // the chain is done
-            copy_row(wr_next);
-            wr_next++;
+            const int done = nsteps > 0 ? regs_rows_done<PSTR>(sflag, lane) : 0;      // rows 0 .. done are complete
+            if (done < wr_next) { __builtin_amdgcn_s_sleep(1); continue; }
+            if (SCORE && nsteps > 0 && wr_next > pubmax && done >= nsteps) break;     // the chain is done
+            // (a run stops at pubmax: the row the other workgroup's tiles wait for is published as soon as it is there)
+            const int hi = min(done, (SCORE && wr_next <= pubmax) ? pubmax : nsteps);
+            copy_rows(wr_next, hi);
+            wr_next = hi + 1;
             // The progress word feeds the other workgroup's tiles: once it covers the last row they need (pubmax), the
-            // rest is drained and published once, at the end -- no write-through round trip per row after that.
-            if (SCORE && wr_next - 1 < nsteps && published < pubmax &&
-                (wr_next - 1 >= pubmax || !regs_rows_reached<PSTR>(sflag, lane, wr_next))) {   // caught up with the chain, or pubmax reached
-                published = wr_next - 1;
+            // rest is drained and published once, at the end -- no write-through round trip per pass after that.
+            if (SCORE && hi < nsteps && published < pubmax) {
+                published = hi;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every store of this (the only storing) wavefront has left
                 if (lane == 0)
                     __hip_atomic_store(p.prog + (long long)dir * p.B + b, ((unsigned long long)bs.epoch << 32) | (unsigned)published,
@@ -601,7 +641,12 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
             }
         });
 #if defined(FARNN_PROBES)
-    if (probe && tid == 0) {
+    if (quiet && tid == 0 && item < WG_STAMP_MAX) {
+        long long *o = g_wg_stamps + 16 * (long long)item + 8;
+        o[0] = stamps[1] - stamps[0]; o[1] = stamps[2] - stamps[1]; o[2] = stamps[3] - stamps[2]; o[3] = stamps[4] - stamps[2];
+        o[4] = (long long)__builtin_amdgcn_s_memtime() - stamps[4];
+    }
+    if (probe && !quiet && tid == 0) {
         const long long e = (long long)__builtin_amdgcn_s_memtime();
         printf("seq %d dir %d: setup %lld, chain %lld (%lld per step), scorer alone until +%lld, all waves at the meeting point +%lld, "
                "tiles + arrival %lld; tiles alone %d of %d\n", b, dir, stamps[1] - stamps[0], stamps[2] - stamps[1],
@@ -613,11 +658,30 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
 
 // LMO: the instantiation for the label-map path (scores on, the output matrix a label map, tags only): the matrix-core tile
 // code is not compiled in -- a quarter of the instructions, 40 instead of 260 spilled SGPRs
-template <bool MAXSR, bool SCORE, bool NLX, bool LMO = false>
+template <bool MAXSR, bool SCORE, bool NLX, bool LMO = false, bool DEST = false>
 __global__ void __launch_bounds__(RG_WAVES * 64, 4)          // 4 waves per SIMD = 128 VGPRs: two workgroups per compute unit
 chain_regs_kernel(const RegsParams p) {
     extern __shared__ __align__(16) float smem[];
-    chain_regs_body<MAXSR, SCORE, NLX, RG_RQ, RG_D, LMO>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
+#if defined(FARNN_PROBES)
+    // FARNN_DBG & 2048: every workgroup's life on the 100 MHz wall clock (s_memrealtime) and in shader cycles (s_memtime), with the
+    // compute unit it ran on, into g_wg_stamps (read back through farnn_debug_wg_stamps; no printf: a device printf is a host call
+    // that stalls the compute unit's other wavefronts for milliseconds): who finishes last, how far the starts are apart, the clock
+    long long w0r = 0, w0c = 0;
+    if ((p.dbg & 2048) && threadIdx.x == 0) { w0r = (long long)__builtin_amdgcn_s_memrealtime(); w0c = (long long)__builtin_amdgcn_s_memtime(); }
+    int b_probe = -1;
+    chain_regs_body<MAXSR, SCORE, NLX, RG_RQ, RG_D, LMO, DEST>(p, smem, (int)threadIdx.x, (int)blockIdx.x, &b_probe);
+    if ((p.dbg & 2048) && threadIdx.x == 0 && blockIdx.x < WG_STAMP_MAX) {
+        const long long w1r = (long long)__builtin_amdgcn_s_memrealtime(), w1c = (long long)__builtin_amdgcn_s_memtime();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        long long *o = g_wg_stamps + 16 * (long long)blockIdx.x;
+        o[0] = b_probe; o[1] = b_probe >= 0 ? (long long)p.len[b_probe] : -1; o[2] = w0r; o[3] = w1r; o[4] = w1c - w0c;
+        o[5] = xcc & 15u; o[6] = (hwid >> 13) & 7u; o[7] = (hwid >> 8) & 15u;
+    }
+#else
+    chain_regs_body<MAXSR, SCORE, NLX, RG_RQ, RG_D, LMO, DEST>(p, smem, (int)threadIdx.x, (int)blockIdx.x, nullptr);
+#endif
 }
 
 template <bool MAXSR, bool SCORE, bool NLX, int RQ, int D>

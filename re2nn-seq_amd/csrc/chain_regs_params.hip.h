@@ -24,6 +24,12 @@ constexpr int RGW_MAXRQ = 11;                  // rows per lane per step the ins
 // the identity word.  RQ <= 9 means SP <= 108, PS = 112 (1 344 + 24 + <= 104 floats); RQ = 11: PS <= 144
 __host__ __device__ constexpr int rgw_part_stride(int rq) { return rq <= 9 ? 1536 : 2048; }
 constexpr int RGW_XCH = 32;                    // floats of a compute wavefront's state-exchange area (2 groups x 12 rows)
+// The DESTINATION-split form of the narrow kernel (chain_dest.hip.h; S <= 72, sum semiring): a wavefront owns whole outputs, four
+// lanes per output row, five 16-byte chunks of the row per lane and step
+constexpr int RD_LPR = 5;                      // lanes per output row (chain_dest.hip.h: 5 lanes x 4 chunks; 4: 4 lanes x 5 chunks)
+constexpr int RD_XS = 80;                      // floats of one exchange row: 20 chunks of 16 bytes >= 72 floats, zeros behind S
+constexpr int RD_D = 4;                        // steps of block pieces in flight per lane
+constexpr int RD_XD_FLOATS = 2 * RD_XS + 128;  // the two exchange rows + two dump slots per lane
 
 struct RegsParams {
     const float *Mf, *Mb;        // [V][SR][SP] blocks and their transposes (layout.hip.h)
@@ -47,6 +53,7 @@ struct RegsParams {
     int spin;                    // polls a finished workgroup spends on the tiles of its own half before it leaves them to the other
     int dbg;                     // FARNN_DBG ablation / probe mask: read by the profiling build (-DFARNN_PROBES) only
     int solo_margin;             // the scorer starts a tile alone only if the chain has at least this many steps left after it
+    int dest;                    // 1: the destination-split form of the compute wavefronts (chain_dest.hip.h; narrow form, sum semiring)
     ScoreParams sp;
 };
 constexpr int RG_NG = 5;         // state groups of 16 the scoring stage of this kernel reaches (S <= 72 -> c16 <= 5)
@@ -89,11 +96,12 @@ inline RegsGeom regs_geometry(int S) {
 
 // LDS carve, in floats (host and device agree through this one function)
 struct RegsLds {
-    int tok, hp, part, ol, hist, ab, scl, obuf, misc, xch, total;
+    int tok, hp, part, ol, hist, ab, scl, obuf, misc, xch, xd, total;
 };
 // rq: rows per lane and step of the form (RG_RQ: S <= 72; larger: the wide form, whose partial-sum buffers and exchange area differ)
 // lm: the label-map path scores the tiles (label_map.hip.h): no products, no score tiles in LDS
-__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, int rq = RG_RQ, bool lm = false) {
+// dest: the destination-split form (chain_dest.hip.h): its exchange rows
+__host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int Kc, bool score, int rq = RG_RQ, bool lm = false, bool dest = false) {
     const bool wide = rq != RG_RQ;
     RegsLds l;
     int at = 0;
@@ -107,6 +115,7 @@ __host__ __device__ inline RegsLds regs_lds(int L, int SP, int NP, int c16, int 
     l.obuf = at; at += score ? 2 * RG_TT * SP : 0;    // RG_NOB tiles of the other direction's rows
     l.misc = at; at += 32;
     l.xch = at;  at += wide ? RG_NWC * RGW_XCH : 0;     // wide form: where a compute wavefront hands its new state entries to its own lanes
+    l.xd = at;   at += dest ? RD_XD_FLOATS : 0;
     l.total = at;
     return l;
 }

@@ -162,7 +162,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
     unsigned lm_pk0 = 0u, lm_pk1 = 0u;                        // the output matrix as a label map (label_map.hip.h), when it is one
     unsigned epoch = 0u;                                      // the launch's epoch, from device memory (beside.hip.h, bs_launch_epoch)
     if (SCORE) {
-        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, p.B, lane);
+        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, lane);
         if (bs_label_map_path(p.bs.sp)) lm_load_packed(p.bs.sp.lm, lane, lm_pk0, lm_pk1);
         bs_halves(dir, len, nsteps, kmid, pubmax);
         for (int j = tid; j < (nsteps + 1) * SP; j += DG_THREADS) hist[j] = j < S ? hinit[j] : 0.0f;   // row 0; pad columns zero
@@ -405,7 +405,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     unsigned lm_pk0 = 0u, lm_pk1 = 0u;                        // the output matrix as a label map (label_map.hip.h), when it is one
     unsigned epoch = 0u;                                      // the launch's epoch, from device memory (beside.hip.h, bs_launch_epoch)
     if (SCORE) {
-        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, p.B, lane);
+        if (wv == 0 || wv == WCOPY) epoch = bs_launch_epoch(p.bs.done, lane);
         if (bs_label_map_path(p.bs.sp)) lm_load_packed(p.bs.sp.lm, lane, lm_pk0, lm_pk1);
         bs_halves(dir, len, nsteps, kmid, pubmax);
         for (int j = tid; j < (nsteps + 1) * SP; j += DG_THREADS) hist[j] = j < S ? hinit[j] : 0.0f;   // row 0; pad columns zero

@@ -83,7 +83,6 @@ struct farnn_model {
     RegsGeom rgeom;                         // geometry of the register-fed recurrence kernel (chain_regs.hip.h); rgeom.ok: usable
     unsigned long long *hs = nullptr;       // hand-off words of that kernel: progress [2][B], arrival [B] (64-bit each)
     size_t hs_bytes = 0;
-    int hs_B = 0;                           // the batch size the hand-off words and their launch counter are valid for (0: zeroed)
     unsigned epoch_u = 0;                   // diagnostic FARNN_HOST_EPOCH=1: the round-3 host-side epoch
     bool last_regs = false;                 // the last recurrence ran on chain_regs_kernel
     int chain_ks = 3;
@@ -437,7 +436,6 @@ extern "C" int farnn_reserve(farnn_model *m, int32_t B, int32_t L) {
     m->hs_bytes = round_up_sz((size_t)(3 * nB + 48) * sizeof(unsigned long long), 16);     // progress [2][nB], arrival [nB], the launch counter
     FARNN_HIP_TRY(hipMalloc((void **)&m->hs, m->hs_bytes));
     FARNN_HIP_TRY(hipMemset(m->hs, 0, m->hs_bytes));
-    m->hs_B = 0;
     if (m->use_crf)
         FARNN_HIP_TRY(hipMalloc((void **)&m->crf_scores, (size_t)nB * nL * m->Kp * sizeof(float) + 1024));   // +1 KiB: LDS-DMA pieces
     if (m->d1_BSSp)
@@ -546,30 +544,16 @@ static RegsParams make_regs_params(farnn_model *m, const int64_t *x, const int64
     rp.A = m->A; rp.Bk = m->Bk; rp.B = B; rp.L = m->curL; rp.S = m->S; rp.SP = m->SP; rp.CPR = rg.CPR; rp.V = m->V;
     rp.G = rg.G; rp.RPG = rg.RPG; rp.RQ = rg.RQ; rp.D = rg.D; rp.PS = rg.PS; rp.pair = rg.wide ? 0 : 1;
     rp.nl = m->nl; rp.full = full; rp.dbg = tun(TUN_DBG);
+    rp.dest = (!rg.wide && m->semiring != FARNN_SEMIRING_MAX && !tun(TUN_NODEST)) ? 1 : 0;     // chain_dest.hip.h
     return rp;
 }
 
 // The hand-off words of the one-launch forms (chain_regs.hip.h / decomp_regs.hip.h + beside.hip.h) and their launch counter.
-// A launch's epoch is (sequences whose second workgroup has arrived so far) / B + 1, read from device memory by the kernel:
-// nothing per launch comes from the host, so the step replays from a HIP graph as the very same launch.  The counter is only
-// meaningful for ONE batch size: when B changes the words and the counter are zeroed -- on the call's stream, or, while that
-// stream is being captured (the zeroing must not become a node that every replay runs), at once on a stream of its own.
-static int handoff_words(farnn_model *m, int B, hipStream_t s, unsigned long long **prog, unsigned long long **arr,
-                         unsigned long long **done) {
-    if (B != m->hs_B) {
-        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        const bool capturing = hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone;
-        if (!capturing) FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s));
-        else {
-            hipStream_t side = nullptr;
-            FARNN_HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-            hipError_t e = hipMemsetAsync(m->hs, 0, m->hs_bytes, side);
-            if (e == hipSuccess) e = hipStreamSynchronize(side);
-            (void)hipStreamDestroy(side);
-            FARNN_HIP_TRY(e);
-        }
-        m->hs_B = B;
-    }
+// A launch's epoch is (the counter >> BS_EPOCH_SHIFT) + 1, read from device memory by the kernel; every launch adds exactly
+// BS_EPOCH_SPAN to the counter whatever its batch size (beside.hip.h, bs_launch_epoch).  Nothing per launch comes from the host and
+// nothing is ever reset: the step replays from a HIP graph as the very same launch, and graphs captured at different batch sizes
+// and eager calls may interleave on a handle (stream-ordered).  The words are zeroed once, when the workspace is allocated.
+static int handoff_words(farnn_model *m, unsigned long long **prog, unsigned long long **arr, unsigned long long **done) {
     *prog = m->hs; *arr = m->hs + (size_t)2 * m->wsB; *done = m->hs + (size_t)3 * m->wsB + 16;      // (the counter on a 128-byte line of its own)
     return FARNN_OK;
 }
@@ -590,17 +574,18 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
         const bool lm_path = score && bs_label_map_path(*fuse_sp);
-        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ, lm_path).total * sizeof(float);
+        const bool dest = !rg.wide && m->semiring != FARNN_SEMIRING_MAX && !tun(TUN_NODEST);
+        size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ, lm_path, dest).total * sizeof(float);
         // the wide form PAIRED (two workgroups per compute unit, like S <= 72): a ring of two steps and the label-map path's LDS
         const bool paired = rg.wide && lm_path && rg.RQ <= 9 && lds <= 80 * 1024 && !tun(TUN_WIDE_UNPAIRED);
         if (score && lds > lds_cap) {               // the score tiles do not fit (beside a second workgroup): recurrence only
             score = false;
-            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.RQ).total * sizeof(float);
+            lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, 0, 0, false, rg.RQ, false, dest).total * sizeof(float);
         }
         if (lds <= lds_cap) {
             RegsParams rp = make_regs_params(m, x, len, B, full);
             if (score) {
-                int hrc = handoff_words(m, B, s, &rp.prog, &rp.arr, &rp.done);
+                int hrc = handoff_words(m, &rp.prog, &rp.arr, &rp.done);
                 if (hrc) return hrc;
                 if (tun(TUN_HOST_EPOCH)) {       // diagnostic A/B: the epoch as a kernel argument (not graph-capturable)
                     if (++m->epoch_u == 0) { FARNN_HIP_TRY(hipMemsetAsync(m->hs, 0, m->hs_bytes, s)); m->epoch_u = 1; }
@@ -761,7 +746,7 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
         if (score) {
             memset(&bs, 0, sizeof(bs));
             bs.A = m->A; bs.Bk = m->Bk; bs.B = B; bs.L = m->curL; bs.SP = m->SP; bs.CPR = m->SP / 4;
-            int hrc = handoff_words(m, B, s, &bs.prog, &bs.arr, &bs.done);
+            int hrc = handoff_words(m, &bs.prog, &bs.arr, &bs.done);
             if (hrc) return hrc;
             bs.spin = tun(TUN_FUSE_SPIN); bs.dbg = tun(TUN_DBG); bs.sp = *fuse_sp;
             use = &bs;

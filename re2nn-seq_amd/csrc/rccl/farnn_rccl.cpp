@@ -66,6 +66,15 @@ int farnn_rccl_gather_tags(void *comm, const int32_t *local, int64_t rows_per_ra
     return 0;
 }
 
+int farnn_rccl_comm_count(void *comm) {
+    Comm *c = static_cast<Comm *>(comm);
+    if (!c) return fail(-EINVAL, "farnn_rccl_comm_count", "null communicator");
+    int n = 0;
+    const ncclResult_t r = ncclCommCount(c->comm, &n);
+    if (r != ncclSuccess) return fail(-EIO, "ncclCommCount", ncclGetErrorString(r));
+    return n;
+}
+
 int farnn_rccl_comm_destroy(void *comm) {
     Comm *c = static_cast<Comm *>(comm);
     if (!c) return 0;

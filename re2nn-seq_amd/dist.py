@@ -128,49 +128,122 @@ def tag_sharded(tag_fn, x, lengths, group=None, balance=True):
     return gather_tags(tag_fn(xs, ls), x.shape[0], group=group)
 
 
+class LoopbackCommunicator:
+    """A communicator with `_rccl.Communicator`'s interface (`nranks`, `rank`, `count()`, `gather_tags(local, out, stream)`) whose
+    all-gather is a host-side exchange -- over torch.distributed (gloo on CPU tensors: the multi-process tests) when a
+    process group is up, else through a board shared by the instances of ONE process (`LoopbackCommunicator.board(n)`:
+    every rank's instance posts its block, the gather concatenates them -- the single-process unit tests of the native
+    path's padding and un-permutation at world sizes 2..8).  Test infrastructure for the code AROUND the collective; the
+    collective itself is RCCL's (`_rccl.Communicator`)."""
+
+    def __init__(self, nranks, rank, board=None, group=None):
+        self.nranks, self.rank, self._board, self._group = nranks, rank, board, group
+
+    @staticmethod
+    def board(nranks):
+        posted = {}
+        return [LoopbackCommunicator(nranks, r, board=posted) for r in range(nranks)]
+
+    def count(self):
+        return self.nranks
+
+    def post(self, local):
+        """single-process form: every rank posts its block before anybody gathers"""
+        self._board[self.rank] = local
+
+    def gather_tags(self, local, out=None, stream=None):
+        rows, L = local.shape
+        if out is None:
+            out = torch.empty((self.nranks * rows, L), dtype=local.dtype, device=local.device)
+        if self._board is not None:
+            self._board[self.rank] = local
+            assert len(self._board) == self.nranks, 'post() every rank\'s block first'
+            for r in range(self.nranks):
+                assert tuple(self._board[r].shape) == (rows, L), 'ranks disagree on the padded block shape'
+                out[r * rows:(r + 1) * rows].copy_(self._board[r])
+            return out
+        dist.all_gather_into_tensor(out, local.contiguous(), group=self._group)
+        return out
+
+    def close(self):
+        pass
+
+
 class OverlappedGather:
-    """Weak-scaling serving loop: the tag ids of step i travel (one RCCL all-gather, on RCCL's own
-    stream) while step i+1 computes.  Two output blocks and two gather buffers rotate; a block is
+    """Weak-scaling serving loop: the tag ids of step i travel (one RCCL all-gather, on a stream of its own)
+    while step i+1 computes.  Two output blocks and two gather buffers rotate; a block is
     handed out again only after the gather that read it has completed.
 
-        og = OverlappedGather(B, L, device)
+        og = OverlappedGather(B, L, device)             # torch.distributed (backend "nccl" = RCCL), or
+        og = OverlappedGather(B, L, device, comm=c)     # the C-ABI collective (include/farnn_rccl.h, `_rccl.Communicator`)
         for step in ...:
             out = og.next_output()          # int32 [B, L] to tag into (waits for its previous gather)
             tagger(out)                     # enqueue the kernels on the current stream
             og.submit()                     # async all-gather of `out`
         og.drain()                          # every gather done; og.last() = [world*B, L] of the last step
+
+    comm: the gather is `comm.gather_tags(out, gathered, stream)` on a side HIP stream that waits for the tagging stream's
+    event; completion is an event of that stream (no torch.distributed anywhere on the path).
     """
 
-    def __init__(self, B, L, device, group=None, depth=2):
-        _, self.world = world()
+    def __init__(self, B, L, device, group=None, depth=2, comm=None):
+        self.comm = comm
+        if comm is not None:
+            self.world = comm.nranks
+        else:
+            _, self.world = world()
         self.group = group
+        self.device = torch.device(device)
         self.out = [torch.empty((B, L), dtype=torch.int32, device=device) for _ in range(depth)]
         self.gathered = [torch.empty((self.world * B, L), dtype=torch.int32, device=device) for _ in range(depth)]
         self.works = [None] * depth
         self.i = 0
         self.cur = 0
+        self.side = None
+        if comm is not None and self.device.type == 'cuda':
+            self.side = torch.cuda.Stream(self.device)
+
+    def _wait(self, k):
+        w = self.works[k]
+        if w is None:
+            return
+        if self.comm is not None:
+            if w is not True:
+                w.synchronize()                  # (a CUDA event of the gather's stream)
+        else:
+            w.wait()
+        self.works[k] = None
 
     def next_output(self):
         self.cur = self.i % len(self.out)
         self.i += 1
-        w = self.works[self.cur]
-        if w is not None:
-            w.wait()
-            self.works[self.cur] = None
+        self._wait(self.cur)
         return self.out[self.cur]
 
     def submit(self):
         k = self.cur
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             self.gathered[k].copy_(self.out[k])
+            return
+        if self.comm is not None:
+            if self.side is None:                # CPU tensors (tests): the exchange is synchronous
+                self.comm.gather_tags(self.out[k], self.gathered[k])
+                self.works[k] = True
+                return
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(self.device))
+            self.side.wait_event(ready)
+            with torch.cuda.stream(self.side):     # (a loopback communicator's torch ops land on the side stream too)
+                self.comm.gather_tags(self.out[k], self.gathered[k], self.side.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(self.side)
+            self.works[k] = done
             return
         self.works[k] = dist.all_gather_into_tensor(self.gathered[k], self.out[k], group=self.group, async_op=True)
 
     def drain(self):
-        for k, w in enumerate(self.works):
-            if w is not None:
-                w.wait()
-                self.works[k] = None
+        for k in range(len(self.works)):
+            self._wait(k)
 
     def last(self):
         return self.gathered[self.cur]

@@ -33,7 +33,6 @@ def test_library_exports_every_declared_symbol():
 def test_no_torch_types_in_the_abi():
     with open(os.path.join(ROOT, 'include', 'farnn.h')) as f:
         text = f.read()
-    assert 'torch' not in text.replace('PyTorch-ROCm tensors used purely', '').lower() or True
     assert '#include <torch' not in text and 'at::' not in text and 'std::' not in text
 
 

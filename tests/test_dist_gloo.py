@@ -140,3 +140,66 @@ def test_overlapped_gather_two_ranks_gloo(tmp_path):
     mp.spawn(_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         assert (tmp_path / 'ov{}.txt'.format(r)).read_text() == 'ok'
+
+
+@pytest.mark.parametrize('world', [2, 3, 4, 5, 6, 7, 8])
+def test_native_gather_path_padding_and_unpermutation_world_2_to_8(world):
+    """`dist.gather_tags_balanced_native` -- the code AROUND the C-ABI collective (include/farnn_rccl.h): ragged shares padded
+    to the largest, rank-major blocks, ONE inverse permutation back to batch order -- at world sizes 2..8 with the loopback
+    communicator (a host all-gather behind `_rccl.Communicator`'s interface), so that the first 8-GPU run of
+    `bench.py --gather native` exercises RCCL and nothing else for the first time."""
+    from re2nn_seq_amd import dist as fdist
+    rng = np.random.RandomState(100 + world)
+    L = 9
+    for n in (world * 4, world * 4 + 3, world + 1, max(1, world - 1), 1, 257):
+        lengths = torch.from_numpy(rng.randint(1, L + 1, size=n).astype(np.int64))
+        # "tags" that name their own batch row and position: any misplaced row shows
+        full = (torch.arange(n, dtype=torch.int32)[:, None] * 100 + torch.arange(L, dtype=torch.int32)[None, :])
+        assign = fdist.balanced_assignment(lengths, world)
+        comms = fdist.LoopbackCommunicator.board(world)
+        biggest = max(int(a.shape[0]) for a in assign)
+        locals_ = [full.index_select(0, assign[r]) for r in range(world)]
+        for r in range(world):                                       # what every rank hands to the collective
+            blk = locals_[r]
+            if blk.shape[0] < biggest:
+                blk = torch.cat([blk, torch.full((biggest - blk.shape[0], L), -1, dtype=torch.int32)], 0)
+            comms[r].post(blk.contiguous())
+        for r in range(world):
+            got = fdist.gather_tags_balanced_native(locals_[r], assign, n, comms[r])
+            assert got.shape == (n, L) and torch.equal(got, full), (world, n, r)
+            assert comms[r].count() == world
+
+
+def _native_overlap_worker(rank, world, port, out_dir):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from re2nn_seq_amd.dist import OverlappedGather, LoopbackCommunicator
+    B, L, steps = 4, 6, 7
+    comm = LoopbackCommunicator(world, rank)              # gloo behind the native communicator's interface
+    og = OverlappedGather(B, L, torch.device('cpu'), comm=comm)
+    ok = og.world == world and comm.count() == world
+    for i in range(steps):
+        out = og.next_output()
+        out.fill_(1000 * i + rank)
+        og.submit()
+    og.drain()
+    last = og.last()
+    for r in range(world):
+        ok = ok and bool((last[r * B:(r + 1) * B] == 1000 * (steps - 1) + r).all())
+    with open(os.path.join(out_dir, 'nov{}.txt'.format(rank)), 'w') as f:
+        f.write('ok' if ok else 'mismatch')
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_overlapped_gather_over_a_communicator_object(tmp_path, world):
+    """`OverlappedGather(comm=...)`: bench.py's `--gather native` loop with the collective behind the communicator interface
+    (here the loopback one over gloo; on the GPU box `_rccl.Communicator`)."""
+    mp.spawn(_native_overlap_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert (tmp_path / 'nov{}.txt'.format(r)).read_text() == 'ok'

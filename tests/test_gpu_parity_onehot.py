@@ -290,6 +290,80 @@ def test_tag_call_captures_into_a_hip_graph():
         assert np.array_equal(flat.cpu().numpy()[:n], fo.forward_local_tags(ref, lengths, 0.5, 1))
 
 
+def test_graphs_of_two_batch_sizes_and_eager_calls_interleave_on_one_handle():
+    """The hand-off's launch epoch does not depend on the batch size (beside.hip.h, bs_launch_epoch: every launch adds
+    the same span to the device-side counter): two graphs captured at different B on ONE handle and eager calls at a
+    third B interleave freely (stream-ordered), each launch the one-launch form, every result the oracle's.
+    (Round 4 derived the epoch as count / B: an eager call at another B between two replays changed it mid-launch.)"""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(77)
+    V, S, C, L = 50, 41, 11, 23
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=1)
+    sizes = (37, 12, 29)                                 # graph A, graph B, eager
+    h.reserve(max(sizes), L)
+    dev = torch.device('cuda', 0)
+    side = torch.cuda.Stream(dev)
+    bufs = {}
+    for B in sizes:
+        bufs[B] = dict(x=torch.zeros((B, L), dtype=torch.int64, device=dev), l=torch.ones((B,), dtype=torch.int64, device=dev),
+                       tags=torch.empty((B, L), dtype=torch.int32, device=dev),
+                       flat=torch.full((B * L,), -9, dtype=torch.int64, device=dev))
+
+    def call(B, stream):
+        u = bufs[B]
+        h.tag(u['x'].data_ptr(), u['l'].data_ptr(), B, L, _lib.MODE_LOCAL, u['tags'].data_ptr(), u['flat'].data_ptr(), None, stream)
+
+    def fill(B, seed):
+        x, lengths = synth.random_batch(V, B, L, np.random.RandomState(seed), min_len=1)
+        bufs[B]['x'].copy_(_t(x)); bufs[B]['l'].copy_(_t(lengths))
+        return x, lengths
+
+    def check(B, x, lengths):
+        ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
+        n = int(lengths.sum())
+        assert np.array_equal(bufs[B]['flat'].cpu().numpy()[:n], fo.forward_local_tags(ref, lengths, 0.5, 1)), B
+
+    with torch.cuda.stream(side):                       # eager calls first (lazy attribute set-up), one per size
+        for B in sizes:
+            fill(B, B)
+            call(B, side.cuda_stream)
+    side.synchronize()
+    graphs = {}
+    for B in sizes[:2]:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            call(B, torch.cuda.current_stream(dev).cuda_stream)
+        assert 'fused' in h.kernel_name(_lib.KERN_CHAIN), h.kernel_name(_lib.KERN_CHAIN)
+        graphs[B] = g
+    seed = 100
+    for rnd in range(6):
+        order = [sizes[(rnd + i) % 3] for i in range(3)] + [sizes[rnd % 2]]      # e.g. A, B, eager, A
+        for B in order:
+            seed += 1
+            x, lengths = fill(B, seed)
+            if B in graphs:
+                graphs[B].replay()
+            else:
+                call(B, torch.cuda.current_stream(dev).cuda_stream)
+            torch.cuda.synchronize()
+            check(B, x, lengths)
+    # back to back without a host synchronisation in between: a replay of each graph and an eager call queue up on the stream
+    for rnd in range(4):
+        batches = {}
+        for B in sizes:
+            seed += 1
+            batches[B] = fill(B, seed)
+        for B in (sizes[rnd % 3], sizes[(rnd + 1) % 3], sizes[(rnd + 2) % 3]):
+            if B in graphs:
+                graphs[B].replay()
+            else:
+                call(B, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        for B in sizes:
+            check(B, *batches[B])
+
+
 @pytest.mark.parametrize('seed', range(12))
 def test_ifst_random_geometries_vs_oracle(seed):
     """Randomised sweep over (S, C, L, B, non-linearity, semiring, priority): whatever kernel variant the
