@@ -941,6 +941,7 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         # the compact form (bit-packed blocks + active-state walk) reported SEPARATELY; the contract
         # number above stays fp32-dense.  Same batch, same handle; its tags must equal the dense kernel's.
         dense_tags = tags_bufs[(steps - 1) % n_main].clone()
+        xd = xds[last_written[(steps - 1) % n_main]]     # the batch those tags belong to
         h.set_compact(True)
         csteps = max(steps, 50) if name == 'ifst' else steps
         for _ in range(5):

@@ -537,11 +537,12 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
         // =================================================================================================================
         // scorer wavefront: tiles of this workgroup's half, while the chain runs
         // =================================================================================================================
-        {
-            const int fo = bs_flat_offset(bs, b, lane);               // where sequence b starts in the flat output (utils.py:153-164)
-            if (lane == 0) misc[RGM_FOFF] = fo;
-        }
-        const long long foff = misc[RGM_FOFF];
+        // where sequence b starts in the flat output (utils.py:153-164): every lane has the sum (bs_flat_offset's butterfly); the LDS
+        // word is for the other wavefronts, behind the meeting barrier.  (Not read back here: the compiler may serve a lane that did
+        // not store from a load hoisted ABOVE lane 0's store -- seen in round 5, when a second lane of this wavefront stored tags.)
+        const int fo = bs_flat_offset(bs, b, lane);
+        if (lane == 0) misc[RGM_FOFF] = fo;
+        const long long foff = fo;
         unsigned mine = 0u;
         int acq = -1;                 // the other direction's progress as polled before this workgroup's latest acquire
         const unsigned long long *oprog = p.prog + (long long)(dir ^ 1) * p.B + b;

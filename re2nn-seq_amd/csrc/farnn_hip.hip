@@ -18,6 +18,7 @@
 #include "decomp_chain.hip.h"
 #include "decomp1_score.hip.h"
 #include "decomp_rows.hip.h"
+#include "compact_tag.hip.h"
 #include "decomp_regs.hip.h"
 #include "compact.hip.h"
 #include "host_util.hip.h"
@@ -512,7 +513,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
     TunScope tun_scope(&m->tun);
     switch (which) {
         case KERN_CHAIN:
-            if (m->compact_on) return "compact_chain_kernel";
+            if (m->compact_on) return m->last_fused ? "compact_tag_kernel<fused: both chains + label-map scores + decode>" : "compact_chain_kernel";
             if (m->last_regs && m->last_fused && m->use_crf) return "chain_viterbi_kernel<fused: recurrence + scores + CRF decode>";
             if (m->last_regs && m->rgeom.wide) return m->last_fused ? "chain_wide_kernel<fused: scores + decode beside the recurrence>" : "chain_wide_kernel";
             if (m->last_regs) return m->last_fused ? "chain_regs_kernel<fused: scores + decode beside the recurrence>" : "chain_regs_kernel";
@@ -1085,6 +1086,28 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
                 cp.x = x; cp.len = lengths; cp.order = m->order_valid ? m->order : nullptr; cp.A = m->A; cp.Bk = m->Bk;
                 cp.B = B; cp.L = L; cp.S = m->S; cp.SP = m->SP; cp.V = m->V; cp.nl = m->nl; cp.full = full; cp.dbg = tun(TUN_DBG);
                 m->last_fused = false;
+                {
+                    // ONE launch (compact_tag.hip.h: both chains of a sequence in LDS, label-map scores, argmax decode) where it
+                    // applies; FARNN_NOFUSE=1: round 2's two launches
+                    const ScoreParams sp = make_score_params(m, lengths, B, full, tags, flat_tags, scores);
+                    if (m->bmNS <= 2 && sp.lm.on && !sp.P && !scores && !m->use_crf && !tun(TUN_NOFUSE) &&
+                        compact_tag_fits(m->V, m->S, m->SP, L) && (B <= 1024 || !flat_tags || sp.offs)) {
+                        const size_t lds = (size_t)compact_tag_lds(L, m->SP).total * 4;
+                        const bool nlx = m->nl != FARNN_NL_NONE && m->nl != FARNN_NL_RELU;
+                        KernelTimer kt(m, KERN_CHAIN, s);
+#define FARNN_LAUNCH_CT(NS_, NX_)                                                              \
+                        do {                                                                   \
+                            if ((rc = raise_lds_limit(compact_tag_kernel<NS_, NX_>, lds))) return rc; \
+                            compact_tag_kernel<NS_, NX_><<<B, CT_WAVES * 64, lds, s>>>(cp, sp); \
+                        } while (0)
+                        if (m->bmNS == 1) { if (nlx) FARNN_LAUNCH_CT(1, true); else FARNN_LAUNCH_CT(1, false); }
+                        else              { if (nlx) FARNN_LAUNCH_CT(2, true); else FARNN_LAUNCH_CT(2, false); }
+#undef FARNN_LAUNCH_CT
+                        FARNN_HIP_TRY(hipGetLastError());
+                        m->last_fused = true;
+                        return FARNN_OK;
+                    }
+                }
                 {
                     KernelTimer kt(m, KERN_CHAIN, s);
                     if ((rc = launch_compact_chain(cp, m->bmNS, s))) return rc;

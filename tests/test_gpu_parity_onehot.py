@@ -109,6 +109,33 @@ def test_atis_scale_ifst_vs_reference():
     assert np.array_equal(scores, fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths))
 
 
+@pytest.mark.parametrize('use_tags,use_flat', [(True, False), (False, True), (True, True)])
+def test_atis_scale_local_mode_outputs_through_device_pointers(use_tags, use_flat):
+    """MODE_LOCAL at the headline shape with every combination of the two outputs a caller may ask for (the [B, L] tags, the
+    flat batch-major predictions of utils.flatten, both): each is the reference's own.  (The bench checks `tags`, the
+    host-buffer path `flat`; a kernel change that only broke the flat offsets of ONE lane went through the bench unseen.)"""
+    from re2nn_seq_amd import _lib, synth
+    g = load_golden('atis_ifst')
+    V, S, C, B, L = [int(v) for v in g['dims']]
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, np.random.RandomState(int(g['seed'])))
+    x = g['x'].astype(np.int64); lengths = g['lengths'].astype(np.int64)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
+    dev = torch.device('cuda', 0)
+    xd, ld = _t(x).to(dev), _t(lengths).to(dev)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    for rep in range(3):
+        tags = torch.full((B, L), -5, dtype=torch.int32, device=dev)
+        flat = torch.full((int(lengths.sum()),), -5, dtype=torch.int64, device=dev)
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr() if use_tags else None,
+              flat.data_ptr() if use_flat else None, None)
+        torch.cuda.synchronize()
+        if use_tags:
+            t = tags.cpu().numpy().astype(np.int64)
+            assert np.array_equal(t[mask], g['tags'].astype(np.int64)[mask]) and (t[~mask] == -1).all()
+        if use_flat:
+            assert np.array_equal(flat.cpu().numpy(), g['flat_pred'].astype(np.int64))
+
+
 @pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (64, 9, 17, 5), (65, 130, 9, 3),
                                      (130, 70, 12, 4), (257, 40, 6, 3), (300, 256, 5, 2), (512, 256, 7, 3),
                                      (1024, 6, 4, 2)])
@@ -625,6 +652,22 @@ def test_compact_form_matches_dense_blocks_and_oracle(S, C, L, B, nl):
                   flat.data_ptr() if mode == _lib.MODE_LOCAL else None, scores.data_ptr())
             torch.cuda.synchronize()
             res[compact, mode] = (scores.cpu().numpy(), tags.cpu().numpy(), flat.cpu().numpy())
+            # the call the tagging loop makes: tags only.  Compact form, S <= 128: ONE launch (compact_tag.hip.h: both chains of a
+            # sequence in LDS, label-map scores, decode) -- its tags and flat predictions equal the two-launch form's of this
+            # very handle bit for bit, whatever the non-linearity (the same state rows, the same label-map scan)
+            tags2 = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+            flat2 = torch.full((int(lengths.sum()),), -7, dtype=torch.int64, device='cuda')
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags2.data_ptr(), flat2.data_ptr() if mode == _lib.MODE_LOCAL else None, None)
+            torch.cuda.synchronize()
+            if compact:
+                assert ('compact_tag_kernel' in h.kernel_name(_lib.KERN_CHAIN)) == (S <= 128), h.kernel_name(_lib.KERN_CHAIN)
+            if nl != 'tanh' or not compact:
+                assert np.array_equal(tags2.cpu().numpy(), res[compact, mode][1])
+                if mode == _lib.MODE_LOCAL:
+                    assert np.array_equal(flat2.cpu().numpy(), res[compact, mode][2])
+            else:       # tanh: the one-launch form takes the uniform-value shortcut (v * count instead of a sum of v's): scores within rounding
+                same = tags2.cpu().numpy() == res[compact, mode][1]
+                assert same.mean() > 0.98
     ref = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths, nl=fo.NL_CODES[nl])
     exact = nl != 'tanh'
     for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
