@@ -69,7 +69,7 @@ BASE_STATES = {k: v[2] for k, v in WORKLOADS.items()}      # (before --states ed
 # (workload, steps, warmup, argument overrides, label): the last decomposed entry is the shape of the reference's shipped example
 # configurations (model_seq/example/*.res: --rank 250 --farnn 2)
 # (an 'env' override: library environment switches for that run only -- the CRF step's two-launch form beside its one-launch default)
-OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, {'env': {'FARNN_NOFUSE': '1'}}, 'ifst_crf_two_launches'),
+OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, {'env': {'FARNN_CV_ONE': '1'}}, 'ifst_crf_one_launch'),
                  # the onehot path at the state count of the reference's SNIPS-BIO / ATIS-ZH-BIO automata (RE.py:56-60): the wide form
                  ('ifst', 1000, 50, {'states': 104}, 'ifst_s104'), ('ifst_crf', 600, 30, {'states': 104}, 'ifst_crf_s104'),
                  ('decomp', 1500, 50, {}, 'decomp'),
@@ -81,7 +81,10 @@ OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, 
                  ('decomp', 300, 20, {'rank': 250, 'farnn': 2, 'crf': True, 'batch': 200, 'seqlen': 30}, 'decomp_r250_farnn2_crf_bz200_len30'),
                  ('decomp', 200, 10, {'rank': 150, 'farnn': 2, 'crf': True, 'states': 134, 'batch': 200, 'seqlen': 30},
                   'decomp_r150_farnn2_crf_s134_bz200_len30'),
-                 ('fst4', 60, 5, {}, 'fst4'))
+                 ('fst4', 60, 5, {}, 'fst4'),
+                 # one GPU's shard of BASELINE configs[4] (V = 20 k, S = 512, C = 256; 1 024 sequences x 128 positions: 42 GB of blocks,
+                 # generated on the device): the HBM-streamed end of the path, in the driver's own line since round 5
+                 ('synth512', 3, 1, {'batch': 1024, 'seqlen': 128}, 'synth512_shard_b1024_len128'))
 
 
 NATIVE_COMM = [None]        # --gather native: this rank's communicator (re2nn_seq_amd._rccl.Communicator)
@@ -206,8 +209,10 @@ def build_workload(name, B, L, rank_id, cp_rank, full_length, farnn=0, semiring=
         h0 = torch.zeros(S, device=dv); h0[0] = 1
         hT = torch.zeros(S, device=dv); hT[0] = 1; hT[S - 1] = 1
         h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl='tanh', device=dev)   # tanh keeps states bounded
+        # (the generated tensor stays on the device -- 21 GB of 288 -- for the post-run check: the blocks a few sequences touch
+        #  are read back and the numpy oracle walks those sequences)
+        extras.update(T_dev=T, W=W.cpu().numpy(), O=O.cpu().numpy(), h0=h0.cpu().numpy(), hT=hT.cpu().numpy())
         del T
-        torch.cuda.empty_cache()
     elif name in ('ifst', 'ifst_crf'):
         T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, wrng)
         crf = name == 'ifst_crf'
@@ -368,6 +373,35 @@ def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
         out['tags_equal'] = bool(np.array_equal(rt[mask[:n]], gpu_tags[:n].astype(np.int64)[mask[:n]]))
         out['sequences_checked'] = n
         out['oracle'] = 'numpy oracle onehot_fst4_scores, first {} sequences, bit-exact tags'.format(n)
+    elif name == 'synth512' and 'T_dev' in extras:
+        # the longest, the shortest and four more sequences: the blocks they touch come back from the device (the tensor was
+        # generated there), the numpy oracle walks them -- scores to 1e-4, tags outside 2e-4 margins (tanh between the steps)
+        rows = np.unique(np.concatenate([[int(np.argmax(lengths)), int(np.argmin(lengths))], np.linspace(0, B - 1, 4).astype(int)]))
+        xs, ls = x[rows].copy(), lengths[rows].copy()
+        toks, inv = np.unique(xs, return_inverse=True)
+        Tsub = extras['T_dev'][torch.from_numpy(toks).to(extras['T_dev'].device)].cpu().numpy()
+        xc = inv.reshape(xs.shape).astype(np.int64)
+        ref = fo.onehot_ifst_scores(Tsub, extras['W'], extras['O'], extras['h0'], extras['hT'], xc, ls, nl=fo.NL_TANH)
+        n = len(rows)
+        xd_ = torch.from_numpy(np.ascontiguousarray(xs)).to(dev); ld_ = torch.from_numpy(np.ascontiguousarray(ls)).to(dev)
+        K = h.num_columns()
+        sc = torch.empty((n, L, K), dtype=torch.float32, device=dev)
+        tg = torch.empty((n, L), dtype=torch.int32, device=dev)
+        h.tag(xd_.data_ptr(), ld_.data_ptr(), n, L, _lib.MODE_LOCAL, tg.data_ptr(), None, sc.data_ptr())
+        torch.cuda.synchronize(dev)
+        Lmax = ref.shape[1]
+        m = (np.arange(Lmax)[None, :] < ls[:, None])
+        err = float(np.abs(sc.cpu().numpy()[:, :Lmax][m] - ref[m]).max())
+        rt = fo.decode_argmax(ref, 0.5, 0)
+        refc = ref.copy(); refc[..., -1] = np.minimum(refc[..., -1], 0.5)
+        top2 = np.sort(refc[m], axis=1)[:, -2:]
+        safe = (top2[:, 1] - top2[:, 0]) > 2e-4
+        same_fresh = np.array_equal(tg.cpu().numpy()[:, :Lmax][m][safe], rt[m][safe])
+        same_timed = np.array_equal(gpu_tags[rows][:, :Lmax][m][safe], rt[m][safe])
+        out.update(max_score_err=err, sequences_checked=n, tags_compared=int(safe.sum()), tags_within_margin_skipped=int((~safe).sum()),
+                   tags_equal=bool(same_fresh and same_timed and err <= 1e-4 * max(1.0, float(np.abs(ref[m]).max()))),
+                   oracle='numpy oracle on the blocks read back from the device, {} whole sequences (longest, shortest, four more): '
+                          'scores <= 1e-4, tags outside 2e-4 margins'.format(n))
     else:
         out['oracle'] = 'none at this size (weights exist on the device only); covered by tests/test_gpu_fullsize_properties.py'
         out['sequences_checked'] = 0
@@ -376,37 +410,41 @@ def parity_check(name, h, extras, x, lengths, gpu_tags, dev):
 
 # ------------------------------------------------------------------------------------------ CPU baselines
 def cpu_baseline(extras, x, lengths, seconds):
-    """The C port of the oracle on this host's cores, same batch, bounded sample: the "fair" CPU number
-    (T+W hoisted, stops at len).  Parallel over (sequence, direction) chains, then over sequences for the
-    scoring; a short sweep picks the fastest thread count and `cores` reports the threads actually used."""
+    """The C port of the oracle on ALL of this host's cores (north_star: "all host cores, count stated"), same batch, bounded
+    sample: the "fair" CPU number (T+W hoisted, stops at len).  Round 5: the barrier-free throughput form
+    (oracle_onehot_ifst_tag_stream: passes x B whole sequences -- both chains, the score rows, the decode -- dealt to the threads
+    dynamically); the two-phase form (chains, barrier, score rows: round 4) peaked at 16-32 of 256 threads and is timed beside it.
+    A short sweep picks the fastest thread count; `cores` reports the threads used, `cores_all` the rate on every hardware thread."""
     from oracle import c_port
     c_port.load(native=True)
     ncpu = os.cpu_count() or 1
     args = (extras['Tf'], extras['O'], extras['h0'], extras['hT'], x, lengths)
     tok = int(lengths.sum())
 
-    def rate(nthreads, budget):
-        # passes inside ONE parallel region (a hot thread team: oracle/farnn_oracle.c, oracle_onehot_ifst_tag_reps), `chunk` per call
-        c_port.onehot_ifst_tag(*args, nthreads=nthreads, reps=2)
+    def rate(nthreads, budget, stream=True):
+        c_port.onehot_ifst_tag(*args, nthreads=nthreads, reps=2, stream=stream)
         chunk = 20
         n, t0 = 0, time.perf_counter()
         while True:
-            c_port.onehot_ifst_tag(*args, nthreads=nthreads, reps=chunk)
+            c_port.onehot_ifst_tag(*args, nthreads=nthreads, reps=chunk, stream=stream)
             n += chunk
             el = time.perf_counter() - t0
-            if el >= budget or n >= 20000:
+            if el >= budget or n >= 40000:
                 return tok * n / el, n, el
             if el < 0.1 * budget:
-                chunk = min(chunk * 2, 640)
+                chunk = min(chunk * 2, 1280)
 
     cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16, 8) if 1 <= c <= ncpu})
-    best = max(cands, key=lambda c: rate(c, 0.5)[0])
+    sweep = {c: rate(c, 0.5)[0] for c in cands}
+    best = max(cands, key=lambda c: sweep[c])
     value, n, el = rate(best, seconds)
-    # (the tags of the timed configuration equal the numpy oracle's: tests/test_oracle_c.py)
+    two_phase = max(rate(c, 0.4, stream=False)[0] for c in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}))
+    # (the tags of both forms equal the numpy oracle's and the reference's: tests/test_oracle_c.py)
     return {'value': value, 'unit': 'tokens/s', 'cores': int(best), 'host_threads': ncpu, 'kind': 'port',
+            'rate_by_threads': {str(c): round(v) for c, v in sweep.items()}, 'two_phase_form_best': two_phase,
             'sample': '{} passes of the same {}x{} batch ({} valid tokens) in {:.1f} s; C port of the '
-                      'oracle (T+W hoisted, OpenMP over the sequence-direction chains, longest first, then over the score rows; '
-                      'the passes of a call share one parallel region so the thread team stays hot), best of thread counts {} '
+                      'oracle (T+W hoisted; OpenMP over passes x sequences, longest first, no barrier: one parallel region, each '
+                      'thread walks both chains of a sequence and scores it), best of thread counts {} '
                       'on a {}-thread host'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu)}
 
 

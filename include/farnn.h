@@ -27,13 +27,18 @@
  * Environment switches (read ONCE per handle, when farnn_*_create / farnn_train_create builds it; no call on the tagging path
  * touches the environment).  Every one selects between code paths that the test suite holds to the same results:
  *   FARNN_NOFUSE=1          the multi-launch forms (recurrence kernel, then score / Viterbi kernel) instead of one launch per step
+ *                           (also: the compact form's two launches instead of compact_tag_kernel)
  *   FARNN_NOREGS=1          the LDS-ring recurrence kernel where the register-fed one (S <= 128) would run
+ *   FARNN_NODEST=1          S <= 72, sum semiring: round 3's compute wavefronts (a block split by SOURCE rows, partial sums reduced
+ *                           across the wavefronts) instead of the destination-split ones (chain_dest.hip.h, the default since round 5)
  *   FARNN_NOLABELMAP=1      scores on the matrix cores even when the output matrix is a label map (one state, one label, weight 1)
- *   FARNN_CV_WIDE=1         72 < S <= 108 with a CRF: recurrence + scores + Viterbi in ONE launch (default there: two, which is faster)
+ *   FARNN_CV_ONE=1          a CRF on the onehot i-FST, S <= 108: recurrence + scores + Viterbi in ONE launch (chain_viterbi_kernel).
+ *                           Not the default since round 5: two launches are faster at every measured shape
+ *   FARNN_WIDE_UNPAIRED=1   72 < S <= 108: one workgroup per compute unit for the wide recurrence (default: two, label-map scores)
  *   FARNN_CV_STASH=1        the one-launch CRF kernel with the state rows through the stash instead of LDS
  *   FARNN_VITERBI_BP=1 / FARNN_VITERBI_UNFUSED=1   the stored-back-pointer Viterbi kernel / scores through HBM in front of it
  *   FARNN_PREP=1, FARNN_NOSORT=1                   the separate batch-prep kernel / the batch's own launch order
- *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1, FARNN_DECOMP_OLD=1   the decomposed recurrence's earlier kernels
+ *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1     the decomposed recurrence's LDS-fed kernels instead of the register forms
  *   FARNN_ROWS_LPR4=1|2     gated decomposed models (farnn = 2, S <= 160): 1 = four lanes per row instead of eight (round 3's forms),
  *                           2 = eight lanes per row but P2 swept from LDS (without the all-in-registers / mixed eight-lane forms)
  *   FARNN_TRAIN_NOLDS=1|2, FARNN_TRAIN_NSEQ=2|4    training chains with the matrices read through L2 / sequences per workgroup

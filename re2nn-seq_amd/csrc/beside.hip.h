@@ -365,11 +365,12 @@ __device__ __forceinline__ void bs_label_map_tiles(const BesideParams &p, const 
             o1[q] = __hip_atomic_load(orow + lr.st1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    const float two = sp.lm.nq > 1 ? 1.0f : 0.0f;        // one register in use: the second one's products are zero
+    const bool two = sp.lm.nq > 1;                       // one register in use: the second one's products are zero (selected, not
+                                                         // multiplied by 0: an infinite state must not turn into a NaN there)
 #pragma unroll
     for (int q = 0; q < NTOK; q += 2) {
         float ya0, ya1, yb0, yb1;
-        lm_scan_scores2(lr, a0[q] * o0[q], a1[q] * o1[q] * two, a0[q + 1] * o0[q + 1], a1[q + 1] * o1[q + 1] * two, ya0, ya1, yb0, yb1);
+        lm_scan_scores2(lr, a0[q] * o0[q], two ? a1[q] * o1[q] : 0.0f, a0[q + 1] * o0[q + 1], two ? a1[q + 1] * o1[q + 1] : 0.0f, ya0, ya1, yb0, yb1);
         float ma = fmaxf(ya0, ya1), mb = fmaxf(yb0, yb1);
         wave_max_dpp2(ma, mb);
         const int taga = lm_tag_from_candidates(sp.lm, lr, ya0, ya1, ma, sp.K, sp.o_idx);

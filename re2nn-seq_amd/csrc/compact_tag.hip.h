@@ -316,7 +316,7 @@ compact_tag_kernel(const CompactParams p, const ScoreParams sp) {
             for (int i = nsteps + lane; i < L; i += WAVE) sp.tags[(long long)b * L + i] = -1;
         LabelMapRegs lr;
         lm_load(sp.lm, lane, lr);
-        const float two = sp.lm.nq > 1 ? 1.0f : 0.0f;
+        const bool two = sp.lm.nq > 1;                              // (second register unused: products selected to zero, not multiplied)
         const int NP = (nsteps + 1) >> 1;                             // token pairs (2 p, 2 p + 1)
         const int mid = min(max((len >> 1) >> 1, 0), max(NP - 1, 0));
         const int *progA = misc + 2, *progB = misc + 3;
@@ -337,8 +337,8 @@ compact_tag_kernel(const CompactParams p, const ScoreParams sp) {
             }
             const float *fa = hA + (ia + 1) * SP, *fb = hA + (ib + 1) * SP;
             const float *ba = hB + rowB(ia) * SP, *bb = hB + rowB(ib) * SP;
-            const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = fa[lr.st1] * ba[lr.st1] * two;
-            const float xb0 = fb[lr.st0] * bb[lr.st0], xb1 = fb[lr.st1] * bb[lr.st1] * two;
+            const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = two ? fa[lr.st1] * ba[lr.st1] : 0.0f;
+            const float xb0 = fb[lr.st0] * bb[lr.st0], xb1 = two ? fb[lr.st1] * bb[lr.st1] : 0.0f;
             float ya0, ya1, yb0, yb1;
             lm_scan_scores2(lr, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1);
             float ma = fmaxf(ya0, ya1), mb = fmaxf(yb0, yb1);

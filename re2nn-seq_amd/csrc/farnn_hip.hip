@@ -62,7 +62,7 @@ struct farnn_model {
     float *o = nullptr, *h0 = nullptr, *hT = nullptr;
     float *OT = nullptr, *P = nullptr, *tr = nullptr;
     float *OTm = nullptr; int c16 = 0;       // matrix-core image of OT for score_tiles (ot_to_mfma_kernel)
-    LabelMap lm = {nullptr, 0, 0, -1, 0.0f, 0, 0.0f}; // the output matrix as a label map, when it is one (label_map.hip.h)
+    LabelMap lm = {nullptr, 0, 0, -1, 0.0f, 0, 0, 0.0f}; // the output matrix as a label map, when it is one (label_map.hip.h)
     DecompWeights dw;                       // decomposed model weights
     DecompRowsPack rows;                    // packed rows of the K12 rows kernel (sum semiring)
     int RO = 0, ROp = 0;                    // decomposed independent=1: output factors
@@ -267,6 +267,7 @@ static int build_label_map(farnn_model *m) {
     m->lm.z0 = (m->lm.e0 == clampcol) ? std::min(0.0f, m->threshold) : 0.0f;
     m->lm.nq = n > 64 ? 2 : 1;
     m->lm.clampcol = clampcol; m->lm.threshold = m->threshold;
+    m->lm.clamp_empty = (clampcol >= 0 && clampcol < m->K && !has[clampcol]) ? 1 : 0;
     unsigned *dv = nullptr;
     int rc = dev_alloc(m, (void **)&dv, tab.size() * 4);
     if (rc) return rc;
@@ -659,7 +660,7 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
 // ---- decomposed modes whose step matrix is materialised anyway: dense per-word blocks + the chain kernel ----
 static int build_dense_blocks(farnn_model *m) {
     const DecompWeights &w = m->dw;
-    if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask) || tun(TUN_DECOMP_OLD)) return FARNN_OK;
+    if (w.farnn != 0 || !(w.semiring == FARNN_SEMIRING_MAX || w.mask)) return FARNN_OK;
     pick_chain_geometry(m);
     m->chain_ks = tun(TUN_KS);
     if (m->geom.NCH > 4 || m->geom.SP != m->SP) return FARNN_OK;
@@ -683,7 +684,7 @@ static int build_rows_pack(farnn_model *m) {
     DecompWeights &w = m->dw;
     DecompRowsPack &k = m->rows;
     k.ok = false;
-    if (w.semiring != FARNN_SEMIRING_SUM || w.mask || tun(TUN_DECOMP_OLD)) return FARNN_OK;
+    if (w.semiring != FARNN_SEMIRING_SUM || w.mask) return FARNN_OK;
     const int tvl = m->Rp + (w.farnn >= 1 ? m->SP : 0) + (w.farnn == 2 ? m->SP : 0);
     if (tvl > DR_MAX_PF * DR_THREADS) return FARNN_OK;
     k.nch2 = (m->S + DR_CHUNK - 1) / DR_CHUNK; k.nch3 = (m->Rp + m->S + DR_CHUNK - 1) / DR_CHUNK;
@@ -974,10 +975,12 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         // the decode's LDS fits; else the recurrence kernel followed by the (fused score +) Viterbi kernel
         m->last_fused = false;
         const ScoreParams sp = make_score_params(m, len, B, full, tags, flat, scores);
-        // (wide form, 72 < S <= 108: the one launch exists -- FARNN_CV_WIDE=1, parity-tested -- but is not the default: a compute
-        //  unit then holds BOTH chains of a sequence, each of which alone keeps its L2 port busy at this block size; measured at
-        //  S = 104, K = 130: 113.8 us per step in one launch against 95.7 in two, profiles/r04_*)
-        if (m->rgeom.ok && (!m->rgeom.wide || tun(TUN_CV_WIDE)) && !tun(TUN_NOREGS) && !tun(TUN_NOFUSE) && viterbi_can_fuse(m, sp) &&
+        // The one launch (north_star: "decode fused into the same kernel") exists for S <= 108 and is parity-tested, but is NOT the
+        // default (round 5): a compute unit then holds BOTH chains of a sequence, which run 1 390 cycles per step there against
+        // 780-960 when a long chain shares its unit with a short one, and the decode waits behind them.  Measured at K = 130,
+        // 256 x 64: S = 71 77.7 us in one launch against 72.9 in two (round 4; round 5's recurrence kernel: 69), S = 104 113.8 against
+        // 95.7 (profiles/r04_*, r05_*).  FARNN_CV_ONE=1 selects it.
+        if (tun(TUN_CV_ONE) && m->rgeom.ok && !tun(TUN_NOREGS) && !tun(TUN_NOFUSE) && viterbi_can_fuse(m, sp) &&
             (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp, m->lm.on != 0, m->rgeom.RQ)) {
             const RegsParams rp = make_regs_params(m, x, len, B, full);
             KernelTimer kt(m, KERN_CHAIN, s, /*ext=*/true);
@@ -1566,7 +1569,7 @@ __global__ void gram_kernel(const float *M, int rows, int cols, double *G) {
 // Only the top eigenvalue is needed (the spectral norm of a factor matrix): power iteration on A -- with A squared a few times
 // first, so that the eigenvalue ratio that governs convergence is raised to the 2^k-th power -- instead of diagonalising the
 // matrix (a cyclic Jacobi sweep is n^2/2 rotations of 4n updates; 60 sweeps at n = 250 were seconds of host time per create).
-static double jacobi_largest_eigenvalue(std::vector<double> &A, int n) {
+static double gram_largest_eigenvalue(std::vector<double> &A, int n) {
     if (n <= 0) return 0.0;
     auto matmul_sq = [&](std::vector<double> &M) {       // M <- M . M / trace-scale (keeps the numbers in range)
         double tr = 0.0;
@@ -1674,7 +1677,7 @@ extern "C" int farnn_decomp_ifst_create_folded(const farnn_decomp_ifst_desc *d, 
             for (int q = 0; q < 3; q++) {
                 gram_kernel<<<dim3((unsigned)R, (unsigned)R), 256>>>(mats[q], (int)rows[q], (int)R, Gd);
                 FARNN_HIP_TRY(hipMemcpy(Gh.data(), Gd, R * R * 8, hipMemcpyDeviceToHost));
-                avgs[q] = sqrt(jacobi_largest_eigenvalue(Gh, (int)R)) / ((double)rows[q] * (double)R);
+                avgs[q] = sqrt(gram_largest_eigenvalue(Gh, (int)R)) / ((double)rows[q] * (double)R);
             }
         }
         if (!(avgs[0] > 0.0) || !(avgs[1] > 0.0) || !(avgs[2] > 0.0))
@@ -1757,7 +1760,7 @@ extern "C" int farnn_decomp_ind1_create(const farnn_decomp_ind1_desc *d, int dev
     w.h0 = m->h0; w.hT = m->hT;
     if ((rc = setup_priority(m, d->P, od))) return bail(rc);
     if ((rc = setup_crf(m, d->crf_trans, od))) return bail(rc);
-    if (m->RO <= 16 * D1M_MAXNT && m->S <= 16 * D1M_MAXKQ4 && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30) && !tun(TUN_DECOMP_OLD)) {
+    if (m->RO <= 16 * D1M_MAXNT && m->S <= 16 * D1M_MAXKQ4 && (size_t)m->V * m->S * m->SP * 4 <= ((size_t)32 << 30)) {
         // per-word bss table for the MFMA scoring kernel (unmasked: the mask only enters the recurrence),
         // materialised row-major in a scratch buffer, then re-laid-out in MFMA operand order
         const int MT = (m->S + 15) / 16, NT = (m->RO + 15) / 16, KQ4 = MT;

@@ -32,8 +32,8 @@ inline int env_int(const char *name, int dflt) {
     /* supported */                                                                                            \
     X(NOFUSE, 0, true) X(NOREGS, 0, true) X(NOLABELMAP, 0, true) X(PREP, 0, true) X(NOSORT, 0, true)           \
     X(VITERBI_BP, 0, true) X(VITERBI_UNFUSED, 0, true) X(CV_STASH, 0, true) X(DECOMP_NOREGS, 0, true)          \
-    X(DECOMP_OLD, 0, true) X(ROWS_NOREGS, 0, true) X(TRAIN_NOLDS, 0, true) X(TRAIN_NSEQ, 0, true)              \
-    X(CV_WIDE, 0, true) X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true) X(NODEST, 0, true)                       \
+    X(ROWS_NOREGS, 0, true) X(TRAIN_NOLDS, 0, true) X(TRAIN_NSEQ, 0, true)              \
+    X(CV_ONE, 0, true) X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true) X(NODEST, 0, true)                       \
     /* diagnostic: profiling build only */                                                                     \
     X(DBG, 0, false) X(KS, 3, false) X(RPG, 12, false) X(NLD, 4, false) X(NOFAST, 0, false)                    \
     X(CHAIN_HELPER, 0, false) X(HOST_EPOCH, 0, false) X(CV_NOSORT, 0, false) X(NOKZ, 0, false)                 \

@@ -40,6 +40,8 @@ struct LabelMap {
     int e0;                  // the first label without any state (its score is +0), -1: none
     float z0;                // that label's clamped score
     int clampcol;            // the column whose score is capped at the threshold (K - 1; K - 3 under a CRF)
+    int clamp_empty;         // 1: that column owns no state -- its score is the constant min(0, threshold) (model_decompose.py:353 clamps
+                             //    the column whatever feeds it)
     float threshold;
 };
 
@@ -74,6 +76,10 @@ __device__ __forceinline__ void lm_load(const LabelMap &lm, int lane, LabelMapRe
     lm_unpack(lm, pk0, pk1, r);
 }
 
+// torch.min(score, threshold) as the reference's clamp computes it (model_onehot.py:166, model_decompose.py:353): a NaN score stays a NaN
+// (fminf would turn it into the threshold; clamp_oo_column_kernel keeps it too)
+__device__ __forceinline__ float lm_clamp(float y, float th) { return (y >= th) ? th : y; }
+
 // The candidates of one token from its products x0 / x1 = a[s] * b[s] of this lane's states (x1: 0 when one register is in use):
 // y0 / y1 = the clamped score of label lb0 / lb1 at the lanes that end a run, -inf elsewhere.
 __device__ __forceinline__ void lm_scan_scores(const LabelMapRegs &r, float x0, float x1, float &y0, float &y1) {
@@ -105,8 +111,8 @@ __device__ __forceinline__ void lm_scan_scores(const LabelMapRegs &r, float x0, 
     const float carry = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x0), 63));
     x1 = fmaf(carry, r.cc1, x1);
     // + (+0.0f) turns a -0 into the +0 torch compares equal to 0; + (-inf) removes the lanes that end no run
-    y0 = fminf(x0 + r.tl0, r.th0);
-    y1 = fminf(x1 + r.tl1, r.th1);
+    y0 = lm_clamp(x0 + r.tl0, r.th0);
+    y1 = lm_clamp(x1 + r.tl1, r.th1);
 }
 
 // The same for TWO tokens at once: the four registers' scan steps interleave, so no DPP read waits for the instruction before it
@@ -134,8 +140,8 @@ __device__ __forceinline__ void lm_scan_scores2(const LabelMapRegs &r, float xa0
     const float cb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xb0), 63));
     xa1 = fmaf(ca, r.cc1, xa1);
     xb1 = fmaf(cb, r.cc1, xb1);
-    ya0 = fminf(xa0 + r.tl0, r.th0); ya1 = fminf(xa1 + r.tl1, r.th1);
-    yb0 = fminf(xb0 + r.tl0, r.th0); yb1 = fminf(xb1 + r.tl1, r.th1);
+    ya0 = lm_clamp(xa0 + r.tl0, r.th0); ya1 = lm_clamp(xa1 + r.tl1, r.th1);
+    yb0 = lm_clamp(xb0 + r.tl0, r.th0); yb1 = lm_clamp(xb1 + r.tl1, r.th1);
 }
 
 // own / oth: the two directions' state rows of the token (LDS)
@@ -143,14 +149,16 @@ __device__ __forceinline__ void lm_token_scores(const LabelMap &lm, const LabelM
                                                 float &y0, float &y1) {
     const float x0 = own[r.st0] * oth[r.st0];
     float x1 = 0.0f;
-    if (lm.nq > 1) x1 = own[r.st1] * oth[r.st1];
+    if (lm.nq > 1) x1 = own[r.st1] * oth[r.st1];     // (a select, not a multiply by 0: an infinite state must not become a NaN)
     lm_scan_scores(r, x0, x1, y0, y1);
 }
 
 // CRF decode: the token's emission row [Kp] (zeros, then every label's clamped score at its column: model_decompose.py:351-353).
 // One wavefront; `row` in LDS.  The zeros and the scores are stores of the same wavefront: the LDS keeps their order.
 __device__ __forceinline__ void lm_store_emissions(const LabelMap &lm, const LabelMapRegs &r, float y0, float y1, float *row, int Kp, int lane) {
-    for (int c = lane; c < Kp; c += WAVE) row[c] = 0.0f;
+    // (a clamp column that owns no state: min(0, threshold), not the 0 of a column nothing scores)
+    const float zc = fminf(0.0f, lm.threshold);
+    for (int c = lane; c < Kp; c += WAVE) row[c] = (lm.clamp_empty && c == lm.clampcol) ? zc : 0.0f;
     asm volatile("" ::: "memory");
     if (r.tl0 == 0.0f) row[r.lb0] = y0;
     if (lm.nq > 1 && r.tl1 == 0.0f) row[r.lb1] = y1;

@@ -112,13 +112,13 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         else lm_load(p.lm, lane, lr);
         if (ldsF) {
             // two tokens at a time (their scans interleave: label_map.hip.h), every row entry fetched before the scan
-            const float two = p.lm.nq > 1 ? 1.0f : 0.0f;
+            const bool two = p.lm.nq > 1;                 // (selected, not multiplied by 0: label_map.hip.h)
             for (int tok = wu; tok < n; tok += 2 * nwaves) {
                 const int tk2 = tok + nwaves < n ? tok + nwaves : tok;             // (an odd token out: scored twice, stored once)
                 const float *fa = ldsF + (tok + 1) * SP, *ba = ldsB + (n - (tok + 1)) * SP;
                 const float *fb = ldsF + (tk2 + 1) * SP, *bb = ldsB + (n - (tk2 + 1)) * SP;
-                const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = fa[lr.st1] * ba[lr.st1] * two;
-                const float xb0 = fb[lr.st0] * bb[lr.st0], xb1 = fb[lr.st1] * bb[lr.st1] * two;
+                const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = two ? fa[lr.st1] * ba[lr.st1] : 0.0f;
+                const float xb0 = fb[lr.st0] * bb[lr.st0], xb1 = two ? fb[lr.st1] * bb[lr.st1] : 0.0f;
                 float ya0, ya1, yb0, yb1;
                 lm_scan_scores2(lr, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1);
                 lm_store_emissions(p.lm, lr, ya0, ya1, scl + (size_t)tok * Kp, Kp, lane);

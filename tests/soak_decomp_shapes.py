@@ -56,23 +56,26 @@ def run(n=60, seed=0, verbose=True, only=None):
         ref = fo.decomp_ifst_scores(q, x, lengths)
         mask = np.arange(L)[None, :] < lengths[:, None]
         got = scores.cpu().numpy()
+        # ONE rule (round 5; the round-4 soak excused a geometry whenever the float32 oracle was itself noisy and clamped its error
+        # for the report): every geometry is held to the EXACT value -- the oracle evaluated in float64.  The kernel's distance from
+        # it must stay within the 1e-4 bar, or, on a locally chaotic random gated model, within TWICE the distance the float32
+        # oracle itself keeps from it (two float32 evaluations of such a recurrence are two draws from the same scatter).
+        # Geometries that pass only through the second clause are counted and listed with their unclamped numbers; more than
+        # 0.5 % of them fails the run.
+        with fo.precision(np.float64):
+            ref64 = fo.decomp_ifst_scores({k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v)
+                                           for k, v in q.items()}, x, lengths)
         err = np.abs(got[mask] - ref[mask]).max() if mask.any() else 0.0
-        bar = 1e-4 + 1e-4 * np.abs(ref[mask]).max() if mask.any() else 1e-4
+        e64 = np.abs(got[mask] - ref64[mask]).max() if mask.any() else 0.0
+        noise = np.abs(ref[mask] - ref64[mask]).max() if mask.any() else 0.0
+        bar = 1e-4 + 1e-4 * np.abs(ref64[mask]).max() if mask.any() else 1e-4
         note = ''
-        if err > bar or only is not None:
-            # a random gated model can be locally chaotic: the float32 oracle itself then sits far from a float64 evaluation, and
-            # every float32 implementation scatters by that much.  Such a geometry is held to its own float32 noise (3x the oracle's
-            # distance from float64) around the FLOAT64 value, and reported
-            with fo.precision(np.float64):
-                ref64 = fo.decomp_ifst_scores({k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v)
-                                               for k, v in q.items()}, x, lengths)
-            noise = np.abs(ref[mask] - ref64[mask]).max()
-            e64 = np.abs(got[mask] - ref64[mask]).max()
-            note = ' [float32 oracle vs float64 {:.2e}, kernel vs float64 {:.2e}]'.format(noise, e64)
-            if err > bar and noise > 0.5 * bar and e64 <= 3 * noise:
-                sensitive += 1
-                err, note = min(err, bar), note + ' SENSITIVE MODEL: held to its float32 noise'
-        ok = np.isfinite(got).all() and err <= bar
+        if e64 > bar or only is not None:
+            note = ' [kernel vs float64 {:.2e}, float32 oracle vs float64 {:.2e}, kernel vs float32 oracle {:.2e}, bar {:.2e}]'.format(e64, noise, err, bar)
+        if e64 > bar and e64 <= 2 * noise:
+            sensitive += 1
+            note += ' SENSITIVE MODEL: within twice the float32 oracle\'s own distance from the exact value'
+        ok = np.isfinite(got).all() and e64 <= max(bar, 2 * noise)
         if crf:     # Viterbi on the GPU's own scores, fused and unfused launches
             own = fo.decode_crf(got, lengths, tr, 0.5, 0)
             ok = ok and np.array_equal(own[mask], tags.cpu().numpy()[mask]) and np.array_equal(own[mask], tags2.cpu().numpy()[mask])
@@ -85,7 +88,10 @@ def run(n=60, seed=0, verbose=True, only=None):
                 it, S, R, farnn, crf, C, B, L, h.kernel_name(_lib.KERN_CHAIN), err, 'ok' if ok else 'MISMATCH', note), flush=True)
         h.close()
     if sensitive:
-        print('({} locally chaotic geometries held to their own float32 noise)'.format(sensitive))
+        print('({} of {} geometries beyond the 1e-4 bar but within twice the float32 oracle\'s own distance from float64: listed above)'.format(sensitive, n))
+    if sensitive > max(2, n // 200):
+        print('too many of them: counted as a failure')
+        bad += 1
     return bad
 
 

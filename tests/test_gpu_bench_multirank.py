@@ -69,7 +69,7 @@ def test_bench_default_line_carries_every_single_gpu_config():
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5',
-                        '--cpu-seconds', '2'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+                        '--cpu-seconds', '2'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
     rf = d['roofline']
@@ -83,12 +83,12 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert d['parity']['tags_equal'] is True
     assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
     names = [o['workload'] for o in d['other_configs']]
-    assert names == ['ifst_crf', 'ifst_crf_two_launches', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2',
-                     'decomp_r250_farnn2_crf', 'decomp_r250_farnn2_crf_bz200_len30', 'decomp_r150_farnn2_crf_s134_bz200_len30', 'fst4']
+    assert names == ['ifst_crf', 'ifst_crf_one_launch', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2',
+                     'decomp_r250_farnn2_crf', 'decomp_r250_farnn2_crf_bz200_len30', 'decomp_r150_farnn2_crf_s134_bz200_len30', 'fst4', 'synth512_shard_b1024_len128']
     kern = {o['workload']: o['roofline']['kernel'] for o in d['other_configs']}
     assert 'chain_wide_kernel<fused' in kern['ifst_s104']                # the reference's 104-state automata: the wide form, ONE launch
-    assert 'chain_viterbi_kernel' in kern['ifst_crf']                    # config 4: ONE launch by default ...
-    assert 'chain_viterbi_kernel' not in kern['ifst_crf_two_launches']   # ... its two-launch form beside it (FARNN_NOFUSE for that run only)
+    assert 'chain_viterbi_kernel' not in kern['ifst_crf']                # config 4: the faster form is the default (two launches, round 5) ...
+    assert 'chain_viterbi_kernel' in kern['ifst_crf_one_launch']         # ... the one-launch form beside it (FARNN_CV_ONE for that run only)
     for o in d['other_configs']:
         assert 'error' not in o, o
         assert o['value'] > 0 and o['parity']['tags_equal'] is True, o

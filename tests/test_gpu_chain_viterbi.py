@@ -61,9 +61,9 @@ def _one(rng):
     mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
     what = 'S={} C={} L={} B={} nl={} {} full={}'.format(S, C, L, B, nl, semiring, full)
     names = {}
-    # (72 < S <= 108: the one-launch form is not the default there -- it is slower than two launches, DESIGN.md K1v -- but stays
-    #  selectable and is held to the same results)
-    for env in ({'FARNN_CV_WIDE': '1'} if S > 72 else {}, {'FARNN_CV_STASH': '1', 'FARNN_CV_WIDE': '1'}, {'FARNN_NOFUSE': '1'}):
+    # (round 5: the one-launch form is nowhere the default -- it is slower than two launches, DESIGN.md K1v -- but stays selectable,
+    #  FARNN_CV_ONE=1, and is held to the same results; `default` below = that form, `plain` = what the library picks by itself)
+    for env in ({'FARNN_CV_ONE': '1'}, {'FARNN_CV_STASH': '1', 'FARNN_CV_ONE': '1'}, {'FARNN_NOFUSE': '1'}, {}):
         os.environ.update(env)
         try:
             h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, semiring=semiring, use_crf=True, crf_trans=tr)
@@ -72,7 +72,7 @@ def _one(rng):
         finally:
             for k in env:
                 del os.environ[k]
-        key = 'FARNN_NOFUSE' if 'FARNN_NOFUSE' in env else ('FARNN_CV_STASH' if 'FARNN_CV_STASH' in env else 'default')
+        key = 'FARNN_NOFUSE' if 'FARNN_NOFUSE' in env else ('FARNN_CV_STASH' if 'FARNN_CV_STASH' in env else ('default' if env else 'plain'))
         names[key] = name
         assert np.array_equal(tg[mask].astype(np.int64), want[mask]), (what, key, name)
         assert (tg[~mask] == -1).all(), (what, key, name)
@@ -84,7 +84,7 @@ def _one(rng):
         assert 'chain_viterbi' not in names['default'], (what, names)
     if one_launch:
         assert 'chain_viterbi_kernel' in names['default'], (what, names)
-    assert 'chain_viterbi' not in names['FARNN_NOFUSE'], (what, names)
+    assert 'chain_viterbi' not in names['FARNN_NOFUSE'] and 'chain_viterbi' not in names['plain'], (what, names)
     return what + ' [' + names['default'] + ']'
 
 
@@ -101,9 +101,10 @@ def test_chain_viterbi_random_shapes_vs_oracle():
     assert fused * 3 >= n                                  # a good share of the draws really took the one-launch form
 
 
-def test_chain_viterbi_under_graph_capture():
-    """No epoch, no progress words: the one-launch CRF step replays from a HIP graph (the arg-max form is two launches there)."""
+def test_chain_viterbi_under_graph_capture(monkeypatch):
+    """No epoch, no progress words: the one-launch CRF step (FARNN_CV_ONE=1) replays from a HIP graph."""
     from re2nn_seq_amd import _lib, synth
+    monkeypatch.setenv('FARNN_CV_ONE', '1')              # (switches are read when the handle is created)
     rng = np.random.RandomState(5)
     V, S, C, B, L = 200, 71, 128, 64, 48
     K = C + 2

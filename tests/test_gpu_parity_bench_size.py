@@ -16,6 +16,7 @@ import pytest
 import torch
 
 from oracle import farnn_oracle as fo
+from util import assert_float_path, in_float64
 
 pytestmark = pytest.mark.gpu
 
@@ -262,10 +263,14 @@ def test_decomposed_ifst_at_bench_size_vs_reference(k):
         assert np.array_equal(fl, fl2)                # fused kernel == score kernel + Viterbi
 
 
-def test_onehot_ifst_crf_at_bench_size_vs_reference():
+@pytest.mark.parametrize('one_launch', [False, True])
+def test_onehot_ifst_crf_at_bench_size_vs_reference(one_launch, monkeypatch):
     """BASELINE configs[3]: FARNN_S_O_I_S.forward_score -> START / STOP columns -> clamp -> CRF._viterbi_decode (crf.py:102-195)
-    as the reference computed it at K = 130, B = 256: every decoded tag equal (integer scores: bit-identical paths)."""
+    as the reference computed it at K = 130, B = 256: every decoded tag equal (integer scores: bit-identical paths) -- in the
+    default form (recurrence kernel + score / Viterbi kernel: the faster one, round 5) and in the one-launch form (FARNN_CV_ONE=1)."""
     from re2nn_seq_amd import _lib, synth
+    if one_launch:
+        monkeypatch.setenv('FARNN_CV_ONE', '1')          # (switches are read when the handle is created)
     g = np.load(os.path.join(GOLDEN, 'bench_crf.npz'))
     V, S, C, K, B, L = (int(v) for v in g['dims'])
     T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C)
@@ -273,14 +278,14 @@ def test_onehot_ifst_crf_at_bench_size_vs_reference():
     h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=True, crf_trans=tr)
     xd, ld = _t(x).cuda(), _t(lengths).cuda()
     flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
-    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), None)          # one launch
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), None)          # the call the tagging loop makes
     name = h.kernel_name(_lib.KERN_CHAIN)
     scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
     flat_u = torch.empty_like(flat)
     h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat_u.data_ptr(), scores.data_ptr())
     torch.cuda.synchronize()
     h.close()
-    assert 'chain_viterbi' in name
+    assert ('chain_viterbi' in name) == one_launch, name
     want = g['flat_pred'].astype(np.int64)
     assert np.array_equal(flat.cpu().numpy(), want)
     assert np.array_equal(flat_u.cpu().numpy(), want)
@@ -338,6 +343,7 @@ def test_gated_rows_forms_with_four_and_eight_lanes_per_row_agree(R, S, monkeypa
     xd, ld = _t(x).cuda(), _t(lengths).cuda()
     K = q['Cout'].shape[0]
     ref = fo.decomp_ifst_scores(q, x, lengths)
+    ref64 = in_float64(fo.decomp_ifst_scores, q, x, lengths)
     mask = np.arange(L)[None, :] < lengths[:, None]
     out = {}
     for sw in ('0', '1', '2'):
@@ -351,11 +357,11 @@ def test_gated_rows_forms_with_four_and_eight_lanes_per_row_agree(R, S, monkeypa
         assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
         got = scores.cpu().numpy()
         assert np.isfinite(got).all()
-        np.testing.assert_allclose(got[mask], ref[mask], rtol=2e-4, atol=2e-4)
+        assert_float_path(got[mask], ref[mask], ref64[mask], err_msg='FARNN_ROWS_LPR4=' + sw)      # util.assert_float_path: the ONE 1e-4 rule
         out[sw] = (got, tags.cpu().numpy())
         h.close()
     for sw in ('1', '2'):
-        np.testing.assert_allclose(out[sw][0][mask], out['0'][0][mask], rtol=2e-4, atol=2e-4)
+        # (the forms against each other: each within 1e-4 of the exact value, so within 2e-4 of one another -- no bar of its own)
         # tags: equal wherever the two leading scores of the reference are further apart than the forms' float noise
         srt = np.sort(ref, axis=-1)
         clear = mask & ((srt[..., -1] - srt[..., -2]) > 1e-3) & (np.abs(srt[..., -1] - 0.5) > 1e-3)

@@ -774,3 +774,39 @@ def test_local_scores_zero_rows_at_pads_and_mode_re_clamp(C, use_p):
     assert np.array_equal(s_re, want)
     assert_scores(s_full[mask], ref[mask], exact=True)
     h.close()
+
+
+@pytest.mark.parametrize('env', [{}, {'FARNN_CV_ONE': '1'}, {'FARNN_NOLABELMAP': '1'}])
+def test_crf_clamp_column_without_any_state_and_a_negative_threshold(env, monkeypatch):
+    """model_decompose.py:353 clamps column K - 3 of the emissions whatever feeds it: with no state labelled `oo` and a threshold
+    below zero the column is min(0, threshold) at every position, not the 0 of a column nothing scores.  (Round-4 advisor: the
+    label-map emission rows wrote 0 there; the matrix form wrote the threshold.)  Both forms, every CRF kernel, against the
+    oracle's decode."""
+    from re2nn_seq_amd import _lib, synth
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.RandomState(123)
+    V, S, C, B, L = 40, 37, 33, 19, 21
+    K = C + 2
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    O[C - 1, :] = 0                                      # no state carries the `oo` label
+    tr = (rng.randn(K, K) * 0.3).astype(np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    tr[:, K - 3] += 0.8                                  # make the empty column attractive: a wrong 0 there changes paths
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+    thr = -0.75
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT, threshold=thr, o_idx=2, use_crf=True, crf_trans=tr)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    tags2 = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, None)
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags2.data_ptr(), None, scores.data_ptr())
+    torch.cuda.synchronize()
+    ext = fo.onehot_crf_extension_scores(fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths))
+    want = fo.decode_crf(ext, lengths, tr, thr, 2)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    assert np.array_equal(tags.cpu().numpy().astype(np.int64)[mask], want[mask]), h.kernel_name(_lib.KERN_CHAIN)
+    assert np.array_equal(tags2.cpu().numpy().astype(np.int64)[mask], want[mask])
+    h.close()

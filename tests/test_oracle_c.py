@@ -41,3 +41,19 @@ def test_c_port_atis_scale():
     tags, _, used = c_port.onehot_ifst_tag(T + W, O, h0, hT, x, l)
     assert used >= 1
     assert np.array_equal(fo.flatten(tags, l).astype(np.int64), g['flat_pred'].astype(np.int64))
+
+
+@pytest.mark.parametrize('reps,nthreads', [(1, 1), (3, 4), (5, 8)])
+def test_c_port_throughput_form_gives_the_same_tags_and_scores(reps, nthreads):
+    """bench.py's cpu_baseline on all host cores (round 5): the barrier-free form -- reps x B whole sequences dealt to the
+    threads -- against the reference's own ATIS-scale outputs and bit-equal to the two-phase form."""
+    from re2nn_seq_amd import synth
+    g = load_golden('atis_ifst')
+    V, S, C, B, L = [int(v) for v in g['dims']]
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, np.random.RandomState(int(g['seed'])))
+    x = g['x'].astype(np.int64); l = g['lengths'].astype(np.int64)
+    tags, scores, used = c_port.onehot_ifst_tag(T + W, O, h0, hT, x, l, want_scores=True, nthreads=nthreads, reps=reps, stream=True)
+    assert used == nthreads
+    assert np.array_equal(fo.flatten(tags, l).astype(np.int64), g['flat_pred'].astype(np.int64))
+    t2, s2, _ = c_port.onehot_ifst_tag(T + W, O, h0, hT, x, l, want_scores=True, nthreads=2)
+    assert np.array_equal(tags, t2) and np.array_equal(scores, s2)

@@ -29,3 +29,28 @@ def assert_scores(sc, ref, exact):
         assert np.array_equal(sc, ref), 'max abs diff {}'.format(np.abs(sc - ref).max())
     else:
         np.testing.assert_allclose(sc, ref, rtol=1e-4, atol=1e-4)
+
+
+def in_float64(fn, params, *args, **kw):
+    """`fn(params, ...)` of the oracle evaluated in float64 (fo.precision): every float array of `params` widened first."""
+    from oracle import farnn_oracle as fo
+    wide = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v) for k, v in params.items()}
+    kw = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) and v.dtype.kind == 'f' else v) for k, v in kw.items()}
+    with fo.precision(np.float64):
+        return fn(wide, *args, **kw)
+
+
+def assert_float_path(got, ref32, ref64, tol=1e-4, err_msg=''):
+    """ONE rule for a floating-point kernel (north_star: "within 1e-4"): within `tol` (absolute + relative) of the EXACT value
+    -- the oracle evaluated in float64 -- and never farther from the float32 oracle than `tol` plus that oracle's own distance
+    from the exact value at the same entry (two float32 evaluations of a sensitive recurrence scatter around the exact value;
+    neither is the other's yardstick beyond its own noise).  No per-shape bars."""
+    got, ref32, ref64 = np.asarray(got, np.float64), np.asarray(ref32, np.float64), np.asarray(ref64, np.float64)
+    e64 = np.abs(got - ref64)
+    bad = e64 > tol * (1.0 + np.abs(ref64))
+    assert not bad.any(), '{} {} of {} entries beyond {} of the float64 value; worst {:.3e}'.format(
+        err_msg, int(bad.sum()), bad.size, tol, float((e64 / (1.0 + np.abs(ref64))).max()))
+    e32 = np.abs(got - ref32)
+    bad = e32 > tol * (1.0 + np.abs(ref32)) + np.abs(ref32 - ref64)
+    assert not bad.any(), '{} {} of {} entries beyond {} + the float32 oracle\'s own error; worst {:.3e}'.format(
+        err_msg, int(bad.sum()), bad.size, tol, float(e32.max()))
