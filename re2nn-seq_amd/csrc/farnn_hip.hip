@@ -86,6 +86,7 @@ struct farnn_model {
     size_t hs_bytes = 0;
     unsigned epoch_u = 0;                   // diagnostic FARNN_HOST_EPOCH=1: the round-3 host-side epoch
     bool last_regs = false;                 // the last recurrence ran on chain_regs_kernel
+    bool last_lm_score = false;             // the last stand-alone score launch was label_map_score_kernel (K2l)
     int chain_ks = 3;
     bool prep_in_kernel = false, sort_in_kernel = false;
     bool dense_decomp = false;              // decomposed model served by dense per-word blocks + chain_kernel
@@ -527,7 +528,7 @@ extern "C" const char *farnn_kernel_name(const farnn_model *m, int32_t which) {
                               : (m->kind == KIND_IND1 ? "ind1_score_kernel"
                               : (m->kind == KIND_DECOMP1 ? (m->d1_BSSp ? "decomp1_br_mfma_kernel+decomp1_label_kernel" : "decomp1_score_kernel")
                               : (m->kind == KIND_DECOMP0 ? "decomp0_score_kernel"
-                              : (m->use_crf ? "score_tile_kernel+viterbi_kernel" : "score_tile_kernel"))));
+                              : (m->use_crf ? "score_tile_kernel+viterbi_kernel" : (m->last_lm_score ? "label_map_score_kernel" : "score_tile_kernel")))));
         case KERN_PREP:  return "batch_prep_kernel";
         default: return "";
     }
@@ -575,6 +576,21 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
+        // Round 5: which form is the faster one is a matter of the batch, and the faster one is the default.  S <= 72 with a
+        // label-map output matrix (tags only): once the launch has more workgroups than the chip has compute units (2 B > CUs)
+        // the recurrence-only kernel followed by the label-map score launch (K2l) wins -- 256 x 64: 30.8 us against 32.3,
+        // 1 024 x 64: 104.9 against 146.2 (every compute unit works through chains only, the tags of ALL sequences are scored in
+        // parallel afterwards instead of behind each chain) -- below that the one launch does (64 x 64: 26.4 against 28.4).
+        // FARNN_FUSE=1 keeps the one launch (north_star's form; what a graph replays as one node) for any batch.
+        if (score && !rg.wide && bs_label_map_path(*fuse_sp) && !tun(TUN_FUSE)) {
+            if (m->n_cu <= 0) {
+                int dev = 0, ncu = 0;
+                FARNN_HIP_TRY(hipGetDevice(&dev));
+                FARNN_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+                m->n_cu = ncu > 0 ? ncu : 256;
+            }
+            if (2 * B > m->n_cu) score = false;
+        }
         const bool lm_path = score && bs_label_map_path(*fuse_sp);
         const bool dest = !rg.wide && m->semiring != FARNN_SEMIRING_MAX && !tun(TUN_NODEST);
         size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ, lm_path, dest).total * sizeof(float);
@@ -940,9 +956,19 @@ static int launch_score_decode(farnn_model *m, const int64_t *len, int B, int fu
         KernelTimer kt(m, KERN_SCORE, s);
         return launch_viterbi(m, p, B, s, true);
     }
+    int rc;
+    if (p.lm.on && !p.P && !scores && !m->use_crf && m->S <= LM_MAXS * 2 && (B <= 1024 || !flat || p.offs)) {
+        // K2l: the output matrix is a label map and only tags are asked for -- S multiply-adds and a scan per token, one workgroup
+        // per sequence (score_decode.hip.h).  FARNN_NOLABELMAP=1 (no label map is built then) keeps the matrix form.
+        KernelTimer kt(m, KERN_SCORE, s);
+        label_map_score_kernel<<<B, LMS_WAVES * 64, 0, s>>>(p);
+        FARNN_HIP_TRY(hipGetLastError());
+        m->last_lm_score = true;
+        return FARNN_OK;
+    }
+    m->last_lm_score = false;
     const size_t lds = score_lds_bytes(m->S, m->Kc);
     const dim3 grid((p.L + SCORE_TT - 1) / SCORE_TT, B), block(SCORE_WAVES * 64);
-    int rc;
     KernelTimer kt(m, KERN_SCORE, s);
 #define FARNN_LAUNCH_SCORE(KCH_)                                                              \
     do {                                                                                      \

@@ -30,7 +30,7 @@ inline int env_int(const char *name, int dflt) {
 // profiling build only (build.py --probes, -DFARNN_PROBES) -- the production library ignores them.
 #define FARNN_TUNABLES(X)                                                                                      \
     /* supported */                                                                                            \
-    X(NOFUSE, 0, true) X(NOREGS, 0, true) X(NOLABELMAP, 0, true) X(PREP, 0, true) X(NOSORT, 0, true)           \
+    X(NOFUSE, 0, true) X(FUSE, 0, true) X(NOREGS, 0, true) X(NOLABELMAP, 0, true) X(PREP, 0, true) X(NOSORT, 0, true)           \
     X(VITERBI_BP, 0, true) X(VITERBI_UNFUSED, 0, true) X(CV_STASH, 0, true) X(DECOMP_NOREGS, 0, true)          \
     X(ROWS_NOREGS, 0, true) X(TRAIN_NOLDS, 0, true) X(TRAIN_NSEQ, 0, true)              \
     X(CV_ONE, 0, true) X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true) X(NODEST, 0, true)                       \

@@ -555,4 +555,71 @@ batch_prep_small_kernel(const int64_t *len, int64_t *offs, int *order, int B, in
     }
 }
 
+// ---- K2l: the stand-alone score + decode launch when the output matrix is a LABEL MAP (label_map.hip.h) and only tags are asked
+// for (round 5).  score_tile_kernel stages products, runs [32 x S].[S x K] on the matrix cores and decodes K columns per token:
+// 10 us for the headline batch.  A label map needs S multiply-adds and one segmented scan per token: one workgroup per sequence,
+// wavefront w takes the token pairs w, w + LMS_WAVES, ...; both state rows come straight from the stash (L2-resident: the
+// recurrence kernel has just written it), the next pair's entries are in flight while the current one is scanned.  No LDS but the
+// flat offset, no barrier but the one behind it.  Reference: model_onehot.py:411-426 (scores), :162-180 (decode).
+constexpr int LMS_WAVES = 8;
+
+__global__ void __launch_bounds__(LMS_WAVES * 64)
+label_map_score_kernel(const ScoreParams p) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int L = p.L, SP = p.SP;
+    const int len = clamp_len(p.len[b], L);
+    const int nsteps = p.full ? L : len;
+    __shared__ int foff_s;
+    if (w == 0) {                                          // the sequence's flat offset (utils.py:153-164)
+        int partsum = 0;
+        if (p.flat) {
+            if (p.offs) partsum = lane == 0 ? (int)p.offs[b] : 0;
+            else for (int j = lane; j < b; j += WAVE) partsum += clamp_len(p.len[j], L);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) partsum += __shfl_xor(partsum, off, WAVE);
+        if (lane == 0) foff_s = partsum;
+    } else if (w == 1 && p.tags) {                         // pad positions of LOCAL mode: tag -1
+        for (int i = nsteps + lane; i < L; i += WAVE) p.tags[(long long)b * L + i] = -1;
+    }
+    LabelMapRegs lr;
+    lm_load(p.lm, lane, lr);
+    const bool two = p.lm.nq > 1;
+    const float *A = p.A + (long long)b * (L + 1) * SP, *Bk = p.Bk + (long long)b * (L + 1) * SP;
+    auto rowB = [&](int i) { return (i + 1 <= len) ? len - (i + 1) : i + 1; };    // beta of token i (pads of FULL mode: row i + 1)
+    // this wavefront's first pair's entries
+    float fa0 = 0.f, fa1 = 0.f, ba0 = 0.f, ba1 = 0.f, fb0 = 0.f, fb1 = 0.f, bb0 = 0.f, bb1 = 0.f;
+    auto fetch = [&](int q) {
+        const int ia = q, ib = q + 1 < nsteps ? q + 1 : q;
+        const float *fa = A + (long long)(ia + 1) * SP, *fb = A + (long long)(ib + 1) * SP;
+        const float *ba = Bk + (long long)rowB(ia) * SP, *bb = Bk + (long long)rowB(ib) * SP;
+        fa0 = fa[lr.st0]; ba0 = ba[lr.st0]; fb0 = fb[lr.st0]; bb0 = bb[lr.st0];
+        if (two) { fa1 = fa[lr.st1]; ba1 = ba[lr.st1]; fb1 = fb[lr.st1]; bb1 = bb[lr.st1]; }
+    };
+    int q = 2 * w;
+    if (q < nsteps) fetch(q);
+    __syncthreads();
+    const long long foff = foff_s;
+    for (; q < nsteps; q += 2 * LMS_WAVES) {
+        const bool hasb = q + 1 < nsteps;
+        const int ia = q, ib = hasb ? q + 1 : q;
+        const float xa0 = fa0 * ba0, xa1 = two ? fa1 * ba1 : 0.0f, xb0 = fb0 * bb0, xb1 = two ? fb1 * bb1 : 0.0f;
+        if (q + 2 * LMS_WAVES < nsteps) fetch(q + 2 * LMS_WAVES);              // the next pair's entries, under this pair's scan
+        float ya0, ya1, yb0, yb1;
+        lm_scan_scores2(lr, xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1);
+        float ma = fmaxf(ya0, ya1), mb = fmaxf(yb0, yb1);
+        wave_max_dpp2(ma, mb);
+        const int taga = lm_tag_from_candidates(p.lm, lr, ya0, ya1, ma, p.K, p.o_idx);
+        const int tagb = lm_tag_from_candidates(p.lm, lr, yb0, yb1, mb, p.K, p.o_idx);
+        if (lane < (hasb ? 2 : 1)) {
+            const int i = lane ? ib : ia;
+            const int tag = lane ? tagb : taga;
+            if (p.tags) p.tags[(long long)b * L + i] = tag;
+            if (p.flat && i < len) p.flat[foff + i] = tag;
+        }
+    }
+}
+
 }  // namespace farnn

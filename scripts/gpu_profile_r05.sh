@@ -11,14 +11,19 @@ Q="--no-cpu-baseline --no-other-configs"
 T="timeout 300"
 $T python bench.py --steps 20 --warmup 5 2>/dev/null > $O/bench_default_driver_form.json
 $T python bench.py 2>/dev/null > $O/bench_ifst.json
+FARNN_FUSE=1 $T python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $O/bench_ifst_one_launch_driver_form.json
+FARNN_FUSE=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_one_launch.json
+FARNN_FUSE=1 FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_one_launch_source_split_r04.json
 FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_source_split_r04.json
-FARNN_NOFUSE=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_two_kernels.json
-FARNN_NOFUSE=1 FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_two_kernels_source_split_r04.json
+FARNN_NOLABELMAP=1 FARNN_NOFUSE=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_two_kernels_matrix_core_scores_r04.json
 $T python bench.py --batches 1 $Q 2>/dev/null > $O/bench_ifst_one_batch_replayed.json
 $T python bench.py --graph 10 $Q 2>/dev/null > $O/bench_ifst_graph_replay.json
 $T python bench.py --full-length $Q 2>/dev/null > $O/bench_ifst_full.json
-FARNN_NODEST=1 $T python bench.py --full-length $Q 2>/dev/null > $O/bench_ifst_full_source_split_r04.json
+FARNN_FUSE=1 $T python bench.py --full-length $Q 2>/dev/null > $O/bench_ifst_full_one_launch.json
 $T python bench.py --batch 1024 $Q 2>/dev/null > $O/bench_ifst_b1024.json
+FARNN_FUSE=1 $T python bench.py --batch 1024 $Q 2>/dev/null > $O/bench_ifst_b1024_one_launch.json
+$T python bench.py --batch 64 $Q 2>/dev/null > $O/bench_ifst_b64.json
+FARNN_NOFUSE=1 $T python bench.py --batch 64 $Q 2>/dev/null > $O/bench_ifst_b64_two_kernels.json
 $T python bench.py --workload ifst --states 104 $Q 2>/dev/null > $O/bench_ifst_s104.json
 $T python bench.py --workload ifst --states 128 $Q 2>/dev/null > $O/bench_ifst_s128.json
 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf.json
@@ -41,7 +46,7 @@ $T python bench.py --workload train --rank 250 --farnn 2 --no-cpu-baseline --ste
 $T python scripts/host_inclusive_rate.py 2>/dev/null | grep host-inclusive > $O/host_inclusive.txt
 R="--no-cpu-baseline --no-other-configs --no-pipelined --no-parity --event-stride 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 bench.py --steps 200 --warmup 20 $R > $O/trace.log 2>&1
-FARNN_NOFUSE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_two -- python3 bench.py --steps 200 --warmup 20 $R > $O/trace_two.log 2>&1
+FARNN_FUSE=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_two -- python3 bench.py --steps 200 --warmup 20 $R > $O/trace_two.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_s104 -- python3 bench.py --workload ifst --states 104 --steps 200 --warmup 20 $R > $O/trace_s104.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_crf -- python3 bench.py --workload ifst_crf --steps 100 --warmup 10 $R > $O/trace_crf.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_decomp -- python3 bench.py --workload decomp --steps 100 --warmup 10 $R > $O/trace_decomp.log 2>&1
@@ -51,6 +56,9 @@ P="--steps 20 --warmup 5 $R"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 bench.py $P > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 bench.py $P > $O/pmc_write.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2 -- python3 bench.py $P > $O/pmc_l2.log 2>&1
+FARNN_FUSE=1 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_onelaunch -- python3 bench.py $P > $O/pmc_fetch_onelaunch.log 2>&1
+FARNN_FUSE=1 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_onelaunch -- python3 bench.py $P > $O/pmc_write_onelaunch.log 2>&1
+FARNN_FUSE=1 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2_onelaunch -- python3 bench.py $P > $O/pmc_l2_onelaunch.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_s104 -- python3 bench.py --workload ifst --states 104 $P > $O/pmc_fetch_s104.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_s104 -- python3 bench.py --workload ifst --states 104 $P > $O/pmc_write_s104.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/pmc_l2_s104 -- python3 bench.py --workload ifst --states 104 $P > $O/pmc_l2_s104.log 2>&1
@@ -60,25 +68,27 @@ i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifst -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifst.log 2>&1
-  FARNN_NODEST=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstsourcesplit -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstsourcesplit.log 2>&1
+  FARNN_FUSE=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstonelaunch -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstonelaunch.log 2>&1
+  FARNN_FUSE=1 FARNN_NODEST=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstonelaunchsourcesplit -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstonelaunchsourcesplit.log 2>&1
 done
 # in-kernel probes (profiling build)
 export FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so
 Z="--steps 3 --warmup 2 --no-cpu-baseline --no-pipelined --no-other-configs --no-parity"
-timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_timeline.txt
-FARNN_DBG=1024 timeout 120 python bench.py $Z 2>/dev/null | grep "^finish\|^meet" | sort | tail -24 > $O/probe_finish_phases.txt
+FARNN_FUSE=1 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_one_launch_timeline.txt
+FARNN_FUSE=1 FARNN_DBG=1024 timeout 120 python bench.py $Z 2>/dev/null | grep "^finish\|^meet" | sort | tail -24 > $O/probe_finish_phases_one_launch.txt
 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases.txt
+FARNN_FUSE=1 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_one_launch.txt
 FARNN_DBG=256 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
-FARNN_NOFUSE=1 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_recurrence_only_timeline.txt
+timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_timeline.txt
 FARNN_DBG=4096 timeout 120 python bench.py $Z 2>/dev/null | grep "^compact tag" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -12 > $O/probe_compact_tag.txt
 FARNN_DBG=8192 timeout 120 python bench.py $Z 2>/dev/null | grep "^compact tag" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -8 > $O/probe_compact_tag_step_phases.txt
 FARNN_DBG=8192 FARNN_CV_ONE=1 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_recurrence_then_viterbi_phases.txt
-FARNN_DBG=2048 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch.txt
-FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_source_split_r04.txt
-FARNN_DBG=2048 FARNN_NOFUSE=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only.txt
-FARNN_DBG=2048 FARNN_NOFUSE=1 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only_source_split_r04.txt
-FARNN_DBG=2048 timeout 100 python scripts/debug/wg_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_full_length.txt
+FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch.txt
+FARNN_DBG=2048 FARNN_FUSE=1 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_source_split_r04.txt
+FARNN_DBG=2048 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only.txt
+FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only_source_split_r04.txt
+FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_full_length.txt
 unset FARNN_LIB
 timeout 60 scripts/probe/fastmath_ulp.bin > $O/fastmath_ulp.txt 2>&1
 # keep only the small summaries (kernel_stats + counter collection), drop per-dispatch traces > 4 MB

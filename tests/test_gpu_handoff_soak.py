@@ -50,7 +50,11 @@ def _soak(B, L, launches, seed, full, S=71):
     rng = np.random.RandomState(seed)
     V, C = 950, 128
     T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng)
-    h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
+    os.environ['FARNN_FUSE'] = '1'                         # the one-launch form at every batch size (round 5: the default takes two
+    try:                                                   # launches once 2 B exceeds the compute units -- the hand-off is what is soaked here)
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=0)
+    finally:
+        del os.environ['FARNN_FUSE']
     mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
     nb = 6
     batches = []
