@@ -530,15 +530,17 @@ def batch_variants(name, x, lengths, rank_id, n=4):
 
 
 # ------------------------------------------------------------------------------------------ roofline
-def load_traffic(name, a):
+def load_traffic(name, a, kname=''):
     """Measured fabric-side bytes per launch of the dominant kernel (profiles/traffic.json, separate PMC passes),
-    valid only for the shape it was measured on."""
+    valid only for the shape -- and the form of the kernel: the one-launch step has an entry of its own -- it was measured on."""
     shape_ok = {'ifst': (256, 64), 'fst4': (256, 64), 'synth512': (1024, 128)}.get(name)
     if shape_ok != (a.batch, a.seqlen) or a.full_length:
         return None
     S = WORKLOADS[name][2]
     if S != BASE_STATES[name]:
         name = '{}_s{}'.format(name, S)              # a split measured at another state count has its own entry
+    elif name == 'ifst' and 'fused' in kname:
+        name = 'ifst_one_launch'
     tpath = os.path.join(ROOT, 'profiles', 'traffic.json')
     if not os.path.exists(tpath):
         return None
@@ -582,7 +584,7 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
     if byte_bound:
         alg = h.kernel_algorithmic_bytes(dom, tok_local)
         achieved = alg / dom_s / 1e9
-        traffic = load_traffic(name, a)
+        traffic = load_traffic(name, a, kname)
         SP = (S + 3) // 4 * 4
         ws = (2.0 * V * S * SP * 4) if 'chain' in kname else (1.0 * V * C * S * SP * 4)
         rf.update(achieved=achieved, unit='GB/s', traffic=traffic, algorithmic_bytes_per_launch=alg,

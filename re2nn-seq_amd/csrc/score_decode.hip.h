@@ -561,7 +561,7 @@ batch_prep_small_kernel(const int64_t *len, int64_t *offs, int *order, int B, in
 // wavefront w takes the token pairs w, w + LMS_WAVES, ...; both state rows come straight from the stash (L2-resident: the
 // recurrence kernel has just written it), the next pair's entries are in flight while the current one is scanned.  No LDS but the
 // flat offset, no barrier but the one behind it.  Reference: model_onehot.py:411-426 (scores), :162-180 (decode).
-constexpr int LMS_WAVES = 8;
+constexpr int LMS_WAVES = 16;
 
 __global__ void __launch_bounds__(LMS_WAVES * 64)
 label_map_score_kernel(const ScoreParams p) {

@@ -30,7 +30,7 @@ for f in glob.glob(os.path.join(src, '*.txt')):
         keep.append(ln)
     with open(os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))), 'w') as g:
         g.write('\n'.join(keep) + '\n')
-for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_two_kernels'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
+for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_one_launch'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
                   ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104'), ('trace_decomp_r250', 'decomp_r250_farnn2')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     if ks:
@@ -52,6 +52,8 @@ def agg(path):
 
 rows = []
 runs = [('pmc_fetch', 'ifst ragged U[5,64]'), ('pmc_write', 'ifst ragged U[5,64]'), ('pmc_l2', 'ifst ragged U[5,64]'),
+        ('pmc_fetch_onelaunch', 'ifst ragged U[5,64] one launch (FARNN_FUSE=1)'), ('pmc_write_onelaunch', 'ifst ragged U[5,64] one launch (FARNN_FUSE=1)'),
+        ('pmc_l2_onelaunch', 'ifst ragged U[5,64] one launch (FARNN_FUSE=1)'),
         ('pmc_fetch_full', 'ifst full-length'), ('pmc_fetch_synth512', 'synth512 B1024 L128'),
         ('pmc_fetch_fst4', 'fst4'), ('pmc_fetch_s104', 'ifst S=104 ragged U[5,64]'), ('pmc_write_s104', 'ifst S=104 ragged U[5,64]'),
         ('pmc_l2_s104', 'ifst S=104 ragged U[5,64]')]
@@ -79,6 +81,9 @@ note = ('(2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch from separate rocprofv3
 f_, w_ = pick('ifst ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
     traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel', 'source': note}
+f_, w_ = pick('ifst ragged U[5,64] one launch (FARNN_FUSE=1)', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64] one launch (FARNN_FUSE=1)', 'chain', 'WRITE_SIZE')
+if f_ is not None:
+    traffic['ifst_one_launch'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel<fused>', 'source': note}
 f_, w_ = pick('ifst S=104 ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst S=104 ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
     traffic['ifst_s104'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_wide_kernel', 'source': note}

@@ -19,6 +19,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import farnn_oracle as fo                    # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from util import NO_SWITCH                               # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -69,12 +71,13 @@ def _one(rng, it):
     mask = np.arange(L)[None, :] < lengths[:, None]
     live = np.ones_like(mask) if full else mask
     what = 'S={} C={} L={} B={} nl={} {} full={} P={} scores={} [{}]'.format(S, C, L, B, nl, semiring, full, use_P, want_scores, name)
-    assert name.startswith('chain_regs_kernel' if S <= 72 else 'chain_wide_kernel'), what      # the register-fed recurrence ...
     label_map = P is None and not want_scores              # (every generated output matrix is a label map)
-    if L <= 64 and C <= 128 and (S > 72 or not label_map or B <= 128):
-        assert 'fused' in name, what                       # ... in its one-launch form while states + score tiles fit half a CU's LDS
-    if S <= 72 and label_map and B > 128:
-        assert 'fused' not in name, what                   # (round 5: more workgroups than compute units -> recurrence + label-map score launch)
+    if NO_SWITCH:                                          # (which kernel ran: the default dispatch only; results: under every switch)
+        assert name.startswith('chain_regs_kernel' if S <= 72 else 'chain_wide_kernel'), what      # the register-fed recurrence ...
+        if L <= 64 and C <= 128 and (S > 72 or not label_map or B <= 128):
+            assert 'fused' in name, what                   # ... in its one-launch form while states + score tiles fit half a CU's LDS
+        if S <= 72 and label_map and B > 128:
+            assert 'fused' not in name, what               # (round 5: more workgroups than compute units -> recurrence + label-map score launch)
     tol = 0.0 if exact else 1e-4 * max(1.0, float(np.abs(ref).max()))
     if want_scores:
         got = scores.cpu().numpy()
@@ -106,4 +109,4 @@ def test_chain_regs_random_shapes_vs_oracle():
         fused += 'fused' in what
         seen.add(what.split(' [')[0].split(' nl=')[0])
     assert len(seen) >= min(n, 25)                         # the draw really covered many geometries
-    assert fused * 3 >= n                                  # and a good share of them in the one-launch form
+    assert not NO_SWITCH or fused * 3 >= n                 # and a good share of them in the one-launch form
