@@ -434,18 +434,28 @@ def cpu_baseline(extras, x, lengths, seconds):
             if el < 0.1 * budget:
                 chunk = min(chunk * 2, 1280)
 
-    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16, 8) if 1 <= c <= ncpu})
+    # what this process may actually use: the container's CPU-time quota (cgroup v2 cpu.max = "quota period"; the GPU boxes of this
+    # pool run every job under 16 cores' worth of a 256-thread host -- more threads than that only get throttled)
+    quota = None
+    try:
+        q_, p_ = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q_ != 'max':
+            quota = float(q_) / float(p_)
+    except (OSError, ValueError):
+        pass
+    cands = sorted({c for c in (ncpu, ncpu // 2, ncpu // 4, 64, 32, 16, 8, int(quota) if quota else 0) if 1 <= c <= ncpu})
     sweep = {c: rate(c, 0.5)[0] for c in cands}
     best = max(cands, key=lambda c: sweep[c])
     value, n, el = rate(best, seconds)
     two_phase = max(rate(c, 0.4, stream=False)[0] for c in sorted({c for c in (16, 32, 64) if c <= ncpu} or {ncpu}))
     # (the tags of both forms equal the numpy oracle's and the reference's: tests/test_oracle_c.py)
-    return {'value': value, 'unit': 'tokens/s', 'cores': int(best), 'host_threads': ncpu, 'kind': 'port',
+    return {'value': value, 'unit': 'tokens/s', 'cores': int(best), 'host_threads': ncpu, 'cpu_quota_cores': quota, 'kind': 'port',
             'rate_by_threads': {str(c): round(v) for c, v in sweep.items()}, 'two_phase_form_best': two_phase,
             'sample': '{} passes of the same {}x{} batch ({} valid tokens) in {:.1f} s; C port of the '
                       'oracle (T+W hoisted; OpenMP over passes x sequences, longest first, no barrier: one parallel region, each '
                       'thread walks both chains of a sequence and scores it), best of thread counts {} '
-                      'on a {}-thread host'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu)}
+                      'on a {}-thread host{}'.format(n, x.shape[0], x.shape[1], tok, el, cands, ncpu,
+                                                     ' whose container grants {:g} cores of CPU time (cgroup cpu.max)'.format(quota) if quota else '')}
 
 
 def cpu_baseline_faithful(extras, x, lengths, seconds):
