@@ -35,10 +35,88 @@
 
 namespace farnn {
 
+// What a compute wavefront carries from its priming (before the workgroup's set-up barrier) into the step loop
+template <int D, int LPR>
+struct DestRing {
+    static constexpr int NC = 20 / LPR;
+    v4f r[D][NC];                // the register ring: D steps x NC chunks
+    unsigned voff[NC];           // this lane's chunk offsets inside a block
+    int tkw_lo, tkw_hi;          // byte offsets of 64 steps' blocks (lane l: step window + l)
+};
+
+// this lane's place in the split: LPR lanes per output row (see regs_compute_dest)
+template <int LPR>
+__device__ __forceinline__ void dest_lane(const int lane, int &rj, int &rs, bool &has_row) {
+    if constexpr (LPR == 4) { rj = lane >> 2; rs = lane & 3; has_row = true; }
+    else { const int r16 = lane & 15, bq = r16 / 5; rs = r16 - 5 * bq; rj = 3 * (lane >> 4) + bq; has_row = bq < 3; }
+}
+
+#define FARNN_RD_ISSUE_(ring_, d, base_)                                                       \
+    do {                                                                                       \
+        const char *bp_ = (base_);                                                             \
+        if constexpr (NC == 5)                                                                 \
+            asm volatile("s_nop 4\n\t"                                                         \
+                         "global_load_dwordx4 %0, %5, %10\n\t"                                 \
+                         "global_load_dwordx4 %1, %6, %10\n\t"                                 \
+                         "global_load_dwordx4 %2, %7, %10\n\t"                                 \
+                         "global_load_dwordx4 %3, %8, %10\n\t"                                 \
+                         "global_load_dwordx4 %4, %9, %10"                                     \
+                         : "=&v"(ring_.r[d][0]), "=&v"(ring_.r[d][1]), "=&v"(ring_.r[d][2]), "=&v"(ring_.r[d][3]), "=&v"(ring_.r[d][NC - 1]) \
+                         : "v"(ring_.voff[0]), "v"(ring_.voff[1]), "v"(ring_.voff[2]), "v"(ring_.voff[3]), "v"(ring_.voff[NC - 1]), "s"(bp_)); \
+        else                                                                                   \
+            asm volatile("s_nop 4\n\t"                                                         \
+                         "global_load_dwordx4 %0, %4, %8\n\t"                                  \
+                         "global_load_dwordx4 %1, %5, %8\n\t"                                  \
+                         "global_load_dwordx4 %2, %6, %8\n\t"                                  \
+                         "global_load_dwordx4 %3, %7, %8"                                      \
+                         : "=&v"(ring_.r[d][0]), "=&v"(ring_.r[d][1]), "=&v"(ring_.r[d][2]), "=&v"(ring_.r[d][3]) \
+                         : "v"(ring_.voff[0]), "v"(ring_.voff[1]), "v"(ring_.voff[2]), "v"(ring_.voff[3]), "s"(bp_)); \
+    } while (0)
+
+// PRIMING, before the workgroup's set-up barrier (round 5, the review's "hide the set-up under the first block loads"): the block
+// offsets of the first 64 steps straight from the token ids in global memory (the set-up writes them to LDS for the later windows
+// and for nobody's first loads), and the first D steps' pieces requested -- an L2 / Infinity-Cache round trip at the launch's start,
+// when all 512 workgroups ask at once, that used to begin only behind the barrier.
+template <int D, int LPR>
+__device__ __forceinline__ void regs_dest_prime(const RegsParams &p, const int dir, const int w, const int lane, const int nsteps,
+                                                const int len, const int b, DestRing<D, LPR> &ring) {
+    constexpr int NC = DestRing<D, LPR>::NC;
+    const int S = p.S, SP = p.SP, CPR = p.CPR;
+    const int RW = (S + RG_NWC - 1) / RG_NWC;
+    int rj, rs;
+    bool has_row;
+    dest_lane<LPR>(lane, rj, rs, has_row);
+    const int my_row = w * RW + rj;
+    const bool my_valid = has_row && rj < RW && my_row < S;
+#pragma unroll
+    for (int i = 0; i < NC; i++) {
+        const int ci = rs + LPR * i;
+        // a chunk beyond the row (or a lane without a row) loads the lane's first chunk again -- the same line, no traffic;
+        // its state chunk is zeros
+        ring.voff[i] = ((unsigned)(my_valid ? my_row : 0) * (unsigned)SP + (unsigned)((my_valid && ci < CPR) ? ci : rs < CPR ? rs : 0) * 4u) * 4u;
+    }
+    {
+        const int t = lane < nsteps ? lane : nsteps - 1;
+        const int idx = (dir == 0) ? t : (t < len ? len - 1 - t : t);
+        const long long o_ = (long long)clamp_tok(p.x[(long long)b * p.L + idx], p.V) * p.blk * 4;
+        ring.tkw_lo = (int)(unsigned)o_; ring.tkw_hi = (int)(unsigned)(o_ >> 32);
+    }
+    const char *Mbase = reinterpret_cast<const char *>(dir == 0 ? p.Mb : p.Mf);      // rows = outputs
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int u = 0; u < NC; u++) ring.r[d][u] = v4f{0.f, 0.f, 0.f, 0.f};
+        if (d < nsteps) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane(ring.tkw_lo, d), hi = (unsigned)__builtin_amdgcn_readlane(ring.tkw_hi, d);
+            FARNN_RD_ISSUE_(ring, d, Mbase + (((long long)hi << 32) | lo));
+        }
+    }
+}
+
 template <bool NLX, int D, int LPR>
 __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int dir, const int w, const int lane_in, const int nsteps,
                                                   const long long *tokoff, float *flags, const float *ol, float *hist, float *xd,
-                                                  const bool probe, const int b) {
+                                                  const bool probe, const int b, DestRing<D, LPR> &ring) {
     static_assert(D == 2 || D == 4, "an even ring depth that divides 64 (the exchange row's parity and the address window)");
     static_assert(LPR == 4 || LPR == 5, "four or five lanes per output row");
     // LPR lanes per output row, NC chunks of the row per lane and step (LPR x NC = 20 chunks = RD_XS floats >= the padded row):
@@ -54,20 +132,12 @@ __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int
     const int RW = (S + RG_NWC - 1) / RG_NWC;            // outputs per wavefront (<= 12)
     int rj, rs;
     bool has_row;
-    if constexpr (LPR == 4) { rj = lane >> 2; rs = lane & 3; has_row = true; }
-    else { const int r16 = lane & 15, bq = r16 / 5; rs = r16 - 5 * bq; rj = 3 * (lane >> 4) + bq; has_row = bq < 3; }
+    dest_lane<LPR>(lane, rj, rs, has_row);
     const int my_row = w * RW + rj;
     const bool my_valid = has_row && rj < RW && my_row < S;
     const bool my_writer = my_valid && rs == (LPR == 4 ? 0 : 4);      // the lane the row's sum ends up in
     const bool is_flane = lane == 63;                    // (never a row's lane: RW <= 12 rows take lanes 0 .. 47 / the lanes != 15 mod 16)
-    unsigned voff[NC];
-#pragma unroll
-    for (int i = 0; i < NC; i++) {
-        const int ci = rs + LPR * i;
-        // a chunk beyond the row (or a lane without a row) loads the lane's first chunk again -- the same line, no traffic;
-        // its state chunk is zeros
-        voff[i] = ((unsigned)(my_valid ? my_row : 0) * (unsigned)SP + (unsigned)((my_valid && ci < CPR) ? ci : rs < CPR ? rs : 0) * 4u) * 4u;
-    }
+    (void)CPR;
     const char *Mbase = reinterpret_cast<const char *>(dir == 0 ? p.Mb : p.Mf);      // rows = outputs
     const float my_o = my_valid ? ol[my_row] : 1.0f;
     const float c_pre = dir == 0 ? my_o : 1.0f, c_post = dir == 0 ? 1.0f : my_o;     // (:377-386) / (:393-402)
@@ -84,7 +154,8 @@ __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int
     const bool nl_relu = nl_mode == FARNN_NL_RELU;
     const int *pflag = reinterpret_cast<const int *>(flags) + 4 * (lane < RG_NWC ? lane : 0);
 
-    v4f r[D][NC];
+    v4f (&r)[D][NC] = ring.r;
+    int &tkw_lo = ring.tkw_lo, &tkw_hi = ring.tkw_hi;
 #define FARNN_RD_WINDOW(t_)                                                                    \
     do {                                                                                       \
         const int ti_ = (t_) + lane;                                                           \
@@ -97,27 +168,7 @@ __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int
         lo_ = (unsigned)__builtin_amdgcn_readlane(tkw_lo, li_);                                \
         hi_ = (unsigned)__builtin_amdgcn_readlane(tkw_hi, li_);                                \
     } while (0)
-#define FARNN_RD_ISSUE(d, lo_, hi_)                                                            \
-    do {                                                                                       \
-        const char *bp_ = Mbase + (((long long)(hi_) << 32) | (lo_));                          \
-        if constexpr (NC == 5)                                                                 \
-            asm volatile("s_nop 4\n\t"                                                         \
-                         "global_load_dwordx4 %0, %5, %10\n\t"                                 \
-                         "global_load_dwordx4 %1, %6, %10\n\t"                                 \
-                         "global_load_dwordx4 %2, %7, %10\n\t"                                 \
-                         "global_load_dwordx4 %3, %8, %10\n\t"                                 \
-                         "global_load_dwordx4 %4, %9, %10"                                     \
-                         : "=&v"(r[d][0]), "=&v"(r[d][1]), "=&v"(r[d][2]), "=&v"(r[d][3]), "=&v"(r[d][NC - 1]) \
-                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[NC - 1]), "s"(bp_)); \
-        else                                                                                   \
-            asm volatile("s_nop 4\n\t"                                                         \
-                         "global_load_dwordx4 %0, %4, %8\n\t"                                  \
-                         "global_load_dwordx4 %1, %5, %8\n\t"                                  \
-                         "global_load_dwordx4 %2, %6, %8\n\t"                                  \
-                         "global_load_dwordx4 %3, %7, %8"                                      \
-                         : "=&v"(r[d][0]), "=&v"(r[d][1]), "=&v"(r[d][2]), "=&v"(r[d][3])     \
-                         : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(bp_)); \
-    } while (0)
+#define FARNN_RD_ISSUE(d, lo_, hi_) FARNN_RD_ISSUE_(ring, d, Mbase + (((long long)(hi_) << 32) | (lo_)))
     // ONE wait statement per step (chain_regs.hip.h says why): the D - 1 younger steps' pieces may stay outstanding, the last
     // D - 1 steps of a sequence drain
 #define FARNN_RD_WAITSTR                                                                       \
@@ -138,18 +189,7 @@ __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int
                          : [rem] "s"(rem_), [dm1] "n"(D - 1), [cnt] "n"((D - 1) * NC) : "scc"); \
     } while (0)
 
-    unsigned nlo = 0, nhi = 0;
-    int tkw_lo, tkw_hi;
-    FARNN_RD_WINDOW(0);
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-#pragma unroll
-        for (int u = 0; u < NC; u++) r[d][u] = v4f{0.f, 0.f, 0.f, 0.f};
-        if (d < nsteps) {
-            FARNN_RD_BASE(d, nlo, nhi);
-            FARNN_RD_ISSUE(d, nlo, nhi);
-        }
-    }
+    unsigned nlo = 0, nhi = 0;              // (the ring is primed: regs_dest_prime, before the set-up barrier)
 #if defined(FARNN_PROBES)
     long long ph[4] = {0, 0, 0, 0}, pt = 0;
 #define FARNN_RD_PHASE(i) do { if (probe && w == 0 && (p.dbg & 256)) { const long long n_ = (long long)__builtin_amdgcn_s_memtime(); ph[i] += n_ - pt; pt = n_; } } while (0)

@@ -144,9 +144,10 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     int b = p.order ? p.order[slot] : slot;
     // (a compute unit holds two workgroups of the narrow form: slots i and i + B/2 pair a long with a short sequence; it holds ONE
     //  of the wide form, and workgroups start in slot order as compute units fall free: longest first)
-    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, p.pair ? folded_rank(slot, p.B) : slot, reinterpret_cast<int *>(hist), tid, nthreads);
+    int len_sel = -1;
+    if (p.sort) b = select_by_length_rank(p.len, p.B, p.L, p.pair ? folded_rank(slot, p.B) : slot, reinterpret_cast<int *>(hist), tid, nthreads, &len_sel);
     if (b_out) *b_out = b;
-    const int len = clamp_len(p.len[b], p.L);
+    const int len = len_sel >= 0 ? len_sel : clamp_len(p.len[b], p.L);      // (the selection hands the length back: no len[b] load behind it)
     const int nsteps = p.full ? p.L : len;
     const float *hinit = dir == 0 ? p.h0 : p.hT;
 #if defined(FARNN_PROBES)
@@ -156,6 +157,12 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
     if (w == 0) FARNN_RG_STAMP(0);
 #endif
 
+    // (destination split: the compute wavefronts request their first blocks BEFORE the set-up -- chain_dest.hip.h, regs_dest_prime)
+    // (not in the instantiation that carries the matrix-core tile code: with the ring live across the set-up it spilled 20 VGPRs)
+    constexpr bool PRIME_EARLY = DEST && (!SCORE || LMO);
+    DestRing<RD_D, RD_LPR> dring;
+    if constexpr (PRIME_EARLY)
+        if (w < RG_NWC && nsteps > 0) regs_dest_prime<RD_D, RD_LPR>(p, dir, w, lane, nsteps, len, b, dring);
     // ---- set-up ----------------------------------------------------------------------------------------------------------
     for (int k = tid; k < nsteps; k += nthreads) {
         const int idx = (dir == 0) ? k : (k < len ? len - 1 - k : k);
@@ -220,7 +227,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
 #else
                 const bool probe_ = false;
 #endif
-                regs_compute_dest<NLX, RD_D, RD_LPR>(p, dir, w, lane, nsteps, tokoff, part + NP * PS, ol, hist, smem + lds.xd, probe_, b);
+                if constexpr (!PRIME_EARLY) regs_dest_prime<RD_D, RD_LPR>(p, dir, w, lane, nsteps, len, b, dring);
+                regs_compute_dest<NLX, RD_D, RD_LPR>(p, dir, w, lane, nsteps, tokoff, part + NP * PS, ol, hist, smem + lds.xd, probe_, b, dring);
                 __builtin_amdgcn_s_setprio(0);
                 if (w == 0) FARNN_RG_STAMP(2);
 #if defined(FARNN_PROBES)

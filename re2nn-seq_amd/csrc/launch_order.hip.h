@@ -20,7 +20,7 @@ __device__ __forceinline__ int folded_rank(int slot, int B) {
 // (counts = popcounts of ballots), a ballot per register finds the sequence inside it.  (The histogram form cost every
 // workgroup ~4.5 k cycles, 1.9 us of a 52 us full-length launch: FARNN_NOSORT A/B.)
 template <int NV>
-__device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, int B, int L, int rank, int lane) {
+__device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, int B, int L, int rank, int lane, int *len_out = nullptr) {
     int v[NV];
 #pragma unroll
     for (int i = 0; i < NV; i++) {
@@ -41,6 +41,7 @@ __device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, in
         if (count_ge(mid) > rank) lo = mid; else hi = mid - 1;
     }
     const int cls = lo;
+    if (len_out) *len_out = cls;                         // the selected sequence's (clamped) length: its class
     int rem = rank - count_ge(cls + 1);                  // index inside the class (sequences in index order: register-major, then lane)
     int res = 0;
     bool found = false;
@@ -57,19 +58,22 @@ __device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, in
     return res;
 }
 
+// len_out (optional): the selected sequence's clamped length comes back with it -- the class the search found -- so the caller
+// need not load len[b] behind the selection (a dependent global round trip at the launch's start, when every workgroup loads).
 __device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int rank, int *scratch,
-                                                     int tid, int /*nthreads*/) {
+                                                     int tid, int /*nthreads*/, int *len_out = nullptr) {
     if ((tid >> 6) == 0) {
         const int lane = tid & 63;
-        int res;
-        if (B <= 256) res = select_by_length_rank_wave<4>(len, B, L, rank, lane);
-        else if (B <= 512) res = select_by_length_rank_wave<8>(len, B, L, rank, lane);
-        else res = select_by_length_rank_wave<16>(len, B, L, rank, lane);       // B <= 1024
-        if (lane == 0) scratch[0] = res;
+        int res, cls = 0;
+        if (B <= 256) res = select_by_length_rank_wave<4>(len, B, L, rank, lane, &cls);
+        else if (B <= 512) res = select_by_length_rank_wave<8>(len, B, L, rank, lane, &cls);
+        else res = select_by_length_rank_wave<16>(len, B, L, rank, lane, &cls);       // B <= 1024
+        if (lane == 0) { scratch[0] = res; scratch[1] = cls; }
     }
     __syncthreads();
-    const int b = scratch[0];
+    const int b = scratch[0], l = scratch[1];
     __syncthreads();                     // the scratch is reused by the caller
+    if (len_out) *len_out = __builtin_amdgcn_readfirstlane(l);
     return __builtin_amdgcn_readfirstlane(b);
 }
 
