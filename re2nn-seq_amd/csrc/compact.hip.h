@@ -34,6 +34,9 @@ typedef unsigned long long u64;
 struct CompactParams {
     const u64 *bitsF, *bitsB;     // [V][S][NS]
     const u64 *wF, *wB;           // [S][NS]  bitmaps of W (sources of j / destinations of i)
+    const u64 *mF, *mB;           // [V][S][NS] T | W merged (compact_tag.hip.h; S <= 128), 4 KiB of slack behind the last block
+    const u64 *xF, *xB;           // [V][S][NS] T & W: the edges a word's block and the wildcard block share (almost always none)
+    const unsigned *tokoff;       // [V] byte offset of word v's merged block | 1 when its T & W plane is not empty
     const float *o;               // [SP] output-sum vector or nullptr
     const float *h0, *hT;         // [S]
     const int64_t *x, *len;
@@ -214,6 +217,22 @@ __global__ void edges_to_bits_kernel(const int32_t *word, const int32_t *from, c
     u64 *f = wd >= 0 ? bitsF + (long long)wd * S * NS : wF, *bk = wd >= 0 ? bitsB + (long long)wd * S * NS : wB;
     atomicOr(f + (long long)j * NS + (i >> 6), 1ull << (i & 63));
     atomicOr(bk + (long long)i * NS + (j >> 6), 1ull << (j & 63));
+}
+
+// K1t's form of the blocks: the wildcard bitmap merged into every word's block (one popcount per row word instead of two), the
+// shared edges -- entries 2 of T + W -- as a second plane, and the per-word table {block offset | second plane present}.
+// One thread per (word, row, 64-bit word of the row).
+__global__ void merge_planes_kernel(const u64 *bitsF, const u64 *bitsB, const u64 *wF, const u64 *wB, u64 *mF, u64 *mB, u64 *xF, u64 *xB,
+                                    unsigned *tokoff, int V, int S, int NS) {
+    const long long n = (long long)V * S * NS;
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int rw = (int)(e % ((long long)S * NS));               // (row, word) inside the block
+    const int v = (int)(e / ((long long)S * NS));
+    const u64 tf = bitsF[e], tb = bitsB[e], wf = wF[rw], wbk = wB[rw];
+    mF[e] = tf | wf; mB[e] = tb | wbk;
+    xF[e] = tf & wf; xB[e] = tb & wbk;
+    if ((tf & wf) | (tb & wbk)) atomicOr(tokoff + v, 1u);       // (tokoff[v] holds the offset already: set by the host)
 }
 
 inline int compact_ns(int S) { return S <= 64 ? 1 : S <= 128 ? 2 : S <= 256 ? 4 : S <= 512 ? 8 : 0; }   // 0: not built

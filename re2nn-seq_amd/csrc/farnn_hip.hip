@@ -55,6 +55,8 @@ struct farnn_model {
     float *Mf = nullptr, *Mb = nullptr;     // chain blocks [V][S][SP] (+ transposed)
     u64 *bmF = nullptr, *bmB = nullptr, *bmWF = nullptr, *bmWB = nullptr;   // compact form: bit-packed blocks (compact.hip.h)
     int bmNS = 0;                           // 64-bit words per bitmap row; 0: no compact form
+    u64 *bmMF = nullptr, *bmMB = nullptr, *bmXF = nullptr, *bmXB = nullptr;   // K1t's planes: T | W, T & W (merge_planes_kernel; S <= 128)
+    unsigned *bmTok = nullptr;              // [V] block offset | second-plane flag
     bool compact_on = false;                // farnn_set_compact: the recurrence walks the bitmaps instead of the dense blocks
     float *Ms = nullptr;                    // ind1: unmasked blocks for scoring
     float *A4 = nullptr;                    // fst4: [V][C][S][SP] premixed T4+W4
@@ -296,6 +298,24 @@ static int finish_bitmaps(farnn_model *m, int *bad_dev) {
     FARNN_HIP_TRY(hipMemcpy(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(bad_dev);
     if (bad) m->bmNS = 0;            // a weight other than 0 / 1: the dense blocks are the only form (the bitmaps stay unused)
+    if (m->bmNS >= 1 && m->bmNS <= 2 && (unsigned long long)m->V * m->S * m->bmNS * 8ull < (1ull << 32)) {
+        // compact_tag_kernel's planes (compact_tag.hip.h).  Its lanes without a state read rows past their block: 4 KiB of slack
+        const size_t nb = (size_t)m->V * m->S * m->bmNS * sizeof(u64);
+        int rc;
+        if ((rc = dev_alloc(m, (void **)&m->bmMF, nb + 4096)) || (rc = dev_alloc(m, (void **)&m->bmMB, nb + 4096)) ||
+            (rc = dev_alloc(m, (void **)&m->bmXF, nb + 4096)) || (rc = dev_alloc(m, (void **)&m->bmXB, nb + 4096)) ||
+            (rc = dev_alloc(m, (void **)&m->bmTok, (size_t)m->V * sizeof(unsigned)))) return rc;
+        FARNN_HIP_TRY(hipMemset(m->bmMF + nb / 8, 0, 4096)); FARNN_HIP_TRY(hipMemset(m->bmMB + nb / 8, 0, 4096));
+        FARNN_HIP_TRY(hipMemset(m->bmXF + nb / 8, 0, 4096)); FARNN_HIP_TRY(hipMemset(m->bmXB + nb / 8, 0, 4096));
+        std::vector<unsigned> off((size_t)m->V);
+        for (int v = 0; v < m->V; v++) off[(size_t)v] = (unsigned)((size_t)v * m->S * m->bmNS * 8);
+        FARNN_HIP_TRY(hipMemcpy(m->bmTok, off.data(), off.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        const long long n = (long long)m->V * m->S * m->bmNS;
+        merge_planes_kernel<<<(unsigned)((n + 255) / 256), 256>>>(m->bmF, m->bmB, m->bmWF, m->bmWB, m->bmMF, m->bmMB, m->bmXF, m->bmXB,
+                                                                  m->bmTok, m->V, m->S, m->bmNS);
+        FARNN_HIP_TRY(hipGetLastError());
+        FARNN_HIP_TRY(hipDeviceSynchronize());
+    }
     return FARNN_OK;
 }
 
@@ -1112,6 +1132,7 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
                 if (L > 1024) return fail(FARNN_ERANGE, "compact recurrence: more than 1024 positions%s%s");
                 CompactParams cp;
                 cp.bitsF = m->bmF; cp.bitsB = m->bmB; cp.wF = m->bmWF; cp.wB = m->bmWB; cp.o = m->o; cp.h0 = m->h0; cp.hT = m->hT;
+                cp.mF = m->bmMF; cp.mB = m->bmMB; cp.xF = m->bmXF; cp.xB = m->bmXB; cp.tokoff = m->bmTok;
                 cp.x = x; cp.len = lengths; cp.order = m->order_valid ? m->order : nullptr; cp.A = m->A; cp.Bk = m->Bk;
                 cp.B = B; cp.L = L; cp.S = m->S; cp.SP = m->SP; cp.V = m->V; cp.nl = m->nl; cp.full = full; cp.dbg = tun(TUN_DBG);
                 m->last_fused = false;
@@ -1119,18 +1140,24 @@ static int tag_impl(farnn_model *m, const int64_t *x, const int64_t *lengths, in
                     // ONE launch (compact_tag.hip.h: both chains of a sequence in LDS, label-map scores, argmax decode) where it
                     // applies; FARNN_NOFUSE=1: round 2's two launches
                     const ScoreParams sp = make_score_params(m, lengths, B, full, tags, flat_tags, scores);
-                    if (m->bmNS <= 2 && sp.lm.on && !sp.P && !scores && !m->use_crf && !tun(TUN_NOFUSE) &&
-                        compact_tag_fits(m->V, m->S, m->SP, L) && (B <= 1024 || !flat_tags || sp.offs)) {
-                        const size_t lds = (size_t)compact_tag_lds(L, m->SP).total * 4;
-                        const bool nlx = m->nl != FARNN_NL_NONE && m->nl != FARNN_NL_RELU;
+                    if (m->bmTok && sp.lm.on && !sp.P && !scores && !m->use_crf && !tun(TUN_NOFUSE) &&
+                        compact_tag_fits(m->V, m->S, L) && (B <= 1024 || !flat_tags || sp.offs)) {
+                        const size_t lds = (size_t)compact_tag_lds(L, m->bmNS).total * 4;
+                        const int nlk = m->nl == FARNN_NL_NONE ? 0 : m->nl == FARNN_NL_RELU ? 1 : 2;
+                        const int nw = (m->S + 31) / 32;                       // 32-bit words of a bitmap row in use
                         KernelTimer kt(m, KERN_CHAIN, s);
-#define FARNN_LAUNCH_CT(NS_, NX_)                                                              \
+#define FARNN_LAUNCH_CT(NW_, NL_)                                                              \
                         do {                                                                   \
-                            if ((rc = raise_lds_limit(compact_tag_kernel<NS_, NX_>, lds))) return rc; \
-                            compact_tag_kernel<NS_, NX_><<<B, CT_WAVES * 64, lds, s>>>(cp, sp); \
+                            if ((rc = raise_lds_limit(compact_tag_kernel<NW_, NL_>, lds))) return rc; \
+                            compact_tag_kernel<NW_, NL_><<<B, CT_WAVES * 64, lds, s>>>(cp, sp); \
                         } while (0)
-                        if (m->bmNS == 1) { if (nlx) FARNN_LAUNCH_CT(1, true); else FARNN_LAUNCH_CT(1, false); }
-                        else              { if (nlx) FARNN_LAUNCH_CT(2, true); else FARNN_LAUNCH_CT(2, false); }
+#define FARNN_LAUNCH_CT_NW(NW_)                                                                \
+                        do {                                                                   \
+                            if (nlk == 0) FARNN_LAUNCH_CT(NW_, 0); else if (nlk == 1) FARNN_LAUNCH_CT(NW_, 1); else FARNN_LAUNCH_CT(NW_, 2); \
+                        } while (0)
+                        if (nw <= 1) FARNN_LAUNCH_CT_NW(1); else if (nw == 2) FARNN_LAUNCH_CT_NW(2);
+                        else if (nw == 3) FARNN_LAUNCH_CT_NW(3); else FARNN_LAUNCH_CT_NW(4);
+#undef FARNN_LAUNCH_CT_NW
 #undef FARNN_LAUNCH_CT
                         FARNN_HIP_TRY(hipGetLastError());
                         m->last_fused = true;
@@ -2057,3 +2084,12 @@ extern "C" double farnn_kernel_algorithmic_bytes(const farnn_model *m, int32_t w
     return 0.0;
 }
 
+
+#if defined(FARNN_PROBES)
+// profiling build only (not part of include/farnn.h): the per-workgroup stamps of the last compact_tag_kernel launch under FARNN_DBG=2048
+extern "C" int farnn_debug_ct_stamps(long long *out, int n_workgroups) {
+    if (!out || n_workgroups < 0 || n_workgroups > farnn::CT_STAMP_MAX) return FARNN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return FARNN_EIO;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(farnn::g_ct_stamps), sizeof(long long) * 16 * (size_t)n_workgroups) == hipSuccess ? FARNN_OK : FARNN_EIO;
+}
+#endif

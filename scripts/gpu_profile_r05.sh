@@ -80,8 +80,9 @@ FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" |
 FARNN_FUSE=1 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_one_launch.txt
 FARNN_DBG=256 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_timeline.txt
-FARNN_DBG=4096 timeout 120 python bench.py $Z 2>/dev/null | grep "^compact tag" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -12 > $O/probe_compact_tag.txt
-FARNN_DBG=8192 timeout 120 python bench.py $Z 2>/dev/null | grep "^compact tag" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -8 > $O/probe_compact_tag_step_phases.txt
+FARNN_DBG=4096 timeout 120 python bench.py --full-length $Z 2>/dev/null | grep "^compact tag.*dir" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -16 > $O/probe_compact_tag.txt
+FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes.txt
+FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes_full_length.txt
 FARNN_DBG=8192 FARNN_CV_ONE=1 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_recurrence_then_viterbi_phases.txt
 FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch.txt
@@ -91,6 +92,7 @@ FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1
 FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_full_length.txt
 unset FARNN_LIB
 timeout 60 scripts/probe/fastmath_ulp.bin > $O/fastmath_ulp.txt 2>&1
+timeout 100 scripts/probe/issue_rate.bin > $O/issue_rate.txt 2>&1
 # keep only the small summaries (kernel_stats + counter collection), drop per-dispatch traces > 4 MB
 find $O -name '*.csv' -size +4M -delete
 find $O -name '*kernel_trace.csv' -delete

@@ -624,7 +624,8 @@ def test_a_stale_host_ticket_cannot_consume_a_newer_batch():
     assert m._in_flight == 1                               # (only the deliberately dropped one is still counted)
 
 
-@pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (64, 9, 17, 5), (65, 130, 9, 3), (71, 128, 64, 40),
+@pytest.mark.parametrize('S,C,L,B', [(1, 2, 3, 2), (5, 3, 1, 4), (33, 5, 8, 3), (64, 9, 17, 5), (65, 130, 9, 3), (71, 128, 64, 40),
+                                     (97, 20, 11, 4), (128, 33, 10, 3), (40, 6, 135, 3), (71, 9, 141, 3),
                                      (130, 70, 12, 4), (257, 40, 6, 3), (300, 256, 5, 2), (512, 256, 7, 3)])
 @pytest.mark.parametrize('nl', ['none', 'relu', 'tanh'])
 def test_compact_form_matches_dense_blocks_and_oracle(S, C, L, B, nl):
@@ -681,6 +682,40 @@ def test_compact_form_matches_dense_blocks_and_oracle(S, C, L, B, nl):
         assert np.array_equal(res[True, _lib.MODE_LOCAL][2], fo.forward_local_tags(ref, lengths, 0.5, 1 % C))
     else:
         np.testing.assert_allclose(res[True, _lib.MODE_FULL][0], ref, rtol=1e-4, atol=1e-4)
+    h.close()
+
+
+def test_compact_one_launch_repeats_itself_on_rotating_batches_at_the_benchmark_shape():
+    """compact_tag_kernel at 256 x 64 (V 950, S 71, 128 labels): four ragged batches in rotation, 100 rounds; every launch's tags and
+    flat predictions equal the dense path's of the same batch (the kernel hands rows between wavefronts through LDS progress words
+    and keeps its bitmap rows in flight in registers the compiler does not manage: a race or a stale register shows up here)."""
+    from re2nn_seq_amd import _lib, synth
+    V, S, C, B, L = 950, 71, 128, 256, 64
+    rng = np.random.RandomState(77)
+    T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng)
+    h = _lib.create_onehot_ifst(T, W, O, h0, hT)
+    batches = []
+    for k in range(4):
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1 if k else 5)
+        xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None)
+        torch.cuda.synchronize()
+        batches.append((xd, ld, tags.cpu().numpy(), flat.cpu().numpy()))
+    h.set_compact(True)
+    out_t = [torch.empty((B, L), dtype=torch.int32, device='cuda') for _ in range(4)]
+    out_f = [torch.empty_like(torch.from_numpy(b[3])).cuda() for b in batches]
+    for rnd in range(100):
+        for k, (xd, ld, _, _) in enumerate(batches):
+            out_t[k].fill_(-9); out_f[k].fill_(-9)
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, out_t[k].data_ptr(), out_f[k].data_ptr(), None)
+        torch.cuda.synchronize()
+        if rnd == 0 and NO_SWITCH:
+            assert 'compact_tag_kernel' in h.kernel_name(_lib.KERN_CHAIN)
+        for k, (_, _, tags, flat) in enumerate(batches):
+            assert np.array_equal(out_t[k].cpu().numpy(), tags), (rnd, k)
+            assert np.array_equal(out_f[k].cpu().numpy(), flat), (rnd, k)
     h.close()
 
 
