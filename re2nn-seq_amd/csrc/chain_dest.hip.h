@@ -226,15 +226,20 @@ __device__ __forceinline__ void regs_compute_dest(const RegsParams &p, const int
             FARNN_RD_PHASE(0);                               // the partners' entries of this step's state
             FARNN_RD_WAIT(d, nsteps - 1 - t);                // steps issued after this one: min(D - 1, nsteps - 1 - t)
             FARNN_RD_PHASE(1);                               // this step's block pieces
-            v4f acc = v4f{0.f, 0.f, 0.f, 0.f};
+            // The four accumulators as TWO register pairs, multiplied pair by pair: v_pk_fma_f32 on the halves of the 16-byte chunks as
+            // they lie in the registers.  (Written as four scalar fmaf the compiler packed them too -- but as (x, z) / (y, w), and
+            // shuffled the operands of every chunk into that pairing: 28 v_mov_b32 per step beside 8 v_pk_fma, seen in the ISA.
+            // The compute wavefronts of a compute unit share four SIMDs: the step is their VALU instruction count.)  Same
+            // products into the same accumulators in the same order: bit-identical.
+            v2f a01 = v2f{0.f, 0.f}, a23 = v2f{0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < NC; i++) {
-                acc.x = fmaf(st[i].x, r[d][i].x, acc.x);
-                acc.y = fmaf(st[i].y, r[d][i].y, acc.y);
-                acc.z = fmaf(st[i].z, r[d][i].z, acc.z);
-                acc.w = fmaf(st[i].w, r[d][i].w, acc.w);
+                a01 = __builtin_elementwise_fma(st[i].xy, r[d][i].xy, a01);
+                a23 = __builtin_elementwise_fma(st[i].zw, r[d][i].zw, a23);
             }
-            float s = (acc.x + acc.y) + (acc.z + acc.w);
+            float sa = a01.x + a01.y, sb = a23.x + a23.y;
+            asm volatile("" : "+v"(sa), "+v"(sb));            // (two scalar adds: packed into one v_pk_add they cost three v_mov)
+            float s = sa + sb;
             if constexpr (LPR == 4) s = quad_sum(s);
             else {
                 // the five lanes of a row: lane q = 4 ends up with x4 + x3 + x2 + x1 (+ x0): row_shr 1, row_shr 2, row_shr 4 of the

@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/final
 rm -rf $O; mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/smoke.txt
 s0=$(date +%s.%N)
 timeout 1200 python bench.py --steps 20 --warmup 5 2>$O/driver.err | tail -1 > $O/driver.json
