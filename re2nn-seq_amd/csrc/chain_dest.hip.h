@@ -51,24 +51,28 @@ __device__ __forceinline__ void dest_lane(const int lane, int &rj, int &rs, bool
     else { const int r16 = lane & 15, bq = r16 / 5; rs = r16 - 5 * bq; rj = 3 * (lane >> 4) + bq; has_row = bq < 3; }
 }
 
+// (cache-policy bits of the ring's loads: an experiment switch of the build, empty in the shipped library -- DESIGN.md, K1d)
+#ifndef FARNN_RD_CPOL
+#define FARNN_RD_CPOL ""
+#endif
 #define FARNN_RD_ISSUE_(ring_, d, base_)                                                       \
     do {                                                                                       \
         const char *bp_ = (base_);                                                             \
         if constexpr (NC == 5)                                                                 \
             asm volatile("s_nop 4\n\t"                                                         \
-                         "global_load_dwordx4 %0, %5, %10\n\t"                                 \
-                         "global_load_dwordx4 %1, %6, %10\n\t"                                 \
-                         "global_load_dwordx4 %2, %7, %10\n\t"                                 \
-                         "global_load_dwordx4 %3, %8, %10\n\t"                                 \
-                         "global_load_dwordx4 %4, %9, %10"                                     \
+                         "global_load_dwordx4 %0, %5, %10" FARNN_RD_CPOL "\n\t"                                 \
+                         "global_load_dwordx4 %1, %6, %10" FARNN_RD_CPOL "\n\t"                                 \
+                         "global_load_dwordx4 %2, %7, %10" FARNN_RD_CPOL "\n\t"                                 \
+                         "global_load_dwordx4 %3, %8, %10" FARNN_RD_CPOL "\n\t"                                 \
+                         "global_load_dwordx4 %4, %9, %10" FARNN_RD_CPOL                                     \
                          : "=&v"(ring_.r[d][0]), "=&v"(ring_.r[d][1]), "=&v"(ring_.r[d][2]), "=&v"(ring_.r[d][3]), "=&v"(ring_.r[d][NC - 1]) \
                          : "v"(ring_.voff[0]), "v"(ring_.voff[1]), "v"(ring_.voff[2]), "v"(ring_.voff[3]), "v"(ring_.voff[NC - 1]), "s"(bp_)); \
         else                                                                                   \
             asm volatile("s_nop 4\n\t"                                                         \
-                         "global_load_dwordx4 %0, %4, %8\n\t"                                  \
-                         "global_load_dwordx4 %1, %5, %8\n\t"                                  \
-                         "global_load_dwordx4 %2, %6, %8\n\t"                                  \
-                         "global_load_dwordx4 %3, %7, %8"                                      \
+                         "global_load_dwordx4 %0, %4, %8" FARNN_RD_CPOL "\n\t"                                  \
+                         "global_load_dwordx4 %1, %5, %8" FARNN_RD_CPOL "\n\t"                                  \
+                         "global_load_dwordx4 %2, %6, %8" FARNN_RD_CPOL "\n\t"                                  \
+                         "global_load_dwordx4 %3, %7, %8" FARNN_RD_CPOL                                      \
                          : "=&v"(ring_.r[d][0]), "=&v"(ring_.r[d][1]), "=&v"(ring_.r[d][2]), "=&v"(ring_.r[d][3]) \
                          : "v"(ring_.voff[0]), "v"(ring_.voff[1]), "v"(ring_.voff[2]), "v"(ring_.voff[3]), "s"(bp_)); \
     } while (0)

@@ -719,6 +719,48 @@ def test_compact_one_launch_repeats_itself_on_rotating_batches_at_the_benchmark_
     h.close()
 
 
+def test_compact_one_launch_on_random_shapes_equals_the_dense_path():
+    """compact_tag_kernel over 60 random (S, C, L, B, edge density, non-linearity) draws within its limits (S <= 128; L up to the LDS
+    bound of the row width), half of them with wildcard edges that coincide with word edges (the second plane): LOCAL and FULL mode
+    tags and the flat predictions equal the dense path's of the same handle bit for bit (`none` / `relu`: integer-valued states)."""
+    from re2nn_seq_amd import _lib, synth
+    rng = np.random.RandomState(20251004)
+    seen = set()
+    for case in range(60):
+        S = int(rng.choice([1, 2, 7, 31, 32, 33, 63, 64, 65, 71, 95, 96, 97, 104, 127, 128])) if case % 3 else int(rng.randint(1, 129))
+        C = int(rng.randint(2, 140))
+        L = int(rng.randint(1, 146 if S > 64 else 290)) if case % 4 == 0 else int(rng.randint(1, 70))
+        B = int(rng.randint(1, 9))
+        V = int(rng.randint(3, 40))
+        nl = ['none', 'relu'][case % 2]
+        T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=max(2.0, S * rng.uniform(0.1, 1.0)), n_final=2)
+        if case % 2 == 0 and S > 1:
+            for _ in range(3):                               # wildcard edges on top of word edges: T + W = 2 somewhere
+                i, j = int(rng.randint(S)), int(rng.randint(1, S))
+                W[i, j] = 1.0
+                T[int(rng.randint(V - 1)), i, j] = 1.0
+        x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, o_idx=int(rng.randint(C)))
+        xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+        out = {}
+        for compact in (False, True):
+            h.set_compact(compact)
+            for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+                tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
+                flat = torch.full((int(lengths.sum()),), -7, dtype=torch.int64, device='cuda')
+                h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(), flat.data_ptr() if mode == _lib.MODE_LOCAL else None, None)
+                torch.cuda.synchronize()
+                out[compact, mode] = (tags.cpu().numpy(), flat.cpu().numpy())
+                if compact and NO_SWITCH:
+                    assert 'compact_tag_kernel' in h.kernel_name(_lib.KERN_CHAIN), (S, C, L, B, h.kernel_name(_lib.KERN_CHAIN))
+        for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
+            assert np.array_equal(out[True, mode][0], out[False, mode][0]), (case, S, C, L, B, V, nl, mode)
+        assert np.array_equal(out[True, _lib.MODE_LOCAL][1], out[False, _lib.MODE_LOCAL][1]), (case, S, C, L, B, V, nl)
+        seen.add((S + 31) // 32)
+        h.close()
+    assert seen == {1, 2, 3, 4}                              # every row width the kernel is instantiated for
+
+
 def test_compact_only_handle_from_the_edge_list_and_its_limits():
     """farnn_onehot_ifst_create_compact: the automaton's edges go straight into bit-packed blocks (no dense tensor at
     all); tags and scores equal the dense upload's and the reference loader + oracle.  Weighted edges, the max semiring
