@@ -171,7 +171,8 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
 #endif
     // one step; U: the ring slot (t mod CT_PF), STEADY: the block of step t + CT_PF is requested behind it (t + CT_PF < nsteps)
     using std::integral_constant;
-    int *const progp = reinterpret_cast<int *>(ct_smem) + progi;
+    int progb = 4 * progi;               // the progress word's byte offset in ct_smem, kept in a VGPR (else every step moves it there
+    asm volatile("" : "+v"(progb));      //  from an SGPR; an offset, not a pointer: a laundered pointer is a generic one -- flat_store)
     auto step = [&](auto U_, auto STEADY_, const int t) {
         constexpr int U = decltype(U_)::value;
         constexpr bool STEADY = decltype(STEADY_)::value;
@@ -186,12 +187,14 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
         rowv xr[NS];
         // The sources that hold the value v add v * (their edges into destination j) to it: one pass per DISTINCT value among the
         // active sources (integer values make any grouping of the sum exact).  No active source: one pass over an empty set.
-        auto one_pass = [&](auto SECOND_) {
-            constexpr bool SECOND = decltype(SECOND_)::value;
+        // PLANE 0: the merged T | W rows of this step (cur); PLANE 1: the second plane's rows (xr), counted on top by the rare step whose
+        // word has one -- a loop of its own behind the common one, so that the common step carries no trace of it
+        auto one_pass = [&](auto PLANE_) {
+            constexpr int PLANE = decltype(PLANE_)::value;
             int vi;
             {
-                // (s_ff1 of an empty mask is -1; masked to lane 63, whose value the select below drops or a count of zero multiplies.
-                //  The instruction by hand: __builtin_ctzll of 0 is undefined, its guarded forms cost four instructions)
+                // (s_ff1 of an empty mask is -1; v_readlane takes the lane modulo 64: lane 63, whose value the select below drops or a
+                //  count of zero multiplies.  The instruction by hand: __builtin_ctzll of 0 is undefined, its guarded forms cost four)
                 int i0;
                 asm("s_ff1_i32_b64 %0, %1" : "=s"(i0) : "s"(rem[0]));
                 const int va = __builtin_amdgcn_readlane(__float_as_int(a[0]), i0 & 63);
@@ -213,11 +216,8 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
             for (int k = 0; k < NS; k++) {
                 int cnt = 0;
 #pragma unroll
-                for (int w = 0; w < NW; w++) cnt += __popc(cur[k][w] & (unsigned)(mv[w >> 1] >> (32 * (w & 1))));
-                if constexpr (SECOND) {
-#pragma unroll
-                    for (int w = 0; w < NW; w++) cnt += __popc(xr[k][w] & (unsigned)(mv[w >> 1] >> (32 * (w & 1))));
-                }
+                for (int w = 0; w < NW; w++)
+                    cnt += __popc((PLANE == 0 ? cur[k][w] : xr[k][w]) & (unsigned)(mv[w >> 1] >> (32 * (w & 1))));
                 acc[k] = fmaf(__int_as_float(vi), (float)cnt, acc[k]);
             }
 #if defined(FARNN_PROBES)
@@ -227,11 +227,10 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
         auto left = [&]() { return NS == 2 ? (rem[0] | rem[NS - 1]) != 0ull : rem[0] != 0ull; };
         const bool second = (flagbits & 1ull) != 0ull;           // this word's T and W share an edge: its second plane counts too
         flagbits >>= 1;
-        if (__builtin_expect(!second, 1)) {
-            one_pass(integral_constant<bool, false>());          // the common step: one value, no taken branch
-            if (__builtin_expect(left(), 0))
-                do one_pass(integral_constant<bool, false>()); while (left());
-        } else {
+        one_pass(integral_constant<int, 0>());                   // the common step: one value, no taken branch
+        if (__builtin_expect(left(), 0))
+            do one_pass(integral_constant<int, 0>()); while (left());
+        if (__builtin_expect(second, 0)) {
             const unsigned vx = (unsigned)__builtin_amdgcn_readlane((int)ctkw, t & 63) + voff;
             if constexpr (NS == 2)
                 asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
@@ -241,7 +240,9 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
             else
                 asm volatile("global_load_dwordx2 %0, %1, %2\n\t"
                              "s_waitcnt vmcnt(0)" : "=&v"(xr[0]) : "v"(vx), "s"(xbits) : "memory");
-            do one_pass(integral_constant<bool, true>()); while (left());
+#pragma unroll
+            for (int s = 0; s < NS; s++) rem[s] = __ballot(a[s] != 0.0f);
+            do one_pass(integral_constant<int, 1>()); while (left());
         }
         // the block of step t + CT_PF into the slot that has just been read (its offset: lane (t + CT_PF) & 63 of the window)
         if constexpr (STEADY) FARNN_CT_ISSUE(U, (unsigned)__builtin_amdgcn_readlane((int)tkw, (t + CT_PF) & 63));
@@ -257,7 +258,7 @@ __device__ __forceinline__ void ct_chain(const CompactParams &p, float *ct_smem,
         hrow += HS;
         // rows 0 .. t + 1 of this direction are complete: the progress word, behind the row in this wavefront's LDS order (every
         // lane stores the same word: no exec juggling)
-        __hip_atomic_store(progp, t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_store(reinterpret_cast<int *>(reinterpret_cast<char *>(ct_smem) + progb), t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
     static_assert(CT_PF == 4 && 64 % CT_PF == 0, "the step lists below are written out for a ring of four steps");
     int t0 = 0;
