@@ -636,6 +636,21 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
         if traffic is not None:
             rf['hbm_frac_measured'] = traffic / dom_s / 1e9 / HBM_PEAK_GBS
         rf['frac'] = achieved / rf['peak']
+        if 'chain_regs_kernel' in kname and S <= 72:
+            # The bound that was MEASURED for this kernel at the end of round 5 (scripts/probe/ta_rate.hip,
+            # scripts/debug/pool_probe.py): the compute unit's L1 pipeline -- 16 cycles per vector load instruction whatever its
+            # width or active lanes, plus the 64 B/clk fill of the lines it misses, in the same pipeline.  A workgroup step is 24
+            # load instructions and one block's lines; the floor spreads the launch's workgroup steps evenly over the compute units
+            # at the device's MAXIMUM clock (the launch runs at ~2.2 GHz: the fraction is a lower bound).  Reported beside the
+            # bandwidth reading above, which stays the line's `frac`.
+            props = torch.cuda.get_device_properties(torch.cuda.current_device())
+            ncu = int(getattr(props, 'multi_processor_count', 256))
+            clk = float(getattr(props, 'clock_rate', 2400000)) * 1e3
+            cyc = 16.0 * 24 + S * SP * 4 / 64.0
+            floor_s = 2.0 * tok_local * cyc / (ncu * clk)
+            rf['l1_pipeline'] = {'cycles_per_workgroup_step': cyc, 'load_instructions_per_step': 24, 'cycles_per_load_instruction': 16,
+                                 'fill_bytes_per_step': S * SP * 4, 'fill_bytes_per_clock': 64, 'compute_units': ncu, 'clock_hz': clk,
+                                 'floor_us': floor_s * 1e6, 'frac': floor_s / dom_s}
         return rf
     if dom == _lib.KERN_SCORE and 'mfma_flops_per_token' in extras and 'mfma' in kname:
         fl = extras['mfma_flops_per_token'] * tok_local
