@@ -69,7 +69,7 @@ BASE_STATES = {k: v[2] for k, v in WORKLOADS.items()}      # (before --states ed
 # (workload, steps, warmup, argument overrides, label): the last decomposed entry is the shape of the reference's shipped example
 # configurations (model_seq/example/*.res: --rank 250 --farnn 2)
 # (an 'env' override: library environment switches for that run only -- the CRF step's two-launch form beside its one-launch default)
-OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'), ('ifst_crf', 1000, 50, {'env': {'FARNN_CV_ONE': '1'}}, 'ifst_crf_one_launch'),
+OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'),
                  # the onehot path at the state count of the reference's SNIPS-BIO / ATIS-ZH-BIO automata (RE.py:56-60): the wide form
                  ('ifst', 1000, 50, {'states': 104}, 'ifst_s104'), ('ifst_crf', 600, 30, {'states': 104}, 'ifst_crf_s104'),
                  ('decomp', 1500, 50, {}, 'decomp'),

@@ -395,6 +395,9 @@ int  farnn_train_time(farnn_train_ctx *ctx, double *total_ms, int64_t *steps);
 
 /* ---- introspection / measurement ----------------------------------------------------- */
 int  farnn_abi_version(void);
+/* 1: the A/B (profiling) build of the library (csrc/build.py --probes): it also carries the forms the production build left behind --
+ * FARNN_CV_ONE / FARNN_CV_STASH, the one-launch CRF step -- and the in-kernel probes (FARNN_DBG); 0: the production build. */
+int  farnn_ab_build(void);
 int  farnn_device_count(void);
 const char *farnn_last_error(void);
 int  farnn_num_columns(const farnn_model *m);              /* K of the scores tensor */

@@ -150,6 +150,7 @@ SIGNATURES = {
     'farnn_tag_host_wait': (C.c_int, [_vp, C.c_int32, _vp, C.POINTER(C.c_int64)]),
     'farnn_destroy': (None, [_vp]),
     'farnn_abi_version': (C.c_int, []),
+    'farnn_ab_build': (C.c_int, []),
     'farnn_device_count': (C.c_int, []),
     'farnn_last_error': (C.c_char_p, []),
     'farnn_num_columns': (C.c_int, [_vp]),
@@ -183,6 +184,14 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+AB_LIB_PATH = os.path.join(_HERE, 'csrc', 'libfarnn_hip_probes.so')     # the A/B (profiling) build: csrc/build.py --probes
+
+
+def ab_build():
+    """True when the loaded library is the A/B build (it carries the forms the production build left behind: FARNN_CV_ONE)."""
+    return bool(load().farnn_ab_build())
 
 
 def check(rc, what=''):

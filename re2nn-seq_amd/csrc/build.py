@@ -29,7 +29,9 @@ def _units():
 
 def _flags(probes):
     extra = os.environ.get('FARNN_EXTRA_FLAGS', '').split()
-    return FLAGS + (['-DFARNN_PROBES=1'] if probes else []) + extra
+    # the profiling build is also the A/B build: it carries the forms the production library left behind (FARNN_AB: the one-launch CRF
+    # step, chain_viterbi*.hip) beside the in-kernel probes
+    return FLAGS + (['-DFARNN_PROBES=1', '-DFARNN_AB=1'] if probes else []) + extra
 
 
 def _deps(depfile):

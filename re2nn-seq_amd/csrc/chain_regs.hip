@@ -28,7 +28,19 @@ int launch_chain_regs(const RegsParams &p, bool maxsr, bool score, hipStream_t s
         else                                                                                   \
             chain_regs_kernel<MX, SC, NX, LM, DS><<<grid, block, lds, s>>>(p);                \
     } while (0)
+    // (the sum semiring's source-split compute wavefronts -- round 3's, FARNN_NODEST=1 -- live in the A/B build: six kernels the
+    //  production library's dispatch cannot reach; the max semiring keeps the source split, its only form)
+#if defined(FARNN_AB)
 #define FARNN_LAUNCH_REGS4(MX, SC, NX, LM) do { if (!MX && dest) FARNN_LAUNCH_REGS5(MX, SC, NX, LM, !MX); else FARNN_LAUNCH_REGS5(MX, SC, NX, LM, false); } while (0)
+#else
+#define FARNN_LAUNCH_REGS4(MX, SC, NX, LM)                                                     \
+    do {                                                                                       \
+        if (!MX && dest) FARNN_LAUNCH_REGS5(MX, SC, NX, LM, !MX);                              \
+        else if constexpr (MX) FARNN_LAUNCH_REGS5(MX, SC, NX, LM, false);                      \
+        else return fail(FARNN_EINVAL, "FARNN_NODEST=1: the source-split compute wavefronts of the sum semiring are compiled into the A/B " \
+                                       "build only (FARNN_LIB=.../libfarnn_hip_probes.so, csrc/build.py --probes)%s%s"); \
+    } while (0)
+#endif
 #define FARNN_LAUNCH_REGS3(MX, SC, NX) do { if (SC && lmo) FARNN_LAUNCH_REGS4(MX, SC, NX, SC); else FARNN_LAUNCH_REGS4(MX, SC, NX, false); } while (0)
 #define FARNN_LAUNCH_REGS(MX, SC) do { if (nlx) FARNN_LAUNCH_REGS3(MX, SC, true); else FARNN_LAUNCH_REGS3(MX, SC, false); } while (0)
     if (maxsr) { if (score) FARNN_LAUNCH_REGS(true, true); else FARNN_LAUNCH_REGS(true, false); }

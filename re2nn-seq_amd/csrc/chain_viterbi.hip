@@ -11,6 +11,9 @@
 // leave.  No inter-workgroup hand-off, no epoch, no progress words: the step is graph-capturable.
 // What the two-launch form has and this one has not: a short sequence's compute unit idles while the long ones finish (one
 // sequence per compute unit per round either way for the decode, but the stand-alone recurrence pairs long with short).
+// Compiled into the A/B build only (build.py --probes: -DFARNN_AB): two launches beat this form at every shape measured,
+// so the production library does not carry its 48 kernels; FARNN_CV_ONE=1 there fails with a message that says where the form lives.
+#if defined(FARNN_AB)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -50,3 +53,4 @@ int launch_chain_viterbi(const RegsParams &p_in, const ScoreParams &sp, bool max
 }
 
 }  // namespace farnn
+#endif  // FARNN_AB

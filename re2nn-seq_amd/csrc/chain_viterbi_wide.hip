@@ -2,6 +2,9 @@
 // of 73..108 states: the chains in the wide form (chain_wide.hip.h) with a ring of two steps (the reference's 104-state automata:
 // RE.py:56-60; model_onehot.py:372-426 -> model_decompose.py:351-356 -> crf.py:102-195).
 // build-flags: -fno-slp-vectorize
+// Compiled into the A/B build only (build.py --probes: -DFARNN_AB): two launches beat this form at every shape measured,
+// so the production library does not carry its 48 kernels; FARNN_CV_ONE=1 there fails with a message that says where the form lives.
+#if defined(FARNN_AB)
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -18,3 +21,4 @@ int launch_chain_viterbi_wide(const RegsParams &p, const ScoreParams &sp, const 
 }
 
 }  // namespace farnn
+#endif  // FARNN_AB

@@ -1026,6 +1026,8 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
         // 780-960 when a long chain shares its unit with a short one, and the decode waits behind them.  Measured at K = 130,
         // 256 x 64: S = 71 77.7 us in one launch against 72.9 in two (round 4; round 5's recurrence kernel: 69), S = 104 113.8 against
         // 95.7 (profiles/r04_*, r05_*).  FARNN_CV_ONE=1 selects it.
+        // The production library does not carry the form's 48 kernels: it lives in the A/B build (build.py --probes, -DFARNN_AB).
+#if defined(FARNN_AB)
         if (tun(TUN_CV_ONE) && m->rgeom.ok && !tun(TUN_NOREGS) && !tun(TUN_NOFUSE) && viterbi_can_fuse(m, sp) &&
             (B <= 1024 || !flat || sp.offs) && chain_viterbi_fits(m->curL, m->SP, m->rgeom.NP, m->K, m->Kp, m->lm.on != 0, m->rgeom.RQ)) {
             const RegsParams rp = make_regs_params(m, x, len, B, full);
@@ -1034,6 +1036,11 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
             m->last_regs = true; m->last_fused = true;
             return FARNN_OK;
         }
+#else
+        if (tun(TUN_CV_ONE))
+            return fail(FARNN_EINVAL, "FARNN_CV_ONE=1: the one-launch CRF step is compiled into the A/B build only "
+                                      "(FARNN_LIB=.../libfarnn_hip_probes.so, csrc/build.py --probes)%s%s");
+#endif
         if ((rc = launch_chain(m, x, len, B, L, full, s))) return rc;
     }
     return launch_score_decode(m, len, B, full, tags, flat, scores, s);
@@ -2035,6 +2042,13 @@ extern "C" void farnn_destroy(farnn_model *m) {
 
 // ---- introspection ---------------------------------------------------------------------------
 extern "C" int farnn_abi_version(void) { return FARNN_ABI_VERSION; }
+extern "C" int farnn_ab_build(void) {
+#if defined(FARNN_AB)
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 extern "C" int farnn_device_count(void) {
     int n = 0;

@@ -9,12 +9,13 @@ O=gpurun_out/prof_r05
 rm -rf $O; mkdir -p $O
 Q="--no-cpu-baseline --no-other-configs"
 T="timeout 300"
+AB="FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so"      # the A/B build: the forms the production library left behind (FARNN_NODEST, FARNN_CV_ONE)
 $T python bench.py --steps 20 --warmup 5 2>/dev/null > $O/bench_default_driver_form.json
 $T python bench.py 2>/dev/null > $O/bench_ifst.json
 FARNN_FUSE=1 $T python bench.py --steps 20 --warmup 5 $Q 2>/dev/null > $O/bench_ifst_one_launch_driver_form.json
 FARNN_FUSE=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_one_launch.json
-FARNN_FUSE=1 FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_one_launch_source_split_r04.json
-FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_source_split_r04.json
+env $AB FARNN_FUSE=1 FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_one_launch_source_split_r04.json
+env $AB FARNN_NODEST=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_source_split_r04.json
 FARNN_NOLABELMAP=1 FARNN_NOFUSE=1 $T python bench.py $Q 2>/dev/null > $O/bench_ifst_two_kernels_matrix_core_scores_r04.json
 $T python bench.py --batches 1 $Q 2>/dev/null > $O/bench_ifst_one_batch_replayed.json
 $T python bench.py --graph 10 $Q 2>/dev/null > $O/bench_ifst_graph_replay.json
@@ -27,10 +28,10 @@ FARNN_NOFUSE=1 $T python bench.py --batch 64 $Q 2>/dev/null > $O/bench_ifst_b64_
 $T python bench.py --workload ifst --states 104 $Q 2>/dev/null > $O/bench_ifst_s104.json
 $T python bench.py --workload ifst --states 128 $Q 2>/dev/null > $O/bench_ifst_s128.json
 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf.json
-FARNN_NODEST=1 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf_source_split_r04.json
-FARNN_CV_ONE=1 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf_one_launch.json
+env $AB FARNN_NODEST=1 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf_source_split_r04.json
+env $AB FARNN_CV_ONE=1 $T python bench.py --workload ifst_crf $Q 2>/dev/null > $O/bench_ifst_crf_one_launch.json
 $T python bench.py --workload ifst_crf --states 104 $Q 2>/dev/null > $O/bench_ifst_crf_s104.json
-FARNN_CV_ONE=1 $T python bench.py --workload ifst_crf --states 104 $Q 2>/dev/null > $O/bench_ifst_crf_s104_one_launch.json
+env $AB FARNN_CV_ONE=1 $T python bench.py --workload ifst_crf --states 104 $Q 2>/dev/null > $O/bench_ifst_crf_s104_one_launch.json
 $T python bench.py --workload decomp $Q --steps 300 2>/dev/null > $O/bench_decomp.json
 $T python bench.py --workload decomp --rank 250 --farnn 2 $Q --steps 100 2>/dev/null > $O/bench_decomp_r250_farnn2.json
 $T python bench.py --workload decomp --rank 250 --farnn 2 --crf $Q --steps 100 2>/dev/null > $O/bench_decomp_r250_farnn2_crf.json
@@ -69,7 +70,7 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_WAVE_CYCLES SQ_WAIT_IN
   i=$((i+1))
   rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifst -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifst.log 2>&1
   FARNN_FUSE=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstonelaunch -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstonelaunch.log 2>&1
-  FARNN_FUSE=1 FARNN_NODEST=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstonelaunchsourcesplit -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstonelaunchsourcesplit.log 2>&1
+  FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so FARNN_FUSE=1 FARNN_NODEST=1 rocprofv3 --pmc $grp --output-format csv -d $O/sq${i}_ifstonelaunchsourcesplit -- python3 bench.py --workload ifst --steps 10 --warmup 3 $R > $O/sq${i}_ifstonelaunchsourcesplit.log 2>&1
 done
 # in-kernel probes (profiling build)
 export FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so
@@ -78,17 +79,17 @@ FARNN_FUSE=1 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | t
 FARNN_FUSE=1 FARNN_DBG=1024 timeout 120 python bench.py $Z 2>/dev/null | grep "^finish\|^meet" | sort | tail -24 > $O/probe_finish_phases_one_launch.txt
 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases.txt
 FARNN_FUSE=1 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_one_launch.txt
-FARNN_DBG=256 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
+env $AB FARNN_DBG=256 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_timeline.txt
 FARNN_DBG=4096 timeout 120 python bench.py --full-length $Z 2>/dev/null | grep "^compact tag.*dir" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -16 > $O/probe_compact_tag.txt
 FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes.txt
 FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes_full_length.txt
-FARNN_DBG=8192 FARNN_CV_ONE=1 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
+env $AB FARNN_DBG=8192 FARNN_CV_ONE=1 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_chain_viterbi_phases.txt
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi\|^seq" | sort | tail -8 > $O/probe_recurrence_then_viterbi_phases.txt
 FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch.txt
-FARNN_DBG=2048 FARNN_FUSE=1 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_source_split_r04.txt
+env $AB FARNN_DBG=2048 FARNN_FUSE=1 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_source_split_r04.txt
 FARNN_DBG=2048 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only.txt
-FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only_source_split_r04.txt
+env $AB FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only_source_split_r04.txt
 FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_full_length.txt
 unset FARNN_LIB
 timeout 60 scripts/probe/fastmath_ulp.bin > $O/fastmath_ulp.txt 2>&1

@@ -8,12 +8,12 @@ timeout 150 $B > $O/A_0.json 2>$O/A_0.err || { echo "first launch failed or hung
 timeout 600 python -m pytest tests/test_gpu_parity_onehot.py tests/test_gpu_chain_regs_shapes.py -x -q -m gpu > $O/pytest.txt 2>&1; echo "pytest rc $?" >> $O/pytest.txt
 for rep in 1 2 3; do
 timeout 100 $B > $O/A_$rep.json 2>$O/A_$rep.err
-FARNN_NODEST=1 timeout 100 $B > $O/B_$rep.json 2>$O/B_$rep.err
+FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so FARNN_NODEST=1 timeout 100 $B > $O/B_$rep.json 2>$O/B_$rep.err
 done
 FARNN_NOFUSE=1 timeout 100 $B > $O/A_nofuse.json 2>$O/A_nofuse.err
-FARNN_NOFUSE=1 FARNN_NODEST=1 timeout 100 $B > $O/B_nofuse.json 2>$O/B_nofuse.err
+FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so FARNN_NOFUSE=1 FARNN_NODEST=1 timeout 100 $B > $O/B_nofuse.json 2>$O/B_nofuse.err
 timeout 100 $B --full-length > $O/A_full.json 2>$O/A_full.err
-FARNN_NODEST=1 timeout 100 $B --full-length > $O/B_full.json 2>$O/B_full.err
+FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so FARNN_NODEST=1 timeout 100 $B --full-length > $O/B_full.json 2>$O/B_full.err
 export FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so
 Q="--steps 3 --warmup 2 --no-cpu-baseline --no-pipelined --no-other-configs --no-parity"
 timeout 100 python bench.py $Q 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_timeline.txt

@@ -83,12 +83,11 @@ def test_bench_default_line_carries_every_single_gpu_config():
     assert d['parity']['tags_equal'] is True
     assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
     names = [o['workload'] for o in d['other_configs']]
-    assert names == ['ifst_crf', 'ifst_crf_one_launch', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2',
+    assert names == ['ifst_crf', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2',
                      'decomp_r250_farnn2_crf', 'decomp_r250_farnn2_crf_bz200_len30', 'decomp_r150_farnn2_crf_s134_bz200_len30', 'fst4', 'synth512_shard_b1024_len128']
     kern = {o['workload']: o['roofline']['kernel'] for o in d['other_configs']}
     assert 'chain_wide_kernel<fused' in kern['ifst_s104']                # the reference's 104-state automata: the wide form, ONE launch
-    assert 'chain_viterbi_kernel' not in kern['ifst_crf']                # config 4: the faster form is the default (two launches, round 5) ...
-    assert 'chain_viterbi_kernel' in kern['ifst_crf_one_launch']         # ... the one-launch form beside it (FARNN_CV_ONE for that run only)
+    assert 'chain_viterbi_kernel' not in kern['ifst_crf']                # config 4: two launches (the one-launch form lives in the A/B build: scripts/gpu_profile_r05.sh times it there)
     for o in d['other_configs']:
         assert 'error' not in o, o
         assert o['value'] > 0 and o['parity']['tags_equal'] is True, o

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import farnn_oracle as fo                    # noqa: E402
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
-from util import NO_SWITCH                               # noqa: E402
+from util import NO_SWITCH, ab_build, run_module_in_ab_build     # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -65,7 +65,11 @@ def _one(rng):
     names = {}
     # (round 5: the one-launch form is nowhere the default -- it is slower than two launches, DESIGN.md K1v -- but stays selectable,
     #  FARNN_CV_ONE=1, and is held to the same results; `default` below = that form, `plain` = what the library picks by itself)
+    ab = ab_build()            # (the one-launch form lives in the A/B build: the production library's run checks the other two;
+                               #  test_one_launch_form_in_the_ab_build runs this module again there)
     for env in ({'FARNN_CV_ONE': '1'}, {'FARNN_CV_STASH': '1', 'FARNN_CV_ONE': '1'}, {'FARNN_NOFUSE': '1'}, {}):
+        if not ab and 'FARNN_CV_ONE' in env:
+            continue
         os.environ.update(env)
         try:
             h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, semiring=semiring, use_crf=True, crf_trans=tr)
@@ -79,6 +83,9 @@ def _one(rng):
         assert np.array_equal(tg[mask].astype(np.int64), want[mask]), (what, key, name)
         assert (tg[~mask] == -1).all(), (what, key, name)
         assert np.array_equal(fl, fo.flatten(want, lengths)), (what, key, name)
+    if not ab:
+        assert 'chain_viterbi' not in names['FARNN_NOFUSE'] and 'chain_viterbi' not in names['plain'], (what, names)
+        return what + ' [' + names['plain'] + ']'
     if not NO_SWITCH:
         return what + ' [' + names['default'] + ']'       # (under a dispatch switch: results only)
     one_launch = 32 <= K <= 131 and L <= 64            # (larger tag sets: as far as history + scores + table fit the LDS)
@@ -102,12 +109,22 @@ def test_chain_viterbi_random_shapes_vs_oracle():
             continue
         done += 1
         fused += 'chain_viterbi' in what
-    assert not NO_SWITCH or fused * 3 >= n                 # a good share of the draws really took the one-launch form
+    assert not NO_SWITCH or not ab_build() or fused * 3 >= n      # a good share of the draws really took the one-launch form
+
+
+def test_one_launch_form_in_the_ab_build():
+    """The one-launch CRF step (FARNN_CV_ONE, FARNN_CV_STASH) is compiled into the A/B build only: this module once more, there."""
+    r = run_module_in_ab_build(os.path.abspath(__file__), k='not test_one_launch_form_in_the_ab_build')
+    if r is None:
+        pytest.skip('already the A/B build, or libfarnn_hip_probes.so was not built (csrc/build.py --probes)')
+    assert r.returncode == 0 and ' passed' in r.stdout and ' failed' not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 def test_chain_viterbi_under_graph_capture(monkeypatch):
     """No epoch, no progress words: the one-launch CRF step (FARNN_CV_ONE=1) replays from a HIP graph."""
     from re2nn_seq_amd import _lib, synth
+    if not ab_build():
+        pytest.skip('the one-launch CRF step is compiled into the A/B build only (test_one_launch_form_in_the_ab_build runs it there)')
     monkeypatch.setenv('FARNN_CV_ONE', '1')              # (switches are read when the handle is created)
     rng = np.random.RandomState(5)
     V, S, C, B, L = 200, 71, 128, 64, 48

@@ -16,7 +16,7 @@ import pytest
 import torch
 
 from oracle import farnn_oracle as fo
-from util import assert_float_path, in_float64, NO_SWITCH
+from util import assert_float_path, in_float64, NO_SWITCH, ab_build, run_module_in_ab_build
 
 pytestmark = pytest.mark.gpu
 
@@ -270,6 +270,12 @@ def test_onehot_ifst_crf_at_bench_size_vs_reference(one_launch, monkeypatch):
     default form (recurrence kernel + score / Viterbi kernel: the faster one, round 5) and in the one-launch form (FARNN_CV_ONE=1)."""
     from re2nn_seq_amd import _lib, synth
     if one_launch:
+        if not ab_build():
+            r = run_module_in_ab_build(os.path.abspath(__file__), k='test_onehot_ifst_crf_at_bench_size_vs_reference and True')
+            if r is None:
+                pytest.skip('the one-launch CRF step is compiled into the A/B build only, which was not built (csrc/build.py --probes)')
+            assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+            return
         monkeypatch.setenv('FARNN_CV_ONE', '1')          # (switches are read when the handle is created)
     g = np.load(os.path.join(GOLDEN, 'bench_crf.npz'))
     V, S, C, K, B, L = (int(v) for v in g['dims'])

@@ -10,6 +10,27 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 EXTERNAL_SWITCHES = sorted(k for k in os.environ if k.startswith('FARNN_') and k not in ('FARNN_LIB', 'FARNN_RCCL_LIB') and
                            not k.startswith(('FARNN_SOAK', 'FARNN_SHAPE', 'FARNN_D1_SOAK', 'FARNN_BENCH')))
 NO_SWITCH = not EXTERNAL_SWITCHES
+AB_ONLY_SWITCHES = ('FARNN_CV_ONE', 'FARNN_CV_STASH', 'FARNN_NODEST')      # forms compiled into the A/B build only (csrc/build.py --probes)
+
+
+def ab_build():
+    """the loaded library carries the A/B-only forms (farnn_ab_build)"""
+    from re2nn_seq_amd import _lib
+    return _lib.ab_build()
+
+
+def run_module_in_ab_build(path, extra_env=None, k=None, timeout=1500):
+    """Runs a test module again in a child pytest with FARNN_LIB = the A/B build, where its A/B-only cases are not skipped.
+    Returns None when there is nothing to do (already the A/B build, or it was not built)."""
+    import subprocess
+    import sys
+    from re2nn_seq_amd import _lib
+    if _lib.ab_build() or os.environ.get('FARNN_AB_CHILD') or not os.path.exists(_lib.AB_LIB_PATH):
+        return None
+    env = dict(os.environ, FARNN_LIB=_lib.AB_LIB_PATH, FARNN_AB_CHILD='1')
+    env.update(extra_env or {})
+    cmd = [sys.executable, '-m', 'pytest', path, '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider'] + (['-k', k] if k else [])
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
 def ns(**kw):
