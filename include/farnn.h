@@ -25,19 +25,22 @@
  *     HIP graph is not ordered against other streams.
  *
  * Environment switches (read ONCE per handle, when farnn_*_create / farnn_train_create builds it; no call on the tagging path
- * touches the environment).  Every one selects between code paths that the test suite holds to the same results:
+ * touches the environment).  Every one selects between code paths that the test suite holds to the same results.  Those marked
+ * [A/B build only] select forms the production library does not carry (its dispatch never picks them: 54 kernels): they exist in
+ * the A/B build (csrc/build.py --probes -> libfarnn_hip_probes.so, loaded through FARNN_LIB; farnn_ab_build() says which one is
+ * loaded), and the production library answers them with FARNN_EINVAL and a message that says so:
  *   FARNN_NOFUSE=1          the multi-launch forms (recurrence kernel, then score / Viterbi kernel) instead of one launch per step
  *                           (also: the compact form's two launches instead of compact_tag_kernel)
  *   FARNN_FUSE=1            onehot i-FST, S <= 72, label-map scores: ONE launch per step for any batch size (the default there: one launch
  *                           while 2 B <= compute units, else the recurrence kernel + the label-map score launch, which is faster)
  *   FARNN_NOREGS=1          the LDS-ring recurrence kernel where the register-fed one (S <= 128) would run
- *   FARNN_NODEST=1          S <= 72, sum semiring: round 3's compute wavefronts (a block split by SOURCE rows, partial sums reduced
- *                           across the wavefronts) instead of the destination-split ones (chain_dest.hip.h, the default since round 5)
+ *   FARNN_NODEST=1          [A/B build only] S <= 72, sum semiring: round 3's compute wavefronts (a block split by SOURCE rows,
+ *                           partial sums reduced across the wavefronts) instead of the destination-split ones (chain_dest.hip.h)
  *   FARNN_NOLABELMAP=1      scores on the matrix cores even when the output matrix is a label map (one state, one label, weight 1)
- *   FARNN_CV_ONE=1          a CRF on the onehot i-FST, S <= 108: recurrence + scores + Viterbi in ONE launch (chain_viterbi_kernel).
- *                           Not the default since round 5: two launches are faster at every measured shape
+ *   FARNN_CV_ONE=1          [A/B build only] a CRF on the onehot i-FST, S <= 108: recurrence + scores + Viterbi in ONE launch
+ *                           (chain_viterbi_kernel).  Two launches are faster at every measured shape
  *   FARNN_WIDE_UNPAIRED=1   72 < S <= 108: one workgroup per compute unit for the wide recurrence (default: two, label-map scores)
- *   FARNN_CV_STASH=1        the one-launch CRF kernel with the state rows through the stash instead of LDS
+ *   FARNN_CV_STASH=1        [A/B build only] the one-launch CRF kernel with the state rows through the stash instead of LDS
  *   FARNN_VITERBI_BP=1 / FARNN_VITERBI_UNFUSED=1   the stored-back-pointer Viterbi kernel / scores through HBM in front of it
  *   FARNN_PREP=1, FARNN_NOSORT=1                   the separate batch-prep kernel / the batch's own launch order
  *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1     the decomposed recurrence's LDS-fed kernels instead of the register forms
