@@ -153,7 +153,8 @@ __device__ __forceinline__ void chain_regs_body(const RegsParams &p, float *smem
 #if defined(FARNN_PROBES)
     __shared__ long long stamps[8];
     const bool quiet = (p.dbg & 2048) != 0;                               // 2048: every workgroup stamps, nobody prints (g_wg_stamps)
-    const bool probe = (nsteps == p.L && p.L >= 32) || quiet;
+    const bool probe = ((p.dbg & 32768) && nsteps == p.L && p.L >= 32) || quiet;   // 32768: the full-length workgroups print their timeline
+                                                                                   // (off by default: the A/B build is also what the A/B forms are timed with)
     if (w == 0) FARNN_RG_STAMP(0);
 #endif
 

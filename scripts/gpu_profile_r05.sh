@@ -75,12 +75,12 @@ done
 # in-kernel probes (profiling build)
 export FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so
 Z="--steps 3 --warmup 2 --no-cpu-baseline --no-pipelined --no-other-configs --no-parity"
-FARNN_FUSE=1 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_one_launch_timeline.txt
+FARNN_DBG=32768 FARNN_FUSE=1 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -16 > $O/probe_chain_regs_one_launch_timeline.txt
 FARNN_FUSE=1 FARNN_DBG=1024 timeout 120 python bench.py $Z 2>/dev/null | grep "^finish\|^meet" | sort | tail -24 > $O/probe_finish_phases_one_launch.txt
-FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases.txt
-FARNN_FUSE=1 FARNN_DBG=256 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_one_launch.txt
-env $AB FARNN_DBG=256 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
-timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_timeline.txt
+FARNN_DBG=33024 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases.txt
+FARNN_FUSE=1 FARNN_DBG=33024 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_one_launch.txt
+env $AB FARNN_DBG=33024 FARNN_NODEST=1 timeout 120 python bench.py $Z 2>/dev/null | grep "chain phases" | sort | tail -8 > $O/probe_chain_regs_step_phases_source_split_r04.txt
+FARNN_DBG=32768 timeout 120 python bench.py $Z 2>/dev/null | grep "^seq" | sort | tail -8 > $O/probe_chain_regs_timeline.txt
 FARNN_DBG=4096 timeout 120 python bench.py --full-length $Z 2>/dev/null | grep "^compact tag.*dir" | sed 's/seq [0-9]*/seq N/' | sort | uniq -c | sort -rn | head -16 > $O/probe_compact_tag.txt
 FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes.txt
 FARNN_DBG=2048 timeout 100 python scripts/debug/ct_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/compact_tag_wg_lifetimes_full_length.txt

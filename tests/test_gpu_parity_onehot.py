@@ -740,14 +740,21 @@ def test_compact_one_launch_on_random_shapes_equals_the_dense_path():
                 W[i, j] = 1.0
                 T[int(rng.randint(V - 1)), i, j] = 1.0
         x, lengths = synth.random_batch(V, B, L, rng, min_len=1)
+        if case % 5 == 0 and B > 1:                          # an empty sequence, an out-of-range word id, a length beyond L (clamped)
+            lengths[B - 1] = 0
+            x[B - 1, :] = V - 1
+            x[0, 0] = V + 7
+            if B > 2:
+                lengths[1] = L + 3
         h = _lib.create_onehot_ifst(T, W, O, h0, hT, nl=nl, o_idx=int(rng.randint(C)))
         xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+        nflat = int(np.clip(lengths, 0, L).sum())
         out = {}
         for compact in (False, True):
             h.set_compact(compact)
             for mode in (_lib.MODE_LOCAL, _lib.MODE_FULL):
                 tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
-                flat = torch.full((int(lengths.sum()),), -7, dtype=torch.int64, device='cuda')
+                flat = torch.full((nflat,), -7, dtype=torch.int64, device='cuda')
                 h.tag(xd.data_ptr(), ld.data_ptr(), B, L, mode, tags.data_ptr(), flat.data_ptr() if mode == _lib.MODE_LOCAL else None, None)
                 torch.cuda.synchronize()
                 out[compact, mode] = (tags.cpu().numpy(), flat.cpu().numpy())
