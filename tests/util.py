@@ -7,7 +7,7 @@ import numpy as np
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 # FARNN_* switches the suite was STARTED under (scripts/gpu_r05_switches.sh runs it once per supported switch): a test's assertions
 # about WHICH kernel ran hold for the default dispatch only; everything about results holds under every switch.
-EXTERNAL_SWITCHES = sorted(k for k in os.environ if k.startswith('FARNN_') and k not in ('FARNN_LIB', 'FARNN_RCCL_LIB') and
+EXTERNAL_SWITCHES = sorted(k for k in os.environ if k.startswith('FARNN_') and k not in ('FARNN_LIB', 'FARNN_RCCL_LIB', 'FARNN_AB_CHILD') and
                            not k.startswith(('FARNN_SOAK', 'FARNN_SHAPE', 'FARNN_D1_SOAK', 'FARNN_BENCH')))
 NO_SWITCH = not EXTERNAL_SWITCHES
 AB_ONLY_SWITCHES = ('FARNN_CV_ONE', 'FARNN_CV_STASH', 'FARNN_NODEST')      # forms compiled into the A/B build only (csrc/build.py --probes)
