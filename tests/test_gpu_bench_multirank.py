@@ -80,6 +80,8 @@ def test_bench_default_line_carries_every_single_gpu_config():
             return 0 < rf['frac_all_l2'] <= 1.0 and (rf['frac'] <= 1.0 or rf.get('model_falsified') is True) and 'split_peak_exceeded' not in rf
         return rf['frac'] <= 1.0
     assert rf['launches_timed'] >= 8 and frac_ok(rf) and rf['bound'] in ('infinity_cache', 'hbm'), rf
+    lp = rf['l1_pipeline']              # the measured bound beside the bandwidth reading: a floor, at the device's maximum clock
+    assert lp['cycles_per_workgroup_step'] == 16 * 24 + 71 * 72 * 4 / 64 and 0.5 < lp['frac'] <= 1.0 and lp['floor_us'] < rf['kernel_avg_us'], lp
     assert d['parity']['tags_equal'] is True
     assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
     names = [o['workload'] for o in d['other_configs']]
