@@ -20,7 +20,7 @@ constexpr int NI = 256;     // instructions per timed block (R64 of a 4-instruct
 
 enum {
     T_VADD_DEP = 0, T_VADD_D2, T_VADD_D4, T_VADD_D8, T_FMA_DEP, T_AND_BCNT_DEP, T_AND_BCNT_ILP, T_SALU_DEP, T_VCMP_SALU_VALU,
-    T_READLANE_ROUND, T_DPP_DEP, T_DPP_D2, T_PKFMA_DEP, T_CVT_MUL_DEP, T_BRANCH_TAKEN, T_LDS_ROUND, T_LDS_WRITE_READ, T_COUNT
+    T_READLANE_ROUND, T_DPP_DEP, T_DPP_D2, T_PKFMA_DEP, T_CVT_MUL_DEP, T_BRANCH_TAKEN, T_LDS_ROUND, T_LDS_WRITE_READ, T_MULLO_DEP, T_MULLO_D4, T_EXP_RCP, T_COUNT
 };
 static const char *names[T_COUNT] = {
     "v_add_f32, each consumes the previous result",
@@ -40,6 +40,9 @@ static const char *names[T_COUNT] = {
     "s_branch to the next instruction (taken branch)",
     "ds_read_b32 -> address of the next (dependent LDS round trip)",
     "ds_write_b32 + ds_read_b32 of it + use (store / load / consume round)",
+    "v_mul_lo_u32, each consumes the previous result",
+    "v_mul_lo_u32, dependency distance 4",
+    "v_exp_f32 -> v_rcp_f32 round (2 instructions)",
 };
 
 __global__ void __launch_bounds__(512) probe(long long *out, int test, int reps) {
@@ -107,6 +110,12 @@ __global__ void __launch_bounds__(512) probe(long long *out, int test, int reps)
             unsigned a = (unsigned)(size_t)(void *)word;
             asm volatile(R64("ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)\n") : "+v"(a) :: "memory");
             u1 = a; break; }
+        case T_MULLO_DEP:
+            asm volatile(R64("v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %0, %0, %1\n v_mul_lo_u32 %0, %0, %1\n") : "+v"(u1) : "v"(u0)); break;
+        case T_MULLO_D4:
+            asm volatile(R64("v_mul_lo_u32 %0, %0, %4\n v_mul_lo_u32 %1, %1, %4\n v_mul_lo_u32 %2, %2, %4\n v_mul_lo_u32 %3, %3, %4\n") : "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4) : "v"(u0)); break;
+        case T_EXP_RCP:
+            asm volatile(R64("v_exp_f32 %0, %0\n v_rcp_f32 %0, %0\n v_exp_f32 %0, %0\n v_rcp_f32 %0, %0\n") : "+v"(v0)); break;
         case T_LDS_WRITE_READ: {
             unsigned a = (unsigned)(size_t)(void *)word + 4 * (lane & 31) + 64;
             asm volatile(R64("ds_write_b32 %1, %0\n ds_read_b32 %0, %1\n s_waitcnt lgkmcnt(0)\n v_add_f32 %0, %0, %2\n") : "+v"(v0) : "v"(a), "v"(v1) : "memory");
