@@ -92,8 +92,13 @@ FARNN_DBG=2048 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdg
 env $AB FARNN_DBG=2048 FARNN_NODEST=1 timeout 100 python scripts/debug/wg_stamps.py 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_recurrence_only_source_split_r04.txt
 FARNN_DBG=2048 FARNN_FUSE=1 timeout 100 python scripts/debug/wg_stamps.py --full-length 2>&1 | grep -v amdgpu.ids > $O/wg_lifetimes_one_launch_full_length.txt
 unset FARNN_LIB
+for pb in fastmath_ulp issue_rate ta_rate; do      # (built artefacts, not tracked: built here when the snapshot came without them)
+  [ -x scripts/probe/$pb.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I re2nn-seq_amd/csrc scripts/probe/$pb.hip -o scripts/probe/$pb.bin > /dev/null 2>&1
+done
 timeout 60 scripts/probe/fastmath_ulp.bin > $O/fastmath_ulp.txt 2>&1
 timeout 100 scripts/probe/issue_rate.bin > $O/issue_rate.txt 2>&1
+timeout 200 scripts/probe/ta_rate.bin > $O/ta_rate.txt 2>&1
+timeout 300 python scripts/debug/pool_probe.py 2>&1 | grep -v amdgpu.ids > $O/pool_probe.txt
 # keep only the small summaries (kernel_stats + counter collection), drop per-dispatch traces > 4 MB
 find $O -name '*.csv' -size +4M -delete
 find $O -name '*kernel_trace.csv' -delete
