@@ -90,6 +90,125 @@ OTHER_CONFIGS = (('ifst_crf', 2000, 50, {}, 'ifst_crf'),
 NATIVE_COMM = [None]        # --gather native: this rank's communicator (re2nn_seq_amd._rccl.Communicator)
 
 
+# ------------------------------------------------------------------------------------------ the result line
+LINE_CAP = 4096            # bytes: the ONE result line (round 5's grew to 20 KB and the driver could not parse it)
+OTHER_LINE_CAP = 640       # bytes: each `{"other_config": ...}` line printed before it
+FULL_PATH = os.path.join('gpurun_out', 'bench_full.json')
+
+
+def _sig(v, n=6):
+    """floats to n significant digits, recursively (the line is read by people and parsers, not diffed bit for bit)"""
+    if isinstance(v, bool) or v is None:
+        return v
+    if isinstance(v, float):
+        return float('{:.{}g}'.format(v, n)) if v == v and abs(v) != float('inf') else None
+    if isinstance(v, dict):
+        return {k: _sig(x, n) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_sig(x, n) for x in v]
+    return v
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d and d[k] is not None}
+
+
+ROOFLINE_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_avg_us', 'launches_timed', 'chain_avg_us',
+                 'score_decode_avg_us', 'frac_all_l2', 'model_falsified', 'frac_split', 'peak_split', 'hbm_frac_measured',
+                 'algorithmic_bytes_per_launch', 'algorithmic_flops_per_launch', 'step_latency_us', 'traffic_head')
+
+
+def slim_roofline(rf):
+    out = _pick(rf, ROOFLINE_KEYS)
+    out.setdefault('traffic', None)
+    if len(str(out.get('kernel', ''))) > 64:
+        out['kernel'] = out['kernel'][:61] + '...'
+    if isinstance(rf.get('l1_pipeline'), dict):
+        out['l1_pipeline'] = _pick(rf['l1_pipeline'], ('floor_us', 'frac'))
+    return out
+
+
+def other_config_line(r):
+    """One `{"other_config": label, ...}` line per side measurement, printed BEFORE the result line (every number of it is
+    in gpurun_out/bench_full.json too)."""
+    if 'error' in r:
+        return json.dumps({'other_config': r.get('workload'), 'error': str(r['error'])[:300]})
+    rf, par = r.get('roofline', {}), r.get('parity', {})
+    d = {'other_config': r.get('workload'), 'value': r.get('value'), 'unit': r.get('unit'), 'ms_per_step': r.get('ms_per_step'),
+         'steps': r.get('steps'), 'valid_tokens_per_step': r.get('config', {}).get('valid_tokens_per_step'),
+         'roofline': _pick(slim_roofline(rf), ('bound', 'frac', 'achieved', 'peak', 'unit', 'kernel', 'chain_avg_us', 'score_decode_avg_us',
+                                               'frac_all_l2', 'model_falsified', 'frac_split', 'step_latency_us')),
+         'parity': _pick(par, ('tags_equal', 'tags_compared', 'sequences_checked', 'max_score_err'))}
+    line = json.dumps(_sig(d, 5))
+    if len(line) > OTHER_LINE_CAP:
+        d['roofline'] = _pick(d['roofline'], ('bound', 'frac', 'frac_all_l2', 'model_falsified', 'frac_split', 'chain_avg_us', 'score_decode_avg_us'))
+        line = json.dumps(_sig(d, 5))
+    return line
+
+
+def result_line(out):
+    """The ONE JSON line of the contract, <= LINE_CAP bytes: the contract's keys, `roofline` and `cpu_baseline` as numbers (the
+    prose about them lives in DESIGN.md section 6), one-number summaries of the side measurements.  Everything that was measured
+    goes to gpurun_out/bench_full.json (and, for the other configs, to their own earlier lines)."""
+    d = _pick(out, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling'))
+    d['vs_baseline'] = out.get('vs_baseline')
+    d.update(_pick(out, ('dtype', 'data')))
+    cfg = dict(out.get('config', {}))
+    if len(str(cfg.get('workload', ''))) > 200:
+        cfg['workload'] = cfg['workload'][:197] + '...'
+    d['config'] = cfg
+    d['roofline'] = slim_roofline(out.get('roofline', {}))
+    cb = out.get('cpu_baseline')
+    if cb:
+        d['cpu_baseline'] = _pick(cb, ('value', 'unit', 'cores', 'kind', 'host_threads', 'cpu_quota_cores'))
+        d['cpu_baseline']['sample'] = str(cb.get('sample', ''))[:160]
+    if out.get('cpu_baseline_faithful'):
+        d['cpu_baseline_faithful'] = _pick(out['cpu_baseline_faithful'], ('value', 'unit', 'cores', 'kind'))
+    if out.get('parity'):
+        d['parity'] = _pick(out['parity'], ('tags_equal', 'tags_compared', 'sequences_checked', 'max_score_err', 'batch_checked'))
+    if out.get('gather'):
+        d['gather'] = {k: (str(v)[:96] if isinstance(v, str) else v) for k, v in out['gather'].items()}
+    optional = []
+    if out.get('compact'):
+        d['compact'] = _pick(out['compact'], ('value', 'ms_per_step', 'kernel_avg_us', 'bytes_per_token', 'tags_equal_dense'))
+        optional.append('compact')
+    if out.get('pipelined'):
+        d['pipelined'] = _pick(out['pipelined'], ('streams', 'value', 'ms_per_step'))
+        optional.append('pipelined')
+    if out.get('host_inclusive'):
+        d['host_inclusive'] = _pick(out['host_inclusive'], ('value', 'us_per_batch', 'same_predictions'))
+        optional.append('host_inclusive')
+    if out.get('other_configs'):
+        # label -> ms per step (the full result of each is its own earlier line); errors by name
+        d['other_configs_ms_per_step'] = {o.get('workload'): (o.get('ms_per_step') if 'error' not in o else 'error') for o in out['other_configs']}
+        d['other_configs_parity'] = all(o.get('parity', {}).get('tags_equal') is True for o in out['other_configs'] if 'error' not in o) \
+            and not any('error' in o for o in out['other_configs'])
+        optional.append('other_configs_ms_per_step')
+    if out.get('full'):
+        d['full'] = out['full']
+    line = json.dumps(_sig(d))
+    for k in ['cpu_baseline_faithful'] + optional[::-1]:       # never needed at today's sizes; the cap holds whatever is added later
+        if len(line) <= LINE_CAP:
+            break
+        d.pop(k, None)
+        line = json.dumps(_sig(d))
+    if len(line) > LINE_CAP:
+        raise AssertionError('bench.py: result line of {} bytes exceeds the {} byte cap'.format(len(line), LINE_CAP))
+    return line
+
+
+def write_full(out):
+    """the whole measurement (every note, every side result) beside the line: gpurun_out/ is merged back from the GPU box"""
+    try:
+        path = os.path.join(ROOT, FULL_PATH)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, 'w') as f:
+            json.dump(out, f, indent=1)
+        return FULL_PATH
+    except OSError:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -608,8 +727,8 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
                 # 8 TB/s and printed 1.01.
                 t_floor = traffic / (HBM_PEAK_GBS * 1e9) + (alg - traffic) / (L2_GATHER_GBS * 1e9)
                 peak = alg / t_floor / 1e9
-                rf['peak_note'] = ('{:.1f} GB per launch come from HBM (measured, 8.0 TB/s), {:.1f} GB are re-reads served by '
-                                   'L2 / Infinity Cache (priced at the 16.8 TB/s L2 gather rate)'.format(traffic / 1e9, (alg - traffic) / 1e9))
+                rf['peak_note'] = ('{:.1f} GB per launch leave L2 (fabric-side counter: Infinity-Cache hits included; priced at the 8.0 TB/s '
+                                   'HBM peak), {:.1f} GB are L2 hits (16.8 TB/s L2 gather rate)'.format(traffic / 1e9, (alg - traffic) / 1e9))
             rf.update(bound='hbm', peak=peak)
         else:
             # no traffic measurement for this shape: every row could be an L2 hit, so price against the L2 gather rate
@@ -622,16 +741,15 @@ def roofline_for(name, a, h, extras, tok_local, chain_avg_s, score_avg_s, n_time
                 rf['peak_note'] = ('working set {:.0f} MB is L2/Infinity-Cache resident: {:.0f} MB per launch leave L2 '
                                    '(measured, Infinity-Cache gather 8.6 TB/s), the other {:.0f} MB are L2 hits (L2 gather '
                                    '16.8 TB/s); HBM is not on the path'.format(ws / 1e6, traffic / 1e6, (alg - traffic) / 1e6))
-            # ONE rule, fixed before the run: `peak` is the modelled split (or the L2 gather rate where no split was measured) and
-            # stays that whatever the kernel does.  A kernel that beats it (frac > 1) says something about the guide's rates -- they
-            # are measured on ONE loop shape (72 KiB in flight per CU), and fills from the Infinity Cache overlap with L2 hits
-            # here -- not about the ceiling to quote: the line carries `model_falsified` and, like every cache-resident line,
-            # `frac_all_l2` (all bytes at the L2 gather rate: the stricter reading of the same data).
+            # ONE rule, fixed before the run: `peak` is the modelled split (or the L2 gather rate where no
+            # split was measured).  A kernel that beats the split falsifies the MODEL (the guide's rates are measured on one loop
+            # shape, and fills from the Infinity Cache overlap with L2 hits here), not the hardware: the line then says
+            # `model_falsified` and prices EVERY byte at the L2 gather rate -- `peak` / `frac` are that stricter reading, the split
+            # stays beside them as `peak_split` / `frac_split`.  No line prints a fraction above 1.
+            rf['frac_all_l2'] = achieved / L2_GATHER_GBS
             if achieved > peak:
-                rf['model_falsified'] = True
-                rf['peak_note'] += ('; the kernel BEATS this ceiling (its floor is above the measured time): a finding about the '
-                                    'guide\'s gather rates, which are lower bounds of one loop shape -- read frac_all_l2')
-            rf['frac_all_l2'] = achieved / L2_GATHER_GBS      # every byte at the L2 gather rate: the stricter reading of the same data
+                rf.update(model_falsified=True, peak_split=peak, frac_split=achieved / peak)
+                peak = L2_GATHER_GBS
             rf.update(bound='infinity_cache', peak=peak)
         if traffic is not None:
             rf['hbm_frac_measured'] = traffic / dom_s / 1e9 / HBM_PEAK_GBS
@@ -799,7 +917,7 @@ def run_train(a, world, rank, dev, dist):
         }
         if world == 1 and not a.no_cpu_baseline and not a.crf and not a.farnn:
             out['cpu_baseline'] = train_cpu_baseline(p, beta, x, lengths, labels, a.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        print(result_line(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1168,8 +1286,10 @@ def main():
                 except Exception as e:          # a side measurement must not take the headline line down
                     r = {'workload': name, 'error': '{}: {}'.format(type(e).__name__, e)}
                 others.append(r)
+                print(other_config_line(r), flush=True)       # its own line, BEFORE the result line
             out['other_configs'] = others
-        print(json.dumps(out), flush=True)
+        out['full'] = write_full(out)
+        print(result_line(out), flush=True)                   # the ONE result line: last on stdout, <= LINE_CAP bytes
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

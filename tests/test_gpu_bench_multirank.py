@@ -61,39 +61,51 @@ def test_bench_refuses_a_world_size_mismatch():
 
 
 def test_bench_default_line_carries_every_single_gpu_config():
-    """The default invocation: headline = configs[1] with a roofline fraction against the ceiling that bounds it (ONE rule,
-    fixed before the run: a cache-resident line that beats its modelled split says `model_falsified` and carries
-    `frac_all_l2`; the ceiling is never swapped), a post-run oracle check, both CPU baselines, and the other single-GPU
-    configs with their own checks."""
+    """The default invocation, as the round driver runs it: the LAST stdout line is the ONE result line (<= 4 KB: round 5's
+    20 KB line was unparseable) -- headline = configs[1] with a roofline fraction against the ceiling that bounds it (ONE rule,
+    fixed before the run: a cache-resident kernel that beats its modelled split says `model_falsified` and is priced at the L2
+    gather rate for every byte: no fraction above 1), a post-run oracle check, both CPU baselines; the other single-GPU configs
+    are `{"other_config": ...}` lines before it, and everything is in gpurun_out/bench_full.json."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
     for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '20', '--warmup', '5',
                         '--cpu-seconds', '2'], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines[-1]) <= 4096 and lines[-1].startswith('{"metric"'), len(lines[-1])
+    assert sum(ln.startswith('{"metric"') for ln in lines) == 1
+    assert len(r.stdout) < 8000, len(r.stdout)             # the whole of stdout fits the tail the driver keeps
+    d = json.loads(lines[-1])
     rf = d['roofline']
+
     def frac_ok(rf):
-        if not 0 < rf['frac']:
+        if not 0 < rf['frac'] <= 1.0:
             return False
-        if rf['bound'] == 'infinity_cache':              # cache-resident: both readings on the line, the ceiling never swapped
-            return 0 < rf['frac_all_l2'] <= 1.0 and (rf['frac'] <= 1.0 or rf.get('model_falsified') is True) and 'split_peak_exceeded' not in rf
-        return rf['frac'] <= 1.0
+        if rf['bound'] == 'infinity_cache':              # cache-resident: the stricter reading is the line's `frac` once the split is beaten
+            return 0 < rf['frac_all_l2'] <= 1.0 and (rf.get('model_falsified') is not True or rf['frac_split'] > 1.0)
+        return True
     assert rf['launches_timed'] >= 8 and frac_ok(rf) and rf['bound'] in ('infinity_cache', 'hbm'), rf
-    lp = rf['l1_pipeline']              # the measured bound beside the bandwidth reading (DESIGN.md, K1d): a floor, at the device's maximum clock
-    assert lp['cycles_per_workgroup_step'] == 16 * 24 + 71 * 72 * 4 / 64 and 0.5 < lp['frac'] <= 1.0 and lp['floor_us'] < rf['kernel_avg_us'], lp
+    assert rf['kernel_avg_us'] > 0 and d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1
+    assert rf['l1_pipeline']['floor_us'] > 0            # the measured bound beside the bandwidth reading (DESIGN.md, K1d); no range assertion: clock-dependent
     assert d['parity']['tags_equal'] is True
-    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline_faithful']['value'] > 0
-    names = [o['workload'] for o in d['other_configs']]
+    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['cores'] >= 1 and d['cpu_baseline_faithful']['value'] > 0
+    others = [json.loads(ln) for ln in lines[:-1]]
+    names = [o['other_config'] for o in others]
     assert names == ['ifst_crf', 'ifst_s104', 'ifst_crf_s104', 'decomp', 'decomp_r250_farnn2',
                      'decomp_r250_farnn2_crf', 'decomp_r250_farnn2_crf_bz200_len30', 'decomp_r150_farnn2_crf_s134_bz200_len30', 'fst4', 'synth512_shard_b1024_len128']
-    kern = {o['workload']: o['roofline']['kernel'] for o in d['other_configs']}
-    assert 'chain_wide_kernel<fused' in kern['ifst_s104']                # the reference's 104-state automata: the wide form, ONE launch
-    assert 'chain_viterbi_kernel' not in kern['ifst_crf']                # config 4: two launches (the one-launch form lives in the A/B build: scripts/gpu_profile_r05.sh times it there)
-    for o in d['other_configs']:
+    assert list(d['other_configs_ms_per_step']) == names and d['other_configs_parity'] is True
+    for o in others:
         assert 'error' not in o, o
         assert o['value'] > 0 and o['parity']['tags_equal'] is True, o
         assert frac_ok(o['roofline']), o['roofline']
+    with open(os.path.join(ROOT, 'gpurun_out', 'bench_full.json')) as f:
+        full = json.load(f)
+    kern = {o['workload']: o['roofline']['kernel'] for o in full['other_configs']}
+    assert 'chain_wide_kernel<fused' in kern['ifst_s104']                # the reference's 104-state automata: the wide form, ONE launch
+    assert 'chain_viterbi_kernel' not in kern['ifst_crf']                # config 4: two launches (the one-launch form lives in the A/B build)
+    assert full['roofline']['l1_pipeline']['cycles_per_workgroup_step'] == 16 * 24 + 71 * 72 * 4 / 64
+    assert abs(full['value'] - d['value']) <= 1e-5 * d['value']
 
 
 def test_bench_config5_path_two_ranks_dry_run():
