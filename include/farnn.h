@@ -28,7 +28,9 @@
  * touches the environment).  Every one selects between code paths that the test suite holds to the same results.  Those marked
  * [A/B build only] select forms the production library does not carry (its dispatch never picks them: 54 kernels): they exist in
  * the A/B build (csrc/build.py --probes -> libfarnn_hip_probes.so, loaded through FARNN_LIB; farnn_ab_build() says which one is
- * loaded), and the production library answers them with FARNN_EINVAL and a message that says so:
+ * loaded), and farnn_*_create of the production library answers them with FARNN_EINVAL and a message that says so (like every
+ * switch they are resolved when the handle is created, never at tag time); switches of earlier rounds that no longer exist
+ * (FARNN_CV_WIDE, FARNN_DECOMP_OLD) are refused the same way by both builds:
  *   FARNN_NOFUSE=1          the multi-launch forms (recurrence kernel, then score / Viterbi kernel) instead of one launch per step
  *                           (also: the compact form's two launches instead of compact_tag_kernel)
  *   FARNN_FUSE=1            onehot i-FST, S <= 72, label-map scores: ONE launch per step for any batch size (the default there: one launch

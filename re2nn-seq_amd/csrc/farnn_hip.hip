@@ -1036,10 +1036,6 @@ static int launch_chain_and_decode(farnn_model *m, const int64_t *x, const int64
             m->last_regs = true; m->last_fused = true;
             return FARNN_OK;
         }
-#else
-        if (tun(TUN_CV_ONE))
-            return fail(FARNN_EINVAL, "FARNN_CV_ONE=1: the one-launch CRF step is compiled into the A/B build only "
-                                      "(FARNN_LIB=.../libfarnn_hip_probes.so, csrc/build.py --probes)%s%s");
 #endif
         if ((rc = launch_chain(m, x, len, B, L, full, s))) return rc;
     }

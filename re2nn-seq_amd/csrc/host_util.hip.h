@@ -9,18 +9,36 @@
 
 namespace farnn {
 
+inline int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// Switches a create call refuses instead of ignoring (include/farnn.h): forms that live in the A/B build only, asked of the
+// production library, and switches of earlier rounds that no longer exist.  Checked where the switches are read: once per
+// handle, in farnn_*_create / farnn_train_create -- never on the tagging path.
+inline int check_env_switches() {
+#if !defined(FARNN_AB)
+    for (const char *name : {"FARNN_CV_ONE", "FARNN_CV_STASH", "FARNN_NODEST"})
+        if (env_int(name, 0))
+            return fail(FARNN_EINVAL, "%s is set: that form is compiled into the A/B build only (csrc/build.py --probes; load it with "
+                                      "FARNN_LIB=.../libfarnn_hip_probes.so)%s", name);
+#endif
+    for (const char *name : {"FARNN_CV_WIDE", "FARNN_DECOMP_OLD"})
+        if (env_int(name, 0))
+            return fail(FARNN_EINVAL, "%s is set: that switch was removed (round 5; include/farnn.h lists the supported ones)%s", name);
+    return FARNN_OK;
+}
+
+// first step of every farnn_*_create / farnn_train_create: refuse unsupported switches, then make `device` current
 inline int select_device(int device) {
+    if (int rc = check_env_switches()) return rc;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
         return fail(FARNN_ENODEV, "no HIP device visible%s%s");
     if (device < 0 || device >= n) return fail(FARNN_EINVAL, "device index out of range%s%s");
     FARNN_HIP_TRY(hipSetDevice(device));
     return FARNN_OK;
-}
-
-inline int env_int(const char *name, int dflt) {
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
 }
 
 // ---- the FARNN_* environment switches -------------------------------------------------------------------------------
@@ -31,9 +49,11 @@ inline int env_int(const char *name, int dflt) {
 #define FARNN_TUNABLES(X)                                                                                      \
     /* supported */                                                                                            \
     X(NOFUSE, 0, true) X(FUSE, 0, true) X(NOREGS, 0, true) X(NOLABELMAP, 0, true) X(PREP, 0, true) X(NOSORT, 0, true)           \
-    X(VITERBI_BP, 0, true) X(VITERBI_UNFUSED, 0, true) X(CV_STASH, 0, true) X(DECOMP_NOREGS, 0, true)          \
+    X(VITERBI_BP, 0, true) X(VITERBI_UNFUSED, 0, true) X(DECOMP_NOREGS, 0, true)                               \
     X(ROWS_NOREGS, 0, true) X(TRAIN_NOLDS, 0, true) X(TRAIN_NSEQ, 0, true)              \
-    X(CV_ONE, 0, true) X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true) X(NODEST, 0, true)                       \
+    X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true)                                                            \
+    /* A/B build only (the production library refuses them at create: check_env_switches) */                   \
+    X(CV_ONE, 0, false) X(CV_STASH, 0, false) X(NODEST, 0, false)                                              \
     /* diagnostic: profiling build only */                                                                     \
     X(DBG, 0, false) X(KS, 3, false) X(RPG, 12, false) X(NLD, 4, false) X(NOFAST, 0, false)                    \
     X(CHAIN_HELPER, 0, false) X(HOST_EPOCH, 0, false) X(CV_NOSORT, 0, false) X(NOKZ, 0, false)                 \

@@ -416,13 +416,156 @@ def snips_sized_model(R, farnn, crf, seed=1234, S=104, V=11000, C=73):
     return V, q, gates, tr
 
 
-def atis_sized_crf_model(seed=1234, V=950, S=71, C=128):
+def planted_rule_ifst(seed=1234, V=11000, S=104, C=73, max_pairs=250, max_rule_len=5, words_per_pair=(5, 60)):
+    """A rule automaton at SNIPS-BIO size in edge-list form, with an EXACT rank-`max_pairs` CP form (the layout of
+    decompose_automata.py:373-431: one rank-1 term per (from-state, to-state) pair -- V_embed[:, r] = 1[word in the pair's
+    set], S1[:, r] = 1[from], S2[:, r] = 1[to], wildcard_mat = W): the decomposed i-FST built from these factors computes,
+    with update_nonlinear = none, exactly the path counts of the onehot i-FST of the same automaton.
+
+    State 0: start, final, wildcard self loop (`oo`).  State S-1: accepting sink, wildcard self loop (`oo`).  States 1..S-2:
+    rule chains 0 -> q1 -> ... -> qk (k = 1..max_rule_len) whose states carry one BIO label each (the i-FST property: the label
+    sits on the destination state, fsa_to_tensor.py:586); qk is final and moves to the sink on any token (a wildcard edge), and
+    the sink re-enters every chain on the chain's first word set, so a sentence can match several rules; skip edges
+    q_i -> q_{i+2} fill the pair budget.  The outgoing pairs of one state have disjoint word sets.
+
+    Returns a dict: edge list (word, frm, to: int32; word = -1 for wildcard edges), `state_label` [S] (the label column of every
+    state; C-1 = `oo`), h0, hT, W [S,S], O [C,S], `pairs` [(from, to)], `pair_words` (list of int arrays), `chains` (list of
+    lists of (pair index, state)), and the exact factors Vgen [V,R], S1 [S,R], S2 [S,R] with R = max_pairs."""
+    rng = np.random.RandomState(seed)
+    sink = S - 1
+    n_ent = (C - 2) // 2                          # labels: 0 = 'o', 1 + 2e = b-e, 2 + 2e = i-e; column C-1 = `oo`
+    state_label = np.full(S, C - 1, np.int64)
+    chains, pairs, pair_of = [], [], {}
+    nxt = 1
+
+    def pair(a, b):
+        if (a, b) not in pair_of:
+            pair_of[(a, b)] = len(pairs)
+            pairs.append((a, b))
+        return pair_of[(a, b)]
+
+    while nxt < sink:
+        k = min(int(rng.randint(1, max_rule_len + 1)), sink - nxt)
+        e = int(rng.randint(n_ent))
+        n_ctx = int(rng.randint(0, 2)) if k > 1 else 0           # a leading context state tagged 'o'
+        chain, prev = [], 0
+        for pos in range(k):
+            q = nxt; nxt += 1
+            state_label[q] = 0 if pos < n_ctx else (1 + 2 * e if pos == n_ctx else 2 + 2 * e)
+            chain.append((pair(prev, q), q))
+            prev = q
+        chains.append(chain)
+    first_pairs = [c[0][0] for c in chains]
+    reentry = {c[0][1]: pair(sink, c[0][1]) for c in chains}     # sink -> q1: the same word set as 0 -> q1
+    skips = [(c[i][1], c[i + 2][1]) for c in chains for i in range(len(c) - 2)]
+    for idx in rng.permutation(len(skips)):
+        if len(pairs) >= max_pairs:
+            break
+        pair(*skips[idx])
+    assert len(pairs) <= max_pairs, (len(pairs), max_pairs)
+    # word sets: disjoint among the outgoing pairs of a state; a chain's first set is shared by its entry from 0 and from the sink
+    pair_words = [None] * len(pairs)
+    by_from = {}
+    for r, (a, b) in enumerate(pairs):
+        by_from.setdefault(a, []).append(r)
+    for a, rs in by_from.items():
+        if a == sink:
+            continue
+        sizes = rng.randint(words_per_pair[0], words_per_pair[1] + 1, size=len(rs))
+        pool = rng.permutation(V - 1)[:int(sizes.sum())]
+        at = 0
+        for r, n in zip(rs, sizes):
+            pair_words[r] = np.sort(pool[at:at + n]).astype(np.int64)
+            at += n
+    for c in chains:
+        pair_words[reentry[c[0][1]]] = pair_words[c[0][0]]
+    word = np.concatenate([pair_words[r] for r in range(len(pairs))])
+    frm = np.concatenate([np.full(len(pair_words[r]), pairs[r][0]) for r in range(len(pairs))])
+    to = np.concatenate([np.full(len(pair_words[r]), pairs[r][1]) for r in range(len(pairs))])
+    W = np.zeros((S, S), np.float32)
+    W[0, 0] = 1.0; W[sink, sink] = 1.0
+    hT = np.zeros(S, np.float32); hT[0] = 1.0; hT[sink] = 1.0
+    for c in chains:
+        W[c[-1][1], sink] = 1.0
+        hT[c[-1][1]] = 1.0
+    h0 = np.zeros(S, np.float32); h0[0] = 1.0
+    O = np.zeros((C, S), np.float32)
+    O[state_label, np.arange(S)] = 1.0
+    R = int(max_pairs)
+    Vgen = np.zeros((V, R), np.float32); S1 = np.zeros((S, R), np.float32); S2 = np.zeros((S, R), np.float32)
+    for r, (a, b) in enumerate(pairs):
+        Vgen[pair_words[r], r] = 1.0
+        S1[a, r] = 1.0
+        S2[b, r] = 1.0
+    wa, wb = np.nonzero(W)
+    return {'V': V, 'S': S, 'C': C, 'word': np.concatenate([word, np.full(len(wa), -1)]).astype(np.int32),
+            'frm': np.concatenate([frm, wa]).astype(np.int32), 'to': np.concatenate([to, wb]).astype(np.int32),
+            'state_label': state_label, 'h0': h0, 'hT': hT, 'W': W, 'O': O, 'pairs': pairs, 'pair_words': pair_words,
+            'chains': chains, 'first_pairs': first_pairs, 'Vgen': Vgen, 'S1': S1, 'S2': S2}
+
+
+def planted_rule_batch(A, B, L, seed, min_len=5, fill=0.8, max_rules=9):
+    """A bench-shaped batch (lengths U[min_len, L], one full-length row, Zipf filler tokens, pad id V-1) in which rules of the
+    automaton `A` (planted_rule_ifst) really fire: in about `fill` of the sequences chains are planted back to back (one
+    filler token between two of them: the wildcard move into the sink), at most `max_rules` per sequence (the number of
+    accepting paths doubles with every planted rule; nine keep every count far below 2**24)."""
+    rng = np.random.RandomState(seed)
+    V = A['V']
+    x, lengths = random_batch(V, B, L, rng, min_len=min_len)
+    for b in range(B):
+        if rng.rand() >= fill:
+            continue
+        n = int(lengths[b])
+        t = int(rng.randint(0, 4))
+        for _ in range(max_rules):
+            c = A['chains'][int(rng.randint(len(A['chains'])))]
+            if t + len(c) > n:
+                break
+            for r, _q in c:
+                ws = A['pair_words'][r]
+                x[b, t] = ws[int(rng.randint(len(ws)))]
+                t += 1
+            t += 1 + int(rng.randint(0, 2))            # the token(s) the sink consumes before the next rule
+    return x, lengths
+
+
+def exact_case_transitions(C, rng, scale=0.3):
+    """CRF transitions over C labels + START / STOP for the automaton-derived decomposed model: CRF.__init__'s defaults
+    (crf.py:31-46) plus noise small enough that the emission scores still decide most positions"""
+    K = C + 2
+    tr = np.zeros((K, K), np.float32)
+    tr[:, K - 2] = -10000.0
+    tr[K - 1, :] = -10000.0
+    return tr + (rng.randn(K, K) * scale).astype(np.float32)
+
+
+def exact_case_gates(S, R, farnn, rng):
+    """GRU-style gates as the reference initialises them around an automaton's factors (model_decompose_single.py:93-123: small
+    weights, a positive bias -- the gates start nearly open)"""
+    f = lambda a: np.asarray(a, np.float32)                       # noqa: E731
+    g = {'Wss1': f(rng.randn(S, S) * 0.03), 'Wrs1': f(rng.randn(R, S) * 0.03), 'bs1': f(np.full(S, 1.0))}
+    if farnn == 2:
+        g.update(Wss2=f(rng.randn(S, S) * 0.03), Wrs2=f(rng.randn(R, S) * 0.03), bs2=f(np.full(S, 1.0)))
+    return g
+
+
+def dense_from_edges(A):
+    """the dense [V,S,S] language tensor of a planted_rule_ifst automaton (476 MB of float32 at SNIPS size: generator and
+    oracle side only)"""
+    T = np.zeros((A['V'], A['S'], A['S']), np.float32)
+    m = A['word'] >= 0
+    T[A['word'][m], A['frm'][m], A['to'][m]] = 1.0
+    return T
+
+
+def atis_sized_crf_model(seed=1234, V=950, S=71, C=128, tr_scale=0.1):
     """BASELINE configs[3] as `bench.py --workload ifst_crf` builds it: the onehot i-FST and the transitions of a CRF over
-    its C labels + START / STOP."""
+    its C labels + START / STOP (`tr_scale`: the spread of the transition scores; the bench-size fixture uses a larger one so
+    that the decoded path really differs from the per-position arg-max)."""
     wrng = np.random.RandomState(seed)
     T, W, O, h0, hT = random_ifst_tensors(V, S, C, wrng)
     K = C + 2
-    tr = (wrng.randn(K, K) * 0.1).astype(np.float32)
+    tr = (wrng.randn(K, K) * tr_scale).astype(np.float32)
     tr[:, K - 2] = -10000.0
     tr[K - 1, :] = -10000.0
     return T, W, O, h0, hT, tr

@@ -116,11 +116,34 @@ def run_onehot(T, W, O, h0, hT, x, lengths):
     return scores, pred.numpy(), re_pred.numpy()
 
 
+CRF_TR_SCALE = 0.14         # spread of the transition scores of bench_crf (bench.py times 0.1): 0.13 moves 7 % of the positions off the per-position arg-max, 0.14 makes a cycle of transitions pay against the 0.5 margin of `O`: 46 %
+
+
+def plant_accepting_walks(T, x, lengths, rng, every=2):
+    """rules fire in every `every`-th sequence: from a random position on, the tokens walk the automaton from state 0"""
+    succ = {}
+    for w, s_, j in zip(*np.nonzero(T)):
+        succ.setdefault(int(s_), []).append((int(w), int(j)))
+    for b in range(0, x.shape[0], every):
+        n = int(lengths[b]); at = int(rng.randint(0, max(1, n - 4))); st = 0
+        for t in range(at, n):
+            if st not in succ:
+                break
+            w, st = succ[st][int(rng.randint(len(succ[st])))]
+            x[b, t] = w
+    return x
+
+
 def gen_bench_crf():
-    T, W, O, h0, hT, tr = synth.atis_sized_crf_model()
+    """Round 6: accepting walks planted in every second sequence (round 5's plain random batch decoded to 97 % `O`: the K = 130
+    dynamic programme was checked almost only on all-O paths) and transitions spread wide enough that the Viterbi path differs
+    from the per-position arg-max at >= 5 % of the positions (printed, stored, asserted)."""
+    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(tr_scale=CRF_TR_SCALE)
     V, S, C = T.shape[0], T.shape[1], O.shape[0]
-    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(BATCH_SEED))
-    scores, _, _ = run_onehot(T, W, O, h0, hT, x, lengths)
+    rng = np.random.RandomState(BATCH_SEED)
+    x, lengths = synth.random_batch(V, B, L, rng)
+    x = plant_accepting_walks(T, x, lengths, rng)
+    scores, pred_argmax, _ = run_onehot(T, W, O, h0, hT, x, lengths)
     K = C + 2
     lt = torch.from_numpy(lengths)
     with torch.no_grad():
@@ -132,10 +155,16 @@ def gen_bench_crf():
         _, paths = crf._viterbi_decode(ext, mask)
         flat = flatten(paths, lt)
         flat[flat == K - 3] = 0                                                      # :356, o_idx = 0
+    flat = flat.numpy()
+    differs = float((flat != pred_argmax).mean())
+    tags, counts = np.unique(flat, return_counts=True)
+    print('bench_crf: valid tokens', int(lengths.sum()), 'non-O tags', int((flat != 0).sum()), 'distinct tags', len(tags),
+          'largest share %.3f' % float(counts.max() / counts.sum()), 'Viterbi != per-position arg-max at %.3f of the positions' % differs)
+    assert differs >= 0.05 and len(tags) >= 10
     save('bench_crf', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), dims=np.array([V, S, C, K, B, L]),
-         flat_pred=flat.numpy().astype(np.int16), raw_paths=paths.numpy().astype(np.int16),
+         tr_scale=np.float64(CRF_TR_SCALE), x=x.astype(np.int16), lengths=lengths.astype(np.int16),
+         flat_pred=flat.astype(np.int16), raw_paths=paths.numpy().astype(np.int16), argmax_pred=pred_argmax.astype(np.int16),
          sample_rows=ROWS, sample_scores=scores.numpy()[ROWS].astype(np.float32))
-    print('bench_crf: valid tokens', int(lengths.sum()), 'non-O tags', int((flat.numpy() != 0).sum()))
 
 
 def gen_bench_ifst104():
@@ -143,17 +172,7 @@ def gen_bench_ifst104():
     T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, np.random.RandomState(1234))    # bench.py --workload ifst --states 104
     rng = np.random.RandomState(BATCH_SEED)
     x, lengths = synth.random_batch(V, B, L, rng)
-    # plant accepting paths in every second sequence so that rules fire (as gen_atis_scale does): walk the automaton from state 0
-    succ = {}
-    for w, s_, j in zip(*np.nonzero(T)):
-        succ.setdefault(int(s_), []).append((int(w), int(j)))
-    for b in range(0, B, 2):
-        n = int(lengths[b]); at = int(rng.randint(0, max(1, n - 4))); st = 0
-        for t in range(at, n):
-            if st not in succ:
-                break
-            w, st = succ[st][int(rng.randint(len(succ[st])))]
-            x[b, t] = w
+    x = plant_accepting_walks(T, x, lengths, rng)       # rules fire in every second sequence
     scores, pred, re_pred = run_onehot(T, W, O, h0, hT, x, lengths)
     save('bench_ifst104', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), dims=np.array([V, S, C, B, L]),
          x=x.astype(np.int16), lengths=lengths.astype(np.int16),
@@ -162,7 +181,86 @@ def gen_bench_ifst104():
     print('bench_ifst104: valid tokens', int(lengths.sum()), 'non-O tags', int((pred != 0).sum()))
 
 
+EXACT_CASES = [                 # (farnn, use_crf, update_nonlinear): the automaton's exact rank-250 factors under each
+    (0, 0, 'none'),             # == the onehot i-FST of the same automaton, bit for bit (integer path counts)
+    (2, 1, 'tanh'),             # the shipped example configurations' switches (--farnn 2 --use_crf 1) on an automaton's factors
+]
+
+
+def gen_bench_decomp_exact():
+    """A decomposed model that ENCODES an automaton (round 5's bench-size decomposed fixtures were random factors: two distinct
+    tags over 8 766 tokens).  synth.planted_rule_ifst: a 104-state rule automaton at SNIPS-BIO size (V = 11 000, C = 73) whose
+    <= 250 (from, to) pairs give an exact rank-250 CP form in the layout of decompose_automata.py:373-431; the batch plants
+    rule matches (synth.planted_rule_batch).  The reference's FARNN_S_D_W_I_S on those factors; with update_nonlinear = none its
+    scores must equal the reference's ONEHOT model (FARNN_S_O_I_S) of the same automaton exactly -- asserted here."""
+    A = synth.planted_rule_ifst()
+    V, S, C, R = A['V'], A['S'], A['C'], A['Vgen'].shape[1]
+    x, lengths = synth.planted_rule_batch(A, B, L, BATCH_SEED)
+    blob = {}
+    xt, lt = torch.from_numpy(x), torch.from_numpy(lengths)
+    for k, (farnn, crf, nl) in enumerate(EXACT_CASES):
+        gates, tr, Cout = None, None, A['O'].copy()
+        wrng = np.random.RandomState(1234 + k)
+        if crf:
+            Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
+            tr = synth.exact_case_transitions(C, wrng)
+        if farnn:
+            gates = synth.exact_case_gates(S, R, farnn, wrng)
+        a = ns(independent=2, farnn=farnn, use_crf=crf, update_nonlinear=nl, beta=1.0, sigmoid_exponent=5)
+        E = np.zeros((V, 4)); E[:, 0] = 1.0
+        torch.manual_seed(7)
+        m = quiet(FARNN_S_D_W_I_S, V=A['Vgen'].astype(np.float64), S1=A['S1'].astype(np.float64), S2=A['S2'].astype(np.float64),
+                  C_output_mat=Cout[:C].astype(np.float64), wildcard_mat=A['W'].astype(np.float64),
+                  wildcard_output_vector=np.zeros(S), final_vector=A['hT'].astype(np.float64),
+                  start_vector=A['h0'].astype(np.float64), pretrained_word_embed=E, priority_mat=np.eye(C + (2 if crf else 0) - 1),
+                  args=a, o_idx=0, is_cuda=False)
+        with torch.no_grad():
+            if crf:
+                m.C_output_mat[C:] = torch.from_numpy(Cout[C:])
+                m.crf.transitions.copy_(torch.from_numpy(tr))
+            for name in ('Wss1', 'Wrs1', 'Wss2', 'Wrs2'):
+                if gates and name in gates:
+                    getattr(m, name).copy_(torch.from_numpy(gates[name]))
+            for name in ('bs1', 'bs2'):
+                if gates and name in gates:
+                    getattr(m, name).copy_(torch.from_numpy(gates[name]).reshape(1, -1))
+        captured = {}
+        orig_decode = m.decode
+
+        def spy(all_scores, flat, mask, lens, _c=captured, _o=orig_decode):
+            _c['scores'] = all_scores.detach().numpy().copy()
+            return _o(all_scores, flat, mask, lens)
+        m.decode = spy
+        with torch.no_grad():
+            _, pred, _ = m.forward_local(xt, torch.zeros_like(xt), lt, train=False)
+        sc, pred = captured['scores'], pred.numpy()
+        tags, counts = np.unique(pred, return_counts=True)
+        share = float(counts.max() / counts.sum())
+        print('bench_decomp_exact case', k, (farnn, crf, nl), 'distinct tags', len(tags), 'largest share %.3f' % share,
+              'max |score| %.1f' % float(np.abs(sc).max()))
+        assert len(tags) >= 10 and share <= 0.70, (len(tags), share)
+        if (farnn, crf, nl) == (0, 0, 'none'):
+            # the same automaton through the reference's ONEHOT model: identical scores (integer path counts), identical tags
+            T = synth.dense_from_edges(A)
+            so, po, _ = run_onehot(T, A['W'], A['O'], A['h0'], A['hT'], x, lengths)
+            del T
+            so = so.numpy()[:, :sc.shape[1]]
+            mask = np.arange(sc.shape[1])[None, :] < lengths[:, None]
+            assert float(np.abs(sc).max()) < 2.0 ** 22
+            assert np.array_equal(so[mask], sc[mask]), float(np.abs(so - sc)[mask].max())
+            assert np.array_equal(po, pred)
+            print('   == the reference\'s onehot FARNN_S_O_I_S on the same automaton: scores and tags identical')
+        pre = 'c{}.'.format(k)
+        blob[pre + 'dims'] = np.array([V, S, C, R, farnn, crf, B, L])
+        blob[pre + 'nl'] = np.array(nl)
+        blob[pre + 'flat_pred'] = pred.astype(np.int16)
+        blob[pre + 'sample_scores'] = sc[DECOMP_ROWS].astype(np.float32)
+    save('bench_decomp_exact', seed=np.int64(1234), batch_seed=np.int64(BATCH_SEED), sample_rows=DECOMP_ROWS,
+         x=x.astype(np.int16), lengths=lengths.astype(np.int16), **blob)
+
+
 if __name__ == '__main__':
+    gen_bench_decomp_exact()
     gen_bench_ifst104()
     gen_bench_crf()
     gen_bench_decomp()

@@ -128,3 +128,20 @@ def test_rccl_gather_library_exports_its_header():
         pytest.skip('librccl.so does not load here: %s' % e)
     for name in declared:
         assert hasattr(lib, name), name
+
+
+@pytest.mark.parametrize('name,why', [('FARNN_CV_ONE', 'A/B build only'), ('FARNN_CV_STASH', 'A/B build only'), ('FARNN_NODEST', 'A/B build only'),
+                                      ('FARNN_CV_WIDE', 'removed'), ('FARNN_DECOMP_OLD', 'removed')])
+def test_create_refuses_ab_only_and_removed_switches(name, why, monkeypatch):
+    """include/farnn.h: switches are resolved when a handle is created.  The production library refuses the forms that live in the
+    A/B build only, and both refuse the switches earlier rounds removed -- at create, with a message that names the switch, before
+    any device is touched (so this runs without a GPU); nothing is silently ignored and no farnn_tag call fails later."""
+    import numpy as np
+    from re2nn_seq_amd import _lib
+    if _lib.ab_build() and why != 'removed':
+        pytest.skip('the A/B build carries this form')
+    monkeypatch.setenv(name, '1')
+    T = np.zeros((3, 2, 2), np.float32)
+    with pytest.raises(_lib.FarnnError) as e:
+        _lib.create_onehot_ifst(T, np.zeros((2, 2)), np.zeros((2, 2)), np.zeros(2), np.zeros(2))
+    assert name in str(e.value) and why in str(e.value), str(e.value)

@@ -263,6 +263,78 @@ def test_decomposed_ifst_at_bench_size_vs_reference(k):
         assert np.array_equal(fl, fl2)                # fused kernel == score kernel + Viterbi
 
 
+def _exact_automaton_case(g, k):
+    """tests/golden/make_golden_bench.py:gen_bench_decomp_exact's model of case k, rebuilt from the seed"""
+    from re2nn_seq_amd import synth
+    V, S, C, R, farnn, crf, B, L = (int(v) for v in g['c%d.dims' % k])
+    A = synth.planted_rule_ifst(seed=int(g['seed']), V=V, S=S, C=C, max_pairs=R)
+    wrng = np.random.RandomState(int(g['seed']) + k)
+    Cout, tr, gates = A['O'].copy(), None, None
+    if crf:
+        Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
+        tr = synth.exact_case_transitions(C, wrng)
+    if farnn:
+        gates = synth.exact_case_gates(S, R, farnn, wrng)
+    return A, Cout, gates, tr, str(g['c%d.nl' % k]), (V, S, C, R, farnn, crf, B, L)
+
+
+@pytest.mark.parametrize('k', range(2))
+def test_decomposed_model_of_an_automaton_at_bench_size_vs_reference(k):
+    """bench_decomp_exact (round 6): a decomposed model that ENCODES an automaton -- the exact rank-250 CP factors of a planted
+    104-state rule automaton at SNIPS-BIO size (V_embed[:, r] = 1[word in pair r's set], S1 = 1[from], S2 = 1[to], wildcard_mat = W:
+    the layout of decompose_automata.py:373-431) -- against the reference's FARNN_S_D_W_I_S on those factors: 44 / 54 distinct
+    tags, none above 70 % (round 5's bench-size decomposed fixtures decoded to two).
+    Case 0 (update_nonlinear = none): the scores are the automaton's path counts -- every score row and every tag equal to the
+    reference's bit for bit, AND to the ONEHOT kernel's on the same automaton built from its edge list.
+    Case 1: the shipped configurations' switches (farnn 2, CRF, tanh) on the same factors: scores to 1e-4, the reference's paths."""
+    from re2nn_seq_amd import _lib
+    g = np.load(os.path.join(GOLDEN, 'bench_decomp_exact.npz'))
+    A, Cout, gates, tr, nl, (V, S, C, R, farnn, crf, B, L) = _exact_automaton_case(g, k)
+    x, lengths = g['x'].astype(np.int64), g['lengths'].astype(np.int64)
+    K = Cout.shape[0]
+    h = _lib.create_decomp_ifst(A['Vgen'], A['S1'], A['S2'], A['W'], Cout, A['h0'], A['hT'], farnn=farnn, gates=gates,
+                                sigmoid_exponent=5, nl=nl, threshold=0.5, o_idx=0, use_crf=bool(crf), crf_trans=tr)
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat.data_ptr(), scores.data_ptr())
+    flat2 = torch.empty_like(flat)                    # the call bench.py times: tags only
+    h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, flat2.data_ptr(), None)
+    torch.cuda.synchronize()
+    h.close()
+    rows = g['sample_rows']
+    got, want = scores.cpu().numpy(), g['c%d.sample_scores' % k]
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    mr = mask[rows]
+    ref_flat = g['c%d.flat_pred' % k].astype(np.int64)
+    tags, counts = np.unique(ref_flat, return_counts=True)
+    assert len(tags) >= 10 and counts.max() <= 0.7 * counts.sum()
+    fl, fl2 = flat.cpu().numpy(), flat2.cpu().numpy()
+    if nl == 'none':
+        assert np.array_equal(got[rows][mr], want[mr])                   # integer path counts (up to 2.4e6 < 2**22): exact
+        assert np.array_equal(fl, ref_flat) and np.array_equal(fl2, ref_flat)
+        # the onehot kernel on the same automaton (edge list -> HBM scatter: no dense 476 MB tensor on the host)
+        lab = np.where(A['word'] >= 0, A['state_label'][A['to']], -1)    # the label sits on the destination state
+        extra = np.arange(S)                                              # label-only entries: every state's column, wildcard states -> `oo`
+        ho = _lib.create_onehot_ifst_from_edges(V, S, C, np.concatenate([A['word'], np.full(S, -2)]),
+                                                np.concatenate([A['frm'], extra]), np.concatenate([A['to'], extra]),
+                                                np.concatenate([lab, A['state_label']]), A['h0'], A['hT'])
+        so = torch.empty((B, L, C), dtype=torch.float32, device='cuda')
+        fo_ = torch.empty_like(flat)
+        ho.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, None, fo_.data_ptr(), so.data_ptr())
+        torch.cuda.synchronize()
+        ho.close()
+        assert np.array_equal(so.cpu().numpy()[mask], got[mask])         # the decomposed kernel == the onehot kernel, every score
+        assert np.array_equal(fo_.cpu().numpy(), ref_flat)
+    else:
+        np.testing.assert_allclose(got[rows][mr], want[mr], rtol=1e-4, atol=1e-4)
+        own = fo.decode_crf(got, lengths, tr, 0.5, 0)                    # the DP is the same f32 expression: bit-equal on the GPU's own scores
+        assert np.array_equal(fo.flatten(own, lengths), fl) and np.array_equal(fl, fl2)
+        offs = np.concatenate([[0], np.cumsum(lengths)])
+        n_diff = sum(1 for b in range(B) if not np.array_equal(fl[offs[b]:offs[b + 1]], ref_flat[offs[b]:offs[b + 1]]))
+        assert n_diff <= 6, n_diff                                        # whole paths; near-ties only
+
+
 @pytest.mark.parametrize('one_launch', [False, True])
 def test_onehot_ifst_crf_at_bench_size_vs_reference(one_launch, monkeypatch):
     """BASELINE configs[3]: FARNN_S_O_I_S.forward_score -> START / STOP columns -> clamp -> CRF._viterbi_decode (crf.py:102-195)
@@ -279,8 +351,10 @@ def test_onehot_ifst_crf_at_bench_size_vs_reference(one_launch, monkeypatch):
         monkeypatch.setenv('FARNN_CV_ONE', '1')          # (switches are read when the handle is created)
     g = np.load(os.path.join(GOLDEN, 'bench_crf.npz'))
     V, S, C, K, B, L = (int(v) for v in g['dims'])
-    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C)
-    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(int(g['batch_seed'])))
+    # (round 6's fixture: walks planted in every second sequence, transitions spread so that 46 % of the positions leave the
+    #  per-position arg-max and 84 distinct tags are decoded -- round 5's decoded to 97 % `O`)
+    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C, tr_scale=float(g['tr_scale']))
+    x, lengths = g['x'].astype(np.int64), g['lengths'].astype(np.int64)
     h = _lib.create_onehot_ifst(T, W, O, h0, hT, use_crf=True, crf_trans=tr)
     xd, ld = _t(x).cuda(), _t(lengths).cuda()
     flat = torch.empty((int(lengths.sum()),), dtype=torch.int64, device='cuda')

@@ -4,6 +4,7 @@ the reference's FARNN_S_D_W_I_S / FARNN_S_O_I_S / CRF classes run on the seeded 
     bench_decomp    BASELINE configs[2]: V = 11 000, C = 73, B = 256, L = 64; five (rank, farnn, CRF, S) shapes
     bench_crf       BASELINE configs[3]: onehot scores -> START / STOP columns -> clamp -> CRF._viterbi_decode, K = 130
     bench_ifst104   the onehot i-FST at the reference's 104-state automata (RE.py:56-60)
+    bench_decomp_exact   (round 6) a decomposed model that ENCODES an automaton: exact rank-250 CP factors of a planted rule automaton
 
 The decomposed scores are held to 1e-4 against the reference's rows on the sampled sequences.  One case documents where
 float32 itself scatters: on sequence 77 of the rank-250, 134-state model the REFERENCE's float32 scores lie 1.7e-4 from a
@@ -67,10 +68,12 @@ def test_decomposed_bench_size_sample_rows(k):
 
 
 def test_onehot_crf_bench_size_all_tags():
+    """Round 6's fixture: accepting walks planted in every second sequence and transitions spread so that the decoded path
+    leaves the per-position arg-max at a good share of the positions (round 5's decoded to 97 % `O`)."""
     g = np.load(os.path.join(GOLDEN, 'bench_crf.npz'))
     V, S, C, K, b_, l_ = (int(v) for v in g['dims'])
-    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C)
-    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(int(g['batch_seed'])))
+    T, W, O, h0, hT, tr = synth.atis_sized_crf_model(seed=int(g['seed']), V=V, S=S, C=C, tr_scale=float(g['tr_scale']))
+    x, lengths = g['x'].astype(np.int64), g['lengths'].astype(np.int64)
     sc = fo.onehot_ifst_scores(T, W, O, h0, hT, x, lengths)
     rows = g['sample_rows']
     assert np.array_equal(sc[rows], g['sample_scores'])            # integer-valued: bit-exact
@@ -81,6 +84,63 @@ def test_onehot_crf_bench_size_all_tags():
     clamped = ext.copy(); clamped[..., K - 3] = np.minimum(clamped[..., K - 3], np.float32(0.5))
     raw = fo.viterbi_paths(clamped, lengths, tr)
     assert np.array_equal(raw[mask], g['raw_paths'].astype(np.int64)[mask])
+    # the fixture means something: the dynamic programme decides, not the emissions alone
+    flat = g['flat_pred'].astype(np.int64)
+    assert np.array_equal(fo.forward_local_tags(sc, lengths, 0.5, 0), g['argmax_pred'].astype(np.int64))
+    assert float((flat != g['argmax_pred']).mean()) >= 0.05
+    tags, counts = np.unique(flat, return_counts=True)
+    assert len(tags) >= 10 and counts.max() <= 0.7 * counts.sum()
+
+
+def _exact_case(g, k):
+    V, S, C, R, farnn, crf, b_, l_ = (int(v) for v in g['c%d.dims' % k])
+    A = synth.planted_rule_ifst(seed=int(g['seed']), V=V, S=S, C=C, max_pairs=R)
+    wrng = np.random.RandomState(int(g['seed']) + k)
+    Cout, tr, gates = A['O'].copy(), None, None
+    if crf:
+        Cout = np.concatenate([Cout, (wrng.rand(2, S) * 0.01).astype(np.float32)], 0)
+        tr = synth.exact_case_transitions(C, wrng)
+    if farnn:
+        gates = synth.exact_case_gates(S, R, farnn, wrng)
+    nl = str(g['c%d.nl' % k])
+    q = {'Vgen': A['Vgen'], 'S1': A['S1'], 'S2': A['S2'], 'W': A['W'], 'Cout': Cout, 'h0': A['h0'], 'hT': A['hT'], 'farnn': farnn,
+         'nl': {'none': fo.NL_NONE, 'tanh': fo.NL_TANH}[nl], 'semiring': 0, 'sig_k': 5}
+    if gates:
+        q.update(gates)
+    return A, q, gates, tr, nl
+
+
+@pytest.mark.parametrize('k', range(2))
+def test_decomposed_model_of_an_automaton_at_bench_size(k):
+    """bench_decomp_exact (round 6): the reference's FARNN_S_D_W_I_S on the exact rank-250 factors of a planted 104-state rule
+    automaton (decompose_automata.py:373-431's layout) -- a decomposed fixture whose tags mean something (>= 10 distinct, none
+    above 70 %).  Case 0 (update_nonlinear = none) is the automaton's path counts: the oracle's decomposed scores equal the
+    reference's bit for bit AND equal the oracle's onehot scores of the same automaton; every tag equal.  Case 1: the shipped
+    configurations' switches (farnn 2, CRF, tanh) on the same factors."""
+    g = np.load(os.path.join(GOLDEN, 'bench_decomp_exact.npz'))
+    A, q, gates, tr, nl = _exact_case(g, k)
+    x, lengths = g['x'].astype(np.int64), g['lengths'].astype(np.int64)
+    rows = g['sample_rows']
+    want = g['c%d.sample_scores' % k]
+    flat = g['c%d.flat_pred' % k].astype(np.int64)
+    tags, counts = np.unique(flat, return_counts=True)
+    assert len(tags) >= 10 and counts.max() <= 0.7 * counts.sum()
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    if nl == 'none':
+        got = fo.decomp_ifst_scores(q, x, lengths)
+        assert np.array_equal(got[rows][mask[rows]], want[mask[rows]])          # integer path counts: exact
+        assert np.array_equal(fo.forward_local_tags(got, lengths, 0.5, 0), flat)
+        T = synth.dense_from_edges(A)
+        toks, inv = np.unique(x, return_inverse=True)                            # (the words the batch uses: 0.5 GB dense otherwise)
+        so = fo.onehot_ifst_scores(T[toks], A['W'], A['O'], A['h0'], A['hT'], inv.reshape(x.shape).astype(np.int64), lengths)
+        assert np.array_equal(so[mask], got[mask])                               # the decomposed form IS the automaton
+    else:
+        got = fo.decomp_ifst_scores(q, x[rows], lengths[rows])
+        np.testing.assert_allclose(got[mask[rows]], want[mask[rows]], rtol=1e-4, atol=1e-4)
+        mine = fo.forward_local_tags(got, lengths[rows], 0.5, 0, crf_tr=tr)
+        offs = np.concatenate([[0], np.cumsum(lengths)])
+        ref = np.concatenate([flat[offs[b]:offs[b + 1]] for b in rows])
+        assert int((mine != ref).sum()) <= 2                                     # near-ties only
 
 
 def test_onehot_ifst_104_states_all_tags():
