@@ -25,7 +25,7 @@ inline ChainViterbiPlan chain_viterbi_plan(int L, int SP, int NP, int K, int Kp,
     const RegsLds rl = regs_lds(L, SP, NP, 0, 0, false, rq);
     pl.half = (rl.total + 3) & ~3;
     const size_t v = viterbi_hist_lds_bytes(K, Kp, SP, L, true);
-    const int abT = SP * (((L + 3) & ~3) + 16);
+    const int abT = (int)viterbi_products_floats(SP, L);
     const int sc_pieces = (L * Kp * 4 + 1023) / 1024, tr_pieces = (K * Kp * 4 + 1023) / 1024;
     pl.image_off = (int)viterbi_hist_floats(Kp, SP, L, true) + sc_pieces * 256;       // = the transition table's area (viterbi_hist_body)
     pl.image_pieces = ((K + 15) >> 4) * c16;

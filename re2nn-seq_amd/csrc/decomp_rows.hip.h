@@ -570,6 +570,43 @@ decomp_rows_kernel(const DecompRowsParams p) {
         if constexpr (NP3R > 0)                                                                                              \
             load_rows_regs<NP3R, NCH3K, LPR>(w3, p.P3[dir], p.n3, ld3, p.nch3 < NCH3K * (LPR / 4) ? p.nch3 : NCH3K * (LPR / 4), tid); \
     } while (0)
+    // Round 6: the set-up's barriers order LDS traffic only (a __syncthreads() drains the vector-memory counter of ALL wavefronts:
+    // round 5's "selection 10 k cycles" was the wait for everybody's weights), the selection hands the length back (no dependent load
+    // of len[b]), and the LDS fills below are DMAs in front of the weights: set-up 17.3 k -> 16.3 k cycles at rank 250
+    // (profiles/r06_base_probe_decomp_rows_* / r06_probe_decomp_rows_*).  What remains is the weights themselves: at the start of a
+    // launch every compute unit pulls the same ~0.5 MB out of L2 at once -- 128 MB through ~7 KB per clock: ~12 k cycles whatever the
+    // order.  (Measured and dropped: wavefront 0 -- selection, tokens -- issuing its share of the weights BEHIND that chain, 19.4 k: its
+    // loads only join the end of the same queue.)
+    const int wv0 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The LDS-resident rows (and, all-in-registers form, the output rows' last chunks) go to LDS by LDS-DMA, FIRST: no register
+    // round trip -- as `st4(dst, ld4(src))` loops behind the weights every store waited for a load that returned behind ~50 weight
+    // loads (a wavefront's loads return in order), one round trip per iteration: 3.7 k cycles for 53 KB at rank 250, 10 k for the
+    // 134-state mixed form's rows.  Lanes past a region's end are masked off (a DMA writes at M0 + lane * 16 for its active lanes).
+    constexpr int R1 = NP1R * RPPR, R2 = NP2R * RPPR, R3 = NP3R * RPPR;       // rows held in registers: the resident rows start there
+    {
+        const int lane = tid & 63;
+        const float *src[3] = {p.P1 + (long long)R1 * ld2, p.P2[dir] + (long long)R2 * ld2, p.P3[dir] + (long long)R3 * ld3};
+        float *dst[3] = {L1, L2, L3};
+        const long long cnt[3] = {(long long)p.res1 * ld2, (long long)p.res2 * ld2, (long long)p.res3 * ld3};
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const long long bytes = cnt[q] * 4;
+            const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)dst[q]);
+            for (long long k = wv0; k * 1024 < bytes; k += DR_THREADS / 64) {
+                const long long off = k * 1024 + lane * 16;
+                if (off < bytes) lds_dma16((unsigned)off, reinterpret_cast<const char *>(src[q]), d0 + (unsigned)(k * 1024));
+            }
+        }
+        if constexpr (LPR == 8 && NP2R > 0 && NP3R > 0) {      // the output rows' last chunks (NCH3L below): [n3][DR_T3LD]; a row's 32 pieces
+            float *t3 = L3 + cnt[2];                           // ride on lanes 0..31 of one DMA (the row stride is not the data's width)
+            const int c0 = (NCH3R - DR_T3_CHUNKS) * 64, q = lane * 4;
+            const bool in = lane < DR_T3_CHUNKS * 16 && c0 + q < p.nch3 * DR_CHUNK;
+            for (int row = wv0; row < p.n3; row += DR_THREADS / 64) {
+                const unsigned d0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(t3 + row * DR_T3LD));
+                if (in) lds_dma16((unsigned)(((long long)row * ld3 + c0 + q) * 4), reinterpret_cast<const char *>(p.P3[dir]), d0);
+            }
+        }
+    }
     if constexpr (EARLYW) FARNN_DR_LOAD_WEIGHTS();
     glb_cv4f *g3src = nullptr;                                // this lane's piece of its output row, for the streamed chunks
     if constexpr (NCH3G > 0) {
@@ -583,17 +620,29 @@ decomp_rows_kernel(const DecompRowsParams p) {
     for (int s = 0; s < NSEQ; s++) {
         const int r = grp * NSEQ + s;                         // rank by length (descending)
         const bool have = r < p.B;
-        int b = 0;
+        int b = 0, l = -1;
         if (have) {
             const int half = p.B / 2;
             b = p.order ? p.order[r < half ? r : half + (p.B - 1 - r)] : r;     // undo the fold
         }
-        if (p.sort && have) b = select_by_length_rank(p.len, p.B, p.L, r, reinterpret_cast<int *>(smem), tid, DR_THREADS);
+        // (the selection hands the sequence's length back with it -- its class: no dependent load of len[b] behind it)
+        if (p.sort && have) b = select_by_length_rank<true>(p.len, p.B, p.L, r, reinterpret_cast<int *>(smem), tid, DR_THREADS, &l);
         b = __builtin_amdgcn_readfirstlane(b);                // workgroup-uniform: keep it in SGPRs
         bseq[s] = b;
-        slen[s] = have ? __builtin_amdgcn_readfirstlane(clamp_len(p.len[b], p.L)) : 0;
+        if (have && l < 0) l = __builtin_amdgcn_readfirstlane(clamp_len(p.len[b], p.L));     // (a given launch order: FARNN_PREP / FARNN_NOSORT)
+        slen[s] = have ? l : 0;
         nst[s] = have ? (p.full ? p.L : slen[s]) : -1;        // -1: no sequence in this slot
         nmax = nst[s] > nmax ? nst[s] : nmax;
+    }
+    // the tokens: wavefront 0 alone (the selection's wavefront)
+    int *tok0 = reinterpret_cast<int *>(smem);
+    if (wv0 == 0) {
+#pragma unroll
+        for (int s = 0; s < NSEQ; s++)
+            for (int k = tid; k < nst[s]; k += 64) {
+                const int idx = (dir == 0) ? k : (k < slen[s] ? slen[s] - 1 - k : k);
+                tok0[s * ((p.L + 3) & ~3) + k] = clamp_tok(p.x[(long long)bseq[s] * p.L + idx], p.V);
+            }
     }
     const float *hinit = dir == 0 ? p.h0 : p.hT;
     float *stash_base = dir == 0 ? p.A : p.Bk;
@@ -611,33 +660,20 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // into the arrays behind the vector -- with zero weights, but LDS keeps what earlier workgroups left there (-inf pads of the
     // Viterbi kernel: -inf x 0 = NaN).  Vectors and per-token buffers are zeroed here, the tail behind the resident rows below.
     for (int i = tid; i < (int)(L1 - Hinit); i += DR_THREADS) Hinit[i] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < NSEQ; s++)
-        for (int k = tid; k < nst[s]; k += DR_THREADS) {
-            const int idx = (dir == 0) ? k : (k < slen[s] ? slen[s] - 1 - k : k);
-            tok[s * Lr + k] = clamp_tok(p.x[(long long)bseq[s] * p.L + idx], p.V);
-        }
-    // A register form may hold only a matrix's first NPxR passes (mixed forms: S in 129..160 needs three passes of gate rows or
+    // (A register form may hold only a matrix's first NPxR passes -- mixed forms: S in 129..160 needs three passes of gate rows or
     // two of output rows; the registers hold the first passes, the few rows behind them are LDS-resident like any other
-    // matrix's, or streamed): R1 / R2 / R3 = rows held in registers, the resident / streamed rows start there.
-    constexpr int R1 = NP1R * RPPR, R2 = NP2R * RPPR, R3 = NP3R * RPPR;
+    // matrix's, or streamed: R1 / R2 / R3 above.)
     if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_1 = (long long)__builtin_amdgcn_s_memtime();
-    {   // resident rows: global -> LDS
-        const float *src[3] = {p.P1 + (long long)R1 * ld2, p.P2[dir] + (long long)R2 * ld2, p.P3[dir] + (long long)R3 * ld3};
-        float *dst[3] = {L1, L2, L3};
-        const long long cnt[3] = {(long long)p.res1 * ld2, (long long)p.res2 * ld2, (long long)p.res3 * ld3};
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-            for (long long i = (long long)tid * 4; i < cnt[q]; i += DR_THREADS * 4) st4(dst[q] + i, ld4(src[q] + i));
-        float *tail = L3 + cnt[2];
-        if constexpr (LPR == 8 && NP2R > 0 && NP3R > 0) {      // the output rows' last chunk (NCH3L below): [n3][DR_T3LD], zero past the model
+    {   // what the DMAs at the top do not write: columns past the model, the rows' pads, the LDS behind the rows
+        float *tail = L3 + (long long)p.res3 * ld3;
+        if constexpr (LPR == 8 && NP2R > 0 && NP3R > 0) {
             constexpr int QPR = DR_T3_CHUNKS * 16;              // 16-byte pieces per row
             const int c0 = (NCH3R - DR_T3_CHUNKS) * 64;
-            for (int i = tid; i < p.n3 * QPR; i += DR_THREADS) {
-                const int row = i / QPR, q = (i % QPR) * 4;
-                const bool in = c0 + q < p.nch3 * DR_CHUNK;
-                st4(tail + row * DR_T3LD + q, in ? ld4(p.P3[dir] + (long long)row * ld3 + c0 + q) : make_float4(0.f, 0.f, 0.f, 0.f));
-            }
+            if (c0 + DR_T3_CHUNKS * 64 > p.nch3 * DR_CHUNK)     // (a rank below the form's chunk count: zero past the model)
+                for (int i = tid; i < p.n3 * QPR; i += DR_THREADS) {
+                    const int row = i / QPR, q = (i % QPR) * 4;
+                    if (c0 + q >= p.nch3 * DR_CHUNK) st4(tail + row * DR_T3LD + q, make_float4(0.f, 0.f, 0.f, 0.f));
+                }
             for (int i = tid; i < p.n3 * 32; i += DR_THREADS) tail[(i >> 5) * DR_T3LD + DR_T3_CHUNKS * 64 + (i & 31)] = 0.0f;
             tail += p.n3 * DR_T3LD;
         }
@@ -647,7 +683,9 @@ decomp_rows_kernel(const DecompRowsParams p) {
     if constexpr (!EARLYW) FARNN_DR_LOAD_WEIGHTS();
 #undef FARNN_DR_LOAD_WEIGHTS
     if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) { st_2 = st_3 = (long long)__builtin_amdgcn_s_memtime(); }
-    __syncthreads();
+    // (LDS traffic only: the zeroing against the state rows, wavefront 0's tokens against the first per-token vectors' addresses.
+    //  The weights stay in flight; the first vectors' loads join them, and the barrier behind those drains everything once.)
+    wg_barrier_lds();
     for (int j = tid; j < S; j += DR_THREADS) {
         const float hv = hinit[j];
         Hinit[j] = hv;

@@ -814,7 +814,7 @@ static int launch_viterbi(farnn_model *m, const ScoreParams &p, int B, hipStream
     // (K >= 224 never takes this form: the transposed transition table alone is 196 KiB -- no IB4 = 7, 8 instantiations)
     if (hlds <= 158 * 1024 && viterbi_hist_ib4(m->K) <= 6 && !tun(TUN_VITERBI_BP)) {
         // partition history in LDS, back-pointers recomputed along the path
-        const int threads = viterbi_hist_threads(m->K);
+        const int threads = viterbi_hist_score_threads(m->K, fused);
 #define FARNN_LAUNCH_VITH(N)                                                                  \
     case N:                                                                                   \
         if (fused) {                                                                          \

@@ -60,6 +60,10 @@ __device__ __forceinline__ int select_by_length_rank_wave(const int64_t *len, in
 
 // len_out (optional): the selected sequence's clamped length comes back with it -- the class the search found -- so the caller
 // need not load len[b] behind the selection (a dependent global round trip at the launch's start, when every workgroup loads).
+// LDS_ONLY: the two workgroup barriers order LDS traffic only (wg_barrier_lds) -- a __syncthreads() also drains the vector-memory
+// counter, i.e. every wavefront would wait here for whatever global loads it has in flight (decomp_rows_kernel: the ~0.5 MB of
+// register-resident weights it issues first -- round 5's "selection 10 k cycles" was that drain, not the selection).
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, int L, int rank, int *scratch,
                                                      int tid, int /*nthreads*/, int *len_out = nullptr) {
     if ((tid >> 6) == 0) {
@@ -70,9 +74,9 @@ __device__ __forceinline__ int select_by_length_rank(const int64_t *len, int B, 
         else res = select_by_length_rank_wave<16>(len, B, L, rank, lane, &cls);       // B <= 1024
         if (lane == 0) { scratch[0] = res; scratch[1] = cls; }
     }
-    __syncthreads();
+    if constexpr (LDS_ONLY) wg_barrier_lds(); else __syncthreads();
     const int b = scratch[0], l = scratch[1];
-    __syncthreads();                     // the scratch is reused by the caller
+    if constexpr (LDS_ONLY) wg_barrier_lds(); else __syncthreads();      // the scratch is reused by the caller
     if (len_out) *len_out = __builtin_amdgcn_readfirstlane(l);
     return __builtin_amdgcn_readfirstlane(b);
 }

@@ -30,11 +30,34 @@ __device__ __forceinline__ long long flat_offset_in_kernel(const int64_t *len, i
 }
 
 
-// floats of the history area of viterbi_hist_kernel: [L][Kp] partitions; the fused form first stages the [SP][L]
-// alpha*beta products there (row stride L + 16)
+// The fused form's alpha*beta products, staged where the history will be: row-major [token][SPq] (round 6; rounds 2-5 staged them
+// transposed, [state][L + 16]: the 26 lanes that share a token wrote 320 floats apart -- one bank, a 26-way conflict on every one
+// of the staging's stores: 7.3 k cycles at S = 104, L = 64).  SPq / 4 is odd, so the sixteen token rows of a matrix-core A fragment
+// start in sixteen different groups of four banks and its four state columns fill the group: reads and writes conflict-free.
+// A row holds whole groups of 16 states (the pad columns are zeroed): the matrix-core loop reads its A entries at fixed offsets from
+// ONE address it advances by a group, with no clamp into the row.
+__host__ __device__ inline int viterbi_products_stride(int SP) { const int q = (SP + 15) & ~15; return ((q >> 2) & 1) ? q : q + 4; }
+__host__ __device__ inline size_t viterbi_products_floats(int SP, int L) {
+    return (size_t)((L + 15) & ~15) * viterbi_products_stride(SP);
+}
+// floats of the history area of viterbi_hist_kernel: [L][Kp] partitions; the fused form first stages the products there
 __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, bool fused) {
-    const size_t a = (size_t)L * Kp, c = fused ? (size_t)SP * (((L + 3) & ~3) + 16) : 0;
+    const size_t a = (size_t)L * Kp, c = fused ? viterbi_products_floats(SP, L) : 0;
     return a > c ? a : c;
+}
+
+// 1 KiB pieces of the LDS area behind the scores: the transposed transition table -- and, for the fused form with a dense output
+// matrix, first the matrix-core image of that matrix ((K / 16) x (S / 16) pieces).  Rounds 2-5 kept the image in LDS only when it
+// fitted the table's own size; K = 75 tags over S = 104 states (the shipped configurations: a 23-piece table, a 35-piece image)
+// read every B fragment from L2 instead -- two dependent round trips per pair of state groups, 10.8 k cycles for a product whose
+// matrix-core time is 5.4 k.  The area is now the larger of the two whenever the LDS holds it (62 + 12 KB at that shape).
+__host__ __device__ inline int viterbi_table_pieces(int K, int Kp, int SP, int L, bool fused) {
+    const int tr_pieces = (K * Kp * 4 + 1023) / 1024;
+    if (!fused) return tr_pieces;
+    const int otm_pieces = ((K + 15) >> 4) * ((SP + 15) >> 4);
+    if (otm_pieces <= tr_pieces) return tr_pieces;
+    const size_t with_image = viterbi_hist_floats(Kp, SP, L, true) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 + (size_t)otm_pieces * 1024;
+    return with_image <= 158 * 1024 ? otm_pieces : tr_pieces;
 }
 
 // History variant of the DP (used when the LDS holds it): the forward pass keeps only the partition
@@ -70,16 +93,26 @@ __host__ __device__ inline size_t viterbi_hist_floats(int Kp, int SP, int L, boo
 // the output matrix's matrix-core image is already in the transition table's LDS area.
 // lm_pk: the caller's copy of this lane's two packed label-map words (label_map.hip.h), fetched long ago (chain_viterbi_kernel: at
 // the kernel's start), or nullptr: they are fetched here, an L2 round trip in front of the first token
+// ns (round 6): the threads that run the body up to the end of the SCORES (ns >= nthreads, whole wavefronts): the dynamic programme
+// takes nthreads = 8 lanes per tag pair (K = 75: five wavefronts, two of them on one SIMD), the scores want every SIMD's matrix
+// core and more loads in flight -- the stand-alone kernel is launched with up to sixteen wavefronts, threads nthreads .. ns - 1
+// leave behind the scores' last barrier (a workgroup barrier counts the wavefronts that are still there).
 template <int IB4, bool FUSED>
 __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *smem, const int tid, const int nthreads, const int b,
                                                   const float *ldsF = nullptr, const float *ldsB = nullptr, const bool image_staged = false,
-                                                  const unsigned *lm_pk = nullptr, const int *pre = nullptr) {
+                                                  const unsigned *lm_pk = nullptr, const int *pre = nullptr, const int ns_in = 0) {
+    const int ns = (FUSED && ns_in > nthreads) ? ns_in : nthreads;
     // pre (chain_viterbi_kernel): {the sequence's length, its flat-output offset} in LDS, worked out by an idle wavefront while the
     // chains ran -- else two global round trips (the length, then the lengths in front of it) open the decode
     static_assert(IB4 <= 6, "K >= 224: the transition table does not fit the LDS beside a history (launch_viterbi: viterbi_kernel)");
     constexpr int IB = IB4 * 4;
     const int lane = tid & 63, w = tid >> 6;
-    const int n = pre ? pre[0] : clamp_len(p.len[b], p.L);
+    // The loads that open the decode are ISSUED together and used behind the flat offset's barriers (round 6): the sequence's length,
+    // the label-map words and the lengths in front of the sequence used to be three dependent L2 round trips in a row at the head of
+    // every workgroup (~2 k cycles each; then the state rows, a fourth).
+    const long long len_raw = pre ? 0 : p.len[b];
+    unsigned lm_own[2] = {0u, 0u};
+    if (FUSED && p.lm.on && !lm_pk) lm_load_packed(p.lm, lane, lm_own[0], lm_own[1]);
     (void)p.full;
     const int K = p.K, Kp = p.Kp;
     const int PW = Kp;                                   // partition row stride (K rounded up to 4), pads -inf
@@ -88,13 +121,66 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     float *scl = hist + viterbi_hist_floats(Kp, p.SP, p.L, FUSED);   // [L][Kp] clamped scores of this sequence (whole KiB)
     float *trl = scl + sc_pieces * 256;                  // [K][Kp] trT: trl[j][i] = transitions[i][j]
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
-    const long long foff = p.offs ? p.offs[b] : (p.flat ? (pre ? (long long)pre[1] : flat_offset_in_kernel(p.len, b, p.L, tid, nthreads)) : 0);
+    const long long foff = p.offs ? p.offs[b] : (p.flat ? (pre ? (long long)pre[1] : flat_offset_in_kernel(p.len, b, p.L, tid, ns)) : 0);
+    const int n = pre ? pre[0] : clamp_len(len_raw, p.L);
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
-    const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6, nsw = ns >> 6;
     const bool probe = FARNN_PROBE_ON(p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
-    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0;
+    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0, pw = 0;
 
+    // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
+    // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
+    // that e.g. K = 130 (64 pairs + START/STOP) costs the ninth wavefront 3 source slots per lane instead of 17
+    const int npairs = (K + 1) >> 1, nfull = npairs >> 3, rem = npairs & 7;
+    const int GT = rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8;
+    // (rem >= 5 -- e.g. K = 75: 38 pairs -- would give the tail eight lanes per pair too: the same source slots as a full wavefront
+    //  through the tail's simpler, unpipelined loop; the last wavefront then runs the full wavefronts' loop with its spare groups idle)
+    const bool tail = wu >= nfull && GT > 8;             // wave-uniform
+    const int g = tail ? (lane & (GT - 1)) : (tid & 7);  // lane of its group
+    const int grp = tail ? lane / GT : 0;
+    const int pair = tail ? nfull * 8 + grp : (tid >> 3);
+    const int j0 = 2 * pair;
+    const bool own0 = j0 < K && (!tail || grp < rem), own1 = own0 && j0 + 1 < K;
+    const bool writer = own0 && (tail ? g == GT - 1 : g == 0);
+    const int XS = (K - 8 * IB + 7) >> 3;                // full wavefronts: leftover source slots per lane (0..4)
+    const int nst = (K + GT - 1) / GT;                   // tail wavefront: source slots per lane (<= IB + 4)
+    constexpr int NSL = IB + 4;
+    v2f trs[NSL];                                        // tr[i][j0], tr[i][j0+1] of this lane's sources
+#define FARNN_TRS_SET(SL, X, Y) do { trs[SL] = v2f{(X), (Y)}; } while (0)
+    int ixs[4];                                          // full: leftover sources (clamped into the row; their tr is -inf)
+    // (round 6: requested HERE, in front of the scores -- the entries depend on the lane only, and their L2 round trip used to open
+    //  the decode behind the scores' last barrier.  Round 4 had measured this at -0.8 us for the stand-alone kernel and dropped it
+    //  for the one-launch form's sake, which has since moved to the A/B build.)
+    if (tid < nthreads) {
+        const float *row0 = p.trT + (long long)(own0 ? j0 : 0) * Kp, *row1 = p.trT + (long long)(own1 ? j0 + 1 : 0) * Kp;
+        if (!tail) {
+#pragma unroll
+            for (int k4 = 0; k4 < IB4; k4++) {           // sources 32*k4 + 4*g + u: a 128-byte span per read, no bank conflicts
+                const float4 a = ld4(row0 + k4 * 32 + g * 4), c = ld4(row1 + k4 * 32 + g * 4);
+                trs[k4 * 4 + 0] = v2f{own0 ? a.x : ninf, own1 ? c.x : ninf}; trs[k4 * 4 + 1] = v2f{own0 ? a.y : ninf, own1 ? c.y : ninf};
+                trs[k4 * 4 + 2] = v2f{own0 ? a.z : ninf, own1 ? c.z : ninf}; trs[k4 * 4 + 3] = v2f{own0 ? a.w : ninf, own1 ? c.w : ninf};
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) {
+                const int i = 8 * IB + 8 * xk + g;
+                const bool ok = i < K;
+                ixs[xk] = ok ? i : K - 1;
+                FARNN_TRS_SET(IB + xk, (ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf);
+            }
+        } else {
+#pragma unroll
+            for (int sl = 0; sl < NSL; sl++) {
+                const int i = g + GT * sl;
+                const bool ok = i < K;
+                FARNN_TRS_SET(sl, (ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf);
+            }
+#pragma unroll
+            for (int xk = 0; xk < 4; xk++) ixs[xk] = 0;
+        }
+    }
+    const v2f t_start = (writer && tid < nthreads) ? v2f{p.trT[(long long)j0 * Kp + START], own1 ? p.trT[(long long)(j0 + 1) * Kp + START] : 0.0f}
+                               : v2f{0.f, 0.f};                                                  // before the table DMA
     // set-up without a register round trip: the scores and (behind them) the transition table stream
     // into LDS by LDS-DMA; the table is only needed by the backtrace, so its pieces stay in flight
     // during the forward pass (counted vmcnt: this wavefront's table pieces are its youngest operations)
@@ -109,12 +195,12 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         const int SP = p.SP;
         LabelMapRegs lr;
         if (lm_pk) lm_unpack(p.lm, lm_pk[0], lm_pk[1], lr);
-        else lm_load(p.lm, lane, lr);
+        else lm_unpack(p.lm, lm_own[0], lm_own[1], lr);
         if (ldsF) {
             // two tokens at a time (their scans interleave: label_map.hip.h), every row entry fetched before the scan
             const bool two = p.lm.nq > 1;                 // (selected, not multiplied by 0: label_map.hip.h)
-            for (int tok = wu; tok < n; tok += 2 * nwaves) {
-                const int tk2 = tok + nwaves < n ? tok + nwaves : tok;             // (an odd token out: scored twice, stored once)
+            for (int tok = wu; tok < n; tok += 2 * nsw) {
+                const int tk2 = tok + nsw < n ? tok + nsw : tok;                   // (an odd token out: scored twice, stored once)
                 const float *fa = ldsF + (tok + 1) * SP, *ba = ldsB + (n - (tok + 1)) * SP;
                 const float *fb = ldsF + (tk2 + 1) * SP, *bb = ldsB + (n - (tk2 + 1)) * SP;
                 const float xa0 = fa[lr.st0] * ba[lr.st0], xa1 = two ? fa[lr.st1] * ba[lr.st1] : 0.0f;
@@ -128,7 +214,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             // rows from the stash: every load of this wavefront's tokens in flight before the first is used
             const float *Ab = p.A + (long long)b * (p.L + 1) * SP, *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
             constexpr int NT = 4;                        // tokens per batch
-            for (int t0 = wu * NT; t0 < n; t0 += nwaves * NT) {
+            for (int t0 = wu * NT; t0 < n; t0 += nsw * NT) {
                 float a0[NT], b0[NT], a1[NT], b1[NT];
 #pragma unroll
                 for (int u = 0; u < NT; u++) {
@@ -149,52 +235,53 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         __syncthreads();
         if (probe) { pa = (long long)__builtin_amdgcn_s_memtime(); pb = pa; }
     } else {
-        const int SP = p.SP, SP4 = SP >> 2, Lq = ((p.L + 3) & ~3) + 16;   // row stride of the products: the four state rows of an
-                                                                            // A-fragment read land in different banks (L = 64: 80)
+        const int SP = p.SP, SP4 = SP >> 2, SPq = viterbi_products_stride(SP);   // row stride of the products: viterbi_products_floats
         // the matrix-core image of the output matrix (K2: one 1 KiB piece per (column block, state group)) borrows the
         // transition table's LDS area until the scores are done, when it fits
         const int otm_pieces = ((K + 15) >> 4) * p.c16;
-        const bool otm_lds = otm_pieces <= tr_pieces;
+        const bool otm_lds = otm_pieces <= viterbi_table_pieces(K, Kp, SP, p.L, true);
         if (otm_lds && !image_staged) {
             const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
-            for (int k = wu; k < otm_pieces; k += nwaves)
+            for (int k = wu; k < otm_pieces; k += nsw)
                 lds_dma16((unsigned)k * 1024u + (unsigned)lane * 16u, reinterpret_cast<const char *>(p.OTm), lds0 + (unsigned)k * 1024u);
         }
-        float *abT = hist;                               // [SP][Lq] alpha*beta, token-contiguous (aliases hist)
+        __shared__ int vh_queue[4];                      // next unit of each SIMD's queue (product_lds)
+        if (tid < 4) vh_queue[tid] = tid;
+        float *ab = hist;                                // [tokens][SPq] alpha*beta (aliases hist); rows of tokens >= n are never
+                                                         // written: a matrix-core row depends on its own A row only, and is not stored
         const float *Ab = p.A + (long long)b * (p.L + 1) * SP;
         const float *Bb = p.Bk + (long long)b * (p.L + 1) * SP;
+        // consecutive lanes take consecutive quads of ONE token's row: coalesced 16-byte loads, consecutive 16-byte LDS stores
+        {
+            const int pq = (SPq - SP) >> 2;              // pad quads of a row: zero (the output matrix's image is zero there too: 0 x 0)
+            for (int idx = tid; idx < n * pq; idx += ns) {
+                const int tok = idx / pq;
+                *reinterpret_cast<v4f *>(ab + tok * SPq + SP + (idx - tok * pq) * 4) = v4f{0.f, 0.f, 0.f, 0.f};
+            }
+        }
         if (ldsF) {                                      // the chains ran in this workgroup: their rows never left the LDS
             lds_cfloat *lf = (lds_cfloat *)ldsF, *lb = (lds_cfloat *)ldsB;
-            for (int idx = tid; idx < (Lq - 16) * SP4; idx += nthreads) {
+            for (int idx = tid; idx < n * SP4; idx += ns) {
                 const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
-                v4f a4 = v4f{0.f, 0.f, 0.f, 0.f}, b4 = a4;
-                if (tok < n) {
-                    a4 = *(lds_cv4f *)(lf + (tok + 1) * SP + s4);
-                    b4 = *(lds_cv4f *)(lb + (n - (tok + 1)) * SP + s4);
-                }
-                abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
-                abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
+                const v4f a4 = *(lds_cv4f *)(lf + (tok + 1) * SP + s4), b4 = *(lds_cv4f *)(lb + (n - (tok + 1)) * SP + s4);
+                *reinterpret_cast<v4f *>(ab + tok * SPq + s4) = v4f{a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
             }
         } else
-        for (int idx = tid; idx < (Lq - 16) * SP4; idx += nthreads) {
+        for (int idx = tid; idx < n * SP4; idx += ns) {
             const int tok = idx / SP4, s4 = (idx - tok * SP4) * 4;
-            float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = a4;
-            if (tok < n) {       // alpha = state after tok+1 tokens; beta = backward state before token tok+1 (:415-420)
-                a4 = ld4(Ab + (long long)(tok + 1) * SP + s4);
-                b4 = ld4(Bb + (long long)(n - (tok + 1)) * SP + s4);
-            }
-            abT[(s4 + 0) * Lq + tok] = a4.x * b4.x; abT[(s4 + 1) * Lq + tok] = a4.y * b4.y;
-            abT[(s4 + 2) * Lq + tok] = a4.z * b4.z; abT[(s4 + 3) * Lq + tok] = a4.w * b4.w;
+            // alpha = state after tok+1 tokens; beta = backward state before token tok+1 (:415-420)
+            const float4 a4 = ld4(Ab + (long long)(tok + 1) * SP + s4), b4 = ld4(Bb + (long long)(n - (tok + 1)) * SP + s4);
+            *reinterpret_cast<v4f *>(ab + tok * SPq + s4) = v4f{a4.x * b4.x, a4.y * b4.y, a4.z * b4.z, a4.w * b4.w};
         }
         __syncthreads();                                 // (drains vmcnt too: the image has landed)
         if (probe) pa = (long long)__builtin_amdgcn_s_memtime();
         // scores[n][K] = abT^T . O^T on the f32 matrix cores (v_mfma_f32_16x16x4_f32: the ascending-s fmaf chain of K2, same
         // bits): units of one 16-token block x two 16-tag blocks (shared A fragments from the staged products, independent
         // accumulators), B fragments from the matrix-core image of the output matrix (OTm, K2: staged in LDS by LDS-DMA when
-        // it fits the transition table's area, else from L2), two state groups ahead.  At most eight wavefronts take units
-        // -- two per SIMD (wavefront w sits on SIMD w % 4, HW_ID).  Measured: 12.9 k cycles for the config-3 sequence against
-        // 14 k for r02a's 4 x 4 VALU blocking (1 136 FMAs per lane on nine wavefronts, three of them on one SIMD); the
-        // matrix cores are not the bound (720 MFMAs = 5.8 k cycles over four SIMDs), the 4-way bank conflicts of the LDS waits are.
+        // it fits the transition table's area, else from L2), two state groups ahead.  Every score-phase wavefront takes units
+        // (wavefront w sits on SIMD w % 4, HW_ID).  Rounds 2-5 ran this phase on the dynamic programme's wavefronts only: K = 75
+        // = five, two of them on SIMD 0, which so carried five of a 64-token sequence's twelve units -- 16.7 k cycles for 672
+        // matrix-core instructions whose own time is 5.4 k over four SIMDs (profiles/r06_base_probe_viterbi_k75_*).
         {
             typedef float f32x4 __attribute__((ext_vector_type(4)));
             const int lr = lane & 15, lk = lane >> 4;
@@ -203,25 +290,91 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             // (token block, column-block pair) units fall on the eight wavefronts in two even rounds instead of 20 in three
             const int kz = (p.kz > 0 && p.kz < K) ? p.kz : K;
             const int c16 = p.c16, ntb = (n + 15) >> 4, ncb = (kz + 15) >> 4, nblk = ntb * ncb;
-            for (int i = tid; i < n * (Kp - 16 * ncb); i += nthreads) {       // (nothing when every block is computed: 16 ncb >= Kp)
+            for (int i = tid; i < n * (Kp - 16 * ncb); i += ns) {             // (nothing when every block is computed: 16 ncb >= Kp)
                 const int w_ = Kp - 16 * ncb, tok = i / w_, col = 16 * ncb + i - tok * w_;
                 scl[(long long)tok * Kp + col] = 0.0f;
             }
-            const int ngw = nwaves < 8 ? nwaves : 8;
+            const int ngw = nsw;                         // every score-phase wavefront takes units: wavefront w sits on SIMD w % 4, so
+                                                         // units w, w + ngw, ... load the four matrix cores evenly
             const int clamp_col = K - 3;                 // model_decompose.py:353
+            // Both operands in LDS (the usual case): units of ONE 16-token block x ONE 16-tag block, drawn from four queues -- one
+            // per SIMD (HW_ID[5:4]; unit u belongs to queue u % 4, a wavefront takes its SIMD's next unit with an LDS atomic).  Every
+            // matrix core gets a quarter of the units whatever wavefronts the hardware placed on its SIMD, and a SIMD's wavefronts
+            // share its queue.  (Rounds 2-5, and round 6's first form, dealt units to wavefront w by w's index on the assumption
+            // "wavefront w sits on SIMD w % 4": wavefront 0's unit was done 5.8 k cycles after the products, the last one 9.5 k --
+            // profiles/r06_probe_viterbi_k75_*.)  The reads of a state group are explicit instructions, issued a group ahead and
+            // retired by a counted wait (five per group: four A entries, one B fragment; LDS returns in order): left to the compiler
+            // the loop waited lgkmcnt(0) in front of every eight matrix-core instructions and read the odd groups' operands one at
+            // a time, each behind a full wait -- ~8 exposed LDS round trips per pair of groups (from the ISA).
+            auto product_lds = [&]() {
+                const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);      // HW_ID[5:4]
+                const int nunits = ntb * ncb;
+                for (;;) {
+                    int unit = 0;
+                    if (lane == 0) unit = atomicAdd(&vh_queue[simd], 4);
+                    unit = __builtin_amdgcn_readfirstlane(unit);
+                    if (unit >= nunits) break;
+                    const int tb = unit / ncb, cb = unit - tb * ncb;
+                    // this lane's entries of a state group: A = its token row at columns 16 g + 4 e + lk (e = 0..3: 16 bytes apart --
+                    // offset immediates; the row is padded with zeros to whole groups, so nothing is clamped), B = its 16 bytes of the
+                    // image's piece g.  ONE address per operand, advanced once per group: left as index arithmetic the loop spent 14
+                    // vector instructions per group on addresses (scripts/probe/score_product.hip: 60 -> 42 cycles per matrix-core
+                    // instruction and SIMD at sixteen wavefronts).
+                    unsigned pa = (unsigned)(size_t)(ab + (tb * 16 + lr) * SPq + lk);
+                    unsigned pb_ = (unsigned)(size_t)(trl + (size_t)cb * c16 * 256 + lane * 4);
+                    auto issue = [&](float (&a)[4], f32x4 &bf) {
+                        asm volatile("ds_read_b32 %0, %5\n\tds_read_b32 %1, %5 offset:16\n\tds_read_b32 %2, %5 offset:32\n\tds_read_b32 %3, %5 offset:48\n\t"
+                                     "ds_read_b128 %4, %6"
+                                     : "=&v"(a[0]), "=&v"(a[1]), "=&v"(a[2]), "=&v"(a[3]), "=&v"(bf) : "v"(pa), "v"(pb_) : "memory");
+                        pa += 64u; pb_ += 1024u;
+                    };
+                    auto landed = [&](float (&a)[4], f32x4 &bf, auto cnt) {                            // all but the `cnt` youngest reads have landed
+                        asm volatile("s_waitcnt lgkmcnt(%5)" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(bf) : "n"(decltype(cnt)::value));
+                    };
+                    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                    auto mfma4 = [&](const float (&a)[4], const f32x4 &bf) {                          // the ascending-s fmaf chain of K2
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], bf.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], bf.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], bf.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], bf.w, acc, 0, 0, 0);
+                    };
+                    float ae[4], ao[4];
+                    f32x4 be, bo;
+                    issue(ae, be);
+#pragma unroll 1
+                    for (int g = 0; g < c16; g += 2) {
+                        issue(ao, bo);                                                                 // (past the last group: read, never used)
+                        landed(ae, be, std::integral_constant<int, 5>{});
+                        mfma4(ae, be);
+                        issue(ae, be);
+                        landed(ao, bo, std::integral_constant<int, 5>{});
+                        if (g + 1 < c16) mfma4(ao, bo);
+                    }
+                    landed(ae, be, std::integral_constant<int, 0>{});                                  // (the trailing, unused group)
+                    const float av[4] = {acc.x, acc.y, acc.z, acc.w};                                  // rows lk*4 + r of the token block, column lr
+                    const int col = cb * 16 + lr;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int tok = tb * 16 + lk * 4 + r;
+                        float v = av[r] + 0.0f;                                                        // -0.0 -> +0.0 like score_tile_kernel
+                        if (col == clamp_col) v = fminf(v, p.threshold);
+                        if (tok < n && col < Kp) scl[(long long)tok * Kp + col] = v;
+                    }
+                }
+            };
             auto product = [&](auto otm) {               // otm: this lane's entry of the image, typed LDS or global pointer
             const int ncp = (ncb + 1) >> 1;              // a unit = one token block x TWO column blocks: shared A fragments,
 #pragma unroll 1                                         // two independent accumulators
             for (int unit = wu; unit < ntb * ncp && wu < ngw; unit += ngw) {
                 const int tb = unit / ncp, cb0 = 2 * (unit - tb * ncp), cb1 = cb0 + 1 < ncb ? cb0 + 1 : cb0;
                 auto bp0 = otm + cb0 * c16 * 64, bp1 = otm + cb1 * c16 * 64;
-                lds_cfloat *ap = (lds_cfloat *)abT + tb * 16 + lr;
+                lds_cfloat *ap = (lds_cfloat *)ab + (tb * 16 + lr) * SPq;     // this lane's token row
                 auto a_group = [&](int g, float (&a)[4]) {
                     const int gc = g < c16 ? g : c16 - 1;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int s = 16 * gc + 4 * e + lk;                   // this lane's k of k-step 4g + e
-                        a[e] = ap[(s < SP ? s : SP - 1) * Lq];                // (no product row there: B is zero, any finite A will do)
+                        a[e] = ap[s < SP ? s : SP - 1];                       // (no product column there: B is zero, any finite A will do)
                     }
                 };
                 auto b_group = [&](decltype(bp0) bp, int g) -> f32x4 { const v4f t = bp[(g < c16 ? g : c16 - 1) * 64]; return f32x4{t.x, t.y, t.z, t.w}; };
@@ -263,59 +416,14 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
                 if (cb1 != cb0) store(acc1, cb1);
             }
             };
-            if (otm_lds) product((lds_cv4f *)((lds_cfloat *)trl) + lane);
-            else product((glb_cv4f *)p.OTm + lane);
+            if (otm_lds) product_lds();
+            else product((glb_cv4f *)p.OTm + lane);                             // (the image does not fit the LDS: B fragments from L2)
         }
-        __syncthreads();                                 // abT (aliasing hist) is free again
+        if (probe) pw = (long long)__builtin_amdgcn_s_memtime();                // (wavefront 0's own units are done)
+        __syncthreads();                                 // the products (aliasing hist) are free again
         if (probe) pb = (long long)__builtin_amdgcn_s_memtime();
     }
-    // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
-    // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
-    // that e.g. K = 130 (64 pairs + START/STOP) costs the ninth wavefront 3 source slots per lane instead of 17
-    const int npairs = (K + 1) >> 1, nfull = npairs >> 3, rem = npairs & 7;
-    const bool tail = wu >= nfull;                       // wave-uniform
-    const int GT = rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8;
-    const int g = tail ? (lane & (GT - 1)) : (tid & 7);  // lane of its group
-    const int grp = tail ? lane / GT : 0;
-    const int pair = tail ? nfull * 8 + grp : (tid >> 3);
-    const int j0 = 2 * pair;
-    const bool own0 = j0 < K && (!tail || grp < rem), own1 = own0 && j0 + 1 < K;
-    const bool writer = own0 && (tail ? g == GT - 1 : g == 0);
-    const int XS = (K - 8 * IB + 7) >> 3;                // full wavefronts: leftover source slots per lane (0..4)
-    const int nst = (K + GT - 1) / GT;                   // tail wavefront: source slots per lane (<= IB + 4)
-    constexpr int NSL = IB + 4;
-    v2f trs[NSL];                                        // tr[i][j0], tr[i][j0+1] of this lane's sources
-#define FARNN_TRS_SET(SL, X, Y) do { trs[SL] = v2f{(X), (Y)}; } while (0)
-    int ixs[4];                                          // full: leftover sources (clamped into the row; their tr is -inf)
-    {
-        const float *row0 = p.trT + (long long)(own0 ? j0 : 0) * Kp, *row1 = p.trT + (long long)(own1 ? j0 + 1 : 0) * Kp;
-        if (!tail) {
-#pragma unroll
-            for (int k4 = 0; k4 < IB4; k4++) {           // sources 32*k4 + 4*g + u: a 128-byte span per read, no bank conflicts
-                const float4 a = ld4(row0 + k4 * 32 + g * 4), c = ld4(row1 + k4 * 32 + g * 4);
-                trs[k4 * 4 + 0] = v2f{own0 ? a.x : ninf, own1 ? c.x : ninf}; trs[k4 * 4 + 1] = v2f{own0 ? a.y : ninf, own1 ? c.y : ninf};
-                trs[k4 * 4 + 2] = v2f{own0 ? a.z : ninf, own1 ? c.z : ninf}; trs[k4 * 4 + 3] = v2f{own0 ? a.w : ninf, own1 ? c.w : ninf};
-            }
-#pragma unroll
-            for (int xk = 0; xk < 4; xk++) {
-                const int i = 8 * IB + 8 * xk + g;
-                const bool ok = i < K;
-                ixs[xk] = ok ? i : K - 1;
-                FARNN_TRS_SET(IB + xk, (ok && own0) ? row0[ixs[xk]] : ninf, (ok && own1) ? row1[ixs[xk]] : ninf);
-            }
-        } else {
-#pragma unroll
-            for (int sl = 0; sl < NSL; sl++) {
-                const int i = g + GT * sl;
-                const bool ok = i < K;
-                FARNN_TRS_SET(sl, (ok && own0) ? row0[ok ? i : K - 1] : ninf, (ok && own1) ? row1[ok ? i : K - 1] : ninf);
-            }
-#pragma unroll
-            for (int xk = 0; xk < 4; xk++) ixs[xk] = 0;
-        }
-    }
-    const v2f t_start = writer ? v2f{p.trT[(long long)j0 * Kp + START], own1 ? p.trT[(long long)(j0 + 1) * Kp + START] : 0.0f}
-                               : v2f{0.f, 0.f};                                                  // before the table DMA
+    if (tid >= nthreads) return;                         // the score phase's extra wavefronts leave (behind its last barrier)
     int my_tr = 0;
     {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)trl);
@@ -459,32 +567,47 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     __syncthreads();
     if (probe) pc2 = (long long)__builtin_amdgcn_s_memtime();
     if (w == 0 && n > 0) {
-        // One wavefront walks the path, and a lone wavefront issues one instruction every ~4-5 cycles: the step is bound by its
-        // instruction COUNT plus one LDS round trip (r02: eight 4-byte reads, a six-level DPP max, three ballots -- 590 cycles).
-        // Lane q holds FOUR consecutive candidates (4q .. 4q+3; PW / 4 <= 64 lanes cover a row): the table's row and the
-        // partitions' row are one 16-byte read each, the latter fetched a step ahead.  There is NO reduction: the maximum of a
+        // One wavefront walks the path, and a lone wavefront issues one instruction every ~4-5 cycles: a step is bound by its
+        // instruction COUNT plus one LDS round trip (r02: eight 4-byte reads, a six-level DPP max, three ballots -- 590 cycles;
+        // rounds 3-5: four consecutive candidates per lane, 16-byte reads, no reduction -- 437).
+        // Round 6: candidate i of a step sits on lane i % 64 of slice i / 64 (NU <= 4 slices of a row).  The comparison of a slice
+        // against the step's maximum IS its ballot (v_cmp_eq writes the 64-lane mask to a scalar pair), and the first arg-max of
+        // the row (torch.max's rule, crf.py:147-149) is the lowest set bit of the first non-empty slice: s_ff1 on scalars -- no
+        // per-lane "first hit of my four", no readlane, half the vector instructions.  There is NO reduction: the maximum of a
         // step's candidates IS part_t[ptr], which the forward pass took over exactly these values (a max returns one of its
         // operands' bits) -- two broadcast reads fetch it and the score f_t[ptr] beside the table's row.
-        const int nq = PW >> 2, q = lane < nq ? lane : nq - 1;
-        const unsigned long long valid = nq >= 64 ? ~0ull : ((1ull << nq) - 1ull);
-        const float *hq = hist + 4 * q, *tq = trl + 4 * q;
-        auto first_equal = [&](const float4 &c, float m) {                    // first index (torch.max's rule); 0 if none (NaN)
-            const bool h0 = c.x == m, h1 = c.y == m, h2 = c.z == m, h3 = c.w == m;
-            const int e = h0 ? 0 : h1 ? 1 : h2 ? 2 : 3;                       // this lane's first hit, if it has one
-            const unsigned long long any = (__ballot(h0) | __ballot(h1) | __ballot(h2) | __ballot(h3)) & valid;
-            const int l = __builtin_ctzll(any | (1ull << 63));
-            return any ? 4 * l + __builtin_amdgcn_readlane(e, l) : 0;
+        constexpr int NU = (32 * IB4 + 32 + 63) / 64;                         // PW <= 32 IB4 + 32
+        unsigned hq_a[NU], tq_a[NU];                                          // byte addresses of this lane's entries of a row
+        unsigned long long valid[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+            const int i = lane + 64 * u;
+            const bool ok = i < PW;                                           // (entries in [K, PW) are -inf through the partitions' pads)
+            valid[u] = __ballot(ok);
+            hq_a[u] = (unsigned)(size_t)(hist + (ok ? i : PW - 1));
+            tq_a[u] = (unsigned)(size_t)(trl + (ok ? i : PW - 1));
+        }
+        auto first_equal = [&](const float (&c)[NU], float m) {               // first index (torch.max's rule); 0 if none (NaN)
+            int r = 0;
+#pragma unroll
+            for (int u = NU - 1; u >= 0; u--) {
+                const unsigned long long hit = __ballot(c[u] == m) & valid[u];
+                r = hit ? 64 * u + (int)__builtin_ctzll(hit) : r;
+            }
+            return __builtin_amdgcn_readfirstlane(r);
         };
-        auto candidates = [&](float f, const float4 &tr, const float4 &pp) {  // (feat + trans) + partition: crf.py:123,145
-            return make_float4((f + tr.x) + pp.x, (f + tr.y) + pp.y, (f + tr.z) + pp.z, (f + tr.w) + pp.w);
-        };
-        float4 prv = *reinterpret_cast<const float4 *>(hq + (n - 1) * PW);
-        float4 c = candidates(0.0f, *reinterpret_cast<const float4 *>(tq + STOP * Kp), prv);      // crf.py:168-169 (0 + x = x)
-        // (candidates in [K, PW) are -inf through the partitions' pads; lanes beyond the row repeat its last four)
-        int ptr = first_equal(c, wave_max_dpp(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w))));
-        prv = *reinterpret_cast<const float4 *>(hq + (n > 1 ? n - 2 : 0) * PW);                    // part_{t-1} of the first step
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const unsigned hq0 = (unsigned)(size_t)hq, tq0 = (unsigned)(size_t)tq, h0 = (unsigned)(size_t)hist;
+        auto lds_f = [](unsigned a) { return *(lds_cfloat *)(size_t)a; };
+        float prv[NU], c[NU];
+        float mx = ninf;
+#pragma unroll
+        for (int u = 0; u < NU; u++) {                                        // crf.py:168-169: part_{n-1}[i] + tr[i][STOP]  (0 + x = x)
+            c[u] = (0.0f + lds_f(tq_a[u] + 4u * (unsigned)(STOP * Kp))) + lds_f(hq_a[u] + 4u * (unsigned)((n - 1) * PW));
+            mx = fmaxf(mx, c[u]);
+        }
+        int ptr = first_equal(c, wave_max_dpp(mx));
+#pragma unroll
+        for (int u = 0; u < NU; u++) prv[u] = lds_f(hq_a[u] + 4u * (unsigned)((n > 1 ? n - 2 : 0) * PW));   // part_{t-1} of the first step
+        const unsigned h0 = (unsigned)(size_t)hist;
         const unsigned sc_off = (unsigned)(size_t)scl - h0;
         int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
         for (int t = n - 1; t >= 0; t--) {
@@ -492,14 +615,16 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             // reads are ISSUED first; the tag's bookkeeping (a v_writelane through M0, the flush of 64 positions) runs under their
             // round trip -- in front of them it sat on the chain ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
             const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
-            const unsigned a_pre = hq0 + 4u * (unsigned)(tp * PW), a_tr = tq0 + 4u * (unsigned)(ptr * Kp);
+            const unsigned o_pre = 4u * (unsigned)(tp * PW), o_tr = 4u * (unsigned)(ptr * Kp);
             const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
-            f32x4 pre4, tr;
-            float m, f;
-            // one statement, so that the order is this one: the row fetched ahead first (its latency hides behind the others'
-            // -- LDS reads return in order), then the three the step waits for
-            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7"
-                         : "=&v"(pre4), "=&v"(tr), "=&v"(m), "=&v"(f) : "v"(a_pre), "v"(a_tr), "v"(a_m), "v"(a_f) : "memory");
+            float pre[NU], tr[NU], m, f;
+            // the rows fetched ahead first (their latency hides behind the others' -- LDS reads return in order), then what the step
+            // waits for; volatile statements keep this order
+#pragma unroll
+            for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(pre[u]) : "v"(hq_a[u] + o_pre) : "memory");
+#pragma unroll
+            for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(tr[u]) : "v"(tq_a[u] + o_tr) : "memory");
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(m), "=&v"(f) : "v"(a_m), "v"(a_f) : "memory");
             {
                 const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
                 const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
@@ -513,36 +638,47 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
                     if (p.flat) p.flat[foff + t + lane] = mytag;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(pre4), "+v"(tr), "+v"(m), "+v"(f) : : "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m), "+v"(f) : : "memory");
+#pragma unroll
+            for (int u = 0; u < NU; u++) asm volatile("" : "+v"(pre[u]), "+v"(tr[u]));            // (behind the wait)
             if (t > 0) {
-                c = candidates(f, make_float4(tr.x, tr.y, tr.z, tr.w), prv);
+#pragma unroll
+                for (int u = 0; u < NU; u++) c[u] = (f + tr[u]) + prv[u];     // (feat + trans) + partition: crf.py:123,145
                 ptr = first_equal(c, m);
-                prv = make_float4(pre4.x, pre4.y, pre4.z, pre4.w);
+#pragma unroll
+                for (int u = 0; u < NU; u++) prv[u] = pre[u];
             }
         }
     }
     if (probe && tid == 0) {
         pc3 = (long long)__builtin_amdgcn_s_memtime();
-        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (products staged at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
-               b, n, nthreads, pc1 - pc0, pa - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
+        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (products staged at %lld, wavefront 0's units done at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
+               b, n, nthreads, pc1 - pc0, pa - pc0, (pw ? pw : pa) - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
     }
     if (p.tags)
         for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)
 }
 
+// blockDim.x = the score phase's threads (viterbi_hist_score_threads: up to sixteen wavefronts for the fused form); the dynamic
+// programme runs on the first viterbi_hist_threads(K) of them
 template <int IB4, bool FUSED>
-__global__ void __launch_bounds__(128 * IB4 + 128)                          // K < 32*IB4 + 32: 8 lanes per tag pair
+__global__ void __launch_bounds__(1024)
 viterbi_hist_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
-    viterbi_hist_body<IB4, FUSED>(p, smem, (int)threadIdx.x, (int)blockDim.x, (int)blockIdx.x);
+    const int dp_threads = ((((p.K + 1) >> 1) * 8) + 63) & ~63;             // = viterbi_hist_threads(K): 8 lanes per tag pair
+    viterbi_hist_body<IB4, FUSED>(p, smem, (int)threadIdx.x, dp_threads, (int)blockIdx.x, nullptr, nullptr, false, nullptr, nullptr,
+                                  (int)blockDim.x);
 }
 
 // viterbi_hist_kernel: contiguous float4 blocks per lane (K = 32*IB4 + leftovers) and its thread count
 inline int viterbi_hist_ib4(int K) { return K / 32; }
 inline int viterbi_hist_threads(int K) { return round_up(((K + 1) / 2) * 8, 64); }
+// the stand-alone kernel's block: the fused form computes its scores on sixteen wavefronts (four per SIMD: every matrix core, more
+// state rows in flight), of which all but the dynamic programme's leave behind the scores
+inline int viterbi_hist_score_threads(int K, bool fused) { const int t = viterbi_hist_threads(K); return fused && t < 1024 ? 1024 : t; }
 inline size_t viterbi_hist_lds_bytes(int K, int Kp, int SP, int L, bool fused) {
     return viterbi_hist_floats(Kp, SP, L, fused) * 4 + ((size_t)L * Kp * 4 + 1023) / 1024 * 1024 +
-           ((size_t)K * Kp * 4 + 1023) / 1024 * 1024;
+           (size_t)viterbi_table_pieces(K, Kp, SP, L, fused) * 1024;
 }
 
 }  // namespace farnn
