@@ -30,6 +30,11 @@ __device__ __forceinline__ long long flat_offset_in_kernel(const int64_t *len, i
 }
 
 
+// The dynamic programme's wavefronts: eight lanes per tag pair on full wavefronts (eight pairs each); up to four pairs left over go
+// to ONE tail wavefront that spreads a pair over GT lanes (sources at stride GT); five to seven run as one more full wavefront.
+__host__ __device__ inline int viterbi_tail_lanes(int rem) { return rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8; }
+__host__ __device__ inline int viterbi_dp_threads(int K) { return (((((K + 1) >> 1) * 8) + 63) & ~63); }
+
 // The fused form's alpha*beta products, staged where the history will be: row-major [token][SPq] (round 6; rounds 2-5 staged them
 // transposed, [state][L + 16]: the 26 lanes that share a token wrote 320 floats apart -- one bank, a 26-way conflict on every one
 // of the staging's stores: 7.3 k cycles at S = 104, L = 64).  SPq / 4 is odd, so the sixteen token rows of a matrix-core A fragment
@@ -133,9 +138,12 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
     // that e.g. K = 130 (64 pairs + START/STOP) costs the ninth wavefront 3 source slots per lane instead of 17
     const int npairs = (K + 1) >> 1, nfull = npairs >> 3, rem = npairs & 7;
-    const int GT = rem <= 1 ? 64 : rem == 2 ? 32 : rem <= 4 ? 16 : 8;
-    // (rem >= 5 -- e.g. K = 75: 38 pairs -- would give the tail eight lanes per pair too: the same source slots as a full wavefront
-    //  through the tail's simpler, unpipelined loop; the last wavefront then runs the full wavefronts' loop with its spare groups idle)
+    // (round 6: five to seven left-over pairs -- K = 75: 38 pairs, six left over -- would give the tail eight lanes per pair too: the
+    //  same source slots as a full wavefront through the tail's simpler, unpipelined loop, which then set the step: 795 cycles.  The
+    //  last wavefront runs the full wavefronts' loop instead, its spare groups idle: 635.  Measured behind it and dropped, both at
+    //  625-640: the left-over pairs on three light tail wavefronts of 32 lanes per pair; (f + tr) computed under the reads' round
+    //  trip.  The step is one wavefront's chain -- reads, ~250 cycles of adds and maxima, DPP, write, barrier -- not a SIMD's load.)
+    const int GT = viterbi_tail_lanes(rem);
     const bool tail = wu >= nfull && GT > 8;             // wave-uniform
     const int g = tail ? (lane & (GT - 1)) : (tid & 7);  // lane of its group
     const int grp = tail ? lane / GT : 0;
@@ -525,9 +533,11 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         }
     };
     auto tail_steps = [&]() {
+        v2f fnext = n > 1 ? scores_at(1) : v2f{0.f, 0.f};
         for (int t = 1; t < n; t++) {
             const float *pin = hist + (size_t)(t - 1) * PW;
-            const v2f f = scores_at(t);
+            const v2f f = fnext;
+            fnext = scores_at(t + 1 < n ? t + 1 : t);    // (the coming step's scores: fetched beside this step's partitions)
             auto f_tr = [&](int sl) { return f + trs[sl]; };
             v2f best = v2f{ninf, ninf};
 #pragma unroll
@@ -609,44 +619,49 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         for (int u = 0; u < NU; u++) prv[u] = lds_f(hq_a[u] + 4u * (unsigned)((n > 1 ? n - 2 : 0) * PW));   // part_{t-1} of the first step
         const unsigned h0 = (unsigned)(size_t)hist;
         const unsigned sc_off = (unsigned)(size_t)scl - h0;
-        int mytag = 0;                                   // lane t % 64 keeps the tag of position t until the next flush
-        for (int t = n - 1; t >= 0; t--) {
-            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values.  The step's LDS
-            // reads are ISSUED first; the tag's bookkeeping (a v_writelane through M0, the flush of 64 positions) runs under their
-            // round trip -- in front of them it sat on the chain ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
-            const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
-            const unsigned o_pre = 4u * (unsigned)(tp * PW), o_tr = 4u * (unsigned)(ptr * Kp);
-            const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
-            float pre[NU], tr[NU], m, f;
-            // the rows fetched ahead first (their latency hides behind the others' -- LDS reads return in order), then what the step
-            // waits for; volatile statements keep this order
+        int mytag = 0;                                   // lane t % 64 keeps the tag of position t until its block of 64 is flushed
+        auto keep_tag = [&](int t) {                     // position t's tag (model_decompose.py:356) into lane t % 64: a v_writelane through M0
+            const int tag = (ptr == K - 3) ? p.o_idx : ptr;
+            const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
+            unsigned keep;                               // (one SGPR per instruction: the lane select rides in M0)
+            asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                         : "+v"(mytag), "=&s"(keep) : "s"(tg), "s"(tl));
+        };
+        // Blocks of 64 positions, last block first.  The loop over a block's positions has NO test inside (round 6: the flush test, the
+        // t == 0 test and the loop's own layout were three taken branches per position, each a refill of the instruction buffer --
+        // ~60 of a step's ~400 cycles): position 0 is peeled off (it has no back-pointer to find), a block is flushed behind its loop.
+        for (int t_hi = n - 1; t_hi >= 0; t_hi = (t_hi & ~63) - 1) {
+            const int t_lo = t_hi & ~63, t_stop = t_lo > 0 ? t_lo : 1;
+#pragma unroll 1
+            for (int t = t_hi; t >= t_stop; t--) {
+                // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values.  The step's LDS
+                // reads are ISSUED first; the tag's bookkeeping runs under their round trip -- in front of them it sat on the chain
+                // ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
+                const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
+                const unsigned o_pre = 4u * (unsigned)(tp * PW), o_tr = 4u * (unsigned)(ptr * Kp);
+                const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
+                float pre[NU], tr[NU], m, f;
+                // the rows fetched ahead first (their latency hides behind the others' -- LDS reads return in order), then what the step
+                // waits for; volatile statements keep this order
 #pragma unroll
-            for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(pre[u]) : "v"(hq_a[u] + o_pre) : "memory");
+                for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(pre[u]) : "v"(hq_a[u] + o_pre) : "memory");
 #pragma unroll
-            for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(tr[u]) : "v"(tq_a[u] + o_tr) : "memory");
-            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(m), "=&v"(f) : "v"(a_m), "v"(a_f) : "memory");
-            {
-                const int tag = (ptr == K - 3) ? p.o_idx : ptr;               // model_decompose.py:356
-                const int tl = __builtin_amdgcn_readfirstlane(t & 63), tg = __builtin_amdgcn_readfirstlane(tag);
-                unsigned keep;                                        // (one SGPR per instruction: the lane select rides in M0)
-                asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                             : "+v"(mytag), "=&s"(keep) : "s"(tg), "s"(tl));
-            }
-            if ((t & 63) == 0) {                         // 64 positions at a time, coalesced
-                if (t + lane < n) {
-                    if (p.tags) p.tags[(long long)b * p.L + t + lane] = mytag;
-                    if (p.flat) p.flat[foff + t + lane] = mytag;
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m), "+v"(f) : : "memory");
+                for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(tr[u]) : "v"(tq_a[u] + o_tr) : "memory");
+                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(m), "=&v"(f) : "v"(a_m), "v"(a_f) : "memory");
+                keep_tag(t);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m), "+v"(f) : : "memory");
 #pragma unroll
-            for (int u = 0; u < NU; u++) asm volatile("" : "+v"(pre[u]), "+v"(tr[u]));            // (behind the wait)
-            if (t > 0) {
+                for (int u = 0; u < NU; u++) asm volatile("" : "+v"(pre[u]), "+v"(tr[u]));            // (behind the wait)
 #pragma unroll
                 for (int u = 0; u < NU; u++) c[u] = (f + tr[u]) + prv[u];     // (feat + trans) + partition: crf.py:123,145
                 ptr = first_equal(c, m);
 #pragma unroll
                 for (int u = 0; u < NU; u++) prv[u] = pre[u];
+            }
+            if (t_lo == 0) keep_tag(0);
+            if (t_lo + lane <= t_hi) {                   // the block's 64 positions at a time, coalesced
+                if (p.tags) p.tags[(long long)b * p.L + t_lo + lane] = mytag;
+                if (p.flat) p.flat[foff + t_lo + lane] = mytag;
             }
         }
     }
@@ -665,14 +680,14 @@ template <int IB4, bool FUSED>
 __global__ void __launch_bounds__(1024)
 viterbi_hist_kernel(const ScoreParams p) {
     extern __shared__ __align__(16) float smem[];
-    const int dp_threads = ((((p.K + 1) >> 1) * 8) + 63) & ~63;             // = viterbi_hist_threads(K): 8 lanes per tag pair
+    const int dp_threads = viterbi_dp_threads(p.K);                         // = viterbi_hist_threads(K)
     viterbi_hist_body<IB4, FUSED>(p, smem, (int)threadIdx.x, dp_threads, (int)blockIdx.x, nullptr, nullptr, false, nullptr, nullptr,
                                   (int)blockDim.x);
 }
 
 // viterbi_hist_kernel: contiguous float4 blocks per lane (K = 32*IB4 + leftovers) and its thread count
 inline int viterbi_hist_ib4(int K) { return K / 32; }
-inline int viterbi_hist_threads(int K) { return round_up(((K + 1) / 2) * 8, 64); }
+inline int viterbi_hist_threads(int K) { return viterbi_dp_threads(K); }
 // the stand-alone kernel's block: the fused form computes its scores on sixteen wavefronts (four per SIMD: every matrix core, more
 // state rows in flight), of which all but the dynamic programme's leave behind the scores
 inline int viterbi_hist_score_threads(int K, bool fused) { const int t = viterbi_hist_threads(K); return fused && t < 1024 ? 1024 : t; }
