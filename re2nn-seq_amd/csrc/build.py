@@ -70,8 +70,34 @@ def _unit_flags(src):
     return []
 
 
+def _unit_checks(src):
+    """ISA checks a unit asks for: lines `// build-check: ring-registers <kernel-name substring>` in its first lines.  The unit is
+    compiled with -save-temps=obj and scripts/check_ring_registers.py walks the device assembly of the matching kernels: no
+    compiler-generated copy or spill may read a register whose asm-issued global load is still in flight (the kernels that keep a
+    ring of loads in ordinary asm outputs: chain_dest.hip.h).  A finding fails the build."""
+    out = []
+    with open(src) as f:
+        for _, line in zip(range(16), f):
+            if line.startswith('// build-check: ring-registers'):
+                out.append(line.split('ring-registers', 1)[1].strip())
+    return out
+
+
+def _run_checks(src, objdir, checks):
+    name = os.path.splitext(os.path.basename(src))[0]
+    asm = os.path.join(objdir, name + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+    script = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'scripts', 'check_ring_registers.py')
+    for pat in checks:
+        r = subprocess.run([sys.executable, script, asm, '--kernels', pat], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('ring-register check failed for {} ({}):\n{}'.format(name, pat, (r.stdout + r.stderr)[-3000:]))
+
+
 def _compile(src, flags, force, verbose, objdir):
     flags = flags + _unit_flags(src)
+    checks = _unit_checks(src)
+    if checks:
+        flags = flags + ['-save-temps=obj']
     name = os.path.splitext(os.path.basename(src))[0]
     obj, dep, stamp = (os.path.join(objdir, name + ext) for ext in ('.o', '.d', '.sha'))
     if not force and os.path.exists(obj):
@@ -87,6 +113,8 @@ def _compile(src, flags, force, verbose, objdir):
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, check=True, cwd=HERE)
+    if checks:
+        _run_checks(src, objdir, checks)
     digest = _digest([src] + (_deps(dep) or []), flags)
     with open(stamp, 'w') as f:
         f.write(digest or '')
