@@ -33,8 +33,8 @@
  * (FARNN_CV_WIDE, FARNN_DECOMP_OLD) are refused the same way by both builds:
  *   FARNN_NOFUSE=1          the multi-launch forms (recurrence kernel, then score / Viterbi kernel) instead of one launch per step
  *                           (also: the compact form's two launches instead of compact_tag_kernel)
- *   FARNN_FUSE=1            onehot i-FST, S <= 72, label-map scores: ONE launch per step for any batch size (the default there: one launch
- *                           while 2 B <= compute units, else the recurrence kernel + the label-map score launch, which is faster)
+ *   FARNN_FUSE=1            onehot i-FST, S <= 72, label-map scores: ONE launch per step (scores + decode beside the recurrence) instead of
+ *                           the default there, the recurrence kernel + the label-map score launch (faster at every measured shape)
  *   FARNN_NOREGS=1          the LDS-ring recurrence kernel where the register-fed one (S <= 128) would run
  *   FARNN_NODEST=1          [A/B build only] S <= 72, sum semiring: round 3's compute wavefronts (a block split by SOURCE rows,
  *                           partial sums reduced across the wavefronts) instead of the destination-split ones (chain_dest.hip.h)

@@ -53,13 +53,13 @@ __device__ __forceinline__ float dg_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]
     return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
+// Branch-free (round 6): the mode is a kernel argument, and as a `switch` it was three taken scalar branches on the step's chain
+// (~20 cycles each: scripts/probe/issue_rate.hip) in front of a dozen instructions.  Bit 0 of the mode = relu first, bit 1 = tanh
+// (FARNN_NL_NONE 0, RELU 1, TANH 2, RELUTANH 3); the tanh is always computed (finite for every input: e in [0, 1]) and selected.
 __device__ __forceinline__ float dg_nl(float x, int nl) {
-    switch (nl) {
-        case FARNN_NL_RELU: return fmaxf(x, 0.0f);
-        case FARNN_NL_TANH: return dg_tanh(x);
-        case FARNN_NL_RELUTANH: return dg_tanh(fmaxf(x, 0.0f));
-        default: return x;
-    }
+    const float y = (nl & 1) ? fmaxf(x, 0.0f) : x;
+    const float th = dg_tanh(y);
+    return (nl & 2) ? th : y;
 }
 
 // four FMAs of a 16-byte piece into two pairs of partial sums: two v_pk_fma_f32.  (-DFARNN_DG_SCALAR_FMA builds them as four

@@ -497,13 +497,10 @@ __device__ __forceinline__ float dr_tanh(float x) {
     else return copysignf((1.0f - e) / (1.0f + e), x);
 }
 template <bool FAST = false>
-__device__ __forceinline__ float dr_nl(float x, int nl) {
-    switch (nl) {
-        case FARNN_NL_RELU: return fmaxf(x, 0.0f);
-        case FARNN_NL_TANH: return dr_tanh<FAST>(x);
-        case FARNN_NL_RELUTANH: return dr_tanh<FAST>(fmaxf(x, 0.0f));
-        default: return x;
-    }
+__device__ __forceinline__ float dr_nl(float x, int nl) {                // branch-free, like dg_nl (decomp_regs.hip.h)
+    const float y = (nl & 1) ? fmaxf(x, 0.0f) : x;
+    const float th = dr_tanh<FAST>(y);
+    return (nl & 2) ? th : y;
 }
 
 // NP1R / NP2R / NP3R > 0: the matrix lives in REGISTERS (that many 128-row passes of NCH2R / NCH3R chunks) instead of LDS /

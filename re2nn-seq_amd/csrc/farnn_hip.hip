@@ -596,21 +596,14 @@ static int launch_chain(farnn_model *m, const int64_t *x, const int64_t *len, in
         const size_t lds_cap = rg.wide ? 158 * 1024 : 80 * 1024;
         bool score = fuse_sp && m->hs && m->OTm && m->c16 >= 1 && m->c16 <= (rg.wide ? RGW_NG : RG_NG) && m->Kc <= 256 && m->curL <= 31 * RG_TT &&
                      (B <= 1024 || !fuse_sp->flat || fuse_sp->offs) && !tun(TUN_NOFUSE);
-        // Round 5: which form is the faster one is a matter of the batch, and the faster one is the default.  S <= 72 with a
-        // label-map output matrix (tags only): once the launch has more workgroups than the chip has compute units (2 B > CUs)
-        // the recurrence-only kernel followed by the label-map score launch (K2l) wins -- 256 x 64: 30.8 us against 32.3,
-        // 1 024 x 64: 104.9 against 146.2 (every compute unit works through chains only, the tags of ALL sequences are scored in
-        // parallel afterwards instead of behind each chain) -- below that the one launch does (64 x 64: 26.4 against 28.4).
-        // FARNN_FUSE=1 keeps the one launch (north_star's form; what a graph replays as one node) for any batch.
-        if (score && !rg.wide && bs_label_map_path(*fuse_sp) && !tun(TUN_FUSE)) {
-            if (m->n_cu <= 0) {
-                int dev = 0, ncu = 0;
-                FARNN_HIP_TRY(hipGetDevice(&dev));
-                FARNN_HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-                m->n_cu = ncu > 0 ? ncu : 256;
-            }
-            if (2 * B > m->n_cu) score = false;
-        }
+        // Which form is the faster one was measured, and the faster one is the default.  S <= 72 with a label-map output matrix (tags
+        // only): the recurrence-only kernel followed by the label-map score launch (K2l).  Round 5 kept ONE launch (the scores and
+        // the decode beside the recurrence: north_star's form) while 2 B <= compute units, on measurements at B = 64 / 256 / 1 024 and
+        // L = 64 only; round 6's grid (scripts/gpu_r06_dispatch_grid.py -> profiles/r06_dispatch_grid.txt: B = 16..128 x L = 16..100)
+        // has two launches ahead at 32 of its 35 points -- by 5-20 % at the reference's default --seq_max_len 30 and below, within
+        // 1 % either way at L = 64 -- so the rule no longer looks at the batch.  FARNN_FUSE=1 keeps the one launch (what a HIP graph
+        // replays as one node); tests/test_gpu_dispatch_ab.py holds the default to "not the slower form" at nine (B, L) points.
+        if (score && !rg.wide && bs_label_map_path(*fuse_sp) && !tun(TUN_FUSE)) score = false;
         const bool lm_path = score && bs_label_map_path(*fuse_sp);
         const bool dest = !rg.wide && m->semiring != FARNN_SEMIRING_MAX && !tun(TUN_NODEST);
         size_t lds = (size_t)regs_lds(m->curL, m->SP, rg.NP, score ? m->c16 : 0, score ? m->Kc : 0, score, rg.RQ, lm_path, dest).total * sizeof(float);

@@ -54,7 +54,16 @@ def _one(rng, it):
     P = None
     if use_P:
         P = np.eye(C, dtype=np.float32) + (rng.rand(C, C) < 0.05).astype(np.float32) * 0.5
-    h = _lib.create_onehot_ifst(T, W, O, h0, hT, P=P, nl=nl, semiring=semiring, threshold=0.5, o_idx=1 % C)
+    # (round 6: the label-map path's default is two launches at every batch size; every second draw that takes it asks for the
+    #  one-launch form instead -- FARNN_FUSE=1, read when the handle is created -- so that both forms stay under the random shapes)
+    force_fuse = NO_SWITCH and P is None and not want_scores and S <= 72 and bool(it & 1)
+    if force_fuse:
+        os.environ['FARNN_FUSE'] = '1'
+    try:
+        h = _lib.create_onehot_ifst(T, W, O, h0, hT, P=P, nl=nl, semiring=semiring, threshold=0.5, o_idx=1 % C)
+    finally:
+        if force_fuse:
+            del os.environ['FARNN_FUSE']
     xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
     mode = _lib.MODE_FULL if full else _lib.MODE_LOCAL
     tags = torch.full((B, L), -7, dtype=torch.int32, device='cuda')
@@ -74,10 +83,10 @@ def _one(rng, it):
     label_map = P is None and not want_scores              # (every generated output matrix is a label map)
     if NO_SWITCH:                                          # (which kernel ran: the default dispatch only; results: under every switch)
         assert name.startswith('chain_regs_kernel' if S <= 72 else 'chain_wide_kernel'), what      # the register-fed recurrence ...
-        if L <= 64 and C <= 128 and (S > 72 or not label_map or B <= 128):
+        if L <= 64 and C <= 128 and (S > 72 or not label_map or force_fuse):
             assert 'fused' in name, what                   # ... in its one-launch form while states + score tiles fit half a CU's LDS
-        if S <= 72 and label_map and B > 128:
-            assert 'fused' not in name, what               # (round 5: more workgroups than compute units -> recurrence + label-map score launch)
+        if S <= 72 and label_map and not force_fuse:
+            assert 'fused' not in name, what               # (rounds 5-6: the recurrence kernel + the label-map score launch: the faster form)
     tol = 0.0 if exact else 1e-4 * max(1.0, float(np.abs(ref).max()))
     if want_scores:
         got = scores.cpu().numpy()

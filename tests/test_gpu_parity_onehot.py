@@ -278,13 +278,16 @@ def test_fst4_and_ind1_built_on_device_from_edges(independent):
     assert (fe != s2i['o']).sum() > 10
 
 
-def test_tag_call_captures_into_a_hip_graph():
+@pytest.mark.parametrize('one_launch', [True, False])
+def test_tag_call_captures_into_a_hip_graph(one_launch, monkeypatch):
     """farnn_reserve() + farnn_tag() allocate nothing and call no synchronising API afterwards, so a
     tagging step can be captured into a HIP graph and replayed on new inputs (same buffers)."""
     from re2nn_seq_amd import _lib, synth
     rng = np.random.RandomState(21)
     V, S, C, B, L = 60, 33, 9, 37, 19
     T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    if one_launch:
+        monkeypatch.setenv('FARNN_FUSE', '1')             # (switches are read when the handle is created)
     h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=1)
     h.reserve(B, L)
     dev = torch.device('cuda', 0)
@@ -304,9 +307,9 @@ def test_tag_call_captures_into_a_hip_graph():
     with torch.cuda.graph(g, stream=side):
         h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), flat.data_ptr(), None,
               torch.cuda.current_stream(dev).cuda_stream)
-    # the captured step is the ONE-launch form (round 4: the hand-off's epoch comes from device memory, nothing per launch from
-    # the host), i.e. a graph replays the kernel the headline is quoted on
-    assert not NO_SWITCH or 'fused' in h.kernel_name(_lib.KERN_CHAIN), h.kernel_name(_lib.KERN_CHAIN)
+    # the captured step: the ONE-launch form (FARNN_FUSE=1; round 4: the hand-off's epoch comes from device memory, nothing per
+    # launch from the host) or the default's two launches (round 6: the faster form at every measured shape)
+    assert not NO_SWITCH or ('fused' in h.kernel_name(_lib.KERN_CHAIN)) == one_launch, h.kernel_name(_lib.KERN_CHAIN)
     for seed in (1, 2, 3, 4, 5, 6, 7):
         x, lengths = synth.random_batch(V, B, L, np.random.RandomState(seed), min_len=1)
         xd.copy_(_t(x)); ld.copy_(_t(lengths))
@@ -317,7 +320,8 @@ def test_tag_call_captures_into_a_hip_graph():
         assert np.array_equal(flat.cpu().numpy()[:n], fo.forward_local_tags(ref, lengths, 0.5, 1))
 
 
-def test_graphs_of_two_batch_sizes_and_eager_calls_interleave_on_one_handle():
+@pytest.mark.parametrize('one_launch', [True, False])
+def test_graphs_of_two_batch_sizes_and_eager_calls_interleave_on_one_handle(one_launch, monkeypatch):
     """The hand-off's launch epoch does not depend on the batch size (beside.hip.h, bs_launch_epoch: every launch adds
     the same span to the device-side counter): two graphs captured at different B on ONE handle and eager calls at a
     third B interleave freely (stream-ordered), each launch the one-launch form, every result the oracle's.
@@ -326,6 +330,8 @@ def test_graphs_of_two_batch_sizes_and_eager_calls_interleave_on_one_handle():
     rng = np.random.RandomState(77)
     V, S, C, L = 50, 41, 11, 23
     T, W, O, h0, hT = synth.random_ifst_tensors(V, S, C, rng, edges_per_word=6.0)
+    if one_launch:
+        monkeypatch.setenv('FARNN_FUSE', '1')             # (switches are read when the handle is created)
     h = _lib.create_onehot_ifst(T, W, O, h0, hT, o_idx=1)
     sizes = (37, 12, 29)                                 # graph A, graph B, eager
     h.reserve(max(sizes), L)
@@ -361,7 +367,7 @@ def test_graphs_of_two_batch_sizes_and_eager_calls_interleave_on_one_handle():
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):
             call(B, torch.cuda.current_stream(dev).cuda_stream)
-        assert not NO_SWITCH or 'fused' in h.kernel_name(_lib.KERN_CHAIN), h.kernel_name(_lib.KERN_CHAIN)
+        assert not NO_SWITCH or ('fused' in h.kernel_name(_lib.KERN_CHAIN)) == one_launch, h.kernel_name(_lib.KERN_CHAIN)
         graphs[B] = g
     seed = 100
     for rnd in range(6):
