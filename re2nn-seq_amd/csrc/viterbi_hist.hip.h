@@ -115,6 +115,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     // The loads that open the decode are ISSUED together and used behind the flat offset's barriers (round 6): the sequence's length,
     // the label-map words and the lengths in front of the sequence used to be three dependent L2 round trips in a row at the head of
     // every workgroup (~2 k cycles each; then the state rows, a fourth).
+    const long long pt0 = FARNN_PROBE_ON(p.dbg & 8192) ? (long long)__builtin_amdgcn_s_memtime() : 0;      // the body's entry
     const long long len_raw = pre ? 0 : p.len[b];
     unsigned lm_own[2] = {0u, 0u};
     if (FUSED && p.lm.on && !lm_pk) lm_load_packed(p.lm, lane, lm_own[0], lm_own[1]);
@@ -128,11 +129,12 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     const float *sc = p.crf_scores + (long long)b * p.L * Kp;
     const long long foff = p.offs ? p.offs[b] : (p.flat ? (pre ? (long long)pre[1] : flat_offset_in_kernel(p.len, b, p.L, tid, ns)) : 0);
     const int n = pre ? pre[0] : clamp_len(len_raw, p.L);
+    const long long pf0 = FARNN_PROBE_ON(p.dbg & 8192) ? (long long)__builtin_amdgcn_s_memtime() : 0;     // (the opening loads have landed)
     const int START = K - 2, STOP = K - 1;
     const float ninf = -INFINITY;
     const int wu = __builtin_amdgcn_readfirstlane(w), nwaves = nthreads >> 6, nsw = ns >> 6;
     const bool probe = FARNN_PROBE_ON(p.dbg & 8192) && n == p.L;       // diagnostic: cycle counts of the phases of a full-length sequence
-    long long pc0 = probe ? (long long)__builtin_amdgcn_s_memtime() : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0, pw = 0;
+    long long pc0 = probe ? pt0 : 0, pc1 = 0, pc2 = 0, pc3 = 0, pa = 0, pb = 0, pw = 0;
 
     // ---- who does what: full wavefronts own eight tag pairs each (eight lanes per pair); the pairs left over go to one
     // TAIL wavefront that spreads them over all its lanes (GT = 64, 32, 16 or 8 lanes per pair, sources at stride GT), so
@@ -231,6 +233,7 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
                     a0[u] = ar[lr.st0]; b0[u] = br[lr.st0];
                     a1[u] = ar[lr.st1]; b1[u] = br[lr.st1];
                 }
+                if (probe && t0 == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pw = (long long)__builtin_amdgcn_s_memtime(); }   // (the first batch's rows have landed)
 #pragma unroll
                 for (int u = 0; u < NT; u++) {
                     if (t0 + u >= n) break;
@@ -667,8 +670,8 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
     }
     if (probe && tid == 0) {
         pc3 = (long long)__builtin_amdgcn_s_memtime();
-        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (products staged at %lld, wavefront 0's units done at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
-               b, n, nthreads, pc1 - pc0, pa - pc0, (pw ? pw : pa) - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
+        printf("viterbi wg %d (%d positions, %d threads): set-up + scores %lld cycles (opening loads landed at %lld, products / label-map scores staged at %lld, wavefront 0's first rows landed or its units done at %lld, scores done at %lld), forward pass %lld (%lld per step), backtrace %lld (%lld per step)\n",
+               b, n, nthreads, pc1 - pc0, pf0 - pc0, pa - pc0, (pw ? pw : pa) - pc0, pb - pc0, pc2 - pc1, (pc2 - pc1) / (n > 1 ? n - 1 : 1), pc3 - pc2, (pc3 - pc2) / n);
     }
     if (p.tags)
         for (int i = n + tid; i < p.L; i += nthreads) p.tags[(long long)b * p.L + i] = -1;   // pads (LOCAL and FULL)

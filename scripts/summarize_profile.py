@@ -15,10 +15,10 @@ src = os.path.join(ROOT, 'gpurun_out', 'prof_' + tag)
 dst = os.path.join(ROOT, 'profiles')
 os.makedirs(dst, exist_ok=True)
 
-for f in glob.glob(os.path.join(src, 'bench_*.json')):
+for f in glob.glob(os.path.join(src, 'bench_*.json')) + glob.glob(os.path.join(src, 'bench_*_stdout.txt')):
     if os.path.getsize(f) > 0:
         shutil.copy(f, os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))))
-for f in glob.glob(os.path.join(src, '*.txt')):
+for f in [f_ for f_ in glob.glob(os.path.join(src, '*.txt')) if not f_.endswith('_stdout.txt')]:
     # (a probe's printf lines and the bench's JSON line share stdout: keep the probe text only)
     keep = []
     for ln in open(f, errors='replace').read().splitlines():
@@ -31,7 +31,8 @@ for f in glob.glob(os.path.join(src, '*.txt')):
     with open(os.path.join(dst, '{}_{}'.format(tag, os.path.basename(f))), 'w') as g:
         g.write('\n'.join(keep) + '\n')
 for sub, name in (('trace', 'ifst'), ('trace_two', 'ifst_one_launch'), ('trace_crf', 'ifst_crf'), ('trace_decomp', 'decomp'),
-                  ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104'), ('trace_decomp_r250', 'decomp_r250_farnn2')):
+                  ('trace_fst4', 'fst4'), ('trace_s104', 'ifst_s104'), ('trace_crf_s104', 'ifst_crf_s104'), ('trace_decomp_r250', 'decomp_r250_farnn2'),
+                  ('trace_decomp_r250_bz200', 'decomp_r250_farnn2_crf_bz200_len30')):
     ks = sorted(glob.glob(os.path.join(src, sub, '*', '*_kernel_stats.csv')), key=os.path.getmtime)
     if ks:
         shutil.copy(ks[-1], os.path.join(dst, '{}_{}_kernel_stats.csv'.format(tag, name)))
@@ -75,23 +76,34 @@ def pick(label, kernel, counter):
 
 
 traffic = {}
+try:                                     # entries this profile did not re-measure keep their own stamp
+    with open(os.path.join(dst, 'traffic.json')) as f:
+        traffic = {k: v for k, v in json.load(f).items() if not k.startswith('_')}
+except (OSError, ValueError):
+    pass
+measured_now = []
 note = ('(2*FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch from separate rocprofv3 --pmc passes; on gfx950 '
         'FETCH_SIZE tallies 128-B requests at 64 B for 16-B/lane streams, hence the factor 2 '
         '(MI355X_MICROARCH.md, HBM section)')
 f_, w_ = pick('ifst ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
+    measured_now.append('ifst')
     traffic['ifst'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel', 'source': note}
 f_, w_ = pick('ifst ragged U[5,64] one launch (FARNN_FUSE=1)', 'chain', 'FETCH_SIZE'), pick('ifst ragged U[5,64] one launch (FARNN_FUSE=1)', 'chain', 'WRITE_SIZE')
 if f_ is not None:
+    measured_now.append('ifst_one_launch')
     traffic['ifst_one_launch'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_regs_kernel<fused>', 'source': note}
 f_, w_ = pick('ifst S=104 ragged U[5,64]', 'chain', 'FETCH_SIZE'), pick('ifst S=104 ragged U[5,64]', 'chain', 'WRITE_SIZE')
 if f_ is not None:
+    measured_now.append('ifst_s104')
     traffic['ifst_s104'] = {'hbm_bytes_per_launch': (2 * f_ + (w_ or 0)) * 1024, 'kernel': 'chain_wide_kernel', 'source': note}
 f_ = pick('synth512 B1024 L128', 'chain', 'FETCH_SIZE')
 if f_ is not None:
+    measured_now.append('synth512')
     traffic['synth512'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'chain_kernel', 'source': note + ' (reads only)'}
 f_ = pick('fst4', 'fst4_score', 'FETCH_SIZE')
 if f_ is not None:
+    measured_now.append('fst4')
     traffic['fst4'] = {'hbm_bytes_per_launch': 2 * f_ * 1024, 'kernel': 'fst4_score_kernel', 'source': note + ' (reads only)'}
 # SQ counter groups (instruction mix, waits, LDS conflicts) of the dominant kernels
 sq = collections.defaultdict(lambda: [0.0, 0])
@@ -114,12 +126,19 @@ with open(os.path.join(dst, tag + '_pmc_sq.csv'), 'w') as f:
         w.writerow([wl, kn, c, '%.1f' % (s_ / n), n])
 # the split is valid for the kernels of the commit it was measured at: stamp it (bench.py prints it as traffic_head)
 import subprocess
-try:
-    head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
-    dirty = bool(subprocess.run(['git', 'status', '--porcelain', '--', 're2nn-seq_amd/csrc'], cwd=ROOT, capture_output=True, text=True).stdout.strip())
-except Exception:
-    head, dirty = 'unknown', False
-traffic['_measured_at'] = {'head': head + ('+dirty' if dirty else ''), 'profile': tag}
+stamp = os.path.join(ROOT, 'gpurun_out', 'prof_{}_head.txt'.format(tag))
+if os.path.exists(stamp):        # written by the launcher (scripts/run_profile_r06.sh) from the tree it shipped: "<head>[+dirty]"
+    head, dirty = open(stamp).read().strip(), False
+else:
+    try:
+        head = subprocess.run(['git', 'rev-parse', '--short=12', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+        dirty = bool(subprocess.run(['git', 'status', '--porcelain', '--', 're2nn-seq_amd/csrc'], cwd=ROOT, capture_output=True, text=True).stdout.strip())
+    except Exception:
+        head, dirty = 'unknown', False
+for k_ in traffic:
+    if traffic[k_].get('source', '').startswith('(2*FETCH') and k_ in measured_now:
+        traffic[k_]['head'] = head + ('+dirty' if dirty else '')
+traffic['_measured_at'] = {'head': head + ('+dirty' if dirty else ''), 'profile': tag, 'entries': measured_now}
 with open(os.path.join(dst, 'traffic.json'), 'w') as f:
     json.dump(traffic, f, indent=1)
 for r in rows:
