@@ -434,7 +434,8 @@ compact_tag_kernel(const CompactParams p, const ScoreParams sp) {
 // the geometries the one-launch form covers
 inline bool compact_tag_fits(int V, int S, int L) {
     return S <= 128 && (size_t)compact_tag_lds(L, S <= 64 ? 1 : 2).total * 4 <= (size_t)150 * 1024 &&
-           (unsigned long long)V * S * (S <= 64 ? 1 : 2) * 8ull < (1ull << 32);
+           (unsigned long long)V * S * (S <= 64 ? 1 : 2) * 8ull < (1ull << 32) - 4096;    // (the kernel adds lane * NS * 8 and an offset:1024 to the
+                                                                                       //  last block's 32-bit offset: 4 KiB short of 4 GiB, it cannot wrap)
 }
 
 }  // namespace farnn

@@ -298,7 +298,7 @@ static int finish_bitmaps(farnn_model *m, int *bad_dev) {
     FARNN_HIP_TRY(hipMemcpy(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost));
     (void)hipFree(bad_dev);
     if (bad) m->bmNS = 0;            // a weight other than 0 / 1: the dense blocks are the only form (the bitmaps stay unused)
-    if (m->bmNS >= 1 && m->bmNS <= 2 && (unsigned long long)m->V * m->S * m->bmNS * 8ull < (1ull << 32)) {
+    if (m->bmNS >= 1 && m->bmNS <= 2 && (unsigned long long)m->V * m->S * m->bmNS * 8ull < (1ull << 32) - 4096) {     // (= compact_tag_fits' bound)
         // compact_tag_kernel's planes (compact_tag.hip.h).  Its lanes without a state read rows past their block: 4 KiB of slack
         const size_t nb = (size_t)m->V * m->S * m->bmNS * sizeof(u64);
         int rc;
