@@ -85,6 +85,25 @@ __device__ __forceinline__ float oct_sum(float x) {
     return x;
 }
 
+// FOUR row sums over the eight lanes of a group, reduce-scattered (round 6): three DPP levels in all -- the mirrored partner (lanes
+// 0-3 keep passes {0, 1}, lanes 4-7 keep {2, 3}), the partner two lanes away (bit 1 of the lane picks one of the two), the neighbour
+// (which holds the same pass) -- four DPP adds and six selects where four oct_sums took twelve and four.  Lane k ends with the total
+// of pass oct_pass(k); both lanes of a pair {2m, 2m + 1} hold it.
+__device__ __forceinline__ int oct_pass(int k) { return ((k >> 2) << 1) | ((k >> 1) & 1); }
+__device__ __forceinline__ float oct_reduce_scatter4(float v0, float v1, float v2, float v3, int k) {
+    auto dpp = [](float x, auto ctrl) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, true)); };
+    const bool hi = (k & 4) != 0, b1 = (k & 2) != 0;
+    float ka = hi ? v2 : v0, kb = hi ? v3 : v1;
+    const float sa = hi ? v0 : v2, sb = hi ? v1 : v3;                         // what the mirrored partner keeps
+    ka += dpp(sa, std::integral_constant<int, 0x141>{});                      // row_half_mirror
+    kb += dpp(sb, std::integral_constant<int, 0x141>{});
+    float kk = b1 ? kb : ka;
+    const float ss = b1 ? ka : kb;                                            // what the partner two lanes away keeps
+    kk += dpp(ss, std::integral_constant<int, 0x4E>{});                       // quad_perm [2,3,0,1]
+    kk += dpp(kk, std::integral_constant<int, 0xB1>{});                       // quad_perm [1,0,3,2]: the neighbour holds the same pass
+    return kk;
+}
+
 // NCH2 / NCH3: 32-column chunks of the two input vectors (h: S columns; [rr | h]: Rp + S columns); NP3: passes of P3;
 // CS: leading chunks of [rr | h] that hold rr entries (they can only be read behind the step's first barrier)
 // (Tried in r02 and dropped: both chains of a sequence in one eight-wavefront workgroup with the scores + decode as its
@@ -476,6 +495,16 @@ decomp_regs8_kernel(const DecompRegsParams p) {
         // ---- phase A (needs h only): P2, rr[r] = v[r] * <Sa[:, r], h>, and the part of P3 that does not depend on rr -- the
         // chunks of [rr | h] that hold state entries only (W(^T) . h and the tail of nothing else) --------------------------
         v2f pl3[NP3], ph3[NP3];
+        // (round 6) the chunks of [rr | h] that hold state entries only are READ here -- they are the last step's, complete behind its
+        // barrier -- but their products with P3 run in phase B, under the round trip of the rr chunks' reads: in front of the
+        // barrier (rounds 2-5) those 8 (NCH3 - CS) packed FMAs per lane delayed every wavefront's arrival at it
+        constexpr int NH3 = NCH3 - CS > 0 ? NCH3 - CS : 0;
+        v4f xh[NH3 > 0 ? NH3 : 1];
+        {
+            lds_cfloat *xq0 = (lds_cfloat *)X3c + k * 4;
+#pragma unroll
+            for (int c = CS; c < NCH3; c++) xh[c - CS] = *(lds_cv4f *)(xq0 + c * DR_CHUNK);
+        }
         {
             v2f tl[NP2], th[NP2];
 #pragma unroll
@@ -496,18 +525,6 @@ decomp_regs8_kernel(const DecompRegsParams p) {
                 acc2 = (k == i) ? a : acc2;
             }
             if (own2) X3c[row2] = acc2 * v0;
-            lds_cfloat *xq = (lds_cfloat *)X3c + k * 4;
-#pragma unroll
-            for (int i = 0; i < NP3; i++) { pl3[i] = v2f{0.f, 0.f}; ph3[i] = v2f{0.f, 0.f}; }
-#pragma unroll
-            for (int c = 0; c < NCH3; c++) {
-                if (c < CS) continue;                         // the chunks that hold rr entries wait for the barrier
-                const v4f x0 = *(lds_cv4f *)(xq + c * DR_CHUNK);
-#pragma unroll
-                for (int i = 0; i < NP3; i++) {
-                    dg_fma4(pl3[i], ph3[i], w3[i][c], x0);
-                }
-            }
         }
         // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products, so that the step
         //  starts with its LDS reads -- at the step's top this bookkeeping sat between the barrier and them: 59.6 -> 56.5 us per
@@ -534,27 +551,36 @@ decomp_regs8_kernel(const DecompRegsParams p) {
         if (FARNN_PROBE_ON(p.dbg & 4096)) { const long long c1 = __builtin_amdgcn_s_memtime(); cyc[1] += c1 - c0; c0 = c1; }
         // ---- phase B: the rr chunks of P3, h'[j] = nl(<[Sb[j, :] | Wd[:, j]], [rr | h]>), into the other buffers and the stash
         {
-            lds_cfloat *xq = (lds_cfloat *)X3c + k * 4;
+            // the rr chunks' reads are ISSUED (explicit instructions: they stay in front), the state chunks' products run under
+            // their round trip, then the rr chunks' products
+            const unsigned xq_a = (unsigned)(size_t)(X3c + k * 4);
+            v4f xr[CS];
+            static_for<0, CS>([&](auto c) { lds_read16_at<decltype(c)::value * DR_CHUNK * 4>(xr[decltype(c)::value], xq_a); });
 #pragma unroll
-            for (int c = 0; c < NCH3; c++) {
-                if (c >= CS) continue;
-                const v4f x0 = *(lds_cv4f *)(xq + c * DR_CHUNK);
+            for (int j = 0; j < NH3; j++) asm volatile("" : "+v"(xh[j]));         // (behind the reads' issue)
 #pragma unroll
-                for (int i = 0; i < NP3; i++) {
-                    dg_fma4(pl3[i], ph3[i], w3[i][c], x0);
-                }
+            for (int i = 0; i < NP3; i++) { pl3[i] = v2f{0.f, 0.f}; ph3[i] = v2f{0.f, 0.f}; }
+#pragma unroll
+            for (int c = CS; c < NCH3; c++) {
+#pragma unroll
+                for (int i = 0; i < NP3; i++) dg_fma4(pl3[i], ph3[i], w3[i][c], xh[c - CS]);
             }
-            // every lane of a quad gets the row sums; lane k finishes row pass k (k < NP3), so the non-linearity of all the
-            // passes runs once, on different lanes
-            float mine = 0.0f;
+            static_for<0, CS>([&](auto c) { lds_wait_for<CS - 1 - decltype(c)::value>(xr[decltype(c)::value]); });
 #pragma unroll
-            for (int i = 0; i < NP3; i++) {
-                const v2f tt = pl3[i] + ph3[i];
-                const float acc = oct_sum(tt.x + tt.y);
-                mine = (k == i) ? acc : mine;
+            for (int c = 0; c < CS; c++) {
+#pragma unroll
+                for (int i = 0; i < NP3; i++) dg_fma4(pl3[i], ph3[i], w3[i][c], xr[c]);
             }
-            const int row = k * DG8 + rslot;
-            if (k < NP3 && row < SP) {
+            // the four passes' row sums are reduce-scattered over the eight lanes of the group (oct_reduce_scatter4): lane k ends
+            // with pass oct_pass(k); the even lane of a pair finishes it, so the non-linearity of all the passes runs once
+            static_assert(NP3 <= 4, "oct_reduce_scatter4: at most four passes of P3");
+            float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < NP3; i++) { const v2f tt = pl3[i] + ph3[i]; rs[i] = tt.x + tt.y; }
+            const float mine = oct_reduce_scatter4(rs[0], rs[1], rs[2], rs[3], k);
+            const int pass3 = oct_pass(k);
+            const int row = pass3 * DG8 + rslot;
+            if ((k & 1) == 0 && pass3 < NP3 && row < SP) {
                 float hn = 0.0f;                              // pad columns of the stash stay zero
                 if (row < S) {
                     hn = dg_nl(mine, nl_mode);
