@@ -501,11 +501,6 @@ decomp_regs8_kernel(const DecompRegsParams p) {
         constexpr int NH3 = NCH3 - CS > 0 ? NCH3 - CS : 0;
         v4f xh[NH3 > 0 ? NH3 : 1];
         {
-            lds_cfloat *xq0 = (lds_cfloat *)X3c + k * 4;
-#pragma unroll
-            for (int c = CS; c < NCH3; c++) xh[c - CS] = *(lds_cv4f *)(xq0 + c * DR_CHUNK);
-        }
-        {
             v2f tl[NP2], th[NP2];
 #pragma unroll
             for (int i = 0; i < NP2; i++) { tl[i] = v2f{0.f, 0.f}; th[i] = v2f{0.f, 0.f}; }
@@ -525,6 +520,10 @@ decomp_regs8_kernel(const DecompRegsParams p) {
                 acc2 = (k == i) ? a : acc2;
             }
             if (own2) X3c[row2] = acc2 * v0;
+            // (issued BEHIND the products of P2 and the rr store, as explicit instructions: in front of them the three reads delayed
+            //  the state chunks P2 waits for)
+            const unsigned xq_h = (unsigned)(size_t)(X3c + k * 4);
+            static_for<0, NH3>([&](auto c) { lds_read16_at<(CS + decltype(c)::value) * DR_CHUNK * 4>(xh[decltype(c)::value], xq_h); });
         }
         // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products, so that the step
         //  starts with its LDS reads -- at the step's top this bookkeeping sat between the barrier and them: 59.6 -> 56.5 us per
