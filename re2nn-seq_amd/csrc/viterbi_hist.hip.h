@@ -320,11 +320,14 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             auto product_lds = [&]() {
                 const int simd = (int)(__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4) & 3);      // HW_ID[5:4]
                 const int nunits = ntb * ncb;
-                for (;;) {
+                // a wavefront drains its own SIMD's queue, then the others' (nothing guarantees that every SIMD hosts one of the
+                // workgroup's wavefronts -- a three-wavefront body inside the one-launch kernel does not: round 6's switch matrix)
+                for (int qi = 0; qi < 4;) {
+                    const int q = (simd + qi) & 3;
                     int unit = 0;
-                    if (lane == 0) unit = atomicAdd(&vh_queue[simd], 4);
+                    if (lane == 0) unit = atomicAdd(&vh_queue[q], 4);
                     unit = __builtin_amdgcn_readfirstlane(unit);
-                    if (unit >= nunits) break;
+                    if (unit >= nunits) { qi++; continue; }
                     const int tb = unit / ncb, cb = unit - tb * ncb;
                     // this lane's entries of a state group: A = its token row at columns 16 g + 4 e + lk (e = 0..3: 16 bytes apart --
                     // offset immediates; the row is padded with zeros to whole groups, so nothing is clamped), B = its 16 bytes of the
