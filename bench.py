@@ -134,9 +134,10 @@ def other_config_line(r):
     if 'error' in r:
         return json.dumps({'other_config': r.get('workload'), 'error': str(r['error'])[:300]})
     rf, par = r.get('roofline', {}), r.get('parity', {})
-    d = {'other_config': r.get('workload'), 'value': r.get('value'), 'unit': r.get('unit'), 'ms_per_step': r.get('ms_per_step'),
+    # (value in tokens/s like the result line's; the ceiling's `peak` and units are in gpurun_out/bench_full.json)
+    d = {'other_config': r.get('workload'), 'value': r.get('value'), 'ms_per_step': r.get('ms_per_step'),
          'steps': r.get('steps'), 'valid_tokens_per_step': r.get('config', {}).get('valid_tokens_per_step'),
-         'roofline': _pick(slim_roofline(rf), ('bound', 'frac', 'achieved', 'peak', 'unit', 'kernel', 'chain_avg_us', 'score_decode_avg_us',
+         'roofline': _pick(slim_roofline(rf), ('bound', 'frac', 'achieved', 'kernel', 'chain_avg_us', 'score_decode_avg_us',
                                                'frac_all_l2', 'model_falsified', 'frac_split', 'step_latency_us')),
          'parity': _pick(par, ('tags_equal', 'tags_compared', 'sequences_checked', 'max_score_err'))}
     line = json.dumps(_sig(d, 5))
