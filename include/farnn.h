@@ -48,6 +48,8 @@
  *   FARNN_DECOMP_NOREGS=1, FARNN_ROWS_NOREGS=1     the decomposed recurrence's LDS-fed kernels instead of the register forms
  *   FARNN_ROWS_LPR4=1|2     gated decomposed models (farnn = 2, S <= 160): 1 = four lanes per row instead of eight (round 3's forms),
  *                           2 = eight lanes per row but P2 swept from LDS (without the all-in-registers / mixed eight-lane forms)
+ *   FARNN_ROWS_NOROUNDS=1   the decomposed recurrence's register forms with one workgroup per sequence and direction (round 5) instead of
+ *                           one per compute unit walking its sequences with the weights kept in registers
  *   FARNN_TRAIN_NOLDS=1|2, FARNN_TRAIN_NSEQ=2|4    training chains with the matrices read through L2 / sequences per workgroup
  * Diagnostic switches (ablations, geometry overrides: FARNN_DBG, FARNN_KS, FARNN_RPG, FARNN_NLD, FARNN_FUSE_SPIN, FARNN_SOLO_MARGIN,
  * ...) exist only in the profiling build of the library (csrc/build.py --probes); the production library ignores them.

@@ -12,7 +12,7 @@
 //                  h' = farnn ? (1-z) h + z nl(nx) : nl(nx)
 //
 // The token-dependent halves of the gates, v_t . Wrs + bs, do not depend on the state: they are
-// folded into per-word tables Gz/Gr[V][S] when the handle is built (weights are frozen on the
+// folded into per-word gate rows when the handle is built (weights are frozen on the
 // tagging path), like Vgen.  The o scaling (:156-157 input side backward, :180-181 output side
 // forward) is folded into the packed rows.
 //
@@ -62,7 +62,7 @@ struct DecompRowsParams {
     const float *P3[2];           // [S][ld3]    per direction
     int n1, n2, n3, ld2, ld3, nch2, nch3;
     int res1, res2, res3;         // leading rows of each matrix kept in LDS
-    const float *Vgen, *Gz, *Gr;  // [V][Rp], [V][SP], [V][SP]
+    const float *TVt;             // [V][tvl]: per word [Vgen row (Rp) | update-gate row (SP, farnn >= 1) | reset-gate row (SP, farnn == 2)]
     const float *h0, *hT;
     const int64_t *x, *len;
     const int *order;             // folded launch order (batch_prep) or nullptr
@@ -72,6 +72,7 @@ struct DecompRowsParams {
     float sig_k;
     int dbg;                      // diagnostic ablation mask (FARNN_DBG); 0 in production
     int lds_floats;               // the launch's dynamic LDS size (a whole KiB), in floats
+    int groups;                   // groups of NSEQ sequences per direction: a workgroup walks groups slot, 2 slots - 1 - slot, ... (gridDim.x / 2 slots)
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -522,12 +523,15 @@ decomp_rows_kernel(const DecompRowsParams p) {
     constexpr bool OPA = (!MIXED && (LPR == 8 || NCH3R <= 8)) || NPLX;
     constexpr bool FASTQ = !MIXED;                            // (the 134-state fixtures sit at the 1e-4 bar: the mixed form keeps the division)
     extern __shared__ __align__(16) float smem[];
-    const long long t_start = FARNN_PROBE_ON((p.dbg & 16) != 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const long long t_kernel = FARNN_PROBE_ON((p.dbg & 16) != 0) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x;
-    const int dir = blockIdx.x & 1, grp = blockIdx.x >> 1;
+    const int dir = blockIdx.x & 1;
     const int S = p.S, SP = p.SP, R = p.R, Rp = p.Rp, ld2 = p.ld2, ld3 = p.ld3;
     const int c2p = p.nch2 * DR_CHUNK, c3p = p.nch3 * DR_CHUNK;      // floats of the input vectors
-    const int farnn = p.farnn;
+    // (a form with gate rows in registers is chosen for farnn = 2 only -- rows_plan_try: A_ > 0 needs n1 > 0 -- and the compiler should
+    //  know: with the farnn != 2 prefetch block compiled in beside P1, it took the prefetch registers' re-use in P1 for a possible pending
+    //  load and opened every step with s_waitcnt vmcnt(0) -- a wait for the previous step's stash stores to be acknowledged)
+    const int farnn = NP1R > 0 ? 2 : p.farnn;
     const int Lr = (p.L + 3) & ~3;
     const int tvl = Rp + (farnn >= 1 ? SP : 0) + (farnn == 2 ? SP : 0);
 
@@ -610,7 +614,21 @@ decomp_rows_kernel(const DecompRowsParams p) {
         const int row = tid >> 2;
         g3src = (glb_cv4f *)(p.P3[dir] + (long long)(row < p.n3 ? row : p.n3 - 1) * ld3 + (tid & (DR_LPR - 1)) * 4);
     }
-    // ---- sequences of this workgroup -------------------------------------------------------------
+    // ---- the workgroup's sequences, one ROUND after the other (round 6) --------------------------------------------------------
+    // The launcher starts no more workgroups than the device runs at once (a register form: one per compute unit) and each walks the
+    // length-ranked groups of its direction in snake order -- slot q of Q takes groups q, 2Q - 1 - q, 2Q + q, ...: the longest with the
+    // shortest, like the hardware's in-order dispatch of 2 x groups workgroups did -- keeping its weights in registers and its
+    // resident rows in LDS: a second group used to start with the whole set-up again (~0.5 MB per compute unit, ~14 k cycles).
+    const int slots = gridDim.x >> 1, slot = blockIdx.x >> 1;
+    for (int rnd = 0;; rnd++) {
+    const int grp = (rnd & 1) ? (rnd + 1) * slots - 1 - slot : rnd * slots + slot;
+    if (grp >= p.groups) break;
+    // (the round's own copy of the thread index, opaque: what the set-up derives from it -- zeroing, staging and stash addresses -- is
+    //  loop-invariant, the compiler hoisted it out of the rounds and kept it alive across the time loop: 38 registers spilled)
+    int tid_r = tid;
+    asm volatile("" : "+v"(tid_r));
+    const int tid = tid_r;
+    const long long t_start = rnd == 0 ? t_kernel : (FARNN_PROBE_ON((p.dbg & 16) != 0) ? (long long)__builtin_amdgcn_s_memtime() : 0);
     int bseq[NSEQ], nst[NSEQ], slen[NSEQ];
     int nmax = 0;
 #pragma unroll
@@ -661,7 +679,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // two of output rows; the registers hold the first passes, the few rows behind them are LDS-resident like any other
     // matrix's, or streamed: R1 / R2 / R3 above.)
     if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_1 = (long long)__builtin_amdgcn_s_memtime();
-    {   // what the DMAs at the top do not write: columns past the model, the rows' pads, the LDS behind the rows
+    if (rnd == 0) {   // what the DMAs at the top do not write: columns past the model, the rows' pads, the LDS behind the rows
         float *tail = L3 + (long long)p.res3 * ld3;
         if constexpr (LPR == 8 && NP2R > 0 && NP3R > 0) {
             constexpr int QPR = DR_T3_CHUNKS * 16;              // 16-byte pieces per row
@@ -677,7 +695,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
         for (int i = tid; tail + i < smem + p.lds_floats; i += DR_THREADS) tail[i] = 0.0f;
     }
     const float *T3 = L3 + (long long)p.res3 * ld3;
-    if constexpr (!EARLYW) FARNN_DR_LOAD_WEIGHTS();
+    if constexpr (!EARLYW) { if (rnd == 0) FARNN_DR_LOAD_WEIGHTS(); }
 #undef FARNN_DR_LOAD_WEIGHTS
     if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) { st_2 = st_3 = (long long)__builtin_amdgcn_s_memtime(); }
     // (LDS traffic only: the zeroing against the state rows, wavefront 0's tokens against the first per-token vectors' addresses.
@@ -703,17 +721,14 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 stash_base[((long long)bseq[s] * (p.L + 1) + q / (SP - S)) * SP + S + q % (SP - S)] = 0.0f;
     }
 
-    // per-token vectors: element e of sequence s at step t
-    auto tv_load = [&](int s, int e, int t) -> float {
+    // per-token vectors: one row of the combined table per (sequence, step).  A prefetch slot's load is ONE global load off a base that
+    // sits in scalar registers, with the token id read from LDS a step earlier (pf_tk): round 5's form selected one of three table
+    // pointers per lane, which the compiler turned into a load of the pointer from the kernel arguments, a full vmcnt wait and then the
+    // value load, behind an LDS read of the token -- three dependent latencies between P1 and its barrier, every step
+    auto tok_at = [&](int s, int t) -> int {
         const int n = pick(nst, s);
-        if (n <= 0) return 0.0f;
-        const int tk = tok[s * Lr + (t < n ? t : n - 1)];
-        // one load through a selected base (three loads behind branches kept three hoisted 64-bit addresses per prefetch slot alive
-        // over the step: the mixed register forms spilled them)
-        const int seg = e < Rp ? 0 : (e < Rp + SP ? 1 : 2);
-        const float *base = seg == 0 ? p.Vgen : (seg == 1 ? p.Gz : p.Gr);
-        const int col = e - (seg == 0 ? 0 : (seg == 1 ? Rp : Rp + SP)), ld = seg == 0 ? Rp : SP;
-        return base[(long long)tk * ld + col];
+        const int i = t < n ? t : n - 1;
+        return tok[s * Lr + (i < 0 ? 0 : i)];             // (a dead sequence reads some row; nothing of it is ever stored)
     };
     const int ntv = NSEQ * tvl;
     constexpr int NPF = (NP1R > 0 || NP2R > 0 || NP3R > 0) ? DR_FORM_PF : DR_MAX_PF;
@@ -724,8 +739,22 @@ decomp_rows_kernel(const DecompRowsParams p) {
         pf_s[i] = e < ntv ? e / tvl : 0;
         pf_e[i] = e < ntv ? e % tvl : -1;
     }
+    constexpr int NTK = NSEQ == 1 ? 1 : NPF;                  // one sequence: every slot reads the same (wavefront-uniform) token
+    int pf_tk[NTK];
+    auto next_tokens = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NTK; i++) pf_tk[i] = tok_at(NSEQ == 1 ? 0 : pf_s[i], t);
+    };
+    auto tv_load = [&](int i) -> float {
+        int tk = pf_tk[NSEQ == 1 ? 0 : i];
+        if (NSEQ == 1) tk = __builtin_amdgcn_readfirstlane(tk);
+        return p.TVt[(long long)tk * tvl + pf_e[i]];
+    };
+    next_tokens(0);
+#pragma unroll
     for (int i = 0; i < NPF; i++)
-        if (pf_e[i] >= 0) TV[tid + i * DR_THREADS] = tv_load(pf_s[i], pf_e[i], 0);
+        if (pf_e[i] >= 0) TV[tid + i * DR_THREADS] = tv_load(i);
+    next_tokens(1);
     if (FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0 && tid == 0) st_4 = (long long)__builtin_amdgcn_s_memtime();
     __syncthreads();
 
@@ -733,7 +762,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
     const int nl_mode = p.nl;
     const bool probe = FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0;     // diagnostic: cycle counts of the phases of a step
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (probe && tid == 0) printf("rows wg 0: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
+    if (probe && tid == 0) printf("rows wg 0 round %d: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", rnd, (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
     // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
     for (int t = 0; t < nmax; t++) {
         const bool pr = probe && t == 8;
@@ -750,8 +779,11 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #define FARNN_DR_ISSUE_PREFETCH()                                                                                  \
         _Pragma("unroll")                                                                                          \
         for (int i = 0; i < NPF; i++)                                                                              \
-            pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(pf_s[i], pf_e[i], t + 1) : 0.0f;
-        if (farnn != 2) { FARNN_DR_ISSUE_PREFETCH() }
+            pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(i) : 0.0f;
+        // (the token of the vectors prefetched in this step: read at the step's top, used behind P1 -- read beside the prefetch for the
+        //  NEXT step's, its LDS latency sat between P1's last store and the barrier)
+        if (farnn == 2) next_tokens(t + 1);
+        if (farnn != 2) { FARNN_DR_ISSUE_PREFETCH() next_tokens(t + 2); }
         // The element-wise work rides in the row epilogues: the lane that finishes a row sum turns it into
         // a gate, an rr entry or the new state right away, so a step is 2 barriers (3 with farnn==2).
         // hb and [rr | hb] ping-pong because P3's epilogue writes the next step's hb while other
@@ -878,6 +910,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
             float *TVn = TV + nxt * ntv;
+            // (a use on every path: the loads are waited for HERE whatever the slot's condition -- left to the conditional store, the
+            //  compiler carried "maybe pending" round the loop and waited vmcnt(0) at the next step's first re-use of the registers)
+#pragma unroll
+            for (int i = 0; i < NPF; i++) asm volatile("" :: "v"(pf[i]));
 #pragma unroll
             for (int i = 0; i < NPF; i++)
                 if (pf_e[i] >= 0) TVn[tid + i * DR_THREADS] = pf[i];
@@ -949,6 +985,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                        tid >> 6, pt[1] - pt[0], pt[2] - pt[1], pt[3] - pt[2], pt[4] - pt[3], pt[5] - pt[4], pt[6] - pt[5], pt[6] - pt[0]);
         }
     }
+    }   // rounds
 }
 
 // ---- packing (create time) ------------------------------------------------------------------------
@@ -999,7 +1036,8 @@ __global__ void pack_p3_kernel(PackSrc q, float *out, int ld, int dir) {
 }
 
 // G[v][j] = sum_r Vgen[v][r] Wrs[r][j] + bs[j]   (the token half of a gate, :144-148)
-__global__ void gate_table_kernel(const float *Vgen, const float *Wrs, const float *bs, float *G,
+// written at column `col0` of the combined per-word table T[V][ldt]
+__global__ void gate_table_kernel(const float *Vgen, const float *Wrs, const float *bs, float *T, int ldt, int col0,
                                   int V, int R, int Rp, int S, int SP) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)V * SP) return;
@@ -1009,13 +1047,21 @@ __global__ void gate_table_kernel(const float *Vgen, const float *Wrs, const flo
         for (int r = 0; r < R; r++) acc = fmaf(Vgen[(long long)v * Rp + r], Wrs[(long long)r * SP + j], acc);
         acc += bs[j];
     }
-    G[idx] = acc;
+    T[(long long)v * ldt + col0 + j] = acc;
+}
+
+// T[v][0..Rp) = Vgen[v][0..Rp): the first segment of the combined per-word table
+__global__ void word_rows_kernel(const float *Vgen, float *T, int ldt, int V, int Rp) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)V * Rp) return;
+    T[idx / Rp * ldt + idx % Rp] = Vgen[idx];
 }
 
 // everything the launcher needs, filled by build_rows_pack() in farnn_hip.hip
 struct DecompRowsPack {
     bool ok = false;
-    float *P1 = nullptr, *P2[2] = {nullptr, nullptr}, *P3[2] = {nullptr, nullptr}, *Gz = nullptr, *Gr = nullptr;
+    float *P1 = nullptr, *P2[2] = {nullptr, nullptr}, *P3[2] = {nullptr, nullptr};
+    const float *TVt = nullptr;     // [V][tvl] per-word rows: Vgen | update-gate table | reset-gate table (farnn = 0: Vgen itself)
     int n1 = 0, n2 = 0, n3 = 0, ld2 = 0, ld3 = 0, nch2 = 0, nch3 = 0;
 };
 
@@ -1139,38 +1185,54 @@ inline bool rows_plan(const DecompRowsPack &k, const DecompWeights &w, int B, in
 }
 
 template <int NSEQ, int A_ = 0, int B_ = 0, int C_ = 0, int D_ = 0, int E_ = 0, bool MIXED = false, int LPR = DR_LPR>
-inline int launch_rows_n(const DecompRowsParams &p, int groups, size_t lds, hipStream_t s) {
+inline int launch_rows_n(const DecompRowsParams &p, int wg_limit, size_t lds, hipStream_t s) {
     static int raised = -1;     // per process and instantiation; the attribute is per (device, function) but monotone in lds
+    const void *fn = reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR>);
     if ((int)lds > raised) {
-        FARNN_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        FARNN_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         raised = 160 * 1024;
     }
-    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR><<<dim3(2 * groups), dim3(DR_THREADS), lds, s>>>(p);
+    // wg_limit > 0 (a register form on a device of wg_limit compute units): no more workgroups than run at once, each walking the
+    // groups of its slot (the kernel's rounds); else one workgroup per group and direction
+    int slots = p.groups;
+    if (wg_limit > 0) {
+        static size_t occ_lds = 0; static int occ = 0;
+        if (occ == 0 || occ_lds != lds) {
+            int n = 0;
+            FARNN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, DR_THREADS, lds));
+            occ = n > 0 ? n : 1; occ_lds = lds;
+        }
+        const int fit = wg_limit * occ / 2;
+        if (fit >= 1 && fit < slots) slots = fit;
+        if (FARNN_PROBE_ON((p.dbg & 16) != 0)) fprintf(stderr, "rows launch: %d groups per direction, %d workgroups per compute unit, %d slots\n", p.groups, occ, slots);
+    }
+    decomp_rows_kernel<NSEQ, A_, B_, C_, D_, E_, MIXED, LPR><<<dim3(2 * slots), dim3(DR_THREADS), lds, s>>>(p);
     FARNN_HIP_TRY(hipGetLastError());
     return FARNN_OK;
 }
 
 inline int launch_decomp_rows(const DecompRowsPack &k, const DecompWeights &w, const RowsPlan &pl,
                               const int64_t *x, const int64_t *len, const int *order, int sort_in_kernel,
-                              float *A, float *Bk, int B, int L, int full, hipStream_t s) {
+                              float *A, float *Bk, int B, int L, int full, int n_cu, hipStream_t s) {
     DecompRowsParams p;
     p.P1 = k.P1; p.P2[0] = k.P2[0]; p.P2[1] = k.P2[1]; p.P3[0] = k.P3[0]; p.P3[1] = k.P3[1];
     p.n1 = k.n1; p.n2 = k.n2; p.n3 = k.n3; p.ld2 = k.ld2; p.ld3 = k.ld3; p.nch2 = k.nch2; p.nch3 = k.nch3;
     p.res1 = pl.res1; p.res2 = pl.res2; p.res3 = pl.res3;
-    p.Vgen = w.Vgen; p.Gz = k.Gz; p.Gr = k.Gr; p.h0 = w.h0; p.hT = w.hT;
+    p.TVt = k.TVt; p.h0 = w.h0; p.hT = w.hT;
     p.x = x; p.len = len; p.order = order; p.sort = sort_in_kernel; p.A = A; p.Bk = Bk;
     p.B = B; p.L = L; p.S = w.S; p.SP = w.SP; p.R = w.R; p.Rp = w.Rp; p.farnn = w.farnn; p.nl = w.nl;
     p.full = full; p.V = w.V; p.sig_k = w.sig_k;
     p.dbg = tun(TUN_DBG);
     p.lds_floats = (int)(pl.lds / 4);
     const int groups = (B + pl.nseq - 1) / pl.nseq;
-#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_), rows_form_lpr(F_)>(p, groups, pl.lds, s);
+    p.groups = groups;
+    const int cu_limit = (pl.form && !tun(TUN_ROWS_NOROUNDS)) ? n_cu : 0;      // (launch_rows_n: the register forms walk their groups in rounds)
+#define FARNN_ROWS_LAUNCH(F_, A_, B_, C_, D_, E_) if (pl.form == F_) return launch_rows_n<1, A_, B_, C_, D_, E_, rows_form_mixed(F_), rows_form_lpr(F_)>(p, cu_limit, pl.lds, s);
     FARNN_ROWS_FORMS(FARNN_ROWS_LAUNCH)
 #undef FARNN_ROWS_LAUNCH
-    if (pl.nseq == 4) return launch_rows_n<4>(p, groups, pl.lds, s);
-    if (pl.nseq == 2) return launch_rows_n<2>(p, groups, pl.lds, s);
-    return launch_rows_n<1>(p, groups, pl.lds, s);
+    if (pl.nseq == 4) return launch_rows_n<4>(p, cu_limit, pl.lds, s);
+    if (pl.nseq == 2) return launch_rows_n<2>(p, cu_limit, pl.lds, s);
+    return launch_rows_n<1>(p, cu_limit, pl.lds, s);
 }
 
 }  // namespace farnn

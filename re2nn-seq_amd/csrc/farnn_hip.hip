@@ -736,13 +736,17 @@ static int build_rows_pack(farnn_model *m) {
         if ((rc = dev_alloc(m, (void **)&k.P1, (size_t)k.n1 * k.ld2 * 4))) return rc;
         pack_p1_kernel<<<blocks((long long)k.n1 * k.ld2), 256>>>(q, k.P1, k.ld2);
     }
-    if (w.farnn >= 1) {
-        if ((rc = dev_alloc(m, (void **)&k.Gz, (size_t)m->V * m->SP * 4))) return rc;
-        gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs1, w.bs1, k.Gz, m->V, m->R, m->Rp, m->S, m->SP);
-    }
-    if (w.farnn == 2) {
-        if ((rc = dev_alloc(m, (void **)&k.Gr, (size_t)m->V * m->SP * 4))) return rc;
-        gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs2, w.bs2, k.Gr, m->V, m->R, m->Rp, m->S, m->SP);
+    // the per-word rows a step reads, side by side: [Vgen row | update-gate row | reset-gate row] (one base, one load per prefetch slot)
+    if (w.farnn == 0) {
+        k.TVt = w.Vgen;
+    } else {
+        float *T = nullptr;
+        if ((rc = dev_alloc(m, (void **)&T, (size_t)m->V * tvl * 4))) return rc;
+        word_rows_kernel<<<blocks((long long)m->V * m->Rp), 256>>>(w.Vgen, T, tvl, m->V, m->Rp);
+        gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs1, w.bs1, T, tvl, m->Rp, m->V, m->R, m->Rp, m->S, m->SP);
+        if (w.farnn == 2)
+            gate_table_kernel<<<blocks((long long)m->V * m->SP), 256>>>(w.Vgen, w.Wrs2, w.bs2, T, tvl, m->Rp + m->SP, m->V, m->R, m->Rp, m->S, m->SP);
+        k.TVt = T;
     }
     FARNN_HIP_TRY(hipGetLastError());
     FARNN_HIP_TRY(hipDeviceSynchronize());
@@ -789,7 +793,7 @@ static int launch_decomp_recurrence(farnn_model *m, const int64_t *x, const int6
     RowsPlan pl;
     if (m->rows.ok && rows_plan(m->rows, m->dw, B, m->curL, pl))
         return launch_decomp_rows(m->rows, m->dw, pl, x, lengths, order, m->sort_in_kernel ? 1 : 0, m->A, m->Bk, B,
-                                  m->curL, full, s);
+                                  m->curL, full, m->n_cu, s);
     return launch_decomp_chain(m->dw, x, lengths, order, m->A, m->Bk, B, m->curL, full, s);
 }
 

@@ -51,7 +51,7 @@ inline int select_device(int device) {
     X(NOFUSE, 0, true) X(FUSE, 0, true) X(NOREGS, 0, true) X(NOLABELMAP, 0, true) X(PREP, 0, true) X(NOSORT, 0, true)           \
     X(VITERBI_BP, 0, true) X(VITERBI_UNFUSED, 0, true) X(DECOMP_NOREGS, 0, true)                               \
     X(ROWS_NOREGS, 0, true) X(TRAIN_NOLDS, 0, true) X(TRAIN_NSEQ, 0, true)              \
-    X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true)                                                            \
+    X(WIDE_UNPAIRED, 0, true) X(ROWS_LPR4, 0, true) X(ROWS_NOROUNDS, 0, true)                                  \
     /* A/B build only (the production library refuses them at create: check_env_switches) */                   \
     X(CV_ONE, 0, false) X(CV_STASH, 0, false) X(NODEST, 0, false)                                              \
     /* diagnostic: profiling build only */                                                                     \

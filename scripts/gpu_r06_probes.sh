@@ -11,13 +11,15 @@ FARNN_DBG=8192 timeout 120 python bench.py $S $Z 2>/dev/null | grep "^viterbi" |
 FARNN_DBG=8192 timeout 120 python bench.py $S --batch 200 --seqlen 30 --full-length $Z 2>/dev/null | grep "^viterbi" | sort | tail -6 > $O/probe_viterbi_k75_b200_l30_full_length.txt
 rows_probe() {     # the set-up's parts (four launches) and step 8's phases, two samples per wavefront
   grep "^rows" > $O/rows_raw.txt
-  grep "set-up" $O/rows_raw.txt | sort | head -4
+  grep "^rows launch" $O/rows_raw.txt | sort | uniq | head -2
+  grep "round 0: set-up" $O/rows_raw.txt | sort | head -4
+  grep "round 1: set-up" $O/rows_raw.txt | sort | head -4
   for w in 0 1 2 3 4 5 6 7; do grep "wave $w step 8" $O/rows_raw.txt | head -2; done
   rm -f $O/rows_raw.txt
 }
-FARNN_DBG=16 timeout 120 python bench.py $S $Z 2>/dev/null | rows_probe > $O/probe_decomp_rows_r250_b256_l64.txt
-FARNN_DBG=16 timeout 120 python bench.py $S --batch 200 --seqlen 30 $Z 2>/dev/null | rows_probe > $O/probe_decomp_rows_r250_b200_l30.txt
-FARNN_DBG=16 timeout 120 python bench.py --workload decomp --rank 150 --farnn 2 --crf --states 134 --batch 200 --seqlen 30 $Z 2>/dev/null | rows_probe > $O/probe_decomp_rows_r150_s134_b200_l30.txt
+FARNN_DBG=16 timeout 120 python bench.py $S $Z 2>&1 | rows_probe > $O/probe_decomp_rows_r250_b256_l64.txt
+FARNN_DBG=16 timeout 120 python bench.py $S --batch 200 --seqlen 30 $Z 2>&1 | rows_probe > $O/probe_decomp_rows_r250_b200_l30.txt
+FARNN_DBG=16 timeout 120 python bench.py --workload decomp --rank 150 --farnn 2 --crf --states 134 --batch 200 --seqlen 30 $Z 2>&1 | rows_probe > $O/probe_decomp_rows_r150_s134_b200_l30.txt
 FARNN_DBG=4096 timeout 120 python bench.py --workload decomp $Z 2>/dev/null | grep "^regs" | sort | tail -8 > $O/probe_decomp_regs8_r50.txt
 FARNN_DBG=8192 timeout 120 python bench.py --workload ifst_crf $Z 2>/dev/null | grep "^viterbi" | sort | tail -6 > $O/probe_viterbi_k130.txt
 head -50 $O/*.txt

@@ -6,7 +6,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r06sw; mkdir -p $O; rm -f $O/*
 T="tests/test_gpu_parity_onehot.py tests/test_gpu_parity_decomposed.py tests/test_gpu_parity_bench_size.py tests/test_gpu_chain_regs_shapes.py tests/test_gpu_chain_viterbi.py"
-for sw in "" FARNN_NOFUSE=1 FARNN_FUSE=1 FARNN_NOREGS=1 FARNN_NODEST=1 FARNN_NOLABELMAP=1 FARNN_CV_ONE=1 FARNN_CV_STASH=1 FARNN_VITERBI_UNFUSED=1 FARNN_VITERBI_BP=1 FARNN_PREP=1 FARNN_NOSORT=1 FARNN_DECOMP_NOREGS=1 FARNN_ROWS_NOREGS=1 FARNN_ROWS_LPR4=1 FARNN_ROWS_LPR4=2 FARNN_WIDE_UNPAIRED=1 $EXTRA_SWITCHES; do
+for sw in "" FARNN_NOFUSE=1 FARNN_FUSE=1 FARNN_NOREGS=1 FARNN_NODEST=1 FARNN_NOLABELMAP=1 FARNN_CV_ONE=1 FARNN_CV_STASH=1 FARNN_VITERBI_UNFUSED=1 FARNN_VITERBI_BP=1 FARNN_PREP=1 FARNN_NOSORT=1 FARNN_DECOMP_NOREGS=1 FARNN_ROWS_NOREGS=1 FARNN_ROWS_LPR4=1 FARNN_ROWS_LPR4=2 FARNN_ROWS_NOROUNDS=1 FARNN_WIDE_UNPAIRED=1 $EXTRA_SWITCHES; do
   lib=""; case "$sw" in FARNN_NODEST=1|FARNN_CV_ONE=1|FARNN_CV_STASH=1) lib="FARNN_LIB=$PWD/re2nn-seq_amd/csrc/libfarnn_hip_probes.so FARNN_AB_CHILD=1";; esac   # (A/B-build forms)
   [ "$sw" = FARNN_CV_STASH=1 ] && sw="FARNN_CV_STASH=1 FARNN_CV_ONE=1"
   log=$O/$(echo "${sw:-default}" | tr ' =' '__').txt

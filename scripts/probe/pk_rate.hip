@@ -29,33 +29,36 @@ __global__ void __launch_bounds__(1024) k(float *out, long long *clk, int iters)
     float s = 0;
     for (int i = 0; i < 8; i++) s += a[i].x + a[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-    if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) { clk[2 * (threadIdx.x >> 6)] = t0; clk[2 * (threadIdx.x >> 6) + 1] = t1; }   // every wavefront: the oldest one alone never waits
 }
 
 template <int MODE>
-static void run(const char *name, int per_iter_scalar_ops) {
-    float *out; long long *clk, h;
-    (void)hipMalloc(&out, 1024 * 4); (void)hipMalloc(&clk, 8);
+static void run(const char *name, int per_iter_instrs) {
+    float *out; long long *clk, h[32];
+    (void)hipMalloc(&out, 1024 * 4); (void)hipMalloc(&clk, 32 * 8);
     const int iters = 2000;
     printf("%-44s", name);
     for (int waves : {4, 8, 16}) {                       // 1, 2, 4 wavefronts per SIMD
         k<MODE><<<1, waves * 64>>>(out, clk, 10);
         k<MODE><<<1, waves * 64>>>(out, clk, iters);
         (void)hipDeviceSynchronize();
-        (void)hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
-        printf("  %d/SIMD: %5.2f cycles per f32 op per SIMD", waves / 4, (double)h / ((double)iters * per_iter_scalar_ops * (waves / 4)));
+        (void)hipMemcpy(h, clk, waves * 16, hipMemcpyDeviceToHost);
+        long long lo = h[0], hi = h[1];
+        for (int w = 0; w < waves; w++) { lo = h[2 * w] < lo ? h[2 * w] : lo; hi = h[2 * w + 1] > hi ? h[2 * w + 1] : hi; }
+        // first start to last end of all wavefronts, per instruction a SIMD issued (per_iter_instrs per wavefront and iteration)
+        printf("  %d/SIMD: %5.2f cycles per instruction per SIMD", waves / 4, (double)(hi - lo) / ((double)iters * per_iter_instrs * (waves / 4)));
     }
     printf("\n");
     (void)hipFree(out); (void)hipFree(clk);
 }
 
 int main() {
-    printf("(cycles of one wavefront's loop / (f32 lane-operations per lane x wavefronts per SIMD): 4.0 = one 64-lane op per 4 cycles)\n");
+    printf("(first start to last end over all wavefronts / instructions one SIMD issued; the x2 rows issue 16 instructions per iteration, the packed rows 8)\n");
     run<0>("v_add_f32 x2", 16);
     run<1>("v_fma_f32 x2 (a * 1 + b)", 16);
-    run<2>("v_pk_add_f32", 16);
-    run<3>("v_pk_fma_f32 (a * 1 + b)", 16);
-    run<4>("v_pk_mul_f32", 16);
+    run<2>("v_pk_add_f32", 8);
+    run<3>("v_pk_fma_f32 (a * 1 + b)", 8);
+    run<4>("v_pk_mul_f32", 8);
     run<5>("v_max_f32 x2", 16);
     run<6>("v_max3_f32 x2", 16);
     return 0;

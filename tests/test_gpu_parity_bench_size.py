@@ -446,3 +446,40 @@ def test_gated_rows_forms_with_four_and_eight_lanes_per_row_agree(R, S, monkeypa
         srt = np.sort(ref, axis=-1)
         clear = mask & ((srt[..., -1] - srt[..., -2]) > 1e-3) & (np.abs(srt[..., -1] - 0.5) > 1e-3)
         assert np.array_equal(out[sw][1][clear], out['0'][1][clear])
+
+
+@pytest.mark.parametrize('B', [127, 129, 200, 256, 300, 513])
+def test_register_forms_walk_their_sequences_in_rounds(B, monkeypatch):
+    """Round 6: a register form of the rows kernel starts no more workgroups than the device runs at once; each walks the
+    length-ranked sequences of its direction in snake order (decomp_rows_kernel's rounds) with its weights kept in registers.
+    Batch sizes around the slot count (one round; a partly filled second; two; three; five): against the oracle, and bit for bit
+    against FARNN_ROWS_NOROUNDS=1 (one workgroup per sequence and direction, round 5's launch) -- the same arithmetic in the same
+    order, only the place a sequence runs at differs."""
+    from re2nn_seq_amd import _lib, synth
+    L, R, S = 40, 250, 104
+    V, q, gates, tr = _snips_model(R, 2, False, S=S)
+    x, lengths = synth.random_batch(V, B, L, np.random.RandomState(4100 + B))
+    lengths[: min(B, 7)] = [L, 1, 0, L, 2, 1, L][: min(B, 7)]          # ties at both ends of the ranking, an empty sequence
+    xd, ld = _t(x).cuda(), _t(lengths).cuda()
+    K = q['Cout'].shape[0]
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    ref64 = in_float64(fo.decomp_ifst_scores, q, x, lengths)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    out = {}
+    for sw in ('0', '1'):
+        monkeypatch.setenv('FARNN_ROWS_NOROUNDS', sw)
+        h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=2, gates=gates,
+                                    sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0)
+        scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+        tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+        for _ in range(2):                                             # (twice: the workspace is reused between calls)
+            h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, scores.data_ptr())
+        torch.cuda.synchronize()
+        assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+        got = scores.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert_float_path(got[mask], ref[mask], ref64[mask], err_msg='FARNN_ROWS_NOROUNDS=' + sw)
+        out[sw] = (got, tags.cpu().numpy())
+        h.close()
+    assert np.array_equal(out['0'][0][mask], out['1'][0][mask])
+    assert np.array_equal(out['0'][1][mask], out['1'][1][mask])
