@@ -44,6 +44,39 @@ inline size_t round_up_sz(size_t v, size_t m) { return (v + m - 1) / m * m; }
 #endif
 
 // ---- device helpers ---------------------------------------------------------------------------
+// tanh of a SMALL argument by its odd series (|x| < 1/16: x (1 - x^2/3 + 2 x^4/15), exact to 4e-9 relative).  The kernels' fast form
+// (1 - e) / (1 + e), e = exp(-2|x|), is good to ~1e-7 ABSOLUTE, but 1 - e cancels as |x| -> 0: 2e-4 relative at |x| = 1e-4.  State
+// vectors are mostly small entries, a matrix row sums a hundred of their errors, and a locally sensitive gated recurrence amplified that
+// to 8e-4 in one sequence of tests/soak_rows_rounds.py (the float32 oracle with exactly that tanh reproduces the deviation; with the
+// series below the threshold -- 1/4, 1/16 or 1/32 alike -- it is back at 3e-7).  With the threshold at 1/16 the combined function is
+// within 9e-7 relative everywhere (worst just above it).  Branch-free use: compute both, select on |x| < 1/16 (six instructions).
+constexpr float TANH_SERIES_BELOW = 0.0625f;
+__device__ __forceinline__ float tanh_series(float x) {
+    const float s = x * x;
+    return x * fmaf(fmaf(s, 2.0f / 15.0f, -1.0f / 3.0f), s, 1.0f);
+}
+// The update non-linearity's MODE as two scalars (FARNN_NL_NONE 0, RELU 1, TANH 2, RELUTANH 3: bit 0 = relu first, bit 1 = tanh):
+// `lo` = 0 or -inf -- y = max(x, lo) is the relu or nothing, ONE instruction -- and `keep` = all ones or zero -- the result is
+// (tanh(y) & keep) | (y & ~keep), one v_bfi_b32.  As selects on the mode's bits the same took a canonicalising max, a max, a select
+// and a second select on a 64-bit mask the register-tight kernels re-read from spilled scalars: ten instructions of a step's critical
+// tail.  (A NaN input comes out as `lo` -- max returns its number operand; the selects handed it through.  Nothing finite changes.)
+struct NlMode { float lo; unsigned keep; };
+__device__ __forceinline__ NlMode nl_mode_of(int nl) {
+    NlMode m;
+    m.lo = (nl & 1) ? 0.0f : -__builtin_inff();
+    m.keep = (nl & 2) ? 0xffffffffu : 0u;
+    asm volatile("" : "+s"(m.keep));                    // (opaque: seen as 0 / ~0 the compiler turns the insert back into a select on a 64-bit mask)
+    return m;
+}
+__device__ __forceinline__ float nl_floor(float x, NlMode m) {
+    float y;
+    asm("v_max_f32 %0, %1, %2" : "=v"(y) : "s"(m.lo), "v"(x));
+    return y;
+}
+__device__ __forceinline__ float nl_pick(float th, float y, NlMode m) {
+    return __uint_as_float((__float_as_uint(th) & m.keep) | (__float_as_uint(y) & ~m.keep));
+}
+
 // update_nonlinear dispatch (reference model_onehot.py:379-386).  `nl` is wave-uniform.
 __device__ __forceinline__ float apply_nl(float v, int nl) {
     switch (nl) {

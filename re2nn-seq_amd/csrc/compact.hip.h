@@ -52,7 +52,8 @@ constexpr int CC_WAVES = 4;       // chains per workgroup
 // `none` / `relu` stay exact)
 __device__ __forceinline__ float cc_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));
-    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    const float big = copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    return fabsf(x) < TANH_SERIES_BELOW ? tanh_series(x) : big;    // (common.hip.h: 1 - e cancels for small |x|)
 }
 __device__ __forceinline__ float cc_nl(float v, int nl) {
     switch (nl) {

@@ -48,18 +48,18 @@ struct DecompRegsParams {
     BesideParams bs;              // SCORE instantiations: the scores + decode stage that runs beside the recurrence (beside.hip.h)
 };
 
-// tanh on the hardware exponential and reciprocal: |error| ~2e-7 against the 1e-4 parity bar
+// tanh on the hardware exponential and reciprocal (|error| ~2e-7 absolute), the odd series below 1/16 (common.hip.h: tanh_series)
 __device__ __forceinline__ float dg_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]
-    return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    const float big = copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
+    return fabsf(x) < TANH_SERIES_BELOW ? tanh_series(x) : big;
 }
 // Branch-free (round 6): the mode is a kernel argument, and as a `switch` it was three taken scalar branches on the step's chain
-// (~20 cycles each: scripts/probe/issue_rate.hip) in front of a dozen instructions.  Bit 0 of the mode = relu first, bit 1 = tanh
-// (FARNN_NL_NONE 0, RELU 1, TANH 2, RELUTANH 3); the tanh is always computed (finite for every input: e in [0, 1]) and selected.
-__device__ __forceinline__ float dg_nl(float x, int nl) {
-    const float y = (nl & 1) ? fmaxf(x, 0.0f) : x;
-    const float th = dg_tanh(y);
-    return (nl & 2) ? th : y;
+// (~20 cycles each: scripts/probe/issue_rate.hip) in front of a dozen instructions; then selects on its bits; now two scalars
+// (common.hip.h: NlMode -- one max, one bit-field insert).  The tanh is always computed (finite for every input: e in [0, 1]).
+__device__ __forceinline__ float dg_nl(float x, NlMode m) {
+    const float y = nl_floor(x, m);
+    return nl_pick(dg_tanh(y), y, m);
 }
 
 // four FMAs of a 16-byte piece into two pairs of partial sums: two v_pk_fma_f32.  (-DFARNN_DG_SCALAR_FMA builds them as four
@@ -236,7 +236,7 @@ decomp_regs_kernel(const DecompRegsParams p) {
     auto v_addr = [&](int tk) -> const float * { return p.Vgen + (long long)tk * Rp + vcol; };
     float v0 = *v_addr(tok[0]), v1 = *v_addr(tok[nsteps > 1 ? 1 : 0]);
     int tk2 = tok[nsteps > 2 ? 2 : nsteps - 1];
-    const int nl_mode = p.nl;
+    const NlMode nl_mode = nl_mode_of(p.nl);
     static_assert(NP3 <= 4, "one lane of the quad per row pass");
     static_assert(CS >= 1 && CS <= NCH3, "rr chunks");
     long long cyc[4] = {0, 0, 0, 0};
@@ -481,7 +481,7 @@ decomp_regs8_kernel(const DecompRegsParams p) {
     auto v_addr = [&](int tk) -> const float * { return p.Vgen + (long long)tk * Rp + vcol; };
     float v0 = *v_addr(tok[0]), v1 = *v_addr(tok[nsteps > 1 ? 1 : 0]);
     int tk2 = tok[nsteps > 2 ? 2 : nsteps - 1];
-    const int nl_mode = p.nl;
+    const NlMode nl_mode = nl_mode_of(p.nl);
     static_assert(NP3 <= 8 && NP2 <= 8, "one lane of the eight per row pass");
     static_assert(CS >= 1 && CS <= NCH3, "rr chunks");
     long long cyc[4] = {0, 0, 0, 0};

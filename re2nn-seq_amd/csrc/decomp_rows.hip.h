@@ -494,14 +494,13 @@ __device__ __forceinline__ float gate_sigmoid(float x, float k) {
 template <bool FAST = false>
 __device__ __forceinline__ float dr_tanh(float x) {
     const float e = __expf(-2.0f * fabsf(x));          // in (0, 1]: no overflow for any x
-    if constexpr (FAST) return copysignf((1.0f - e) * dr_rcp(1.0f + e), x);
-    else return copysignf((1.0f - e) / (1.0f + e), x);
+    const float big = FAST ? copysignf((1.0f - e) * dr_rcp(1.0f + e), x) : copysignf((1.0f - e) / (1.0f + e), x);
+    return fabsf(x) < TANH_SERIES_BELOW ? tanh_series(x) : big;    // (common.hip.h: 1 - e cancels for small |x|)
 }
 template <bool FAST = false>
-__device__ __forceinline__ float dr_nl(float x, int nl) {                // branch-free, like dg_nl (decomp_regs.hip.h)
-    const float y = (nl & 1) ? fmaxf(x, 0.0f) : x;
-    const float th = dr_tanh<FAST>(y);
-    return (nl & 2) ? th : y;
+__device__ __forceinline__ float dr_nl(float x, NlMode m) {                // branch-free (common.hip.h: the mode as two scalars)
+    const float y = nl_floor(x, m);
+    return nl_pick(dr_tanh<FAST>(y), y, m);
 }
 
 // NP1R / NP2R / NP3R > 0: the matrix lives in REGISTERS (that many 128-row passes of NCH2R / NCH3R chunks) instead of LDS /
@@ -727,8 +726,12 @@ decomp_rows_kernel(const DecompRowsParams p) {
     // value load, behind an LDS read of the token -- three dependent latencies between P1 and its barrier, every step
     auto tok_at = [&](int s, int t) -> int {
         const int n = pick(nst, s);
+        // (an empty or absent sequence has no token in LDS -- the words there are whatever the last kernel left: word 0's row, and
+        //  nothing of it is ever stored.  Found by tests/soak_rows_rounds.py: a wild row index out of stale LDS, a memory fault.
+        //  The read itself is unconditional -- word 0 of the sequence's slot -- so that the guard is a select, not a branch per step)
         const int i = t < n ? t : n - 1;
-        return tok[s * Lr + (i < 0 ? 0 : i)];             // (a dead sequence reads some row; nothing of it is ever stored)
+        const int v = tok[s * Lr + (i > 0 ? i : 0)];
+        return n > 0 ? v : 0;
     };
     const int ntv = NSEQ * tvl;
     constexpr int NPF = (NP1R > 0 || NP2R > 0 || NP3R > 0) ? DR_FORM_PF : DR_MAX_PF;
@@ -759,7 +762,10 @@ decomp_rows_kernel(const DecompRowsParams p) {
     __syncthreads();
 
     const float sig_k = p.sig_k;
-    const int nl_mode = p.nl;
+    const NlMode nl_mode = nl_mode_of(p.nl);
+    // (the ablation bits of FARNN_DBG -- 1: no products, 2: no non-linearity, 4: no stash stores, 8: no prefetch -- exist in the profiling
+    //  build only: as run-time tests of a kernel argument they were scalar compares and branches in every step of the production kernel)
+    auto dbg_on = [&](int bit) { return FARNN_PROBE_ON((p.dbg & bit) != 0); };
     const bool probe = FARNN_PROBE_ON((p.dbg & 16) != 0) && blockIdx.x == 0;     // diagnostic: cycle counts of the phases of a step
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (probe && tid == 0) printf("rows wg 0 round %d: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", rnd, (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
@@ -779,7 +785,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #define FARNN_DR_ISSUE_PREFETCH()                                                                                  \
         _Pragma("unroll")                                                                                          \
         for (int i = 0; i < NPF; i++)                                                                              \
-            pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !(p.dbg & 8)) ? tv_load(i) : 0.0f;
+            pf[i] = (pf_e[i] >= 0 && t + 1 < nmax && !dbg_on(8)) ? tv_load(i) : 0.0f;
         // (the token of the vectors prefetched in this step: read at the step's top, used behind P1 -- read beside the prefetch for the
         //  NEXT step's, its LDS latency sat between P1's last store and the barrier)
         if (farnn == 2) next_tokens(t + 1);
@@ -838,7 +844,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     }
                 }
             };
-            if (!(p.dbg & 1)) {
+            if (!dbg_on(1)) {
                 if constexpr (NP1R > 0 && OPA) {
                     rowdots_regs<NSEQ, NP1R, NCH2R, 0, LPR, 0, HALF2, NPLX>(w1, p.n1, p.nch2, H, c2p, tid, epi1o, nullptr, nullptr, pre1, L1, ld2);
                 } else if constexpr (NP1R > 0) {
@@ -861,7 +867,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             auto epi2 = [&](int row, const float (&acc)[NSEQ]) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
-                    if (row < R) X3c[s * c3p + row] = acc[s] * TVc[s * tvl + row];
+                    if (farnn != 1 || row < R) X3c[s * c3p + row] = acc[s] * TVc[s * tvl + row];      // (rows R.. exist with farnn = 1 only)
                     else Z[s * SP + (row - R)] = gate_sigmoid(acc[s] + TVc[s * tvl + Rp + (row - R)], sig_k);
                 }
             };
@@ -869,17 +875,17 @@ decomp_rows_kernel(const DecompRowsParams p) {
             auto pre2 = [&](int row) {
                 Ops2 o;
 #pragma unroll
-                for (int s = 0; s < NSEQ; s++) o.tv[s] = TVc[s * tvl + (row < R ? row : Rp + (row - R))];
+                for (int s = 0; s < NSEQ; s++) o.tv[s] = TVc[s * tvl + ((farnn != 1 || row < R) ? row : Rp + (row - R))];
                 return o;
             };
             auto epi2o = [&](int row, const float (&acc)[NSEQ], const Ops2 &o) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
-                    if (row < R) X3c[s * c3p + row] = acc[s] * o.tv[s];
+                    if (farnn != 1 || row < R) X3c[s * c3p + row] = acc[s] * o.tv[s];                  // (compile-time for the gated forms)
                     else Z[s * SP + (row - R)] = gate_sigmoid<FASTQ>(acc[s] + o.tv[s], sig_k);
                 }
             };
-            if (!(p.dbg & 1)) {
+            if (!dbg_on(1)) {
                 if constexpr (OPA && NP2R > 0) {
                     rowdots_regs<NSEQ, NP2R, NCH2R, 0, LPR, 0, HALF2, NPLX>(w2, p.n2, p.nch2, HBc, c2p, tid, epi2o, nullptr, nullptr, pre2, L2, ld2);
                 } else if constexpr (LPR == 8) {                // (rows_plan_try: all of P2 LDS-resident, at most 256 rows)
@@ -925,7 +931,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (!act[s]) continue;
-                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl(acc[s], nl_mode);
+                    const float nx = dbg_on(2) ? acc[s] : dr_nl(acc[s], nl_mode);
                     float hn = nx;
                     if (farnn == 2) {
                         const float z = Z[s * SP + row];
@@ -939,7 +945,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
                         HBn[s * c2p + row] = hn;
                         X3n[s * c3p + Rp + row] = hn;
                     }
-                    if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
+                    if (!dbg_on(4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
             };
             struct Ops3 { float z[NSEQ], h[NSEQ]; };             // (the eight-lane forms: farnn = 2)
@@ -953,13 +959,13 @@ decomp_rows_kernel(const DecompRowsParams p) {
 #pragma unroll
                 for (int s = 0; s < NSEQ; s++) {
                     if (!act[s]) continue;
-                    const float nx = (p.dbg & 2) ? acc[s] : dr_nl<FASTQ>(acc[s], nl_mode);
+                    const float nx = dbg_on(2) ? acc[s] : dr_nl<FASTQ>(acc[s], nl_mode);
                     const float hn = (1.0f - o.z[s]) * o.h[s] + o.z[s] * nx;
                     H[s * c2p + row] = hn;
-                    if (!(p.dbg & 4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
+                    if (!dbg_on(4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
             };
-            if (!(p.dbg & 1)) {
+            if (!dbg_on(1)) {
                 if constexpr (NP3R > 0 && OPA) {
                     if constexpr (NPLX) rowdots_regs<NSEQ, NP3R, NCH3K, 0, LPR, NCH3L, 0, 1>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, nullptr, T3, pre3, L3, ld3);
                     else rowdots_regs<NSEQ, NP3R, NCH3K, NCH3G, LPR, NCH3L>(w3, p.n3, p.nch3, X3c, c3p, tid, epi3o, g3, T3, pre3);

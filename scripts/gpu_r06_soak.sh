@@ -13,3 +13,4 @@ PYTHONPATH=. timeout 2400 python tests/soak_decomp_shapes.py 1500 > $O/decomp_sh
 FARNN_SHAPE_SOAK=800 timeout 1800 python -m pytest tests/test_gpu_chain_regs_shapes.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | sed "s/^/chain_regs shapes x 800 (default dispatch; every second label-map draw under FARNN_FUSE=1): /" | tee -a $O/summary.txt
 PYTHONPATH=. timeout 1200 python tests/soak_crf_decomp.py 300 > $O/crf_decomp.txt 2>&1; tail -2 $O/crf_decomp.txt | cut -c1-300 | tee -a $O/summary.txt
 timeout 1500 python -m pytest tests/test_gpu_handoff_soak.py -q -m gpu -p no:cacheprovider 2>&1 | tail -1 | sed "s/^/hand-off soak (tests\/test_gpu_handoff_soak.py, FARNN_FUSE=1 forms): /" | tee -a $O/summary.txt
+for seed in 1 2 3; do PYTHONPATH=. timeout 1800 python -c "import sys; sys.path.insert(0, 'tests'); import soak_rows_rounds as s; sys.exit(s.run(1500, seed=$seed))" 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-300 | sed "s/^/seed $seed: /" | tee -a $O/summary.txt; done
