@@ -734,7 +734,11 @@ decomp_rows_kernel(const DecompRowsParams p) {
         return n > 0 ? v : 0;
     };
     const int ntv = NSEQ * tvl;
-    constexpr int NPF = (NP1R > 0 || NP2R > 0 || NP3R > 0) ? DR_FORM_PF : DR_MAX_PF;
+    // prefetch slots per thread.  A register form whose chunk counts bound the state vector by 128 columns and [rr | h] by 384 has a
+    // per-token vector of at most 384 + 128 = 512 floats: ONE slot (rows_form_pf mirrors this for the plan).  The second slot of the
+    // shipped shape -- tvl = 512 exactly -- was all-inactive, and cost every wavefront a mask, a taken branch and a select per step
+    constexpr int NPF = !(NP1R > 0 || NP2R > 0 || NP3R > 0) ? DR_MAX_PF
+                        : (NP3R > 0 && NCH2R * (LPR == 8 ? 64 : 32) <= 128 && NCH3R * (LPR == 8 ? 64 : 32) <= 384) ? 1 : DR_FORM_PF;
     int pf_s[NPF], pf_e[NPF];                                 // loop-invariant split of the prefetch slots
 #pragma unroll
     for (int i = 0; i < NPF; i++) {
@@ -770,14 +774,18 @@ decomp_rows_kernel(const DecompRowsParams p) {
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (probe && tid == 0) printf("rows wg 0 round %d: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", rnd, (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
     // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
+    // the ping-pong buffers of a step (this step's / the next step's per-token vectors, hb, [rr | hb]) as loop-carried pointers, swapped
+    // in FRONT of the step's last barrier: computed from t & 1 they were a dozen scalar instructions behind it, at the head of P1
+    const float *TVc = TV;
+    float *TVn = TV + ntv;
+    float *HBc = HB, *HBn = HB + NSEQ * c2p;
+    float *X3c = X3, *X3n = X3 + NSEQ * c3p;
     for (int t = 0; t < nmax; t++) {
         const bool pr = probe && t == 8;
         if (pr) pt[0] = (long long)__builtin_amdgcn_s_memtime();
-        const int cur = t & 1, nxt = cur ^ 1;
-        const float *TVc = TV + cur * ntv;
         int act[NSEQ];
 #pragma unroll
-        for (int s = 0; s < NSEQ; s++) act[s] = t < nst[s];
+        for (int s = 0; s < NSEQ; s++) act[s] = NSEQ == 1 || t < nst[s];       // (one sequence: the loop runs to its length)
         // next step's per-token vectors: parked in registers until after P2.  Their loads (a token id from LDS, an address, a
         // global load each) are issued behind P1's products when there is a P1 phase -- at the step's top they sat between the
         // barrier and the step's first LDS reads (the placement that paid 5 % in decomp_regs8_kernel)
@@ -794,8 +802,6 @@ decomp_rows_kernel(const DecompRowsParams p) {
         // a gate, an rr entry or the new state right away, so a step is 2 barriers (3 with farnn==2).
         // hb and [rr | hb] ping-pong because P3's epilogue writes the next step's hb while other
         // wavefronts still read this step's.
-        float *HBc = HB + cur * NSEQ * c2p, *HBn = HB + nxt * NSEQ * c2p;
-        float *X3c = X3 + cur * NSEQ * c3p, *X3n = X3 + nxt * NSEQ * c3p;
         if (farnn == 2) {
             // ---- P1: z, r from h; hb = (1-r) h_init + r h  (:143-151) -----------------------------------
             // (one sigmoid for both kinds of row, every LDS operand read up front: the lanes of a wavefront hold update-gate and
@@ -915,7 +921,6 @@ decomp_rows_kernel(const DecompRowsParams p) {
         }
         {   // park the prefetched per-token vectors BEFORE this step's stash stores are issued: vmcnt retires
             // in order, so waiting for these loads later would also wait for every younger store
-            float *TVn = TV + nxt * ntv;
             // (a use on every path: the loads are waited for HERE whatever the slot's condition -- left to the conditional store, the
             //  compiler carried "maybe pending" round the loop and waited vmcnt(0) at the next step's first re-use of the registers)
 #pragma unroll
@@ -983,6 +988,7 @@ decomp_rows_kernel(const DecompRowsParams p) {
             }
         }
         if (pr) pt[5] = (long long)__builtin_amdgcn_s_memtime();
+        { const float *a = TVc; TVc = TVn; TVn = const_cast<float *>(a); float *b = HBc; HBc = HBn; HBn = b; b = X3c; X3c = X3n; X3n = b; }
         wg_barrier_lds();
         if (pr) {
             pt[6] = (long long)__builtin_amdgcn_s_memtime();
@@ -1097,7 +1103,11 @@ struct RowsPlan { int nseq, res1, res2, res3; size_t lds; int form; };   // form
 #define FARNN_ROWS_FORMS(X) X(9, 4, 4, 2, 2, 6) X(8, 4, 0, 2, 2, 4) X(7, 4, 0, 2, 2, 6) X(10, 4, 2, 3, 2, 5) X(1, 2, 0, 4, 1, 7) X(2, 0, 2, 4, 0, 0) X(3, 2, 0, 4, 1, 12) X(5, 2, 0, 5, 1, 9) X(6, 2, 0, 5, 1, 13) X(4, 3, 0, 5, 0, 0)
 constexpr bool rows_form_mixed(int form) { return form == 5 || form == 6 || form == 10; }
 constexpr int rows_form_lpr(int form) { return (form == 7 || form == 8 || form == 9 || form == 10) ? 8 : DR_LPR; }
-constexpr bool rows_form_tail3(int form) { return form == 9 || form == 10; }       // the output rows' last 64-column chunk in LDS
+constexpr bool rows_form_tail3(int form) { return form == 9 || form == 10; }
+// prefetch slots of a form's instantiation (the kernel's NPF): forms whose chunk bounds keep the per-token vector within 512 floats
+constexpr int rows_form_pf(int lpr, int nch2r, int np3r, int nch3r) {
+    return (np3r > 0 && nch2r * (lpr == 8 ? 64 : 32) <= 128 && nch3r * (lpr == 8 ? 64 : 32) <= 384) ? 1 : DR_FORM_PF;
+}       // the output rows' last 64-column chunk in LDS
 
 // one attempt at `nseq` sequences per workgroup; forms: may a register-resident form be chosen
 inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L, int nseq, bool forms, RowsPlan &pl) {
@@ -1130,7 +1140,8 @@ inline bool rows_plan_try(const DecompRowsPack &k, const DecompWeights &w, int L
                 (D_ == 0 || ((np3 <= D_ || rows_form_mixed(F_)) && nc3 <= E_)) && (A_ > 0 || k.n1 == 0) &&         \
                 (!rows_form_mixed(F_) || (np1 > A_ && np3 > D_)) &&  /* (mixed forms: only where the whole-matrix forms do not reach) */ \
                 (rows_form_lpr(F_) != 8 || (k.n2 <= 4 * rpp && nc2 <= C_ && k.nch3 >= 8)) &&  /* (shorter rows: form 1 is faster) */ \
-                (!(rows_form_mixed(F_) && rows_form_lpr(F_) == 8) || k.nch2 <= 2 * C_ - 1)) {  /* (its last chunk of gate row: the first piece only) */ \
+                (!(rows_form_mixed(F_) && rows_form_lpr(F_) == 8) || k.nch2 <= 2 * C_ - 1) &&  /* (its last chunk of gate row: the first piece only) */ \
+                tvl <= rows_form_pf(rows_form_lpr(F_), C_, D_, E_) * DR_THREADS) {  /* (its prefetch slots hold the per-token vector) */ \
                 /* the matrices left outside the registers go to the LDS as far as it holds them (whole, for forms 1-3 at   \
                    the sizes they were made for), the remainder is streamed as before; a mixed form's rows behind its     \
                    register passes first: they are few */                                                          \
