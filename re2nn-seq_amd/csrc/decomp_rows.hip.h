@@ -774,6 +774,17 @@ decomp_rows_kernel(const DecompRowsParams p) {
     long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (probe && tid == 0) printf("rows wg 0 round %d: set-up %lld cycles: selection %lld, tokens + vectors %lld, rows into LDS + zeroing %lld, register loads issued %lld, their wait + barrier + state rows %lld, the rest %lld\n", rnd, (long long)__builtin_amdgcn_s_memtime() - t_start, st_0 - t_start, st_1 - st_0, st_2 - st_1, st_3 - st_2, st_4 - st_3, (long long)__builtin_amdgcn_s_memtime() - st_4);
     // element-wise phases: element e -> (sequence e % NSEQ, state entry e / NSEQ)
+    // P1's epilogue operands of this lane's row (eight lanes per row, gate rows in registers: rowdots_regs hands lane k of a group
+    // pass k's row, k * 64 + its group, clamped into the matrix)
+    const float *p1_hi = Hinit, *p1_hh = H;
+    int p1_g = 0;
+    if constexpr (LPR == 8 && NP1R > 0) {
+        int row = (tid & 7) * (DR_THREADS / 8) + tid / 8;
+        row = row < p.n1 ? row : p.n1 - 1;
+        const bool isr = row >= S;
+        const int j = isr ? row - S : row;
+        p1_hi = Hinit + j; p1_hh = H + j; p1_g = Rp + (isr ? SP : 0) + j;
+    }
     // the ping-pong buffers of a step (this step's / the next step's per-token vectors, hb, [rr | hb]) as loop-carried pointers, swapped
     // in FRONT of the step's last barrier: computed from t & 1 they were a dozen scalar instructions behind it, at the head of P1
     const float *TVc = TV;
@@ -825,13 +836,21 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             struct Ops1 { float gpre[NSEQ], hh[NSEQ], hi; };
+            // (eight lanes per row: the lane's row is fixed for the launch, and its three operand addresses with it -- p1_hi / p1_hh /
+            //  p1_g above the time loop; derived from the opaque row they were eleven vector instructions at the head of every P1)
             auto pre1 = [&](int row) {
                 Ops1 o;
-                const bool isr = row >= S;
-                const int j = isr ? row - S : row;
-                o.hi = Hinit[j];
+                if constexpr (LPR == 8 && NP1R > 0) {
+                    o.hi = *p1_hi;
 #pragma unroll
-                for (int s = 0; s < NSEQ; s++) { o.gpre[s] = TVc[s * tvl + Rp + (isr ? SP : 0) + j]; o.hh[s] = H[s * c2p + j]; }
+                    for (int s = 0; s < NSEQ; s++) { o.gpre[s] = TVc[s * tvl + p1_g]; o.hh[s] = p1_hh[s * c2p]; }
+                } else {
+                    const bool isr = row >= S;
+                    const int j = isr ? row - S : row;
+                    o.hi = Hinit[j];
+#pragma unroll
+                    for (int s = 0; s < NSEQ; s++) { o.gpre[s] = TVc[s * tvl + Rp + (isr ? SP : 0) + j]; o.hh[s] = H[s * c2p + j]; }
+                }
                 return o;
             };
             auto epi1o = [&](int row, const float (&acc)[NSEQ], const Ops1 &o) {
