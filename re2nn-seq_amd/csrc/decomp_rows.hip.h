@@ -785,6 +785,12 @@ decomp_rows_kernel(const DecompRowsParams p) {
         const int j = isr ? row - S : row;
         p1_hi = Hinit + j; p1_hh = H + j; p1_g = Rp + (isr ? SP : 0) + j;
     }
+    float *p3_z = Z, *p3_h = H;
+    if constexpr (LPR == 8 && NP3R > 0) {
+        int row = (tid & 7) * (DR_THREADS / 8) + tid / 8;
+        row = row < p.n3 ? row : p.n3 - 1;
+        p3_z = Z + row; p3_h = H + row;
+    }
     // the ping-pong buffers of a step (this step's / the next step's per-token vectors, hb, [rr | hb]) as loop-carried pointers, swapped
     // in FRONT of the step's last barrier: computed from t & 1 they were a dozen scalar instructions behind it, at the head of P1
     const float *TVc = TV;
@@ -973,10 +979,15 @@ decomp_rows_kernel(const DecompRowsParams p) {
                 }
             };
             struct Ops3 { float z[NSEQ], h[NSEQ]; };             // (the eight-lane forms: farnn = 2)
+            // (p3_z / p3_h: this lane's row of Z and H, fixed above the time loop like P1's operands -- the same two addresses serve the
+            //  reads in front of the products and the state's write behind them)
             auto pre3 = [&](int row) {
                 Ops3 o;
 #pragma unroll
-                for (int s = 0; s < NSEQ; s++) { o.z[s] = Z[s * SP + row]; o.h[s] = H[s * c2p + row]; }
+                for (int s = 0; s < NSEQ; s++) {
+                    if constexpr (LPR == 8 && NP3R > 0) { o.z[s] = p3_z[s * SP]; o.h[s] = p3_h[s * c2p]; }
+                    else { o.z[s] = Z[s * SP + row]; o.h[s] = H[s * c2p + row]; }
+                }
                 return o;
             };
             auto epi3o = [&](int row, const float (&acc)[NSEQ], const Ops3 &o) {
@@ -985,7 +996,8 @@ decomp_rows_kernel(const DecompRowsParams p) {
                     if (!act[s]) continue;
                     const float nx = dbg_on(2) ? acc[s] : dr_nl<FASTQ>(acc[s], nl_mode);
                     const float hn = (1.0f - o.z[s]) * o.h[s] + o.z[s] * nx;
-                    H[s * c2p + row] = hn;
+                    if constexpr (LPR == 8 && NP3R > 0) p3_h[s * c2p] = hn;
+                    else H[s * c2p + row] = hn;
                     if (!dbg_on(4)) stash_base[((long long)bseq[s] * (p.L + 1) + t + 1) * SP + row] = hn;
                 }
             };
