@@ -280,12 +280,12 @@ decomp_regs_kernel(const DecompRegsParams p) {
             }
         }
         // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products -- decomp_regs8_kernel)
-        if (SCORE && wv == WCOPY && t >= 1) {
+        if (__builtin_expect(SCORE && wv == WCOPY && t >= 1, 0)) {         // (one wavefront's: out of the others' line -- a taken branch is ~20 cycles)
             if (t >= 2) store_row(t - 1);                     // read one step ago
             read_row(t);                                      // the state the last step finished (complete behind its barrier)
             if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
         }
-        if (SCORE && wv == 0) {
+        if (__builtin_expect(SCORE && wv == 0 && (unsigned)(t - t_poll) <= 1u, 0)) {   // (two steps of one wavefront's chain)
             // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
             // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
             if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, epoch);
@@ -528,12 +528,12 @@ decomp_regs8_kernel(const DecompRegsParams p) {
         // (the copying wavefront's row and the poll of the other direction's progress: behind phase A's products, so that the step
         //  starts with its LDS reads -- at the step's top this bookkeeping sat between the barrier and them: 59.6 -> 56.5 us per
         //  launch.  The word-vector prefetch stays at the top: moved here too it cost 0.7 us.)
-        if (SCORE && wv == WCOPY && t >= 1) {
+        if (__builtin_expect(SCORE && wv == WCOPY && t >= 1, 0)) {         // (one wavefront's: out of the others' line -- a taken branch is ~20 cycles)
             if (t >= 2) store_row(t - 1);                     // read one step ago
             read_row(t);                                      // the state the last step finished (complete behind its barrier)
             if (t - 1 == pubmax && published < pubmax) publish(pubmax);   // the other direction's tiles need no row beyond this one
         }
-        if (SCORE && wv == 0) {
+        if (__builtin_expect(SCORE && wv == 0 && (unsigned)(t - t_poll) <= 1u, 0)) {   // (two steps of one wavefront's chain)
             // the other direction's progress, looked at a few steps before this chain ends: polled in one step, acted on in the
             // next (the load has long landed), so that the end-of-chain protocol finds its acquire done
             if (t == t_poll && lane == 0) polled = bs_read_prog(p.bs.prog + (long long)(dir ^ 1) * p.B + b, epoch);
