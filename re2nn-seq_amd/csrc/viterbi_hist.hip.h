@@ -636,33 +636,51 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
         // Blocks of 64 positions, last block first.  The loop over a block's positions has NO test inside (round 6: the flush test, the
         // t == 0 test and the loop's own layout were three taken branches per position, each a refill of the instruction buffer --
         // ~60 of a step's ~400 cycles): position 0 is peeled off (it has no back-pointer to find), a block is flushed behind its loop.
+        // (round 6, late: one lone wavefront issues an instruction per ~5 cycles, so a step costs its instruction COUNT.  The NU slices of a
+        //  row are read off ONE address with immediate offsets -- lane + 64 u lies 256 u bytes further; a lane past the row's end reads
+        //  whatever follows, and `valid` drops its candidate -- instead of NU clamped addresses per row; and two steps per trip hand the
+        //  row fetched ahead to each other in place, instead of NU register copies per step.)
+        const unsigned hq0 = (unsigned)(size_t)(hist + lane), tq0 = (unsigned)(size_t)(trl + lane);
+        auto read_slices = [&](float (&dst)[NU], unsigned a) {
+            asm volatile("ds_read_b32 %0, %1" : "=v"(dst[0]) : "v"(a) : "memory");
+            if constexpr (NU > 1) asm volatile("ds_read_b32 %0, %1 offset:256" : "=v"(dst[1]) : "v"(a) : "memory");
+            if constexpr (NU > 2) asm volatile("ds_read_b32 %0, %1 offset:512" : "=v"(dst[2]) : "v"(a) : "memory");
+            if constexpr (NU > 3) asm volatile("ds_read_b32 %0, %1 offset:768" : "=v"(dst[3]) : "v"(a) : "memory");
+        };
+        auto step = [&](int t, const float (&pin)[NU], float (&pout)[NU]) {
+            // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values.  The step's LDS
+            // reads are ISSUED first; the tag's bookkeeping runs under their round trip -- in front of them it sat on the chain
+            // ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
+            const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
+            const unsigned o_pre = 4u * (unsigned)(tp * PW), o_tr = 4u * (unsigned)(ptr * Kp);
+            const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
+            float tr[NU], m, f;
+            // the row fetched ahead first (its latency hides behind the others' -- LDS reads return in order), then what the step
+            // waits for; volatile statements keep this order
+            read_slices(pout, hq0 + o_pre);
+            read_slices(tr, tq0 + o_tr);
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(m), "=&v"(f) : "v"(a_m), "v"(a_f) : "memory");
+            keep_tag(t);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m), "+v"(f) : : "memory");
+#pragma unroll
+            for (int u = 0; u < NU; u++) asm volatile("" : "+v"(pout[u]), "+v"(tr[u]));              // (behind the wait)
+#pragma unroll
+            for (int u = 0; u < NU; u++) c[u] = (f + tr[u]) + pin[u];         // (feat + trans) + partition: crf.py:123,145
+            ptr = first_equal(c, m);
+        };
+        float pnx[NU];
+        // Blocks of 64 positions, last block first.  The loop over a block's positions has NO test inside (round 6: the flush test, the
+        // t == 0 test and the loop's own layout were three taken branches per position, each a refill of the instruction buffer --
+        // ~60 of a step's ~400 cycles): position 0 is peeled off (it has no back-pointer to find), a block is flushed behind its loop.
         for (int t_hi = n - 1; t_hi >= 0; t_hi = (t_hi & ~63) - 1) {
             const int t_lo = t_hi & ~63, t_stop = t_lo > 0 ? t_lo : 1;
+            int t = t_hi;
 #pragma unroll 1
-            for (int t = t_hi; t >= t_stop; t--) {
-                // the back-pointer of step t at tag ptr (crf.py:147-149), recomputed: same f32 expression, same values.  The step's LDS
-                // reads are ISSUED first; the tag's bookkeeping runs under their round trip -- in front of them it sat on the chain
-                // ptr -> addresses -> reads -> ptr (round 4: -70 cycles per step)
-                const int tp = __builtin_amdgcn_readfirstlane(t > 1 ? t - 2 : 0);
-                const unsigned o_pre = 4u * (unsigned)(tp * PW), o_tr = 4u * (unsigned)(ptr * Kp);
-                const unsigned a_m = h0 + 4u * (unsigned)(t * PW + ptr), a_f = a_m + sc_off;         // (PW == Kp)
-                float pre[NU], tr[NU], m, f;
-                // the rows fetched ahead first (their latency hides behind the others' -- LDS reads return in order), then what the step
-                // waits for; volatile statements keep this order
+            for (; t > t_stop; t -= 2) { step(t, prv, pnx); step(t - 1, pnx, prv); }
+            if (t == t_stop) {
+                step(t, prv, pnx);
 #pragma unroll
-                for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(pre[u]) : "v"(hq_a[u] + o_pre) : "memory");
-#pragma unroll
-                for (int u = 0; u < NU; u++) asm volatile("ds_read_b32 %0, %1" : "=v"(tr[u]) : "v"(tq_a[u] + o_tr) : "memory");
-                asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3" : "=&v"(m), "=&v"(f) : "v"(a_m), "v"(a_f) : "memory");
-                keep_tag(t);
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(m), "+v"(f) : : "memory");
-#pragma unroll
-                for (int u = 0; u < NU; u++) asm volatile("" : "+v"(pre[u]), "+v"(tr[u]));            // (behind the wait)
-#pragma unroll
-                for (int u = 0; u < NU; u++) c[u] = (f + tr[u]) + prv[u];     // (feat + trans) + partition: crf.py:123,145
-                ptr = first_equal(c, m);
-#pragma unroll
-                for (int u = 0; u < NU; u++) prv[u] = pre[u];
+                for (int u = 0; u < NU; u++) prv[u] = pnx[u];
             }
             if (t_lo == 0) keep_tag(0);
             if (t_lo + lane <= t_hi) {                   // the block's 64 positions at a time, coalesced
