@@ -30,7 +30,6 @@ Rank 0 prints ONE JSON line (contract in the task statement), carrying
                 configurations (rank 250, farnn 2), timed for a few hundred ms each with their own roofline and parity.
 """
 import argparse
-import gc
 import json
 import os
 import subprocess
@@ -1037,11 +1036,9 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
         torch.cuda.synchronize(dev)
         if region:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        # (the region is K host-enqueued steps of ~30 us: a collection pause of the interpreter inside the driver's 20 steps would
-        #  be several microseconds on every one of them -- collected before, held off until the region is closed)
-        gc_was = gc.isenabled()
-        gc.collect()
-        gc.disable()
+        # (nothing between the warm-up's synchronize and the region: round 6 tried collecting the interpreter's garbage here and holding the
+        #  collector off inside the region -- the tens of milliseconds the GPU then sat idle made the driver's 20 steps 2-4 us SLOWER each,
+        #  32.9-34.5 against 30.4-30.7 us in alternating runs on one box; running the side configurations first did not help either)
         t0 = time.perf_counter()
         if region:
             ev[0].record(streams[0])
@@ -1061,8 +1058,6 @@ def run_tagging(a, name, steps, warmup, world, rank, dev, dist, want_pipelined, 
             dist.barrier()
             torch.cuda.synchronize(dev)
         el = time.perf_counter() - t0
-        if gc_was:
-            gc.enable()
         if post:
             handles[0].set_profiling(1)
             for _ in range(8):
@@ -1254,11 +1249,15 @@ def main():
         return run_train(a, world, rank, dev, dist)
     stride = a.event_stride if a.event_stride >= 0 else auto_event_stride(a.steps, a.workload)
     want_pipe = not a.no_pipelined and a.streams == 1 and a.workload != 'synth512'   # no second 63 GB replica
-    # The side configurations run FIRST (each its own `{"other_config": ...}` line): the headline's W warm-up steps and K timed steps then
-    # run in a process whose runtime, queues and clocks are warm -- measured first, on a fresh box, the driver's 20 steps of ~30 us
-    # read anything from 30.4 to 38.9 us (profiles/r06_*: the kernels' own durations did not move).
-    others = None
+    res = run_tagging(a, a.workload, a.steps, a.warmup, world, rank, dev, dist, want_pipe, stride, True)
     if rank == 0:
+        out = {'metric': 'tagged tokens/sec @ batch=256, seqlen=64; achieved HBM GB/s vs peak',
+               'value': res.pop('value'), 'unit': res.pop('unit'), 'n_gpus': world,
+               'steps': res.pop('steps'), 'warmup': res.pop('warmup'), 'ms_per_step': res.pop('ms_per_step'),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+        out.update(res)
+        if gather_info is not None:
+            out['gather'] = gather_info
         defaults = (a.batch, a.seqlen, a.rank, a.farnn, a.semiring, a.full_length, a.streams, a.graph) == \
                    (256, 64, 50, 0, 'sum', False, 1, 0)
         if world == 1 and a.workload == 'ifst' and defaults and not a.no_other_configs:
@@ -1292,16 +1291,6 @@ def main():
                     r = {'workload': name, 'error': '{}: {}'.format(type(e).__name__, e)}
                 others.append(r)
                 print(other_config_line(r), flush=True)       # its own line, BEFORE the result line
-    res = run_tagging(a, a.workload, a.steps, a.warmup, world, rank, dev, dist, want_pipe, stride, True)
-    if rank == 0:
-        out = {'metric': 'tagged tokens/sec @ batch=256, seqlen=64; achieved HBM GB/s vs peak',
-               'value': res.pop('value'), 'unit': res.pop('unit'), 'n_gpus': world,
-               'steps': res.pop('steps'), 'warmup': res.pop('warmup'), 'ms_per_step': res.pop('ms_per_step'),
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
-        out.update(res)
-        if gather_info is not None:
-            out['gather'] = gather_info
-        if others is not None:
             out['other_configs'] = others
         out['full'] = write_full(out)
         print(result_line(out), flush=True)                   # the ONE result line: last on stdout, <= LINE_CAP bytes
