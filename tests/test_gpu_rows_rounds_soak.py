@@ -16,3 +16,47 @@ def test_rounds_agree_with_one_workgroup_per_chain_over_random_shapes():
     import soak_rows_rounds
     n = int(os.environ.get('FARNN_SHAPE_SOAK', '0')) or 60
     assert soak_rows_rounds.run(n, seed=int(os.environ.get('FARNN_SHAPE_SEED', '0'))) == 0
+
+
+def test_empty_sequences_in_every_round_behind_the_viterbi_kernel():
+    """A third of a 300-sequence batch EMPTY (they land in every round of the rows kernel, their token words are never written),
+    the CRF model's score + Viterbi kernel -- -inf pads in LDS on every compute unit -- run in front of each call: against the oracle.
+    (Not a deterministic reproducer of the fault the soak found: on the library with the guard removed this test still passes --
+    the LDS words at the token slot's offset are the Viterbi kernel's small queue counters, valid word ids.  The random soak above
+    hit it within 2 to 6 draws, twice; this test holds the empty-sequence handling to the oracle.)"""
+    import numpy as np
+    import torch
+    from oracle import farnn_oracle as fo
+    from re2nn_seq_amd import _lib, synth
+    from util import assert_float_path, in_float64
+    B, L, R, S = 300, 33, 250, 104
+    Vc, qc, gc, trc = synth.snips_sized_model(R, 2, True, seed=1234, S=S)
+    V, q, gates, _ = synth.snips_sized_model(R, 2, False, seed=1234, S=S)
+    rng = np.random.RandomState(77)
+    x, lengths = synth.random_batch(V, B, L, rng, min_len=0)
+    lengths[rng.randint(B, size=B // 3)] = 0                           # a third of the batch: empty
+    xd, ld = torch.from_numpy(x).cuda(), torch.from_numpy(lengths).cuda()
+    hc = _lib.create_decomp_ifst(qc['Vgen'], qc['S1'], qc['S2'], qc['W'], qc['Cout'], qc['h0'], qc['hT'], farnn=2, gates=gc,
+                                 sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0, use_crf=True, crf_trans=trc)
+    h = _lib.create_decomp_ifst(q['Vgen'], q['S1'], q['S2'], q['W'], q['Cout'], q['h0'], q['hT'], farnn=2, gates=gates,
+                                sigmoid_exponent=5, nl='tanh', threshold=0.5, o_idx=0)
+    K = q['Cout'].shape[0]
+    xf, lf = synth.random_batch(Vc, 256, 64, np.random.RandomState(78))
+    xfd, lfd = torch.from_numpy(xf).cuda(), torch.from_numpy(lf).cuda()
+    tags_c = torch.empty((256, 64), dtype=torch.int32, device='cuda')
+    scores = torch.empty((B, L, K), dtype=torch.float32, device='cuda')
+    tags = torch.empty((B, L), dtype=torch.int32, device='cuda')
+    ref = fo.decomp_ifst_scores(q, x, lengths)
+    ref64 = in_float64(fo.decomp_ifst_scores, q, x, lengths)
+    mask = np.arange(L)[None, :] < lengths[:, None]
+    for _ in range(6):
+        hc.tag(xfd.data_ptr(), lfd.data_ptr(), 256, 64, _lib.MODE_LOCAL, tags_c.data_ptr(), None, None)      # -inf into every CU's LDS
+        scores.fill_(float('nan'))
+        h.tag(xd.data_ptr(), ld.data_ptr(), B, L, _lib.MODE_LOCAL, tags.data_ptr(), None, scores.data_ptr())
+        torch.cuda.synchronize()
+        assert h.kernel_name(_lib.KERN_CHAIN) == 'decomp_rows_kernel'
+        got = scores.cpu().numpy()
+        assert np.isfinite(got[mask]).all()
+        assert_float_path(got[mask], ref[mask], ref64[mask], err_msg='rows kernel behind the Viterbi kernel')
+    hc.close()
+    h.close()
