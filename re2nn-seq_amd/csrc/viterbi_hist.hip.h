@@ -503,11 +503,22 @@ __device__ __forceinline__ void viterbi_hist_body(const ScoreParams &p, float *s
             if constexpr (IB4 > 5) lds_read16_at<640>(p4[5], pin_lane + row);
 #pragma unroll
             for (int xk = 0; xk < XSC; xk++) asm volatile("ds_read_b32 %0, %1" : "=v"(px[xk]) : "v"(px_lane[xk] + row));
+            // (the partition of ONE source added to both tags of the lane: the packed add reads the same half of the register pair for
+            //  both results -- op_sel -- where the compiler built {p, p} pairs with a v_mov per block; the first block starts `best`
+            //  from its own values instead of -inf: round 6, late -- the step is VALU-issue bound over the compute unit's nine wavefronts)
+            auto add_lo = [](v2f a, v2f pr) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(a), "v"(pr)); return r; };
+            auto add_hi = [](v2f a, v2f pr) { v2f r; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(a), "v"(pr)); return r; };
             auto block = [&](int k4) {
-                const v2f v0 = f_tr(k4 * 4 + 0) + v2f{p4[k4].x, p4[k4].x}, v1 = f_tr(k4 * 4 + 1) + v2f{p4[k4].y, p4[k4].y};
-                const v2f v2 = f_tr(k4 * 4 + 2) + v2f{p4[k4].z, p4[k4].z}, v3 = f_tr(k4 * 4 + 3) + v2f{p4[k4].w, p4[k4].w};
-                best.x = fmaxf(fmaxf(best.x, v0.x), v1.x); best.y = fmaxf(fmaxf(best.y, v0.y), v1.y);
-                best.x = fmaxf(fmaxf(best.x, v2.x), v3.x); best.y = fmaxf(fmaxf(best.y, v2.y), v3.y);
+                const v2f xy = v2f{p4[k4].x, p4[k4].y}, zw = v2f{p4[k4].z, p4[k4].w};
+                const v2f v0 = add_lo(f_tr(k4 * 4 + 0), xy), v1 = add_hi(f_tr(k4 * 4 + 1), xy);
+                const v2f v2 = add_lo(f_tr(k4 * 4 + 2), zw), v3 = add_hi(f_tr(k4 * 4 + 3), zw);
+                if (k4 == 0) {                           // (max over the same values: the order of a max does not change its result)
+                    best.x = fmaxf(fmaxf(v0.x, v1.x), v2.x); best.y = fmaxf(fmaxf(v0.y, v1.y), v2.y);
+                    best.x = fmaxf(best.x, v3.x); best.y = fmaxf(best.y, v3.y);
+                } else {
+                    best.x = fmaxf(fmaxf(best.x, v0.x), v1.x); best.y = fmaxf(fmaxf(best.y, v0.y), v1.y);
+                    best.x = fmaxf(fmaxf(best.x, v2.x), v3.x); best.y = fmaxf(fmaxf(best.y, v2.y), v3.y);
+                }
             };
             if constexpr (IB4 > 0) { lds_wait_for<IB4 + XSC - 1>(p4[0]); block(0); }
             if constexpr (IB4 > 1) { lds_wait_for<IB4 + XSC - 2>(p4[1]); block(1); }
